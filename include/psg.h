@@ -1,0 +1,166 @@
+/*
+ * psg.h -- C ABI of libpsg.so: the MI355X (gfx950) implementation of PointSecGuard's
+ * data-parallel hot path (PointNet++ SSG semantic-segmentation forward + colour-gradient backward
+ * inside the NB/NU colour-perturbation attack loops).
+ *
+ * The reference has no FFI layer: its boundary for this path is the Python API that the harness
+ * scripts import.  Each entry point below names the reference expression it
+ * replaces (paths relative to the reference checkout); INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless marked "host";
+ *   - every call is stream-ordered and non-blocking on `stream` (a hipStream_t, 0 = default
+ *     stream); no call synchronises the device or spawns threads;
+ *   - objects (ctx / model / workspace) allocate their device memory at create time only;
+ *   - return value: PSG_OK (0) or a negative PSG_ERR_*; psg_last_error() gives the thread-local text;
+ *   - feature tensors are POINT-MAJOR fp32: [batch][points][channels]; indices are int32.
+ */
+#ifndef PSG_H
+#define PSG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSG_OK 0
+#define PSG_ERR_ARG (-1)   /* bad argument / unsupported size */
+#define PSG_ERR_HIP (-2)   /* a HIP runtime call failed */
+#define PSG_ERR_STATE (-3) /* object used out of order (e.g. backward before forward) */
+
+typedef struct psg_ctx psg_ctx;
+typedef struct psg_pn2_model psg_pn2_model;
+typedef struct psg_pn2_ws psg_pn2_ws;
+typedef void *psg_stream; /* hipStream_t */
+
+const char *psg_last_error(void);
+const char *psg_version(void);
+
+/* One context per (process, device). */
+int psg_ctx_create(int device, psg_ctx **out);
+int psg_ctx_destroy(psg_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------
+ * Geometry unit ops, batched over P independent problems.  Problem p reads cloud (p % n_clouds).
+ * ------------------------------------------------------------------------------------------ */
+
+/* farthest_point_sample, PointNet/models/pointnet_util.py:63-84.
+ * xyz [n_clouds][N][3]; start [P] = the torch.randint draw of :75; out_idx [P][S].
+ * Lowest index wins distance ties (torch.max CPU behaviour).  N <= 8192. */
+int psg_fps(psg_ctx *ctx, const float *xyz, int n_clouds, int P, int N, int S, const int32_t *start,
+            int32_t *out_idx, psg_stream stream);
+
+/* index_points, pointnet_util.py:43-60: out[p][s][:] = points[p % n_clouds][idx[p][s]][:]. */
+int psg_gather_points(psg_ctx *ctx, const float *points, int n_clouds, int P, int N, int C, const int32_t *idx,
+                      int S, float *out, psg_stream stream);
+
+/* query_ball_point, pointnet_util.py:87-107.  xyz [n_clouds][N][3]; new_xyz [P][S][3];
+ * r2 = float32(radius**2); out_idx [P][S][K]: first K indices j (ascending) with
+ * !(square_distance(new_xyz, xyz) > r2), padded with the first hit.  N <= 8192. */
+int psg_ball_query(psg_ctx *ctx, const float *xyz, int n_clouds, const float *new_xyz, int P, int N, int S,
+                   float r2, int K, int32_t *out_idx, psg_stream stream);
+
+/* 3-NN + inverse-distance weights, pointnet_util.py:301-307.  xyz1 [n_clouds1][N][3] (fine),
+ * xyz2 [P][S][3] (coarse); out_idx/out_w [P][N][3].  Stable ascending order.  3 <= S <= 8192. */
+int psg_three_nn(psg_ctx *ctx, const float *xyz1, int n_clouds1, const float *xyz2, int P, int N, int S,
+                 int32_t *out_idx, float *out_w, psg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PointNet++ SSG sem-seg network (get_model, PointNet/models/pointnet2_sem_seg.py:6-40), eval mode.
+ * ------------------------------------------------------------------------------------------ */
+
+#define PSG_PN2_NUM_LAYERS 23 /* sa1..sa4 (3 each), fp4, fp3, fp2 (2 each), fp1 (3), conv1, conv2 */
+#define PSG_PN2_NUM_CLASSES 13
+#define PSG_PN2_IN_CHANNELS 9
+
+/* Build the device-resident, MFMA-packed weights.  `weights[i]` / `biases[i]` are HOST pointers to the
+ * row-major [cout][cin] weight and [cout] bias of layer i with the eval-mode BatchNorm already
+ * folded in, in the order sa1.0-2, sa2.0-2, sa3.0-2, sa4.0-2, fp4.0-1, fp3.0-1, fp2.0-1, fp1.0-2,
+ * conv1(+bn1), conv2.  Layer shapes are fixed by the architecture (pointnet2_sem_seg.py:9-19).
+ * Blocking (uploads synchronously); not for use inside a timed loop. */
+int psg_pn2_model_create(psg_ctx *ctx, const float *const *weights, const float *const *biases,
+                         psg_pn2_model **out);
+int psg_pn2_model_destroy(psg_pn2_model *model);
+
+/* Workspace: geometry plan for up to `max_forwards` forwards of a batch of `batch` rooms of
+ * `n_point` points, plus activations / ReLU masks / gradient buffers for ONE forward in flight. */
+int psg_pn2_ws_create(psg_ctx *ctx, int batch, int n_point, int max_forwards, psg_pn2_ws **out);
+int psg_pn2_ws_destroy(psg_pn2_ws *ws);
+size_t psg_pn2_ws_bytes(const psg_pn2_ws *ws);
+
+/* Geometry for `n_forward` forwards at once (sample_and_group's FPS + ball query of the four SA
+ * levels, and the 3-NN tables of the four FP levels; pointnet_util.py:110-143, :301-307).
+ * x0 [batch][n_point][9] point-major rooms (only channels 0:3 are read);
+ * starts [n_forward][4][batch] = the torch.randint draws in reference call order.
+ * Geometry depends on xyz and the draws only, never on colour, so an attack builds it once for
+ * all of its iterations (n_forward*batch independent problems fill the chip). */
+int psg_pn2_plan_build(psg_pn2_ws *ws, const float *x0, const int32_t *starts, int n_forward, psg_stream stream);
+
+/* Read-back of plan slices for parity tests (device pointers into the workspace).
+ * what: 0 fps idx [S_l], 1 group idx [S_l][32], 2 nn idx [N_l][3], 3 nn weights [N_l][3], 4 xyz of level+1 */
+const void *psg_pn2_plan_ptr(const psg_pn2_ws *ws, int what, int level, int forward, int room);
+
+/* get_model.forward (pointnet2_sem_seg.py:22-40) with the geometry of plan slot `forward`.
+ * x0 [batch][n_point][9]; logp_out [batch][n_point][13] = log_softmax; l4_out (nullable)
+ * [batch][16][512] = l4_points point-major.  Leaves the ReLU / arg-max masks in the workspace. */
+int psg_pn2_forward(psg_pn2_model *model, psg_pn2_ws *ws, int forward, const float *x0, float *logp_out,
+                    float *l4_out, psg_stream stream);
+
+/* Input-gradient backward of the forward that last ran in `ws` (what autograd derives for a leaf on
+ * the input features): dlogp [batch][n_point][13] = d loss / d log-probs;
+ * dx0_out [batch][n_point][9] = d loss / d input features (geometry treated as constant: channels
+ * 3:9 are exact, channels 0:3 exclude the paths through relative coordinates and 3-NN weights,
+ * which no attack uses).  No weight gradients (the attack path never needs them). */
+int psg_pn2_backward(psg_pn2_model *model, psg_pn2_ws *ws, int forward, const float *dlogp, float *dx0_out,
+                     psg_stream stream);
+
+/* Per-layer activations of the last forward, for parity tests: which 0..3 = l1..l4 points (sa1..sa4
+ * outputs), 4..6 = fp4, fp3, fp2 outputs.  Returns a device pointer [batch][points][channels]. */
+const float *psg_pn2_activation_ptr(const psg_pn2_ws *ws, int which);
+
+/* ------------------------------------------------------------------------------------------
+ * Attack-loop arithmetic (PointNet/attacks/torchattacks/attacks/nontarget.py, target.py).
+ * ------------------------------------------------------------------------------------------ */
+
+/* [B][C][N] channel-major (reference layout) <-> [B][N][C] point-major. */
+int psg_to_point_major(const float *src_cn, int B, int C, int N, float *dst_nc, psg_stream stream);
+int psg_to_channel_major(const float *src_nc, int B, int C, int N, float *dst_cn, psg_stream stream);
+
+/* d/dlogp of scale * sum_i CE(logp_i, y_i) with CE applied ON TOP of the log-probs (a second
+ * log_softmax), nontarget.py:26,34 / target.py:27,39.  labels [rows] int32, or a single class
+ * when labels == NULL (`target`).  rows_active: only the first rows_active rows get a gradient
+ * (target.py:36 uses batch row 0 only); the rest are zeroed.  cost_out (nullable): 1 float, += cost. */
+int psg_ce_logp_grad(const float *logp, const int32_t *labels, int target, int rows, int rows_active, int n_cls,
+                     float scale, float *dlogp_out, float *cost_out, psg_stream stream);
+
+/* One NB / tar_NB update on the colour channels 3:6 of point-major rooms x [B][N][9], in place:
+ *   stepped = x + dir*alpha*sign(g);  eta = clamp(stepped - ori, -eps, eps);
+ *   x = last ? stepped : clamp(ori + eta, 0, 1)          (nontarget.py:37-39, target.py:41-43)
+ * `last` reproduces the reference returning the UN-projected final step.
+ * grad [B][N][9] (channels 3:6 read), ori [B][N][3], mask (nullable) [N] uint8 shared by all rooms. */
+int psg_pgd_step(float *x, const float *grad, const float *ori, const uint8_t *mask, int B, int N, float alpha,
+                 float eps, float dir, int last, psg_stream stream);
+
+/* Fused NB_attack / tar_NB_attack on a batch (nontarget.py:18-42, target.py:18-45):
+ * plan_build for `iters` forwards, then iters x (forward, CE grad, backward, pgd_step), all
+ * stream-ordered on `stream` with no host synchronisation.
+ * images/adv_out [B][9][N] channel-major (reference layout); labels [B][N] int32 (ignored when
+ * targeted); starts [iters][4][B] int32 (device); mask (nullable) [N] uint8.
+ * targeted = 0: ascent on CE_sum(all rooms)/N.  targeted = 1: descent on CE_mean(room 0, target). */
+int psg_pn2_nb_attack(psg_pn2_model *model, psg_pn2_ws *ws, const float *images, const int32_t *labels,
+                      const int32_t *starts, const uint8_t *mask, float eps, float alpha, int iters, int targeted,
+                      int target, float *adv_out, psg_stream stream);
+
+/* Segmentation statistics of NB_nontarget_test_semseg.py:199-205: for every class l accumulates
+ * seen[l] += #(gt==l), inter[l] += #(pred==l & gt==l), uni[l] += #(pred==l | gt==l) where
+ * pred = argmax(logp) (first index on ties).  counters: int64 [3][n_cls] = seen, inter, uni.
+ * pred_out (nullable) int32 [rows]. */
+int psg_seg_stats(const float *logp, const int32_t *labels, int rows, int n_cls, long long *counters,
+                  int32_t *pred_out, psg_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSG_H */

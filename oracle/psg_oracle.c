@@ -1,0 +1,276 @@
+/*
+ * psg_oracle.c -- CPU restatement of the PointSecGuard PointNet++ attack hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle: only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product (pointsecguard_amd/, libpsg.so) never
+ * links, imports or falls back to anything in oracle/.
+ *
+ * Every function restates, in plain C, an expression of the reference (paths relative to
+ * /root/reference).  Floating-point evaluation orders that decide integer outputs (grouping
+ * indices) follow SURVEY.md section 8(a'): they were pinned bit-for-bit against the reference
+ * executed in the build container and are re-checked by tests/test_oracle_golden.py against the
+ * committed fixtures in tests/golden/.  Compile with -ffp-contract=off (oracle/Makefile) so that
+ * only the explicit fmaf() calls fuse.
+ *
+ * Parity status: PINNED by tests/golden/ fixtures generated from the reference itself
+ * (tests/golden/make_golden.py).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef double acc_t; /* dot products accumulate in fp64 and round once to fp32 storage */
+
+/* ---- P1: square_distance, PointNet/models/pointnet_util.py:19-40 -------------------------
+ * dist = -2*matmul(src,dst^T); dist += sum(src**2); dist += sum(dst**2)
+ * matmul K=3 == ascending-k FMA chain; sums of squares un-fused, left to right. */
+static inline float sumsq3(const float *p)
+{
+    return ((p[0] * p[0]) + (p[1] * p[1])) + (p[2] * p[2]);
+}
+static inline float sqdist(const float *src, const float *dst, float s_src, float s_dst)
+{
+    float dot = fmaf(src[2], dst[2], fmaf(src[1], dst[1], src[0] * dst[0]));
+    return ((-2.0f * dot) + s_src) + s_dst;
+}
+
+void orc_square_distance(const float *src, const float *dst, int n, int m, float *out)
+{
+    for (int i = 0; i < n; ++i) {
+        float ss = sumsq3(src + 3 * i);
+        for (int j = 0; j < m; ++j)
+            out[(size_t)i * m + j] = sqdist(src + 3 * i, dst + 3 * j, ss, sumsq3(dst + 3 * j));
+    }
+}
+
+/* ---- P3: farthest_point_sample, pointnet_util.py:63-84 ------------------------------------
+ * distance starts at 1e10; per step dist = sum((xyz-c)**2,-1) (direct form, un-fused),
+ * distance = min(distance, dist); next = argmax(distance) with first-index ties (torch.max CPU).
+ * `start` is the torch.randint draw of pointnet_util.py:75, supplied by the caller. */
+void orc_fps(const float *xyz, int n, int s, int start, int32_t *out)
+{
+    float *dist = (float *)malloc(sizeof(float) * (size_t)n);
+    for (int i = 0; i < n; ++i) dist[i] = 1e10f;
+    int far = start;
+    for (int it = 0; it < s; ++it) {
+        out[it] = far;
+        const float cx = xyz[3 * far], cy = xyz[3 * far + 1], cz = xyz[3 * far + 2];
+        float best = -INFINITY;
+        int bi = 0;
+        for (int i = 0; i < n; ++i) {
+            float dx = xyz[3 * i] - cx, dy = xyz[3 * i + 1] - cy, dz = xyz[3 * i + 2] - cz;
+            float d = ((dx * dx) + (dy * dy)) + (dz * dz);
+            if (d < dist[i]) dist[i] = d;
+            if (dist[i] > best) { best = dist[i]; bi = i; }
+        }
+        far = bi;
+    }
+    free(dist);
+}
+
+/* ---- P4: query_ball_point, pointnet_util.py:87-107 ----------------------------------------
+ * sqrdists = square_distance(new_xyz, xyz); keep j (ascending) unless sqrdists > r2; first k;
+ * pad with the first hit.  r2 = float32(radius**2) is computed by the caller. */
+void orc_ball_query(const float *xyz, const float *new_xyz, int n, int s, float r2, int k, int32_t *out)
+{
+    float *sq = (float *)malloc(sizeof(float) * (size_t)n);
+    for (int j = 0; j < n; ++j) sq[j] = sumsq3(xyz + 3 * j);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < s; ++i) {
+        const float *c = new_xyz + 3 * i;
+        float sc = sumsq3(c);
+        int cnt = 0;
+        int32_t *o = out + (size_t)i * k;
+        for (int j = 0; j < n && cnt < k; ++j) {
+            float d = sqdist(c, xyz + 3 * j, sc, sq[j]);
+            if (!(d > r2)) o[cnt++] = j;
+        }
+        /* reference would index out of range on an empty ball (group_first == N); unreachable
+         * because every centroid is one of the points.  Emit N so a caller can detect it. */
+        int first = cnt ? o[0] : n;
+        for (; cnt < k; ++cnt) o[cnt] = first;
+    }
+    free(sq);
+}
+
+/* ---- P7 (geometry half): 3-NN + inverse-distance weights, pointnet_util.py:301-307 --------
+ * dists = square_distance(xyz1, xyz2) (src = fine points); ascending sort, ties -> lower index;
+ * rc = 1/(d + 1e-8f); w = rc / ((rc0+rc1)+rc2). */
+void orc_three_nn(const float *xyz1, const float *xyz2, int n, int s, int32_t *idx, float *w)
+{
+    float *sq2 = (float *)malloc(sizeof(float) * (size_t)s);
+    for (int j = 0; j < s; ++j) sq2[j] = sumsq3(xyz2 + 3 * j);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        const float *p = xyz1 + 3 * i;
+        float sp = sumsq3(p);
+        float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+        int i0 = 0, i1 = 0, i2 = 0;
+        for (int j = 0; j < s; ++j) {
+            float d = sqdist(p, xyz2 + 3 * j, sp, sq2[j]);
+            if (d < d0) { d2 = d1; i2 = i1; d1 = d0; i1 = i0; d0 = d; i0 = j; }
+            else if (d < d1) { d2 = d1; i2 = i1; d1 = d; i1 = j; }
+            else if (d < d2) { d2 = d; i2 = j; }
+        }
+        float r0 = 1.0f / (d0 + 1e-8f), r1 = 1.0f / (d1 + 1e-8f), r2 = 1.0f / (d2 + 1e-8f);
+        float norm = (r0 + r1) + r2;
+        idx[3 * i] = i0; idx[3 * i + 1] = i1; idx[3 * i + 2] = i2;
+        w[3 * i] = r0 / norm; w[3 * i + 1] = r1 / norm; w[3 * i + 2] = r2 / norm;
+    }
+    free(sq2);
+}
+
+/* ---- P2/P5: index_points + sample_and_group concat, pointnet_util.py:126-140 --------------
+ * rows[s*k] = [xyz[idx]-new_xyz[s] (3), feat[idx] (d)]  (xyz first, pointnet_util.py:137) */
+void orc_group(const float *xyz, const float *feat, const float *new_xyz, const int32_t *idx,
+               int s, int k, int d, float *rows)
+{
+    const int c = 3 + d;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < s; ++i)
+        for (int j = 0; j < k; ++j) {
+            int src = idx[(size_t)i * k + j];
+            float *r = rows + ((size_t)i * k + j) * c;
+            for (int t = 0; t < 3; ++t) r[t] = xyz[3 * src + t] - new_xyz[3 * i + t];
+            memcpy(r + 3, feat + (size_t)src * d, sizeof(float) * (size_t)d);
+        }
+}
+
+/* backward of the feature half of the gather (index_points backward = scatter-add) */
+void orc_group_bwd(const float *drows, const int32_t *idx, int s, int k, int d, int n, float *dfeat)
+{
+    const int c = 3 + d;
+    double *acc = (double *)malloc(sizeof(double) * (size_t)n * d);
+    for (size_t t = 0; t < (size_t)n * d; ++t) acc[t] = dfeat[t];
+    for (int i = 0; i < s; ++i)
+        for (int j = 0; j < k; ++j) {
+            int src = idx[(size_t)i * k + j];
+            const float *r = drows + ((size_t)i * k + j) * c + 3;
+            for (int t = 0; t < d; ++t) acc[(size_t)src * d + t] += r[t];
+        }
+    for (size_t t = 0; t < (size_t)n * d; ++t) dfeat[t] = (float)acc[t];
+    free(acc);
+}
+
+/* ---- P6/P7/P8: 1x1 conv (+ folded eval BatchNorm) + optional ReLU --------------------------
+ * pointnet_util.py:200-203, :317-319, pointnet2_sem_seg.py:36-37.  W is [cout][cin] with the
+ * eval-mode BatchNorm affine already folded in by the caller (oracle/pn2.py: fold_bn). */
+void orc_linear_fwd(const float *x, const float *w, const float *b, int m, int cin, int cout,
+                    int relu, float *y)
+{
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < m; ++r) {
+        const float *xr = x + (size_t)r * cin;
+        float *yr = y + (size_t)r * cout;
+        for (int o = 0; o < cout; ++o) {
+            const float *wo = w + (size_t)o * cin;
+            acc_t a = b[o];
+            for (int i = 0; i < cin; ++i) a += (acc_t)xr[i] * (acc_t)wo[i];
+            float v = (float)a;
+            yr[o] = (relu && !(v > 0.0f)) ? 0.0f : v;
+        }
+    }
+}
+
+/* dX = (dY * [Y>0]) . W   (input gradient only; the attack path never needs dW) */
+void orc_linear_bwd(const float *dy, const float *y, const float *w, int m, int cin, int cout,
+                    int relu, float *dx)
+{
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < m; ++r) {
+        const float *dyr = dy + (size_t)r * cout;
+        const float *yr = y + (size_t)r * cout;
+        float *dxr = dx + (size_t)r * cin;
+        acc_t acc[1024];
+        for (int i = 0; i < cin; ++i) acc[i] = 0;
+        for (int o = 0; o < cout; ++o) {
+            float g = dyr[o];
+            if (relu && !(yr[o] > 0.0f)) g = 0.0f;
+            if (g == 0.0f) continue;
+            const float *wo = w + (size_t)o * cin;
+            for (int i = 0; i < cin; ++i) acc[i] += (acc_t)g * (acc_t)wo[i];
+        }
+        for (int i = 0; i < cin; ++i) dxr[i] = (float)acc[i];
+    }
+}
+
+/* max over the k samples of a group, pointnet_util.py:205 (first index on ties) */
+void orc_maxpool_fwd(const float *h, int s, int k, int c, float *out, int32_t *arg)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < s; ++i)
+        for (int ch = 0; ch < c; ++ch) {
+            float best = -INFINITY;
+            int bj = 0;
+            for (int j = 0; j < k; ++j) {
+                float v = h[((size_t)i * k + j) * c + ch];
+                if (v > best) { best = v; bj = j; }
+            }
+            out[(size_t)i * c + ch] = best;
+            arg[(size_t)i * c + ch] = bj;
+        }
+}
+
+void orc_maxpool_bwd(const float *dout, const int32_t *arg, int s, int k, int c, float *dh)
+{
+    memset(dh, 0, sizeof(float) * (size_t)s * k * c);
+    for (int i = 0; i < s; ++i)
+        for (int ch = 0; ch < c; ++ch)
+            dh[((size_t)i * k + arg[(size_t)i * c + ch]) * c + ch] = dout[(size_t)i * c + ch];
+}
+
+/* ---- P7 (feature half): interpolated = sum_k points2[idx_k] * w_k, pointnet_util.py:308 ---- */
+void orc_interp_fwd(const float *feat2, const int32_t *idx, const float *w, int n, int c, float *out)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        const float *f0 = feat2 + (size_t)idx[3 * i] * c;
+        const float *f1 = feat2 + (size_t)idx[3 * i + 1] * c;
+        const float *f2 = feat2 + (size_t)idx[3 * i + 2] * c;
+        float w0 = w[3 * i], w1 = w[3 * i + 1], w2 = w[3 * i + 2];
+        for (int ch = 0; ch < c; ++ch)
+            out[(size_t)i * c + ch] = ((f0[ch] * w0) + (f1[ch] * w1)) + (f2[ch] * w2);
+    }
+}
+
+void orc_interp_bwd(const float *dout, const int32_t *idx, const float *w, int n, int s, int c,
+                    float *dfeat2)
+{
+    double *acc = (double *)malloc(sizeof(double) * (size_t)s * c);
+    for (size_t t = 0; t < (size_t)s * c; ++t) acc[t] = dfeat2[t];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double wj = w[3 * i + j];
+            double *a = acc + (size_t)idx[3 * i + j] * c;
+            const float *g = dout + (size_t)i * c;
+            for (int ch = 0; ch < c; ++ch) a[ch] += wj * g[ch];
+        }
+    for (size_t t = 0; t < (size_t)s * c; ++t) dfeat2[t] = (float)acc[t];
+    free(acc);
+}
+
+/* ---- NU attacks: k smallest Euclidean colour distances per point -------------------------
+ * nontarget.py:131-135 / target.py:170-175: dist = cdist(adv_colour[0], colour[0]);
+ * sorted ascending; first `nb` kept.  Returns the distances and the matched indices (the
+ * indices feed the backward pass of the Smooth loss). */
+void orc_smooth_knn(const float *a, const float *b, int n, int nb, float *dist, int32_t *idx)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        float bd[16];
+        int bi[16];
+        for (int t = 0; t < nb; ++t) { bd[t] = INFINITY; bi[t] = 0; }
+        for (int j = 0; j < n; ++j) {
+            double dx = (double)a[3 * i] - b[3 * j], dy = (double)a[3 * i + 1] - b[3 * j + 1],
+                   dz = (double)a[3 * i + 2] - b[3 * j + 2];
+            float d = (float)sqrt(dx * dx + dy * dy + dz * dz);
+            if (d < bd[nb - 1]) {
+                int t = nb - 1;
+                while (t > 0 && d < bd[t - 1]) { bd[t] = bd[t - 1]; bi[t] = bi[t - 1]; --t; }
+                bd[t] = d; bi[t] = j;
+            }
+        }
+        for (int t = 0; t < nb; ++t) { dist[(size_t)i * nb + t] = bd[t]; idx[(size_t)i * nb + t] = bi[t]; }
+    }
+}

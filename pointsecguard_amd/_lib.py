@@ -1,0 +1,80 @@
+"""ctypes binding of libpsg.so (the C ABI declared in include/psg.h).
+
+The HIP library IS the product: there is no CPU or PyTorch fallback.  Importing this module never
+touches the GPU; the first call that needs the library loads it and fails loudly if it is missing.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpsg.so")
+
+c_f = ctypes.POINTER(ctypes.c_float)
+c_i = ctypes.POINTER(ctypes.c_int32)
+c_u8 = ctypes.POINTER(ctypes.c_uint8)
+c_ll = ctypes.POINTER(ctypes.c_longlong)
+vp = ctypes.c_void_p
+ci = ctypes.c_int
+cf = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/psg.h one to one (tests/test_abi.py checks the set)
+SIGNATURES = {
+    "psg_last_error": (ctypes.c_char_p, []),
+    "psg_version": (ctypes.c_char_p, []),
+    "psg_ctx_create": (ci, [ci, ctypes.POINTER(vp)]),
+    "psg_ctx_destroy": (ci, [vp]),
+    "psg_fps": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp]),
+    "psg_gather_points": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, vp, vp]),
+    "psg_ball_query": (ci, [vp, vp, ci, vp, ci, ci, ci, cf, ci, vp, vp]),
+    "psg_three_nn": (ci, [vp, vp, ci, vp, ci, ci, ci, vp, vp, vp]),
+    "psg_pn2_model_create": (ci, [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]),
+    "psg_pn2_model_destroy": (ci, [vp]),
+    "psg_pn2_ws_create": (ci, [vp, ci, ci, ci, ctypes.POINTER(vp)]),
+    "psg_pn2_ws_destroy": (ci, [vp]),
+    "psg_pn2_ws_bytes": (ctypes.c_size_t, [vp]),
+    "psg_pn2_plan_build": (ci, [vp, vp, vp, ci, vp]),
+    "psg_pn2_plan_ptr": (vp, [vp, ci, ci, ci, ci]),
+    "psg_pn2_forward": (ci, [vp, vp, ci, vp, vp, vp, vp]),
+    "psg_pn2_backward": (ci, [vp, vp, ci, vp, vp, vp]),
+    "psg_pn2_activation_ptr": (vp, [vp, ci]),
+    "psg_to_point_major": (ci, [vp, ci, ci, ci, vp, vp]),
+    "psg_to_channel_major": (ci, [vp, ci, ci, ci, vp, vp]),
+    "psg_ce_logp_grad": (ci, [vp, vp, ci, ci, ci, ci, cf, vp, vp, vp]),
+    "psg_pgd_step": (ci, [vp, vp, vp, vp, ci, ci, cf, cf, cf, ci, vp]),
+    "psg_pn2_nb_attack": (ci, [vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, vp, vp]),
+    "psg_seg_stats": (ci, [vp, vp, ci, ci, vp, vp, vp]),
+}
+
+_lib = None
+
+
+class PsgError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpsg.so (once) and attach the prototypes.  Raises if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PsgError(
+                "%s not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C pointsecguard_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().psg_last_error().decode("utf-8", "replace")
+        raise PsgError("%s failed (rc=%d): %s" % (what or "libpsg call", rc, msg))
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise PsgError on a non-zero return code."""
+    check(getattr(load(), name)(*args), name)

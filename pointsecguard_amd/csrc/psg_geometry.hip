@@ -1,0 +1,288 @@
+// Geometry kernels of the PointNet++ hot path for gfx950: farthest-point sampling, ball query,
+// 3-NN + inverse-distance weights, row gather.  All of them are integer-output (or feed integer
+// decisions), so the fp32 evaluation order is the one pinned in SURVEY.md section 8(a') and every
+// multiply/add below is written with explicit rounding intrinsics (this file is also compiled with
+// -ffp-contract=off).  VALU fp32 on purpose: MFMA accumulation order would break bit-exact grouping.
+//
+// Reference semantics (paths relative to /root/reference):
+//   farthest_point_sample  PointNet/models/pointnet_util.py:63-84
+//   query_ball_point       PointNet/models/pointnet_util.py:87-107  (square_distance :19-40)
+//   3-NN interpolation     PointNet/models/pointnet_util.py:301-307
+//   index_points           PointNet/models/pointnet_util.py:43-60
+//
+// Batching: every kernel runs P independent "problems" (= rooms x attack iterations).  A problem p
+// reads cloud (p % n_clouds) of a [n_clouds][N][3] array, so the level-0 xyz of a room is shared by
+// all attack iterations while deeper levels have one cloud per problem.
+#include "psg_common.h"
+
+namespace {
+
+__device__ __forceinline__ float sumsq3(float x, float y, float z)
+{
+    return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+}
+
+// square_distance(src, dst) for one pair: ((-2*dot) + |src|^2) + |dst|^2, dot = FMA chain over k
+__device__ __forceinline__ float sqdist(float sx, float sy, float sz, float ssq, float dx, float dy, float dz,
+                                        float dsq)
+{
+    float dot = __fmaf_rn(sz, dz, __fmaf_rn(sy, dy, __fmul_rn(sx, dx)));
+    return __fadd_rn(__fadd_rn(__fmul_rn(-2.0f, dot), ssq), dsq);
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m)
+{
+    unsigned lo = __shfl_xor((unsigned)v, m);
+    unsigned hi = __shfl_xor((unsigned)(v >> 32), m);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FPS: one workgroup per problem, xyz in LDS (for the centroid broadcast) and in registers.
+// Per step: PPT distance updates per thread, wave argmax by shuffles, one LDS slot per wave, ONE
+// barrier (partials are double-buffered), every thread reduces the NW partials itself.
+// argmax key = (dist bits << 32) | ~index  ->  max distance, lowest index on ties (torch.max CPU).
+// ---------------------------------------------------------------------------------------------
+template <int NT, int PPT>
+__global__ __launch_bounds__(NT) void fps_kernel(const float *__restrict__ xyz, int n_clouds, int N, int S,
+                                                 const int32_t *__restrict__ start, int32_t *__restrict__ out)
+{
+    constexpr int NW = NT / 64;
+    extern __shared__ float smem[];
+    float *s_xyz = smem;                                                        // [N*3]
+    unsigned long long *s_part = (unsigned long long *)(smem + ((N * 3 + 1) & ~1));  // [2][NW]
+
+    const int p = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float *src = xyz + (size_t)(p % n_clouds) * N * 3;
+    for (int i = tid; i < N * 3; i += NT) s_xyz[i] = src[i];
+    __syncthreads();
+
+    float px[PPT], py[PPT], pz[PPT], dist[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        int i = tid + q * NT;
+        bool ok = i < N;
+        px[q] = ok ? s_xyz[3 * i] : 0.f;
+        py[q] = ok ? s_xyz[3 * i + 1] : 0.f;
+        pz[q] = ok ? s_xyz[3 * i + 2] : 0.f;
+        dist[q] = 1e10f;
+    }
+    int far = start[p];
+    int32_t *o = out + (size_t)p * S;
+    for (int s = 0; s < S; ++s) {
+        if (tid == 0) o[s] = far;
+        const float cx = s_xyz[3 * far], cy = s_xyz[3 * far + 1], cz = s_xyz[3 * far + 2];
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            int i = tid + q * NT;
+            float dx = __fsub_rn(px[q], cx), dy = __fsub_rn(py[q], cy), dz = __fsub_rn(pz[q], cz);
+            float d = sumsq3(dx, dy, dz);
+            dist[q] = d < dist[q] ? d : dist[q];
+            unsigned long long key =
+                ((unsigned long long)__float_as_uint(dist[q]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+            key = i < N ? key : 0ull;
+            best = key > best ? key : best;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            unsigned long long o2 = shfl_xor_u64(best, m);
+            best = o2 > best ? o2 : best;
+        }
+        if (NW > 1) {
+            unsigned long long *slot = s_part + (s & 1) * NW;
+            if ((tid & 63) == 0) slot[tid >> 6] = best;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                unsigned long long v = slot[w];
+                best = v > best ? v : best;
+            }
+        }
+        far = (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
+    }
+}
+
+// out[p][s][:] = points[p % n_clouds][idx[p][s]][:]
+__global__ void gather_rows_kernel(const float *__restrict__ pts, int n_clouds, int N, int C,
+                                   const int32_t *__restrict__ idx, int S, float *__restrict__ out, int P)
+{
+    size_t total = (size_t)P * S * C;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        int c = (int)(t % C);
+        size_t r = t / C;
+        int s = (int)(r % S);
+        int p = (int)(r / S);
+        out[t] = pts[((size_t)(p % n_clouds) * N + idx[(size_t)p * S + s]) * C + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ball query: the cloud (x,y,z,|p|^2) is staged once per workgroup in LDS; one wave per centroid
+// scans it 64 points at a time in index order, compacting hits with ballot + prefix popcount and
+// stopping at K.  No [S,N] matrix, no sort (the reference materialises both).
+// ---------------------------------------------------------------------------------------------
+constexpr int BQ_THREADS = 256;
+constexpr int BQ_CPB = 64;  // centroids per workgroup
+
+__global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float *__restrict__ xyz, int n_clouds,
+                                                                const float *__restrict__ new_xyz, int N, int S,
+                                                                float r2, int K, int32_t *__restrict__ out)
+{
+    extern __shared__ float4 s_pts[];  // [N]
+    const int p = blockIdx.y;
+    const float *src = xyz + (size_t)(p % n_clouds) * N * 3;
+    for (int i = threadIdx.x; i < N; i += BQ_THREADS) {
+        float x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
+        s_pts[i] = make_float4(x, y, z, sumsq3(x, y, z));
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const int c_end = min(S, (int)(blockIdx.x + 1) * BQ_CPB);
+    for (int c = blockIdx.x * BQ_CPB + wave; c < c_end; c += BQ_THREADS / 64) {
+        const float *cp = new_xyz + ((size_t)p * S + c) * 3;
+        const float cx = cp[0], cy = cp[1], cz = cp[2];
+        const float csq = sumsq3(cx, cy, cz);
+        int32_t *o = out + ((size_t)p * S + c) * K;
+        int cnt = 0, first = N;
+        for (int base = 0; base < N && cnt < K; base += 64) {
+            int j = base + lane;
+            bool in = false;
+            if (j < N) {
+                float4 q = s_pts[j];
+                float d = sqdist(cx, cy, cz, csq, q.x, q.y, q.z, q.w);
+                in = !(d > r2);
+            }
+            unsigned long long m = __ballot(in);
+            if (m) {
+                if (cnt == 0) first = base + __builtin_ctzll(m);
+                int pos = cnt + __popcll(m & lt_mask);
+                if (in && pos < K) o[pos] = j;
+                cnt += __popcll(m);
+            }
+        }
+        // pad with the first hit (pointnet_util.py:104-106); an empty ball emits N (reference would fault)
+        for (int pos = cnt + lane; pos < K; pos += 64) o[pos] = first;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3-NN: one thread per fine point, coarse cloud broadcast from LDS, top-3 kept in registers with
+// strict '<' so equal distances keep the lower index first (stable ascending order).
+// ---------------------------------------------------------------------------------------------
+constexpr int NN_THREADS = 256;
+
+__global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__restrict__ xyz1, int n_clouds1,
+                                                              const float *__restrict__ xyz2, int N, int S,
+                                                              int32_t *__restrict__ idx, float *__restrict__ w)
+{
+    extern __shared__ float4 s_pts[];  // [S] coarse points
+    const int p = blockIdx.y;
+    const float *c2 = xyz2 + (size_t)p * S * 3;
+    for (int i = threadIdx.x; i < S; i += NN_THREADS) {
+        float x = c2[3 * i], y = c2[3 * i + 1], z = c2[3 * i + 2];
+        s_pts[i] = make_float4(x, y, z, sumsq3(x, y, z));
+    }
+    __syncthreads();
+    const int i = blockIdx.x * NN_THREADS + threadIdx.x;
+    if (i >= N) return;
+    const float *fp = xyz1 + ((size_t)(p % n_clouds1) * N + i) * 3;
+    const float fx = fp[0], fy = fp[1], fz = fp[2];
+    const float fsq = sumsq3(fx, fy, fz);
+    float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+    int i0 = 0, i1 = 0, i2 = 0;
+    for (int j = 0; j < S; ++j) {
+        float4 q = s_pts[j];
+        float d = sqdist(fx, fy, fz, fsq, q.x, q.y, q.z, q.w);
+        if (d < d2) {
+            if (d < d1) {
+                d2 = d1; i2 = i1;
+                if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = j; }
+                else { d1 = d; i1 = j; }
+            } else { d2 = d; i2 = j; }
+        }
+    }
+    float r0 = __fdiv_rn(1.0f, __fadd_rn(d0, 1e-8f));
+    float r1 = __fdiv_rn(1.0f, __fadd_rn(d1, 1e-8f));
+    float r2 = __fdiv_rn(1.0f, __fadd_rn(d2, 1e-8f));
+    float norm = __fadd_rn(__fadd_rn(r0, r1), r2);
+    size_t o = ((size_t)p * N + i) * 3;
+    idx[o] = i0; idx[o + 1] = i1; idx[o + 2] = i2;
+    w[o] = __fdiv_rn(r0, norm); w[o + 1] = __fdiv_rn(r1, norm); w[o + 2] = __fdiv_rn(r2, norm);
+}
+
+template <int NT, int PPT>
+int launch_fps(const float *xyz, int n_clouds, int P, int N, int S, const int32_t *start, int32_t *out,
+               hipStream_t st)
+{
+    size_t lds = (size_t)((N * 3 + 1) & ~1) * 4 + 2 * (NT / 64) * 8;
+    if (lds > 48 * 1024)
+        PSG_CHECK_HIP(hipFuncSetAttribute((const void *)fps_kernel<NT, PPT>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((fps_kernel<NT, PPT>), dim3(P), dim3(NT), lds, st, xyz, n_clouds, N, S, start, out);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+}  // namespace
+
+extern "C" int psg_fps(psg_ctx *ctx, const float *xyz, int n_clouds, int P, int N, int S, const int32_t *start,
+                       int32_t *out_idx, psg_stream stream)
+{
+    PSG_REQUIRE(ctx && xyz && start && out_idx, "psg_fps: null argument");
+    PSG_REQUIRE(P > 0 && n_clouds > 0 && N > 0 && S > 0 && S <= N, "psg_fps: bad sizes P=%d N=%d S=%d", P, N, S);
+    PSG_REQUIRE(N <= 8192, "psg_fps: N=%d exceeds the LDS-resident limit 8192", N);
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 64) return launch_fps<64, 1>(xyz, n_clouds, P, N, S, start, out_idx, st);
+    if (N <= 256) return launch_fps<64, 4>(xyz, n_clouds, P, N, S, start, out_idx, st);
+    if (N <= 1024) return launch_fps<256, 4>(xyz, n_clouds, P, N, S, start, out_idx, st);
+    if (N <= 4096) return launch_fps<1024, 4>(xyz, n_clouds, P, N, S, start, out_idx, st);
+    return launch_fps<1024, 8>(xyz, n_clouds, P, N, S, start, out_idx, st);
+}
+
+extern "C" int psg_gather_points(psg_ctx *ctx, const float *points, int n_clouds, int P, int N, int C,
+                                 const int32_t *idx, int S, float *out, psg_stream stream)
+{
+    PSG_REQUIRE(ctx && points && idx && out, "psg_gather_points: null argument");
+    PSG_REQUIRE(P > 0 && n_clouds > 0 && N > 0 && C > 0 && S > 0, "psg_gather_points: bad sizes");
+    size_t total = (size_t)P * S * C;
+    int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, points, n_clouds, N, C,
+                       idx, S, out, P);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+extern "C" int psg_ball_query(psg_ctx *ctx, const float *xyz, int n_clouds, const float *new_xyz, int P, int N,
+                              int S, float r2, int K, int32_t *out_idx, psg_stream stream)
+{
+    PSG_REQUIRE(ctx && xyz && new_xyz && out_idx, "psg_ball_query: null argument");
+    PSG_REQUIRE(P > 0 && n_clouds > 0 && N > 0 && S > 0 && K > 0, "psg_ball_query: bad sizes");
+    PSG_REQUIRE(N <= 8192, "psg_ball_query: N=%d exceeds the LDS-resident limit 8192", N);
+    size_t lds = (size_t)N * sizeof(float4);
+    if (lds > 48 * 1024)
+        PSG_CHECK_HIP(hipFuncSetAttribute((const void *)ball_query_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+    hipLaunchKernelGGL(ball_query_kernel, dim3(psg::ceil_div(S, BQ_CPB), P), dim3(BQ_THREADS), lds,
+                       (hipStream_t)stream, xyz, n_clouds, new_xyz, N, S, r2, K, out_idx);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+extern "C" int psg_three_nn(psg_ctx *ctx, const float *xyz1, int n_clouds1, const float *xyz2, int P, int N, int S,
+                            int32_t *out_idx, float *out_w, psg_stream stream)
+{
+    PSG_REQUIRE(ctx && xyz1 && xyz2 && out_idx && out_w, "psg_three_nn: null argument");
+    PSG_REQUIRE(P > 0 && n_clouds1 > 0 && N > 0 && S >= 3, "psg_three_nn: bad sizes (need S >= 3)");
+    PSG_REQUIRE(S <= 8192, "psg_three_nn: S=%d exceeds the LDS-resident limit 8192", S);
+    size_t lds = (size_t)S * sizeof(float4);
+    if (lds > 48 * 1024)
+        PSG_CHECK_HIP(hipFuncSetAttribute((const void *)three_nn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+    hipLaunchKernelGGL(three_nn_kernel, dim3(psg::ceil_div(N, NN_THREADS), P), dim3(NN_THREADS), lds,
+                       (hipStream_t)stream, xyz1, n_clouds1, xyz2, N, S, out_idx, out_w);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}

@@ -1,0 +1,566 @@
+// Host side of the PointNet++ SSG sem-seg network on gfx950: weight packing, workspace layout,
+// geometry plan, forward, input-gradient backward and the fused NB attack loop.  Everything is
+// stream-ordered; nothing here synchronises the device except psg_pn2_model_create (upload).
+//
+// Architecture (PointNet/models/pointnet2_sem_seg.py:9-19 of the reference):
+//   sa1 (1024, r .1, 32, 12 ->32,32,64)    sa2 (256, .2, 32, 67 ->64,64,128)
+//   sa3 (64, .4, 32, 131->128,128,256)     sa4 (16, .8, 32, 259->256,256,512)
+//   fp4 768->256,256   fp3 384->256,256    fp2 320->256,128    fp1 128->128,128,128
+//   conv1 128->128 (+bn1, ReLU, eval dropout = id), conv2 128->13, log_softmax
+#include <algorithm>
+#include <vector>
+
+#include "psg_common.h"
+#include "psg_pn2_kernels.cuh"
+
+using namespace psg;
+
+namespace {
+
+constexpr int NL = PSG_PN2_NUM_LAYERS;
+constexpr int NCLS = PSG_PN2_NUM_CLASSES;
+// cin / cout of the 23 conv layers (index = position in the weights array)
+const int kCin[NL] = {12, 32, 32, 67, 64, 64, 131, 128, 128, 259, 256, 256, 768, 256, 384, 256, 320, 256,
+                      128, 128, 128, 128, 128};
+const int kCout[NL] = {32, 32, 64, 64, 64, 128, 128, 128, 256, 256, 256, 512, 256, 256, 256, 256, 256, 128,
+                       128, 128, 128, 128, 13};
+constexpr int kNumReal = NL;
+const int kS[4] = {1024, 256, 64, 16};
+const float kRadius[4] = {0.1f, 0.2f, 0.4f, 0.8f};
+const int kSaC[5] = {9, 64, 128, 256, 512};  // feature channels of level 0..4
+constexpr int K = 32;                        // nsample
+
+struct PackedLayer {
+    float4 *wf = nullptr;  // forward packing  [mb(cout)][k8(cin)][64]
+    float4 *wb = nullptr;  // transposed packing [mb(cin)][k8(cout)][64]
+    float *bias = nullptr; // [mb(cout)*32]
+    int cin = 0, cout = 0;
+    int k8f() const { return ceil_div(cin, 8); }
+    int mbf() const { return ceil_div(cout, 32); }
+    int k8b() const { return ceil_div(cout, 8); }
+    int mbb() const { return ceil_div(cin, 32); }
+};
+
+}  // namespace
+
+struct psg_pn2_model {
+    psg_ctx *ctx;
+    PackedLayer L[kNumReal];
+    void *arena = nullptr;
+};
+
+struct psg_pn2_ws {
+    psg_ctx *ctx;
+    int B, N, F;          // batch, points per room, max forwards in the plan
+    int Nl[5];            // points at level 0..4
+    void *arena = nullptr;
+    size_t bytes = 0;
+    // plan
+    float *xyz0;          // [B][N][3]
+    int32_t *starts_dev;  // unused unless the caller has none
+    int32_t *fps[4];      // [F*B][S_l]
+    float *xyz[5];        // xyz[l+1]: [F*B][S_l][3]; xyz[0] = xyz0
+    int32_t *gidx[4];     // [F*B][S_l][32]
+    int32_t *nn_idx[4];   // [F*B][N_l][3]
+    float *nn_w[4];
+    int planned = 0;
+    // activations of one forward
+    float *act[7];        // l1..l4, fp4 out (64 pts), fp3 out (256), fp2 out (1024)
+    uint8_t *arg[4];
+    uint16_t *mask[kNumReal];
+    float *logp, *dlogp;
+    // gradients (one contiguous zeroed arena)
+    float *gzero; size_t gzero_bytes;
+    float *dact[7];
+    float *dx0;           // [B][N][9]
+    // attack state
+    float *x0, *ori;      // [B][N][9], [B][N][3]
+    int fwd_slot = -1;
+};
+
+namespace {
+
+std::vector<float> pack_fwd(const float *w, int cin, int cout)
+{
+    const int k8 = ceil_div(cin, 8), mb = ceil_div(cout, 32);
+    std::vector<float> out((size_t)mb * k8 * 64 * 4, 0.0f);
+    for (int m = 0; m < mb; ++m)
+        for (int k = 0; k < k8; ++k)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int t = 0; t < 4; ++t) {
+                    int o = m * 32 + (lane & 31), c = 8 * k + 2 * t + (lane >> 5);
+                    if (o < cout && c < cin) out[(((size_t)m * k8 + k) * 64 + lane) * 4 + t] = w[(size_t)o * cin + c];
+                }
+    return out;
+}
+
+std::vector<float> pack_bwd(const float *w, int cin, int cout)
+{
+    const int k8 = ceil_div(cout, 8), mb = ceil_div(cin, 32);
+    std::vector<float> out((size_t)mb * k8 * 64 * 4, 0.0f);
+    for (int m = 0; m < mb; ++m)
+        for (int k = 0; k < k8; ++k)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int t = 0; t < 4; ++t) {
+                    int c = m * 32 + (lane & 31), o = 8 * k + 2 * t + (lane >> 5);
+                    if (o < cout && c < cin) out[(((size_t)m * k8 + k) * 64 + lane) * 4 + t] = w[(size_t)o * cin + c];
+                }
+    return out;
+}
+
+struct Bump {
+    char *base = nullptr;
+    size_t off = 0;
+    template <typename T> T *take(size_t n)
+    {
+        off = (off + 255) & ~(size_t)255;
+        T *p = base ? (T *)(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+FwdLayer fwd_layer(const PackedLayer &p, bool relu, uint16_t *mask)
+{
+    FwdLayer f;
+    f.w = p.wf; f.bias = p.bias; f.mask = mask; f.k8 = p.k8f(); f.mb = p.mbf(); f.relu = relu ? 1 : 0;
+    return f;
+}
+BwdLayer bwd_layer(const PackedLayer &p, const uint16_t *mask)
+{
+    BwdLayer f;
+    f.w = p.wb; f.mask = mask; f.k8 = p.k8b(); f.mb = p.mbb();
+    return f;
+}
+
+template <typename KernelT, typename ArgsT>
+int launch_lds(KernelT kern, dim3 grid, int threads, int rows, int ldp, const ArgsT &args, hipStream_t st)
+{
+    size_t lds = (size_t)rows * ldp * sizeof(float);
+    if (lds > 160 * 1024) { set_error("LDS request %zu exceeds 160 KiB", lds); return PSG_ERR_ARG; }
+    if (lds > 48 * 1024)
+        PSG_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, args);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+// points per workgroup / waves per workgroup of each module (forward and backward share P)
+template <int LVL> struct SaCfg;
+template <> struct SaCfg<0> { static constexpr int P = 128, NW = 4; };
+template <> struct SaCfg<1> { static constexpr int P = 64, NW = 4; };
+template <> struct SaCfg<2> { static constexpr int P = 32, NW = 4; };
+template <> struct SaCfg<3> { static constexpr int P = 32, NW = 8; };
+template <int LVL> struct FpCfg { static constexpr int P = 32, NW = 8; };
+template <> struct FpCfg<0> { static constexpr int P = 64, NW = 8; };
+
+template <int LVL>
+int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *x0, hipStream_t st)
+{
+    constexpr int P = SaCfg<LVL>::P, NW = SaCfg<LVL>::NW;
+    const int B = ws->B, S = kS[LVL], Np = ws->Nl[LVL], D = kSaC[LVL];
+    const PackedLayer *L = &m->L[3 * LVL];
+    const size_t prob = (size_t)fwd * B;
+    SaFwdArgs a;
+    a.xyz = LVL == 0 ? x0 : ws->xyz[LVL] + prob * Np * 3;
+    a.xyz_stride = LVL == 0 ? 9 : 3;
+    a.feat = LVL == 0 ? x0 : ws->act[LVL - 1];
+    a.new_xyz = ws->xyz[LVL + 1] + prob * S * 3;
+    a.gidx = ws->gidx[LVL] + prob * S * K;
+    a.out = ws->act[LVL];
+    a.arg = ws->arg[LVL];
+    a.l1 = fwd_layer(L[0], true, ws->mask[3 * LVL]);
+    a.l2 = fwd_layer(L[1], true, ws->mask[3 * LVL + 1]);
+    a.w3 = L[2].wf; a.b3 = L[2].bias; a.k8_3 = L[2].k8f(); a.nb3 = L[2].mbf();
+    a.D = D; a.Np = Np; a.S = S; a.C3 = L[2].cout;
+    a.rows0 = std::max(a.l1.k8 * 8, a.l2.mb * 32);
+    a.rows1 = a.l1.mb * 32;
+    return launch_lds(sa_fwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, a.rows0 + a.rows1, P + 1, a, st);
+}
+
+template <int LVL>
+int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *dx0, int c_lo, int c_hi, hipStream_t st)
+{
+    constexpr int P = SaCfg<LVL>::P, NW = SaCfg<LVL>::NW;
+    const int B = ws->B, S = kS[LVL], Np = ws->Nl[LVL], D = kSaC[LVL];
+    const PackedLayer *L = &m->L[3 * LVL];
+    const size_t prob = (size_t)fwd * B;
+    SaBwdArgs a;
+    a.dout = ws->dact[LVL];
+    a.arg = ws->arg[LVL];
+    a.gidx = ws->gidx[LVL] + prob * S * K;
+    a.dfeat = LVL == 0 ? dx0 : ws->dact[LVL - 1];
+    a.l3t = bwd_layer(L[2], ws->mask[3 * LVL + 1]);
+    a.l2t = bwd_layer(L[1], ws->mask[3 * LVL]);
+    a.l1t = bwd_layer(L[0], nullptr);
+    a.D = D; a.Np = Np; a.S = S; a.C3 = L[2].cout;
+    a.c_lo = c_lo; a.c_hi = c_hi;
+    a.rows0 = std::max(a.C3, a.l2t.mb * 32);
+    a.rows1 = std::max(a.l3t.mb * 32, a.l1t.mb * 32);
+    return launch_lds(sa_bwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, a.rows0 + a.rows1, P + 1, a, st);
+}
+
+// FP module `LVL` (0 = fp1 ... 3 = fp4) upsamples level LVL+1 -> level LVL.
+// layer indices: fp4 12,13  fp3 14,15  fp2 16,17  fp1 18,19,20 (+ head 21,22 fused into fp1)
+const int kFpFirst[4] = {18, 16, 14, 12};
+const int kFpCount[4] = {3, 2, 2, 2};
+
+// activation slots: act[0..3] = l1..l4 (SA outputs); act[4] = fp4 out (level 3), act[5] = fp3 out
+// (level 2), act[6] = fp2 out (level 1)
+inline int fp_out_slot(int lvl) { return 7 - lvl; }          // lvl 3 -> 4, 2 -> 5, 1 -> 6
+inline int fp_in2_slot(int lvl) { return lvl == 3 ? 3 : fp_out_slot(lvl + 1); }
+
+template <int LVL>
+int run_fp_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *logp, hipStream_t st)
+{
+    constexpr int P = FpCfg<LVL>::P, NW = FpCfg<LVL>::NW;
+    const int B = ws->B, N = ws->Nl[LVL], S = ws->Nl[LVL + 1];
+    const size_t prob = (size_t)fwd * B;
+    FpFwdArgs a;
+    a.feat1 = LVL == 0 ? nullptr : ws->act[LVL - 1];
+    a.C1 = LVL == 0 ? 0 : kSaC[LVL];
+    a.feat2 = ws->act[fp_in2_slot(LVL)];
+    a.C2 = m->L[kFpFirst[LVL]].cin - a.C1;
+    a.nn_idx = ws->nn_idx[LVL] + prob * N * 3;
+    a.nn_w = ws->nn_w[LVL] + prob * N * 3;
+    a.N = N; a.S = S;
+    int nl = kFpCount[LVL];
+    for (int i = 0; i < nl; ++i)
+        a.layer[i] = fwd_layer(m->L[kFpFirst[LVL] + i], true, ws->mask[kFpFirst[LVL] + i]);
+    a.out = nullptr; a.logp = nullptr; a.Cout = 0; a.n_cls = 0;
+    if (LVL == 0) {
+        a.layer[nl] = fwd_layer(m->L[21], true, ws->mask[21]);
+        a.layer[nl + 1] = fwd_layer(m->L[22], false, nullptr);
+        nl += 2;
+        a.logp = logp; a.n_cls = NCLS;
+    } else {
+        a.out = ws->act[fp_out_slot(LVL)];
+        a.Cout = m->L[kFpFirst[LVL] + nl - 1].cout;
+    }
+    a.n_layers = nl;
+    a.rows0 = a.layer[0].k8 * 8; a.rows1 = 0;
+    for (int i = 0; i < nl; ++i) {
+        int rows = a.layer[i].mb * 32;
+        if (i & 1) a.rows0 = std::max(a.rows0, rows); else a.rows1 = std::max(a.rows1, rows);
+    }
+    return launch_lds(fp_fwd_kernel<P, NW>, dim3(N / P, B), NW * 64, a.rows0 + a.rows1, P + 1, a, st);
+}
+
+template <int LVL>
+int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, const float *dlogp, hipStream_t st)
+{
+    constexpr int P = FpCfg<LVL>::P, NW = FpCfg<LVL>::NW;
+    const int B = ws->B, N = ws->Nl[LVL], S = ws->Nl[LVL + 1];
+    const size_t prob = (size_t)fwd * B;
+    FpBwdArgs a;
+    a.nn_idx = ws->nn_idx[LVL] + prob * N * 3;
+    a.nn_w = ws->nn_w[LVL] + prob * N * 3;
+    a.N = N; a.S = S;
+    a.C1 = LVL == 0 ? 0 : kSaC[LVL];
+    a.C2 = m->L[kFpFirst[LVL]].cin - a.C1;
+    a.dfeat1 = LVL == 0 ? nullptr : ws->dact[LVL - 1];
+    a.dfeat2 = ws->dact[fp_in2_slot(LVL)];
+    const int first = kFpFirst[LVL], cnt = kFpCount[LVL];
+    int nl = 0;
+    a.dout = nullptr; a.mask_last = nullptr; a.logp = nullptr; a.dlogp = nullptr;
+    a.Cout = 0; a.n_cls = 0; a.mb_last = 0;
+    if (LVL == 0) {
+        a.logp = logp; a.dlogp = dlogp; a.n_cls = NCLS;
+        a.layer[nl++] = bwd_layer(m->L[22], ws->mask[21]);            // conv2^T, then bn1/conv1 ReLU mask
+        a.layer[nl++] = bwd_layer(m->L[21], ws->mask[first + cnt - 1]); // conv1^T, then fp1 last ReLU mask
+    } else {
+        a.dout = ws->dact[fp_out_slot(LVL)];
+        a.mask_last = ws->mask[first + cnt - 1];
+        a.Cout = m->L[first + cnt - 1].cout;
+        a.mb_last = m->L[first + cnt - 1].mbf();
+    }
+    for (int i = cnt - 1; i >= 0; --i)
+        a.layer[nl++] = bwd_layer(m->L[first + i], i > 0 ? ws->mask[first + i - 1] : nullptr);
+    a.n_layers = nl;
+    a.rows0 = LVL == 0 ? a.layer[0].k8 * 8 : a.mb_last * 32;
+    a.rows1 = 0;
+    for (int i = 0; i < nl; ++i) {
+        int rows = a.layer[i].mb * 32;
+        if (i & 1) a.rows0 = std::max(a.rows0, rows); else a.rows1 = std::max(a.rows1, rows);
+    }
+    return launch_lds(fp_bwd_kernel<P, NW>, dim3(N / P, B), NW * 64, a.rows0 + a.rows1, P + 1, a, st);
+}
+
+__global__ void extract_xyz_kernel(const float *__restrict__ x0, float *__restrict__ xyz, size_t rows)
+{
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < rows * 3; t += (size_t)gridDim.x * blockDim.x)
+        xyz[t] = x0[(t / 3) * 9 + (t % 3)];
+}
+
+__global__ void extract_color_kernel(const float *__restrict__ x0, float *__restrict__ ori, size_t rows)
+{
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < rows * 3; t += (size_t)gridDim.x * blockDim.x)
+        ori[t] = x0[(t / 3) * 9 + 3 + (t % 3)];
+}
+
+__global__ void gather_starts_kernel(const int32_t *__restrict__ starts, int32_t *__restrict__ out, int level, int B,
+                                     int P)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P) out[p] = starts[((size_t)(p / B) * 4 + level) * B + (p % B)];
+}
+
+size_t ws_layout(psg_pn2_ws *ws, char *base)
+{
+    Bump bp;
+    bp.base = base;
+    const int B = ws->B, F = ws->F;
+    const size_t PR = (size_t)F * B;
+    ws->xyz0 = bp.take<float>((size_t)B * ws->N * 3);
+    ws->xyz[0] = ws->xyz0;
+    for (int l = 0; l < 4; ++l) {
+        ws->fps[l] = bp.take<int32_t>(PR * kS[l]);
+        ws->xyz[l + 1] = bp.take<float>(PR * kS[l] * 3);
+        ws->gidx[l] = bp.take<int32_t>(PR * kS[l] * K);
+        ws->nn_idx[l] = bp.take<int32_t>(PR * ws->Nl[l] * 3);
+        ws->nn_w[l] = bp.take<float>(PR * ws->Nl[l] * 3);
+    }
+    const int actN[7] = {1024, 256, 64, 16, 64, 256, 1024};
+    const int actC[7] = {64, 128, 256, 512, 256, 256, 128};
+    for (int i = 0; i < 7; ++i) ws->act[i] = bp.take<float>((size_t)B * actN[i] * actC[i]);
+    for (int l = 0; l < 4; ++l) ws->arg[l] = bp.take<uint8_t>((size_t)B * kS[l] * actC[l]);
+    // ReLU masks: one uint16 per (32-channel block, point-lane): rows * mb(cout) * 2 entries
+    for (int i = 0; i < kNumReal; ++i) {
+        size_t rows;
+        if (i < 12) rows = (size_t)B * kS[i / 3] * K;
+        else if (i < 14) rows = (size_t)B * ws->Nl[3];
+        else if (i < 16) rows = (size_t)B * ws->Nl[2];
+        else if (i < 18) rows = (size_t)B * ws->Nl[1];
+        else rows = (size_t)B * ws->Nl[0];
+        ws->mask[i] = bp.take<uint16_t>(rows * ceil_div(kCout[i], 32) * 2);
+    }
+    ws->logp = bp.take<float>((size_t)B * ws->N * NCLS);
+    ws->dlogp = bp.take<float>((size_t)B * ws->N * NCLS);
+    bp.off = (bp.off + 255) & ~(size_t)255;
+    size_t g0 = bp.off;
+    for (int i = 0; i < 7; ++i) ws->dact[i] = bp.take<float>((size_t)B * actN[i] * actC[i]);
+    ws->dx0 = bp.take<float>((size_t)B * ws->N * 9);
+    bp.off = (bp.off + 255) & ~(size_t)255;
+    ws->gzero = base ? (float *)(base + g0) : nullptr;
+    ws->gzero_bytes = bp.off - g0;
+    ws->x0 = bp.take<float>((size_t)B * ws->N * 9);
+    ws->ori = bp.take<float>((size_t)B * ws->N * 3);
+    return (bp.off + 255) & ~(size_t)255;
+}
+
+}  // namespace
+
+// ================================================================================== C ABI: model
+extern "C" int psg_pn2_model_create(psg_ctx *ctx, const float *const *weights, const float *const *biases,
+                                    psg_pn2_model **out)
+{
+    PSG_REQUIRE(ctx && weights && biases && out, "psg_pn2_model_create: null argument");
+    PSG_CHECK_HIP(hipSetDevice(ctx->device));
+    auto *m = new psg_pn2_model();
+    m->ctx = ctx;
+    std::vector<std::vector<float>> wf(kNumReal), wb(kNumReal), bs(kNumReal);
+    size_t total = 0;
+    for (int i = 0; i < kNumReal; ++i) {
+        if (!weights[i] || !biases[i]) { delete m; set_error("psg_pn2_model_create: layer %d is null", i); return PSG_ERR_ARG; }
+        wf[i] = pack_fwd(weights[i], kCin[i], kCout[i]);
+        wb[i] = pack_bwd(weights[i], kCin[i], kCout[i]);
+        bs[i].assign((size_t)ceil_div(kCout[i], 32) * 32, 0.0f);
+        std::copy(biases[i], biases[i] + kCout[i], bs[i].begin());
+        total += ((wf[i].size() + wb[i].size() + bs[i].size()) * 4 + 3 * 256);
+    }
+    PSG_CHECK_HIP(hipMalloc(&m->arena, total));
+    Bump bp;
+    bp.base = (char *)m->arena;
+    for (int i = 0; i < kNumReal; ++i) {
+        PackedLayer &L = m->L[i];
+        L.cin = kCin[i]; L.cout = kCout[i];
+        L.wf = bp.take<float4>(wf[i].size() / 4);
+        L.wb = bp.take<float4>(wb[i].size() / 4);
+        L.bias = bp.take<float>(bs[i].size());
+        PSG_CHECK_HIP(hipMemcpy(L.wf, wf[i].data(), wf[i].size() * 4, hipMemcpyHostToDevice));
+        PSG_CHECK_HIP(hipMemcpy(L.wb, wb[i].data(), wb[i].size() * 4, hipMemcpyHostToDevice));
+        PSG_CHECK_HIP(hipMemcpy(L.bias, bs[i].data(), bs[i].size() * 4, hipMemcpyHostToDevice));
+    }
+    *out = m;
+    return PSG_OK;
+}
+
+extern "C" int psg_pn2_model_destroy(psg_pn2_model *m)
+{
+    if (!m) return PSG_OK;
+    if (m->arena) (void)hipFree(m->arena);
+    delete m;
+    return PSG_OK;
+}
+
+// ============================================================================== C ABI: workspace
+extern "C" int psg_pn2_ws_create(psg_ctx *ctx, int batch, int n_point, int max_forwards, psg_pn2_ws **out)
+{
+    PSG_REQUIRE(ctx && out, "psg_pn2_ws_create: null argument");
+    PSG_REQUIRE(batch > 0 && max_forwards > 0, "psg_pn2_ws_create: batch and max_forwards must be positive");
+    PSG_REQUIRE(n_point >= 1024 && n_point <= 8192 && n_point % 128 == 0,
+                "psg_pn2_ws_create: n_point=%d must be a multiple of 128 in [1024, 8192]", n_point);
+    PSG_CHECK_HIP(hipSetDevice(ctx->device));
+    auto *ws = new psg_pn2_ws();
+    ws->ctx = ctx; ws->B = batch; ws->N = n_point; ws->F = max_forwards;
+    ws->Nl[0] = n_point;
+    for (int l = 0; l < 4; ++l) ws->Nl[l + 1] = kS[l];
+    ws->bytes = ws_layout(ws, nullptr);
+    hipError_t e = hipMalloc(&ws->arena, ws->bytes);
+    if (e != hipSuccess) {
+        set_error("psg_pn2_ws_create: hipMalloc(%zu) failed: %s", ws->bytes, hipGetErrorString(e));
+        delete ws;
+        return PSG_ERR_HIP;
+    }
+    ws_layout(ws, (char *)ws->arena);
+    *out = ws;
+    return PSG_OK;
+}
+
+extern "C" int psg_pn2_ws_destroy(psg_pn2_ws *ws)
+{
+    if (!ws) return PSG_OK;
+    if (ws->arena) (void)hipFree(ws->arena);
+    delete ws;
+    return PSG_OK;
+}
+
+extern "C" size_t psg_pn2_ws_bytes(const psg_pn2_ws *ws) { return ws ? ws->bytes : 0; }
+
+extern "C" int psg_pn2_plan_build(psg_pn2_ws *ws, const float *x0, const int32_t *starts, int n_forward,
+                                  psg_stream stream)
+{
+    PSG_REQUIRE(ws && x0 && starts, "psg_pn2_plan_build: null argument");
+    PSG_REQUIRE(n_forward > 0 && n_forward <= ws->F, "psg_pn2_plan_build: n_forward=%d exceeds workspace capacity %d",
+                n_forward, ws->F);
+    hipStream_t st = (hipStream_t)stream;
+    const int B = ws->B, P = n_forward * B;
+    hipLaunchKernelGGL(extract_xyz_kernel, dim3(std::min(1024, ceil_div(B * ws->N * 3, 256))), dim3(256), 0, st, x0,
+                       ws->xyz0, (size_t)B * ws->N);
+    PSG_LAUNCH_CHECK();
+    int rc;
+    // starts is [n_forward][4][B]; FPS wants start[p], p = f*B + b, per level: gathered by a tiny
+    // kernel into the head of nn_idx[l], which is dead until this level's 3-NN runs (stream order).
+    for (int l = 0; l < 4; ++l) {
+        const int Np = ws->Nl[l], S = kS[l];
+        const int n_clouds = l == 0 ? B : P;
+        int32_t *start_l = ws->nn_idx[l];  // scratch: nn_idx[l] is written only after FPS of this level
+        hipLaunchKernelGGL(gather_starts_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, starts, start_l, l, B, P);
+        PSG_LAUNCH_CHECK();
+        if ((rc = psg_fps(ws->ctx, ws->xyz[l], n_clouds, P, Np, S, start_l, ws->fps[l], st))) return rc;
+        if ((rc = psg_gather_points(ws->ctx, ws->xyz[l], n_clouds, P, Np, 3, ws->fps[l], S, ws->xyz[l + 1], st)))
+            return rc;
+        if ((rc = psg_ball_query(ws->ctx, ws->xyz[l], n_clouds, ws->xyz[l + 1], P, Np, S, kRadius[l] * kRadius[l], K,
+                                 ws->gidx[l], st)))
+            return rc;
+        if ((rc = psg_three_nn(ws->ctx, ws->xyz[l], n_clouds, ws->xyz[l + 1], P, Np, S, ws->nn_idx[l], ws->nn_w[l], st)))
+            return rc;
+    }
+    ws->planned = n_forward;
+    return PSG_OK;
+}
+
+extern "C" const void *psg_pn2_plan_ptr(const psg_pn2_ws *ws, int what, int level, int forward, int room)
+{
+    if (!ws || level < 0 || level > 3 || forward < 0 || forward >= ws->F || room < 0 || room >= ws->B) return nullptr;
+    const size_t p = (size_t)forward * ws->B + room;
+    switch (what) {
+    case 0: return ws->fps[level] + p * kS[level];
+    case 1: return ws->gidx[level] + p * kS[level] * K;
+    case 2: return ws->nn_idx[level] + p * ws->Nl[level] * 3;
+    case 3: return ws->nn_w[level] + p * ws->Nl[level] * 3;
+    case 4: return ws->xyz[level + 1] + p * kS[level] * 3;
+    default: return nullptr;
+    }
+}
+
+extern "C" const float *psg_pn2_activation_ptr(const psg_pn2_ws *ws, int which)
+{
+    if (!ws || which < 0 || which > 6) return nullptr;
+    return ws->act[which];
+}
+
+// ================================================================================ forward / backward
+extern "C" int psg_pn2_forward(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *x0, float *logp_out,
+                               float *l4_out, psg_stream stream)
+{
+    PSG_REQUIRE(m && ws && x0 && logp_out, "psg_pn2_forward: null argument");
+    PSG_REQUIRE(fwd >= 0 && fwd < ws->planned, "psg_pn2_forward: plan slot %d not built (planned %d)", fwd, ws->planned);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = run_sa_fwd<0>(m, ws, fwd, x0, st))) return rc;
+    if ((rc = run_sa_fwd<1>(m, ws, fwd, x0, st))) return rc;
+    if ((rc = run_sa_fwd<2>(m, ws, fwd, x0, st))) return rc;
+    if ((rc = run_sa_fwd<3>(m, ws, fwd, x0, st))) return rc;
+    if ((rc = run_fp_fwd<3>(m, ws, fwd, nullptr, st))) return rc;
+    if ((rc = run_fp_fwd<2>(m, ws, fwd, nullptr, st))) return rc;
+    if ((rc = run_fp_fwd<1>(m, ws, fwd, nullptr, st))) return rc;
+    if ((rc = run_fp_fwd<0>(m, ws, fwd, ws->logp, st))) return rc;
+    if (logp_out != ws->logp)
+        PSG_CHECK_HIP(hipMemcpyAsync(logp_out, ws->logp, (size_t)ws->B * ws->N * NCLS * 4, hipMemcpyDeviceToDevice, st));
+    if (l4_out)
+        PSG_CHECK_HIP(hipMemcpyAsync(l4_out, ws->act[3], (size_t)ws->B * 16 * 512 * 4, hipMemcpyDeviceToDevice, st));
+    ws->fwd_slot = fwd;
+    return PSG_OK;
+}
+
+static int backward_impl(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, const float *dlogp,
+                         float *dx0, int c_lo, int c_hi, hipStream_t st)
+{
+    int rc;
+    // all gradient buffers are accumulated with atomics: zero them (dx0 too when it is workspace-owned)
+    PSG_CHECK_HIP(hipMemsetAsync(ws->gzero, 0, ws->gzero_bytes, st));
+    if (dx0 != ws->dx0) PSG_CHECK_HIP(hipMemsetAsync(dx0, 0, (size_t)ws->B * ws->N * 9 * 4, st));
+    if ((rc = run_fp_bwd<0>(m, ws, fwd, logp, dlogp, st))) return rc;
+    if ((rc = run_fp_bwd<1>(m, ws, fwd, nullptr, nullptr, st))) return rc;
+    if ((rc = run_fp_bwd<2>(m, ws, fwd, nullptr, nullptr, st))) return rc;
+    if ((rc = run_fp_bwd<3>(m, ws, fwd, nullptr, nullptr, st))) return rc;
+    if ((rc = run_sa_bwd<3>(m, ws, fwd, dx0, 3, 3 + kSaC[3], st))) return rc;
+    if ((rc = run_sa_bwd<2>(m, ws, fwd, dx0, 3, 3 + kSaC[2], st))) return rc;
+    if ((rc = run_sa_bwd<1>(m, ws, fwd, dx0, 3, 3 + kSaC[1], st))) return rc;
+    if ((rc = run_sa_bwd<0>(m, ws, fwd, dx0, c_lo, c_hi, st))) return rc;
+    return PSG_OK;
+}
+
+extern "C" int psg_pn2_backward(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *dlogp, float *dx0_out,
+                                psg_stream stream)
+{
+    PSG_REQUIRE(m && ws && dlogp && dx0_out, "psg_pn2_backward: null argument");
+    if (ws->fwd_slot != fwd) {
+        set_error("psg_pn2_backward: forward %d is not the one resident in the workspace (%d)", fwd, ws->fwd_slot);
+        return PSG_ERR_STATE;
+    }
+    // the log_softmax backward reads the log-probs of the resident forward, kept in ws->logp
+    return backward_impl(m, ws, fwd, ws->logp, dlogp, dx0_out, 3, 12, (hipStream_t)stream);
+}
+
+// ====================================================================================== NB attack
+extern "C" int psg_pn2_nb_attack(psg_pn2_model *m, psg_pn2_ws *ws, const float *images, const int32_t *labels,
+                                 const int32_t *starts, const uint8_t *mask, float eps, float alpha, int iters,
+                                 int targeted, int target, float *adv_out, psg_stream stream)
+{
+    PSG_REQUIRE(m && ws && images && starts && adv_out, "psg_pn2_nb_attack: null argument");
+    PSG_REQUIRE(targeted || labels, "psg_pn2_nb_attack: labels required for the non-targeted attack");
+    PSG_REQUIRE(iters > 0 && iters <= ws->F, "psg_pn2_nb_attack: iters=%d exceeds workspace capacity %d", iters, ws->F);
+    hipStream_t st = (hipStream_t)stream;
+    const int B = ws->B, N = ws->N;
+    int rc;
+    if ((rc = psg_to_point_major(images, B, 9, N, ws->x0, st))) return rc;
+    hipLaunchKernelGGL(extract_color_kernel, dim3(std::min(1024, ceil_div(B * N * 3, 256))), dim3(256), 0, st, ws->x0,
+                       ws->ori, (size_t)B * N);
+    PSG_LAUNCH_CHECK();
+    if ((rc = psg_pn2_plan_build(ws, ws->x0, starts, iters, st))) return rc;
+    const int rows = B * N;
+    for (int it = 0; it < iters; ++it) {
+        if ((rc = psg_pn2_forward(m, ws, it, ws->x0, ws->logp, nullptr, st))) return rc;
+        // non-targeted: CE_sum over all rooms / N (nontarget.py:34); targeted: CE_mean of room 0 (target.py:36-39)
+        if ((rc = psg_ce_logp_grad(ws->logp, targeted ? nullptr : labels, target, rows, targeted ? N : rows, NCLS,
+                                   1.0f / (float)N, ws->dlogp, nullptr, st)))
+            return rc;
+        if ((rc = backward_impl(m, ws, it, ws->logp, ws->dlogp, ws->dx0, 6, 9, st))) return rc;
+        if ((rc = psg_pgd_step(ws->x0, ws->dx0, ws->ori, mask, B, N, alpha, eps, targeted ? -1.0f : 1.0f,
+                               it == iters - 1, st)))
+            return rc;
+    }
+    return psg_to_channel_major(ws->x0, B, 9, N, adv_out, st);
+}

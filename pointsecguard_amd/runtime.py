@@ -1,0 +1,250 @@
+"""Thin object layer over the C ABI: PyTorch supplies device memory and the HIP stream, libpsg.so does
+all the computing.  Nothing here falls back to PyTorch ops for the hot path.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+SA_NPOINT = (1024, 256, 64, 16)   # PointNet/models/pointnet2_sem_seg.py:9-12 (reference)
+SA_RADIUS = (0.1, 0.2, 0.4, 0.8)
+NSAMPLE = 32
+NUM_CLASSES = 13
+ACT_SHAPES = ((1024, 64), (256, 128), (64, 256), (16, 512), (64, 256), (256, 256), (1024, 128))
+
+_ctx = {}
+_hip = None
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(t, name, dtype=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.PsgError("%s must be a tensor on the MI355X device (got %r); there is no CPU path" % (
+            name, getattr(t, "device", type(t))))
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.PsgError("%s must have dtype %s (got %s)" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise _lib.PsgError("%s must be contiguous" % name)
+    return t
+
+
+def context(device=None):
+    """One psg_ctx per device index, created on first use."""
+    if device is None:
+        device = torch.cuda.current_device()
+    device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _ctx:
+        lib = _lib.load()
+        torch.cuda.init()
+        h = ctypes.c_void_p()
+        _lib.check(lib.psg_ctx_create(idx, ctypes.byref(h)), "psg_ctx_create")
+        _ctx[idx] = h
+    return _ctx[idx]
+
+
+def _hip_memcpy_d2d(dst_ptr, src_ptr, nbytes):
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        _hip.hipMemcpyAsync.restype = ctypes.c_int
+    rc = _hip.hipMemcpyAsync(dst_ptr, src_ptr, nbytes, 3, stream())
+    if rc != 0:
+        raise _lib.PsgError("hipMemcpyAsync failed with %d" % rc)
+
+
+def fold_state_dict(sd, eps=1e-5):
+    """Eval-mode BatchNorm folded into the preceding 1x1 conv, in the layer order of
+    psg_pn2_model_create.  sd: mapping name -> tensor/ndarray with the reference's state_dict keys
+    (sa{1-4}.mlp_convs.N.weight ..., fp{1-4}..., conv1, bn1, conv2).  fp64 math, fp32 result."""
+    def arr(k):
+        v = sd[k]
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        return np.asarray(v, np.float64)
+
+    def fold(conv, bn):
+        w = arr(conv + ".weight")
+        w = w.reshape(w.shape[0], -1)
+        b = arr(conv + ".bias")
+        if bn is not None:
+            s = arr(bn + ".weight") / np.sqrt(arr(bn + ".running_var") + eps)
+            w = w * s[:, None]
+            b = (b - arr(bn + ".running_mean")) * s + arr(bn + ".bias")
+        return np.ascontiguousarray(w, np.float32), np.ascontiguousarray(b, np.float32)
+
+    out = []
+    for name, nl in (("sa1", 3), ("sa2", 3), ("sa3", 3), ("sa4", 3), ("fp4", 2), ("fp3", 2), ("fp2", 2), ("fp1", 3)):
+        for i in range(nl):
+            out.append(fold("%s.mlp_convs.%d" % (name, i), "%s.mlp_bns.%d" % (name, i)))
+    out.append(fold("conv1", "bn1"))
+    out.append(fold("conv2", None))
+    return out
+
+
+class PN2Model:
+    """Device-resident MFMA-packed weights of get_model (psg_pn2_model)."""
+
+    def __init__(self, folded, device=None):
+        if len(folded) != 23:
+            raise _lib.PsgError("expected 23 folded layers, got %d" % len(folded))
+        self.ctx = context(device)
+        lib = _lib.load()
+        ws = (ctypes.c_void_p * 23)(*[w.ctypes.data_as(ctypes.c_void_p) for w, _ in folded])
+        bs = (ctypes.c_void_p * 23)(*[b.ctypes.data_as(ctypes.c_void_p) for _, b in folded])
+        self._keep = folded
+        self.handle = ctypes.c_void_p()
+        _lib.check(lib.psg_pn2_model_create(self.ctx, ws, bs, ctypes.byref(self.handle)), "psg_pn2_model_create")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().psg_pn2_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class PN2Workspace:
+    """Geometry plan + activations + gradient buffers for a batch (psg_pn2_ws)."""
+
+    def __init__(self, batch, n_point, max_forwards, device=None):
+        self.ctx = context(device)
+        self.batch, self.n_point, self.max_forwards = batch, n_point, max_forwards
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.load().psg_pn2_ws_create(self.ctx, batch, n_point, max_forwards, ctypes.byref(self.handle)),
+                   "psg_pn2_ws_create")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().psg_pn2_ws_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    @property
+    def nbytes(self):
+        return _lib.load().psg_pn2_ws_bytes(self.handle)
+
+    def plan_build(self, x0, starts, n_forward):
+        require_cuda(x0, "x0", torch.float32)
+        require_cuda(starts, "starts", torch.int32)
+        assert x0.shape == (self.batch, self.n_point, 9) and starts.numel() == n_forward * 4 * self.batch
+        _lib.call("psg_pn2_plan_build", self.handle, ptr(x0), ptr(starts), n_forward, stream())
+
+    def forward(self, model, slot, x0, logp=None, l4=None):
+        require_cuda(x0, "x0", torch.float32)
+        if logp is None:
+            logp = torch.empty(self.batch, self.n_point, NUM_CLASSES, device=x0.device, dtype=torch.float32)
+        _lib.call("psg_pn2_forward", model.handle, self.handle, slot, ptr(x0), ptr(logp), ptr(l4), stream())
+        return logp
+
+    def backward(self, model, slot, dlogp, dx0=None):
+        require_cuda(dlogp, "dlogp", torch.float32)
+        if dx0 is None:
+            dx0 = torch.empty(self.batch, self.n_point, 9, device=dlogp.device, dtype=torch.float32)
+        _lib.call("psg_pn2_backward", model.handle, self.handle, slot, ptr(dlogp), ptr(dx0), stream())
+        return dx0
+
+    def nb_attack(self, model, images, labels, starts, eps, alpha, iters, mask=None, target=None, out=None):
+        require_cuda(images, "images", torch.float32)
+        require_cuda(starts, "starts", torch.int32)
+        if labels is not None:
+            require_cuda(labels, "labels", torch.int32)
+        if mask is not None:
+            require_cuda(mask, "mask", torch.uint8)
+        if out is None:
+            out = torch.empty_like(images)
+        _lib.call("psg_pn2_nb_attack", model.handle, self.handle, ptr(images), ptr(labels), ptr(starts), ptr(mask),
+                  float(eps), float(alpha), int(iters), 0 if target is None else 1, 0 if target is None else int(target),
+                  ptr(out), stream())
+        return out
+
+    # ---- read-back helpers (parity tests)
+    def plan_tensor(self, what, level, forward, room):
+        n_l = (self.n_point,) + SA_NPOINT
+        shape, dt = {0: ((SA_NPOINT[level],), torch.int32), 1: ((SA_NPOINT[level], NSAMPLE), torch.int32),
+                     2: ((n_l[level], 3), torch.int32), 3: ((n_l[level], 3), torch.float32),
+                     4: ((SA_NPOINT[level], 3), torch.float32)}[what]
+        src = _lib.load().psg_pn2_plan_ptr(self.handle, what, level, forward, room)
+        if not src:
+            raise _lib.PsgError("psg_pn2_plan_ptr: bad slice")
+        out = torch.empty(shape, dtype=dt, device=self.device)
+        _hip_memcpy_d2d(out.data_ptr(), src, out.numel() * 4)
+        return out
+
+    def activation(self, which):
+        n, c = ACT_SHAPES[which]
+        src = _lib.load().psg_pn2_activation_ptr(self.handle, which)
+        out = torch.empty(self.batch, n, c, dtype=torch.float32, device=self.device)
+        _hip_memcpy_d2d(out.data_ptr(), src, out.numel() * 4)
+        return out
+
+
+# ---- unit ops -----------------------------------------------------------------------------------
+def fps(xyz, npoint, start):
+    """xyz [P,N,3] float32 cuda, start [P] int32 -> idx [P,npoint] int32 (pointnet_util.py:63-84)."""
+    require_cuda(xyz, "xyz", torch.float32)
+    require_cuda(start, "start", torch.int32)
+    P, N, _ = xyz.shape
+    out = torch.empty(P, npoint, dtype=torch.int32, device=xyz.device)
+    _lib.call("psg_fps", context(xyz.device), ptr(xyz), P, P, N, npoint, ptr(start), ptr(out), stream())
+    return out
+
+
+def gather_points(points, idx):
+    require_cuda(points, "points", torch.float32)
+    require_cuda(idx, "idx", torch.int32)
+    P, N, C = points.shape
+    S = idx.shape[1]
+    out = torch.empty(P, S, C, dtype=torch.float32, device=points.device)
+    _lib.call("psg_gather_points", context(points.device), ptr(points), P, P, N, C, ptr(idx), S, ptr(out), stream())
+    return out
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    require_cuda(xyz, "xyz", torch.float32)
+    require_cuda(new_xyz, "new_xyz", torch.float32)
+    P, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    out = torch.empty(P, S, nsample, dtype=torch.int32, device=xyz.device)
+    r2 = float(np.float32(radius ** 2))
+    _lib.call("psg_ball_query", context(xyz.device), ptr(xyz), P, ptr(new_xyz), P, N, S, r2, nsample, ptr(out), stream())
+    return out
+
+
+def three_nn(xyz1, xyz2):
+    require_cuda(xyz1, "xyz1", torch.float32)
+    require_cuda(xyz2, "xyz2", torch.float32)
+    P, N, _ = xyz1.shape
+    S = xyz2.shape[1]
+    idx = torch.empty(P, N, 3, dtype=torch.int32, device=xyz1.device)
+    w = torch.empty(P, N, 3, dtype=torch.float32, device=xyz1.device)
+    _lib.call("psg_three_nn", context(xyz1.device), ptr(xyz1), P, ptr(xyz2), P, N, S, ptr(idx), ptr(w), stream())
+    return idx, w
+
+
+def seg_stats(logp, labels, n_cls=NUM_CLASSES, counters=None):
+    """Accumulate (seen, inter, union) int64 [3, n_cls]; returns (counters, pred)."""
+    require_cuda(logp, "logp", torch.float32)
+    require_cuda(labels, "labels", torch.int32)
+    rows = labels.numel()
+    if counters is None:
+        counters = torch.zeros(3, n_cls, dtype=torch.int64, device=logp.device)
+    pred = torch.empty(rows, dtype=torch.int32, device=logp.device)
+    _lib.call("psg_seg_stats", ptr(logp), ptr(labels), rows, n_cls, ptr(counters), ptr(pred), stream())
+    return counters, pred.view(labels.shape)

@@ -1,0 +1,66 @@
+"""Synthetic S3DIS-shaped rooms (no dataset ships with the reference or this repo).
+
+A "room" is one 4096-point x 9-channel block with the channel contract produced by the
+reference's whole-scene loader (PointNet/data_utils/S3DISDataLoader.py:155-171):
+channels 0:3 block-centred xyz, 3:6 rgb in [0,1], 6:9 room-normalised xyz in [0,1].
+The reference harness feeds blocks channel-major, [B,9,N]
+(PointNet/NB_nontarget_test_semseg.py:163-165).
+"""
+import numpy as np
+import torch
+
+NUM_POINT = 4096
+NUM_CLASSES = 13
+
+
+def make_rooms(batch, seed, num_point=NUM_POINT, structured=False):
+    """Return float32 [batch, num_point, 9] (point-major) rooms, seeded and platform independent."""
+    g = torch.Generator().manual_seed(int(seed))
+    if not structured:
+        u = torch.rand(batch, num_point, 9, generator=g, dtype=torch.float32)
+        rooms = u.clone()
+        rooms[..., 0] = u[..., 0] - 0.5
+        rooms[..., 1] = u[..., 1] - 0.5
+        rooms[..., 2] = u[..., 2] * 3.0
+        return rooms.numpy()
+    # structured rooms: points on floor / ceiling / 4 walls / a box, colour correlated with surface
+    u = torch.rand(batch, num_point, 6, generator=g, dtype=torch.float32)
+    surf = torch.randint(0, 7, (batch, num_point), generator=g)
+    x = u[..., 0] - 0.5
+    y = u[..., 1] - 0.5
+    z = u[..., 2] * 3.0
+    jit = (u[..., 3] - 0.5) * 0.01
+    x = torch.where(surf == 2, -0.5 + jit.abs(), x)
+    x = torch.where(surf == 3, 0.5 - jit.abs(), x)
+    y = torch.where(surf == 4, -0.5 + jit.abs(), y)
+    y = torch.where(surf == 5, 0.5 - jit.abs(), y)
+    z = torch.where(surf == 0, jit.abs(), z)
+    z = torch.where(surf == 1, 3.0 - jit.abs(), z)
+    box = surf == 6
+    x = torch.where(box, x * 0.4, x)
+    y = torch.where(box, y * 0.4, y)
+    z = torch.where(box, 0.8 + jit, z)
+    base = torch.tensor([[.7, .6, .5], [.9, .9, .9], [.8, .3, .3], [.3, .8, .3],
+                         [.3, .3, .8], [.8, .8, .3], [.5, .3, .1]], dtype=torch.float32)
+    rgb = (base[surf] + (u[..., 3:6] - 0.5) * 0.2).clamp(0, 1)
+    rooms = torch.empty(batch, num_point, 9, dtype=torch.float32)
+    rooms[..., 0], rooms[..., 1], rooms[..., 2] = x, y, z
+    rooms[..., 3:6] = rgb
+    rooms[..., 6] = x + 0.5
+    rooms[..., 7] = y + 0.5
+    rooms[..., 8] = z / 3.0
+    return rooms.numpy()
+
+
+def rule_labels(rooms):
+    """Deterministic 13-class labels for synthetic rooms: 3*floor(4z/3) + argmax(rgb), class 12 where x*y > 0.15.
+
+    Gives non-degenerate accuracy / mIoU / attack-success numbers with the fitted fixture weights
+    (tests/golden/pn2_weights.npz). rooms: [B,N,9] -> int64 [B,N].
+    """
+    rooms = np.asarray(rooms)
+    x, y, z = rooms[..., 0], rooms[..., 1], rooms[..., 2]
+    band = np.clip(np.floor(z * np.float32(4.0 / 3.0)).astype(np.int64), 0, 3)
+    lab = 3 * band + np.argmax(rooms[..., 3:6], axis=-1)
+    lab = np.where(x * y > np.float32(0.15), 12, lab)
+    return lab.astype(np.int64)
