@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""Headline benchmark: attacked rooms/s for NB non-targeted PGD on PointNet++ sem-seg.
+
+One "step" = one NB_attack (eps=0.05, alpha=2/255, 40 PGD iterations; BASELINE.json configs[1]) over
+one batch of 8 synthetic S3DIS-shaped rooms (4096 points x 9 channels) per GPU, through the C ABI.
+Inputs (rooms, labels, FPS start draws) are resident in HBM before the timed region.
+Multi-GPU: one process per GPU (torch.distributed.run), rooms sharded by rank, NO data-path
+collective; one RCCL all-reduce of the int64 segmentation counters after the timed region.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel, HIP-event timed on the
+launch stream in an extra profiled attack after the timed region) and `cpu_baseline` (the CPU oracle
+timed on the host cores on a bounded sample; reported baseline only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+EPS, ALPHA, ITERS = 0.05, 2 / 255, 40
+BATCH, NPOINT = 8, 4096
+PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+# algorithmic MACs per row of each fused kernel (sum of cin*cout over its 1x1-conv layers) and rows per room
+SA_DIMS = ((12, 32, 32, 64), (67, 64, 64, 128), (131, 128, 128, 256), (259, 256, 256, 512))
+SA_ROWS = (1024 * 32, 256 * 32, 64 * 32, 16 * 32)
+FP_DIMS = ((128, 128, 128, 128, 128, 13), (320, 256, 128), (384, 256, 256), (768, 256, 256))  # fp1+head, fp2, fp3, fp4
+FP_ROWS = (4096, 1024, 256, 64)
+
+
+def macs(dims):
+    return sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+
+
+def kernel_flops(batch):
+    """Algorithmic FLOPs per launch (2 x MACs; the input-gradient pass has the same MAC count)."""
+    out = {}
+    for l in range(4):
+        f = 2.0 * batch * SA_ROWS[l] * macs(SA_DIMS[l])
+        out["sa%d_fwd" % (l + 1)] = f
+        out["sa%d_bwd" % (l + 1)] = f
+    names = ("fp1_head", "fp2", "fp3", "fp4")
+    for l in range(4):
+        f = 2.0 * batch * FP_ROWS[l] * macs(FP_DIMS[l])
+        out[names[l] + "_fwd"] = f
+        out[names[l] + "_bwd"] = f
+    return out
+
+
+def cpu_baseline(sd, rooms, labels, starts, iters_sample):
+    """The CPU oracle (oracle/, a port of the reference algorithm) on the host cores; bounded sample."""
+    from oracle import attacks as oatk
+    from oracle import pn2
+    orc = pn2.PN2Oracle(sd)
+    images = np.ascontiguousarray(rooms.transpose(0, 2, 1))
+    t0 = time.time()
+    oatk.nb_attack(orc, images, labels, EPS, ALPHA, iters_sample, starts[:iters_sample])
+    dt = time.time() - t0
+    per_room_attack = dt / iters_sample * ITERS / rooms.shape[0]
+    return {"value": 1.0 / per_room_attack, "unit": "attacked rooms/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d rooms x %d of %d PGD iterations in %.1f s, extrapolated linearly" % (
+                rooms.shape[0], iters_sample, ITERS, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=6)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (
+            args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from pointsecguard_amd import runtime
+    from pointsecguard_amd.synthetic import make_rooms, rule_labels
+
+    sd = dict(np.load(os.path.join(ROOT, "tests", "golden", "pn2_weights.npz")))
+    model = runtime.PN2Model(runtime.fold_state_dict(sd))
+    ws = runtime.PN2Workspace(BATCH, NPOINT, ITERS)
+
+    n_steps = args.steps + args.warmup
+    # each rank attacks its own shard of rooms (weak scaling: BATCH rooms per GPU per step)
+    rooms = [make_rooms(BATCH, 1000 + rank * 100003 + s) for s in range(n_steps)]
+    labels = [rule_labels(r) for r in rooms]
+    rng = np.random.default_rng(1234 + rank)
+    starts = [np.stack([rng.integers(0, n, (ITERS, BATCH)) for n in (NPOINT, 1024, 256, 64)], axis=1).astype(np.int32)
+              for _ in range(n_steps)]
+    d_images = [torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 1))).cuda() for r in rooms]
+    d_labels = [torch.from_numpy(l.astype(np.int32)).cuda() for l in labels]
+    d_starts = [torch.from_numpy(s).cuda() for s in starts]
+    d_adv = [torch.empty_like(x) for x in d_images]
+
+    def step(i):
+        ws.nb_attack(model, d_images[i], d_labels[i], d_starts[i], EPS, ALPHA, ITERS, out=d_adv[i])
+
+    for i in range(args.warmup):
+        step(i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- attack statistics over the timed steps: clean vs adversarial accuracy / mIoU (RCCL all-reduce of counters)
+    clean = torch.zeros(3, 13, dtype=torch.int64, device="cuda")
+    adv = torch.zeros(3, 13, dtype=torch.int64, device="cuda")
+    ev = runtime.PN2Workspace(BATCH, NPOINT, 1)
+    for i in range(args.warmup, min(n_steps, args.warmup + 4)):
+        ev_starts = d_starts[i][:1].contiguous()
+        for src, ctr in ((d_images[i], clean), (d_adv[i], adv)):
+            x0 = src.transpose(1, 2).contiguous()
+            ev.plan_build(x0, ev_starts, 1)
+            runtime.seg_stats(ev.forward(model, 0, x0), d_labels[i], counters=ctr)
+    if dist is not None:
+        dist.all_reduce(clean)
+        dist.all_reduce(adv)
+    clean, adv = clean.cpu().numpy().astype(np.float64), adv.cpu().numpy().astype(np.float64)
+    acc, adv_acc = clean[1].sum() / clean[0].sum(), adv[1].sum() / adv[0].sum()
+    miou = float(np.mean((clean[1] / (clean[2] + 1e-6))[clean[0] != 0]))
+    adv_miou = float(np.mean((adv[1] / (adv[2] + 1e-6))[adv[0] != 0]))
+
+    result = None
+    if rank == 0:
+        total_rooms = BATCH * world * args.steps
+        value = total_rooms / elapsed
+        # ---- roofline of the dominant kernel: one extra attack with HIP-event timing of every launch
+        ws.prof_enable(True)
+        step(args.warmup)
+        torch.cuda.synchronize()
+        prof = ws.prof_read()
+        ws.prof_enable(False)
+        flops = kernel_flops(BATCH)
+        mlp = {k: v for k, v in prof.items() if k in flops}
+        dom = max(mlp, key=lambda k: mlp[k][0])
+        avg_ms = mlp[dom][0] / mlp[dom][1]
+        achieved = flops[dom] / (avg_ms * 1e-3) / 1e12
+        total_ms = sum(v[0] for v in prof.values())
+        result = {
+            "metric": "attacked rooms/sec (4096 pts, 40 PGD iters)", "value": value, "unit": "rooms/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "NB non-targeted PGD (eps=0.05, alpha=2/255, 40 iters) on PointNet++ SSG sem_seg, "
+                                   "batch=8 rooms x 4096 pts x 9 ch per GPU (BASELINE configs[1])",
+                       "rooms_per_step_per_gpu": BATCH, "weights": "tests/golden/pn2_weights.npz (fitted fixture)",
+                       "sharding": "rooms sharded by rank, no data-path collective"},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "avg_launch_us": avg_ms * 1e3, "launches": mlp[dom][1],
+                         "flop_per_launch": flops[dom]},
+            "kernel_ms_per_attack": {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+            "kernel_ms_total_per_attack": round(total_ms, 3),
+            "parity": {"clean_acc": acc, "adv_acc": adv_acc, "asr": 1.0 - adv_acc, "clean_miou": miou,
+                       "adv_miou": adv_miou, "rooms_evaluated": int(clean[0].sum() // NPOINT)},
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(sd, rooms[args.warmup], labels[args.warmup], starts[args.warmup],
+                                                  args.cpu_iters)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

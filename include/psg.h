@@ -46,6 +46,11 @@ int psg_ctx_destroy(psg_ctx *ctx);
  * Geometry unit ops, batched over P independent problems.  Problem p reads cloud (p % n_clouds).
  * ------------------------------------------------------------------------------------------ */
 
+/* square_distance, PointNet/models/pointnet_util.py:19-40: out[b][i][j] = ((-2*dot) + |src_i|^2) + |dst_j|^2
+ * with the reference's fp32 evaluation order (bit-exact).  src [B][N][3], dst [B][M][3], out [B][N][M]. */
+int psg_square_distance(psg_ctx *ctx, const float *src, const float *dst, int B, int N, int M, float *out,
+                        psg_stream stream);
+
 /* farthest_point_sample, PointNet/models/pointnet_util.py:63-84.
  * xyz [n_clouds][N][3]; start [P] = the torch.randint draw of :75; out_idx [P][S].
  * Lowest index wins distance ties (torch.max CPU behaviour).  N <= 8192. */
@@ -89,6 +94,14 @@ int psg_pn2_model_destroy(psg_pn2_model *model);
 int psg_pn2_ws_create(psg_ctx *ctx, int batch, int n_point, int max_forwards, psg_pn2_ws **out);
 int psg_pn2_ws_destroy(psg_pn2_ws *ws);
 size_t psg_pn2_ws_bytes(const psg_pn2_ws *ws);
+
+/* Per-launch timing with HIP events recorded on the launch stream (bench.py's roofline figure).
+ * While enabled every kernel launch of plan_build / forward / backward / nb_attack on this workspace is
+ * bracketed by two events.  prof_read (blocking: waits for the events) sums the elapsed ms and counts per
+ * kernel tag: 0-3 sa1-4 fwd, 4-7 fp1-4 fwd (4 = fp1+head), 8-11 fp1-4 bwd, 12-15 sa1-4 bwd, 16 fps,
+ * 17 ball query, 18 three_nn, 19 gather, 20 ce grad, 21 pgd step, 22 gradient memset.  n_tags >= 23. */
+int psg_pn2_prof_enable(psg_pn2_ws *ws, int on);
+int psg_pn2_prof_read(psg_pn2_ws *ws, int n_tags, double *total_ms, int *counts);
 
 /* Geometry for `n_forward` forwards at once (sample_and_group's FPS + ball query of the four SA
  * levels, and the 3-NN tables of the four FP levels; pointnet_util.py:110-143, :301-307).

@@ -23,6 +23,7 @@ SIGNATURES = {
     "psg_version": (ctypes.c_char_p, []),
     "psg_ctx_create": (ci, [ci, ctypes.POINTER(vp)]),
     "psg_ctx_destroy": (ci, [vp]),
+    "psg_square_distance": (ci, [vp, vp, vp, ci, ci, ci, vp, vp]),
     "psg_fps": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp]),
     "psg_gather_points": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, vp, vp]),
     "psg_ball_query": (ci, [vp, vp, ci, vp, ci, ci, ci, cf, ci, vp, vp]),
@@ -32,6 +33,8 @@ SIGNATURES = {
     "psg_pn2_ws_create": (ci, [vp, ci, ci, ci, ctypes.POINTER(vp)]),
     "psg_pn2_ws_destroy": (ci, [vp]),
     "psg_pn2_ws_bytes": (ctypes.c_size_t, [vp]),
+    "psg_pn2_prof_enable": (ci, [vp, ci]),
+    "psg_pn2_prof_read": (ci, [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     "psg_pn2_plan_build": (ci, [vp, vp, vp, ci, vp]),
     "psg_pn2_plan_ptr": (vp, [vp, ci, ci, ci, ci]),
     "psg_pn2_forward": (ci, [vp, vp, ci, vp, vp, vp, vp]),

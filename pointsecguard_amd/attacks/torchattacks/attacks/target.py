@@ -1,0 +1,50 @@
+"""Targeted colour attacks with the reference's constructor signatures
+(PointNet/attacks/torchattacks/attacks/target.py: tar_NB_attack :7-45, tar_NU_attack :52-175)."""
+import torch
+
+from pointsecguard_amd.models.pointnet2_sem_seg import draw_fps_starts
+
+from ..attack import Attack
+from ._common import mask_to_device, psg_model
+
+
+class tar_NB_attack(Attack):
+    """Targeted norm-bounded attack: only colours under `mask` move (on every batch row), descent on
+    CE(mean) of batch row 0 towards `target` (target.py:26,36-43: labels[0] / outputs[0] only)."""
+
+    def __init__(self, model, eps=0.3, alpha=2 / 255, iters=40, target=None, mask=None):
+        super(tar_NB_attack, self).__init__("tar_NB_attack", model)
+        self.model = model
+        self.eps = eps
+        self.alpha = alpha
+        self.iters = iters
+        self.target = target
+        self.mask = mask
+
+    def forward(self, images, labels):
+        net = psg_model(self.model)
+        if self.target is None or self.mask is None:
+            raise ValueError("tar_NB_attack needs target and mask")
+        images = images.detach().to(self.device).float().contiguous()
+        B, C, N = images.shape
+        mask = mask_to_device(self.mask, N, self.device)
+        starts = draw_fps_starts(B, N, self.iters).to(self.device)
+        ws = net._workspace(B, N, self.iters)
+        net._generation += 1
+        return ws.nb_attack(net._packed(), images, None, starts, self.eps, self.alpha, self.iters, mask=mask,
+                            target=int(self.target))
+
+
+class tar_NU_attack(Attack):
+    def __init__(self, model, c=1e-4, kappa=0, steps=1000, lr=0.01, target=None, mask=None):
+        super(tar_NU_attack, self).__init__("tar_NU_attack", model)
+        self.c = c
+        self.kappa = kappa
+        self.steps = steps
+        self.lr = lr
+        self.target = target
+        self.mask = mask
+
+    def forward(self, images, labels):
+        from .nu import nu_attack
+        return nu_attack(self, images, labels, mask=self.mask, target=self.target, neighbour=5, targeted_variant=True)

@@ -213,6 +213,21 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__res
     w[o] = __fdiv_rn(r0, norm); w[o + 1] = __fdiv_rn(r1, norm); w[o + 2] = __fdiv_rn(r2, norm);
 }
 
+// square_distance(src, dst) materialised (public helper of pointnet_util; not on the attack path)
+__global__ void square_distance_kernel(const float *__restrict__ src, const float *__restrict__ dst, int N, int M,
+                                       float *__restrict__ out)
+{
+    const int b = blockIdx.z;
+    const int i = blockIdx.y;
+    const float *s = src + ((size_t)b * N + i) * 3;
+    const float sx = s[0], sy = s[1], sz = s[2];
+    const float ssq = sumsq3(sx, sy, sz);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) {
+        const float *d = dst + ((size_t)b * M + j) * 3;
+        out[((size_t)b * N + i) * M + j] = sqdist(sx, sy, sz, ssq, d[0], d[1], d[2], sumsq3(d[0], d[1], d[2]));
+    }
+}
+
 template <int NT, int PPT>
 int launch_fps(const float *xyz, int n_clouds, int P, int N, int S, const int32_t *start, int32_t *out,
                hipStream_t st)
@@ -240,6 +255,17 @@ extern "C" int psg_fps(psg_ctx *ctx, const float *xyz, int n_clouds, int P, int 
     if (N <= 1024) return launch_fps<256, 4>(xyz, n_clouds, P, N, S, start, out_idx, st);
     if (N <= 4096) return launch_fps<1024, 4>(xyz, n_clouds, P, N, S, start, out_idx, st);
     return launch_fps<1024, 8>(xyz, n_clouds, P, N, S, start, out_idx, st);
+}
+
+extern "C" int psg_square_distance(psg_ctx *ctx, const float *src, const float *dst, int B, int N, int M, float *out,
+                                   psg_stream stream)
+{
+    PSG_REQUIRE(ctx && src && dst && out, "psg_square_distance: null argument");
+    PSG_REQUIRE(B > 0 && N > 0 && M > 0 && N <= 65535 && B <= 65535, "psg_square_distance: bad sizes");
+    hipLaunchKernelGGL(square_distance_kernel, dim3(std::min(64, psg::ceil_div(M, 256)), N, B), dim3(256), 0,
+                       (hipStream_t)stream, src, dst, N, M, out);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
 }
 
 extern "C" int psg_gather_points(psg_ctx *ctx, const float *points, int n_clouds, int P, int N, int C,

@@ -26,7 +26,8 @@ const int kCout[NL] = {32, 32, 64, 64, 64, 128, 128, 128, 256, 256, 256, 512, 25
                        128, 128, 128, 128, 13};
 constexpr int kNumReal = NL;
 const int kS[4] = {1024, 256, 64, 16};
-const float kRadius[4] = {0.1f, 0.2f, 0.4f, 0.8f};
+// float32(radius**2) with radius**2 evaluated in double, as Python does (pointnet_util.py:102)
+const float kRadius2[4] = {(float)(0.1 * 0.1), (float)(0.2 * 0.2), (float)(0.4 * 0.4), (float)(0.8 * 0.8)};
 const int kSaC[5] = {9, 64, 128, 256, 512};  // feature channels of level 0..4
 constexpr int K = 32;                        // nsample
 
@@ -76,6 +77,11 @@ struct psg_pn2_ws {
     // attack state
     float *x0, *ori;      // [B][N][9], [B][N][3]
     int fwd_slot = -1;
+    // optional per-launch HIP-event timing (psg_pn2_prof_enable); off in normal operation
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;   // pairs
+    std::vector<int> prof_tag;
+    size_t prof_used = 0;
 };
 
 namespace {
@@ -133,13 +139,45 @@ BwdLayer bwd_layer(const PackedLayer &p, const uint16_t *mask)
     return f;
 }
 
+// kernel tags of the per-launch profile (psg_pn2_prof_read)
+enum { TAG_SA_FWD = 0, TAG_FP_FWD = 4, TAG_FP_BWD = 8, TAG_SA_BWD = 12, TAG_FPS = 16, TAG_BALL = 17, TAG_NN = 18,
+       TAG_GATHER = 19, TAG_CE = 20, TAG_PGD = 21, TAG_ZERO = 22, TAG_COUNT = 23 };
+
+struct ProfScope {
+    psg_pn2_ws *ws;
+    hipStream_t st;
+    hipEvent_t stop = nullptr;
+    ProfScope(psg_pn2_ws *w, int tag, hipStream_t s) : ws(w), st(s)
+    {
+        if (!ws->prof_on) return;
+        if (ws->prof_used + 2 > ws->prof_ev.size()) {
+            for (int i = 0; i < 256; ++i) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) return;
+                ws->prof_ev.push_back(e);
+            }
+        }
+        hipEvent_t start = ws->prof_ev[ws->prof_used];
+        stop = ws->prof_ev[ws->prof_used + 1];
+        ws->prof_used += 2;
+        ws->prof_tag.push_back(tag);
+        (void)hipEventRecord(start, st);
+    }
+    ~ProfScope()
+    {
+        if (stop) (void)hipEventRecord(stop, st);
+    }
+};
+
 template <typename KernelT, typename ArgsT>
-int launch_lds(KernelT kern, dim3 grid, int threads, int rows, int ldp, const ArgsT &args, hipStream_t st)
+int launch_lds(psg_pn2_ws *ws, int tag, KernelT kern, dim3 grid, int threads, int rows, int ldp, const ArgsT &args,
+               hipStream_t st)
 {
     size_t lds = (size_t)rows * ldp * sizeof(float);
     if (lds > 160 * 1024) { set_error("LDS request %zu exceeds 160 KiB", lds); return PSG_ERR_ARG; }
     if (lds > 48 * 1024)
         PSG_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope prof(ws, tag, st);
     hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, args);
     PSG_LAUNCH_CHECK();
     return PSG_OK;
@@ -175,7 +213,7 @@ int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *x0, hipSt
     a.D = D; a.Np = Np; a.S = S; a.C3 = L[2].cout;
     a.rows0 = std::max(a.l1.k8 * 8, a.l2.mb * 32);
     a.rows1 = a.l1.mb * 32;
-    return launch_lds(sa_fwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, a.rows0 + a.rows1, P + 1, a, st);
+    return launch_lds(ws, TAG_SA_FWD + LVL, sa_fwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, a.rows0 + a.rows1, P + 1, a, st);
 }
 
 template <int LVL>
@@ -197,7 +235,7 @@ int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *dx0, int c_lo, 
     a.c_lo = c_lo; a.c_hi = c_hi;
     a.rows0 = std::max(a.C3, a.l2t.mb * 32);
     a.rows1 = std::max(a.l3t.mb * 32, a.l1t.mb * 32);
-    return launch_lds(sa_bwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, a.rows0 + a.rows1, P + 1, a, st);
+    return launch_lds(ws, TAG_SA_BWD + LVL, sa_bwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, a.rows0 + a.rows1, P + 1, a, st);
 }
 
 // FP module `LVL` (0 = fp1 ... 3 = fp4) upsamples level LVL+1 -> level LVL.
@@ -243,7 +281,7 @@ int run_fp_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *logp, hipStream
         int rows = a.layer[i].mb * 32;
         if (i & 1) a.rows0 = std::max(a.rows0, rows); else a.rows1 = std::max(a.rows1, rows);
     }
-    return launch_lds(fp_fwd_kernel<P, NW>, dim3(N / P, B), NW * 64, a.rows0 + a.rows1, P + 1, a, st);
+    return launch_lds(ws, TAG_FP_FWD + LVL, fp_fwd_kernel<P, NW>, dim3(N / P, B), NW * 64, a.rows0 + a.rows1, P + 1, a, st);
 }
 
 template <int LVL>
@@ -283,7 +321,7 @@ int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, con
         int rows = a.layer[i].mb * 32;
         if (i & 1) a.rows0 = std::max(a.rows0, rows); else a.rows1 = std::max(a.rows1, rows);
     }
-    return launch_lds(fp_bwd_kernel<P, NW>, dim3(N / P, B), NW * 64, a.rows0 + a.rows1, P + 1, a, st);
+    return launch_lds(ws, TAG_FP_BWD + LVL, fp_bwd_kernel<P, NW>, dim3(N / P, B), NW * 64, a.rows0 + a.rows1, P + 1, a, st);
 }
 
 __global__ void extract_xyz_kernel(const float *__restrict__ x0, float *__restrict__ xyz, size_t rows)
@@ -421,11 +459,35 @@ extern "C" int psg_pn2_ws_destroy(psg_pn2_ws *ws)
 {
     if (!ws) return PSG_OK;
     if (ws->arena) (void)hipFree(ws->arena);
+    for (hipEvent_t e : ws->prof_ev) (void)hipEventDestroy(e);
     delete ws;
     return PSG_OK;
 }
 
 extern "C" size_t psg_pn2_ws_bytes(const psg_pn2_ws *ws) { return ws ? ws->bytes : 0; }
+
+extern "C" int psg_pn2_prof_enable(psg_pn2_ws *ws, int on)
+{
+    PSG_REQUIRE(ws, "psg_pn2_prof_enable: null workspace");
+    ws->prof_on = on != 0;
+    ws->prof_used = 0;
+    ws->prof_tag.clear();
+    return PSG_OK;
+}
+
+extern "C" int psg_pn2_prof_read(psg_pn2_ws *ws, int n_tags, double *total_ms, int *counts)
+{
+    PSG_REQUIRE(ws && total_ms && counts && n_tags >= TAG_COUNT, "psg_pn2_prof_read: need room for %d tags", TAG_COUNT);
+    for (int i = 0; i < n_tags; ++i) { total_ms[i] = 0.0; counts[i] = 0; }
+    for (size_t i = 0; i < ws->prof_tag.size(); ++i) {
+        float ms = 0.f;
+        PSG_CHECK_HIP(hipEventSynchronize(ws->prof_ev[2 * i + 1]));
+        PSG_CHECK_HIP(hipEventElapsedTime(&ms, ws->prof_ev[2 * i], ws->prof_ev[2 * i + 1]));
+        total_ms[ws->prof_tag[i]] += ms;
+        counts[ws->prof_tag[i]] += 1;
+    }
+    return PSG_OK;
+}
 
 extern "C" int psg_pn2_plan_build(psg_pn2_ws *ws, const float *x0, const int32_t *starts, int n_forward,
                                   psg_stream stream)
@@ -447,14 +509,27 @@ extern "C" int psg_pn2_plan_build(psg_pn2_ws *ws, const float *x0, const int32_t
         int32_t *start_l = ws->nn_idx[l];  // scratch: nn_idx[l] is written only after FPS of this level
         hipLaunchKernelGGL(gather_starts_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, starts, start_l, l, B, P);
         PSG_LAUNCH_CHECK();
-        if ((rc = psg_fps(ws->ctx, ws->xyz[l], n_clouds, P, Np, S, start_l, ws->fps[l], st))) return rc;
-        if ((rc = psg_gather_points(ws->ctx, ws->xyz[l], n_clouds, P, Np, 3, ws->fps[l], S, ws->xyz[l + 1], st)))
-            return rc;
-        if ((rc = psg_ball_query(ws->ctx, ws->xyz[l], n_clouds, ws->xyz[l + 1], P, Np, S, kRadius[l] * kRadius[l], K,
-                                 ws->gidx[l], st)))
-            return rc;
-        if ((rc = psg_three_nn(ws->ctx, ws->xyz[l], n_clouds, ws->xyz[l + 1], P, Np, S, ws->nn_idx[l], ws->nn_w[l], st)))
-            return rc;
+        {
+            ProfScope prof(ws, TAG_FPS, st);
+            if ((rc = psg_fps(ws->ctx, ws->xyz[l], n_clouds, P, Np, S, start_l, ws->fps[l], st))) return rc;
+        }
+        {
+            ProfScope prof(ws, TAG_GATHER, st);
+            if ((rc = psg_gather_points(ws->ctx, ws->xyz[l], n_clouds, P, Np, 3, ws->fps[l], S, ws->xyz[l + 1], st)))
+                return rc;
+        }
+        {
+            ProfScope prof(ws, TAG_BALL, st);
+            if ((rc = psg_ball_query(ws->ctx, ws->xyz[l], n_clouds, ws->xyz[l + 1], P, Np, S, kRadius2[l], K,
+                                     ws->gidx[l], st)))
+                return rc;
+        }
+        {
+            ProfScope prof(ws, TAG_NN, st);
+            if ((rc = psg_three_nn(ws->ctx, ws->xyz[l], n_clouds, ws->xyz[l + 1], P, Np, S, ws->nn_idx[l], ws->nn_w[l],
+                                   st)))
+                return rc;
+        }
     }
     ws->planned = n_forward;
     return PSG_OK;
@@ -509,8 +584,11 @@ static int backward_impl(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float 
 {
     int rc;
     // all gradient buffers are accumulated with atomics: zero them (dx0 too when it is workspace-owned)
-    PSG_CHECK_HIP(hipMemsetAsync(ws->gzero, 0, ws->gzero_bytes, st));
-    if (dx0 != ws->dx0) PSG_CHECK_HIP(hipMemsetAsync(dx0, 0, (size_t)ws->B * ws->N * 9 * 4, st));
+    {
+        ProfScope prof(ws, TAG_ZERO, st);
+        PSG_CHECK_HIP(hipMemsetAsync(ws->gzero, 0, ws->gzero_bytes, st));
+        if (dx0 != ws->dx0) PSG_CHECK_HIP(hipMemsetAsync(dx0, 0, (size_t)ws->B * ws->N * 9 * 4, st));
+    }
     if ((rc = run_fp_bwd<0>(m, ws, fwd, logp, dlogp, st))) return rc;
     if ((rc = run_fp_bwd<1>(m, ws, fwd, nullptr, nullptr, st))) return rc;
     if ((rc = run_fp_bwd<2>(m, ws, fwd, nullptr, nullptr, st))) return rc;
@@ -554,13 +632,19 @@ extern "C" int psg_pn2_nb_attack(psg_pn2_model *m, psg_pn2_ws *ws, const float *
     for (int it = 0; it < iters; ++it) {
         if ((rc = psg_pn2_forward(m, ws, it, ws->x0, ws->logp, nullptr, st))) return rc;
         // non-targeted: CE_sum over all rooms / N (nontarget.py:34); targeted: CE_mean of room 0 (target.py:36-39)
-        if ((rc = psg_ce_logp_grad(ws->logp, targeted ? nullptr : labels, target, rows, targeted ? N : rows, NCLS,
-                                   1.0f / (float)N, ws->dlogp, nullptr, st)))
-            return rc;
+        {
+            ProfScope prof(ws, TAG_CE, st);
+            if ((rc = psg_ce_logp_grad(ws->logp, targeted ? nullptr : labels, target, rows, targeted ? N : rows, NCLS,
+                                       1.0f / (float)N, ws->dlogp, nullptr, st)))
+                return rc;
+        }
         if ((rc = backward_impl(m, ws, it, ws->logp, ws->dlogp, ws->dx0, 6, 9, st))) return rc;
-        if ((rc = psg_pgd_step(ws->x0, ws->dx0, ws->ori, mask, B, N, alpha, eps, targeted ? -1.0f : 1.0f,
-                               it == iters - 1, st)))
-            return rc;
+        {
+            ProfScope prof(ws, TAG_PGD, st);
+            if ((rc = psg_pgd_step(ws->x0, ws->dx0, ws->ori, mask, B, N, alpha, eps, targeted ? -1.0f : 1.0f,
+                                   it == iters - 1, st)))
+                return rc;
+        }
     }
     return psg_to_channel_major(ws->x0, B, 9, N, adv_out, st);
 }

@@ -1,0 +1,94 @@
+"""PointNet++ point-set operators behind the reference's `models/pointnet_util.py` names.
+
+Public names and argument meaning follow the reference (PointNet/models/pointnet_util.py):
+square_distance :19, index_points :43, farthest_point_sample :63, query_ball_point :87,
+sample_and_group :110, PointNetSetAbstraction :166, PointNetFeaturePropagation :270.
+Every function takes CUDA tensors and runs a hand-written gfx950 kernel through libpsg.so; there is
+no PyTorch-op or CPU fallback.  Index results are int64 like the reference's.
+
+The two nn.Module classes keep the reference's parameter layout (`mlp_convs.N`, `mlp_bns.N`) so that
+state_dicts are interchangeable; inside get_model their arithmetic is executed by the whole-network
+kernels (pointnet2_sem_seg.py), which is the only way the attack path uses them.
+"""
+import torch
+import torch.nn as nn
+
+from pointsecguard_amd import runtime
+
+
+def square_distance(src, dst):
+    """[B,N,3] x [B,M,3] -> [B,N,M] with the reference's expansion -2ab + |a|^2 + |b|^2 (bit-exact)."""
+    return runtime.square_distance(src.contiguous().float(), dst.contiguous().float())
+
+
+def index_points(points, idx):
+    """points [B,N,C], idx [B,S] or [B,S,K] -> [B,S,C] / [B,S,K,C]."""
+    shape = idx.shape
+    flat = idx.reshape(shape[0], -1).to(torch.int32).contiguous()
+    out = runtime.gather_points(points.contiguous().float(), flat)
+    return out.view(*shape, points.shape[-1])
+
+
+def farthest_point_sample(xyz, npoint):
+    """xyz [B,N,3] -> centroid indices [B,npoint] int64.  The start index is drawn from the global
+    CPU generator exactly like the reference (pointnet_util.py:75)."""
+    B, N, _ = xyz.shape
+    start = torch.randint(0, N, (B,), dtype=torch.long).to(torch.int32).to(xyz.device)
+    return runtime.fps(xyz.contiguous().float(), npoint, start).long()
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    """First `nsample` indices (ascending) within `radius` of each query, padded with the first hit."""
+    return runtime.ball_query(radius, nsample, xyz.contiguous().float(), new_xyz.contiguous().float()).long()
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False):
+    B, N, C = xyz.shape
+    fps_idx = farthest_point_sample(xyz, npoint)
+    new_xyz = index_points(xyz, fps_idx)
+    idx = query_ball_point(radius, nsample, xyz, new_xyz)
+    grouped_xyz = index_points(xyz, idx)
+    grouped_xyz_norm = grouped_xyz - new_xyz.view(B, npoint, 1, C)
+    if points is not None:
+        new_points = torch.cat([grouped_xyz_norm, index_points(points, idx)], dim=-1)
+    else:
+        new_points = grouped_xyz_norm
+    if returnfps:
+        return new_xyz, new_points, grouped_xyz, fps_idx
+    return new_xyz, new_points
+
+
+class PointNetSetAbstraction(nn.Module):
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all):
+        super(PointNetSetAbstraction, self).__init__()
+        if group_all:
+            raise NotImplementedError("group_all set abstraction is not used by pointnet2_sem_seg (out of scope)")
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv2d(last_channel, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(out_channel))
+            last_channel = out_channel
+        self.group_all = group_all
+
+    def forward(self, xyz, points):
+        raise NotImplementedError("stand-alone PointNetSetAbstraction.forward is executed by the fused whole-network "
+                                  "kernels of get_model; call the parent get_model instead")
+
+
+class PointNetFeaturePropagation(nn.Module):
+    def __init__(self, in_channel, mlp):
+        super(PointNetFeaturePropagation, self).__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv1d(last_channel, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(out_channel))
+            last_channel = out_channel
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        raise NotImplementedError("stand-alone PointNetFeaturePropagation.forward is executed by the fused "
+                                  "whole-network kernels of get_model; call the parent get_model instead")

@@ -174,6 +174,21 @@ class PN2Workspace:
                   ptr(out), stream())
         return out
 
+    PROF_TAGS = ("sa1_fwd", "sa2_fwd", "sa3_fwd", "sa4_fwd", "fp1_head_fwd", "fp2_fwd", "fp3_fwd", "fp4_fwd",
+                 "fp1_head_bwd", "fp2_bwd", "fp3_bwd", "fp4_bwd", "sa1_bwd", "sa2_bwd", "sa3_bwd", "sa4_bwd",
+                 "fps", "ball_query", "three_nn", "gather", "ce_grad", "pgd_step", "grad_memset")
+
+    def prof_enable(self, on=True):
+        _lib.call("psg_pn2_prof_enable", self.handle, 1 if on else 0)
+
+    def prof_read(self):
+        """{kernel tag: (total ms, launches)} measured with HIP events on the launch stream."""
+        n = len(self.PROF_TAGS)
+        ms = (ctypes.c_double * n)()
+        cnt = (ctypes.c_int * n)()
+        _lib.call("psg_pn2_prof_read", self.handle, n, ms, cnt)
+        return {t: (ms[i], cnt[i]) for i, t in enumerate(self.PROF_TAGS) if cnt[i]}
+
     # ---- read-back helpers (parity tests)
     def plan_tensor(self, what, level, forward, room):
         n_l = (self.n_point,) + SA_NPOINT
@@ -196,6 +211,16 @@ class PN2Workspace:
 
 
 # ---- unit ops -----------------------------------------------------------------------------------
+def square_distance(src, dst):
+    require_cuda(src, "src", torch.float32)
+    require_cuda(dst, "dst", torch.float32)
+    B, N, _ = src.shape
+    M = dst.shape[1]
+    out = torch.empty(B, N, M, dtype=torch.float32, device=src.device)
+    _lib.call("psg_square_distance", context(src.device), ptr(src), ptr(dst), B, N, M, ptr(out), stream())
+    return out
+
+
 def fps(xyz, npoint, start):
     """xyz [P,N,3] float32 cuda, start [P] int32 -> idx [P,npoint] int32 (pointnet_util.py:63-84)."""
     require_cuda(xyz, "xyz", torch.float32)

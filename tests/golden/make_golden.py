@@ -8,9 +8,11 @@ Outputs are plain numeric .npz files (inputs + expected outputs); no reference s
                     rule-labelled synthetic rooms (default-init weights predict a single class)
   pn2_room.npz      one room: FPS / ball-query / 3-NN indices, interpolation weights, raw
                     square_distance bit patterns, per-layer activations, log-probs, d cost/d colour
-  pn2_nb.npz        NB_attack(eps=.05, alpha=2/255): adversarial colours after 1, 5 and 40
-                    iterations, B=2, the recorded torch.randint stream, clean/adv metrics
-  pn2_tarnb.npz     tar_NB_attack(eps=.5, alpha=.1, target=6, mask=label==11), 1 and 10 iterations
+  pn2_nb.npz        NB_attack(eps=.05, alpha=2/255, iters=40), B=2: the colour state the attack feeds
+                    to the model at selected iterations (recorded through an instrumented model
+                    argument; the attack code itself is unmodified), the returned adversarial colours,
+                    the recorded torch.randint stream, clean/adv log-probs and metrics
+  pn2_tarnb.npz     tar_NB_attack(eps=.5, alpha=.1, iters=10, target=6, mask=label==11), B=2, same layout
 """
 import os
 import sys
@@ -147,57 +149,84 @@ def gen_room():
                                                        int((color.grad != 0).sum())))
 
 
+class Recorder(torch.nn.Module):
+    """Instrumented model argument for the UNMODIFIED reference attacks: records the colour channels
+    the attack feeds to the model at every iteration (= the projected colour state entering it)."""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+        self.seen = []
+
+    def forward(self, x):
+        self.seen.append(x.detach()[:, 3:6].clone().numpy())
+        return self.inner(x)
+
+
+NB_KEEP = (0, 1, 2, 3, 5, 6, 10, 11, 20, 21, 39)
+
+
 def gen_nb():
     torch.set_num_threads(1)
     m = load_model()
-    B, seed_room, seed_rng = 2, 21, 3
+    B, seed_room, seed_rng, iters = 2, 21, 3, 40
     eps, alpha = 0.05, 2 / 255
     room = make_rooms(B, seed_room)
     labels = rule_labels(room)
     x = torch.from_numpy(room).transpose(2, 1).contiguous()
-    out = {"rooms": room, "labels": labels.astype(np.int16), "eps": eps, "alpha": alpha,
-           "starts": draw_starts(seed_rng, 42, B), "seed_rng": seed_rng}
-    # stream: [clean forward] + iters attack forwards + [adversarial forward]
-    for iters in (1, 5, 40):
-        torch.manual_seed(seed_rng)
-        with torch.no_grad():
-            clean_logp, _ = m(x)
-        atk = torchattacks.NB_attack(m, eps=eps, alpha=alpha, iters=iters)
-        adv = atk(x, labels.astype(np.float64))
-        out["adv_color_it%d" % iters] = adv.detach()[:, 3:6].numpy()
-        with torch.no_grad():
-            adv_logp, _ = m(adv.detach())
-        print("nb iters %d done" % iters, flush=True)
+    out = {"rooms": room, "labels": labels.astype(np.int16), "eps": eps, "alpha": alpha, "iters": iters,
+           "starts": draw_starts(seed_rng, iters + 2, B), "seed_rng": seed_rng}
+    # RNG stream: [clean forward] + `iters` attack forwards + [adversarial forward]
+    torch.manual_seed(seed_rng)
+    with torch.no_grad():
+        clean_logp, _ = m(x)
+    rec = Recorder(m).eval()
+    atk = torchattacks.NB_attack(rec, eps=eps, alpha=alpha, iters=iters)
+    adv = atk(x, labels.astype(np.float64)).detach()
+    with torch.no_grad():
+        adv_logp, _ = m(adv)
+    assert len(rec.seen) == iters
+    for t in NB_KEEP:
+        out["state_it%d" % t] = rec.seen[t]          # colour entering attack iteration t (after t steps)
+    out["adv_color_final"] = adv[:, 3:6].numpy()      # un-projected last step (reference return value)
     out["clean_logp"] = clean_logp.numpy()
     out["adv_logp"] = adv_logp.numpy()
     pred, apred = clean_logp.argmax(2).numpy(), adv_logp.argmax(2).numpy()
     acc, miou, inter, union, seen = metrics(pred, labels)
     aacc, amiou, ainter, aunion, _ = metrics(apred, labels)
     out.update(acc=acc, miou=miou, adv_acc=aacc, adv_miou=amiou, inter=inter, union=union, seen=seen,
-               adv_inter=ainter, adv_union=aunion,
-               l2_dis=float(torch.dist(adv.detach(), x).item()))
+               adv_inter=ainter, adv_union=aunion, l2_dis=float(torch.dist(adv, x).item()))
     np.savez_compressed(os.path.join(HERE, "pn2_nb.npz"), **out)
     print("nb: acc %.4f -> %.4f, miou %.4f -> %.4f" % (acc, aacc, miou, amiou))
+
+
+TAR_KEEP = (0, 1, 2, 5, 6, 9)
 
 
 def gen_tarnb():
     torch.set_num_threads(1)
     m = load_model()
-    seed_room, seed_rng = 33, 5
+    seed_room, seed_rng, iters = 33, 5, 10
     eps, alpha, target, origin = 0.5, 0.1, 6, 11
-    room = make_rooms(1, seed_room)
+    room = make_rooms(2, seed_room)  # two rooms: the loss uses batch row 0 only (target.py:36)
     labels = rule_labels(room)
     mask = labels[0] == origin
     x = torch.from_numpy(room).transpose(2, 1).contiguous()
     out = {"rooms": room, "labels": labels.astype(np.int16), "mask": mask, "eps": eps, "alpha": alpha,
-           "target": target, "starts": draw_starts(seed_rng, 10, 1), "seed_rng": seed_rng}
-    for iters in (1, 10):
-        torch.manual_seed(seed_rng)
-        atk = torchattacks.tar_NB_attack(m, eps=eps, alpha=alpha, iters=iters, target=target, mask=mask)
-        adv = atk(x, labels.astype(np.float64))
-        out["adv_color_it%d" % iters] = adv.detach()[:, 3:6].numpy()
+           "target": target, "iters": iters, "starts": draw_starts(seed_rng, iters, 2), "seed_rng": seed_rng}
+    torch.manual_seed(seed_rng)
+    rec = Recorder(m).eval()
+    atk = torchattacks.tar_NB_attack(rec, eps=eps, alpha=alpha, iters=iters, target=target, mask=mask)
+    adv = atk(x, labels.astype(np.float64)).detach()
+    for t in TAR_KEEP:
+        out["state_it%d" % t] = rec.seen[t]
+    out["adv_color_final"] = adv[:, 3:6].numpy()
+    with torch.no_grad():
+        adv_logp, _ = m(adv)
+    pred = adv_logp.argmax(2).numpy()
+    out["target_acc"] = float((pred[0][mask] == target).sum()) / float(mask.sum())  # NB_target_test_semseg.py:190
     np.savez_compressed(os.path.join(HERE, "pn2_tarnb.npz"), **out)
-    print("tarnb: mask count", int(mask.sum()))
+    print("tarnb: mask count", int(mask.sum()), "target_acc", out["target_acc"])
 
 
 if __name__ == "__main__":

@@ -84,46 +84,123 @@ def test_backward_vs_reference(room_run, golden_room, gpu_model):
     check_grad(dx0[0, :, 3:6].cpu().numpy(), g["dcolor"])
 
 
-def test_nb_attack_vs_reference(gpu_model, golden_nb):
+def _set_color(x0, color_cn):
+    """x0 [B,N,9] point-major device tensor <- colour state [B,3,N] (numpy, reference layout)."""
+    x0[:, :, 3:6] = dev(np.ascontiguousarray(color_cn.transpose(0, 2, 1)))
+
+
+def _one_step(ws, model, x0, ori, labels, slot, alpha, eps, last, mask=None, target=None):
+    """One attack iteration assembled from the C-ABI pieces (what psg_pn2_nb_attack fuses)."""
+    from pointsecguard_amd import _lib, runtime
+    B, N = x0.shape[0], x0.shape[1]
+    logp = ws.forward(model, slot, x0)
+    dlogp = torch.empty_like(logp)
+    if target is None:
+        _lib.call("psg_ce_logp_grad", runtime.ptr(logp), runtime.ptr(labels), 0, B * N, B * N, 13, 1.0 / N,
+                  runtime.ptr(dlogp), None, runtime.stream())
+    else:
+        _lib.call("psg_ce_logp_grad", runtime.ptr(logp), None, int(target), B * N, N, 13, 1.0 / N,
+                  runtime.ptr(dlogp), None, runtime.stream())
+    dx0 = ws.backward(model, slot, dlogp)
+    _lib.call("psg_pgd_step", runtime.ptr(x0), runtime.ptr(dx0), runtime.ptr(ori), runtime.ptr(mask), B, N,
+              float(alpha), float(eps), -1.0 if target is not None else 1.0, 1 if last else 0, runtime.stream())
+    torch.cuda.synchronize()
+    return x0[:, :, 3:6].cpu().numpy().transpose(0, 2, 1)
+
+
+def test_nb_attack_steps_vs_reference(gpu_model, golden_nb):
+    """Teacher-forced NB_attack iterations: start from the colour state the REFERENCE fed to its model
+    at iteration t, run one HIP iteration, compare with the reference's state at t+1.  (A free-running
+    40-iteration comparison cannot be bit-stable between ANY two fp32 implementations: one flipped
+    sign of a ~1e-9 gradient is a 2*alpha colour change that the next iterations amplify; DESIGN.md.)"""
     from pointsecguard_amd import runtime
     g = golden_nb
-    rooms = g["rooms"]
+    rooms, iters = g["rooms"], int(g["iters"])
     B = rooms.shape[0]
-    images = dev(rooms.transpose(0, 2, 1))
     labels = dev(g["labels"].astype(np.int32))
-    ws = runtime.PN2Workspace(B, 4096, 40)
-    # golden stream = [clean forward] + attack forwards + [adversarial forward]: attack draws start at 1
-    for iters in (1, 5, 40):
-        starts = dev(g["starts"][1:1 + iters], torch.int32)
-        adv = ws.nb_attack(gpu_model, images, labels, starts, float(g["eps"]), float(g["alpha"]), iters)
-        torch.cuda.synchronize()
-        got = adv[:, 3:6].cpu().numpy()
-        ref = g["adv_color_it%d" % iters]
-        same = (got.view(np.uint32) == ref.view(np.uint32)).mean()
-        assert same >= 0.999, (iters, same)
-        assert np.abs(got - ref).max() <= 2 * float(g["alpha"]) * iters + 1e-6
-        other = adv.cpu().numpy()
-        assert np.array_equal(other[:, :3], rooms.transpose(0, 2, 1)[:, :3])
-        assert np.array_equal(other[:, 6:], rooms.transpose(0, 2, 1)[:, 6:])
+    x0 = dev(rooms)
+    ori = x0[:, :, 3:6].contiguous()
+    ws = runtime.PN2Workspace(B, 4096, iters)
+    # golden RNG stream = [clean forward] + attack forwards + [adversarial forward]: attack draws start at 1
+    ws.plan_build(x0, dev(g["starts"][1:1 + iters], torch.int32), iters)
+    checked = 0
+    for t in (0, 1, 2, 5, 10, 20, 39):
+        nxt = g["adv_color_final"] if t == iters - 1 else g["state_it%d" % (t + 1)]
+        _set_color(x0, g["state_it%d" % t])
+        got = _one_step(ws, gpu_model, x0, ori, labels, t, g["alpha"], g["eps"], last=(t == iters - 1))
+        same = (np.ascontiguousarray(got).view(np.uint32) == nxt.view(np.uint32)).mean()
+        assert same >= 0.999, (t, same)
+        checked += 1
+    assert checked == 7
 
 
-def test_tar_nb_attack_vs_reference(gpu_model, golden_tarnb):
+def test_nb_attack_free_run_vs_reference(gpu_model, golden_nb):
+    """Fused 40-iteration attack: invariants + statistical parity with the reference's result."""
+    from pointsecguard_amd import runtime
+    g = golden_nb
+    rooms, iters = g["rooms"], int(g["iters"])
+    B = rooms.shape[0]
+    images_np = np.ascontiguousarray(rooms.transpose(0, 2, 1))
+    images, labels = dev(images_np), dev(g["labels"].astype(np.int32))
+    ws = runtime.PN2Workspace(B, 4096, iters)
+    adv = ws.nb_attack(gpu_model, images, labels, dev(g["starts"][1:1 + iters], torch.int32), float(g["eps"]),
+                       float(g["alpha"]), iters)
+    torch.cuda.synchronize()
+    out = adv.cpu().numpy()
+    assert np.array_equal(out[:, :3], images_np[:, :3]) and np.array_equal(out[:, 6:], images_np[:, 6:])
+    # un-projected last step: within eps + alpha of the original, may leave [0,1] by alpha (SURVEY 8a A1)
+    assert np.abs(out[:, 3:6] - images_np[:, 3:6]).max() <= float(g["eps"]) + float(g["alpha"]) + 1e-6
+    ref = g["adv_color_final"]
+    same = (out[:, 3:6].view(np.uint32) == ref.view(np.uint32)).mean()
+    assert same >= 0.5, same  # chaotic amplification of tie / rounding sign flips; see docstring above
+    # adversarial accuracy / mIoU parity on the same RNG slot as the reference's adversarial forward
+    ev = runtime.PN2Workspace(B, 4096, 1)
+    x0 = adv.transpose(1, 2).contiguous()
+    ev.plan_build(x0, dev(g["starts"][iters + 1:iters + 2], torch.int32), 1)
+    counters, _ = runtime.seg_stats(ev.forward(gpu_model, 0, x0), labels)
+    torch.cuda.synchronize()
+    c = counters.cpu().numpy().astype(np.float64)
+    adv_acc = c[1].sum() / c[0].sum()
+    adv_miou = np.mean((c[1] / (c[2] + 1e-6))[c[0] != 0])
+    assert abs(adv_acc - float(g["adv_acc"])) <= 0.01, (adv_acc, float(g["adv_acc"]))
+    assert abs(adv_miou - float(g["adv_miou"])) <= 0.01, (adv_miou, float(g["adv_miou"]))
+    # clean metrics with the reference's clean-forward RNG slot: counters must match EXACTLY
+    x0c = dev(rooms)
+    ev.plan_build(x0c, dev(g["starts"][0:1], torch.int32), 1)
+    counters, _ = runtime.seg_stats(ev.forward(gpu_model, 0, x0c), labels)
+    c = counters.cpu().numpy()
+    assert np.abs(c[1] - g["inter"]).sum() <= 4 and np.abs(c[2] - g["union"]).sum() <= 8
+    assert np.array_equal(c[0], g["seen"])
+
+
+def test_tar_nb_attack_steps_vs_reference(gpu_model, golden_tarnb):
     from pointsecguard_amd import runtime
     g = golden_tarnb
-    rooms = g["rooms"]
-    images = dev(rooms.transpose(0, 2, 1))
+    rooms, iters = g["rooms"], int(g["iters"])
+    B = rooms.shape[0]
+    x0 = dev(rooms)
+    ori = x0[:, :, 3:6].contiguous()
     mask = dev(g["mask"].astype(np.uint8))
-    ws = runtime.PN2Workspace(1, 4096, 10)
-    for iters in (1, 10):
-        starts = dev(g["starts"][:iters], torch.int32)
-        adv = ws.nb_attack(gpu_model, images, None, starts, float(g["eps"]), float(g["alpha"]), iters, mask=mask,
-                           target=int(g["target"]))
-        torch.cuda.synchronize()
-        got = adv[:, 3:6].cpu().numpy()
-        ref = g["adv_color_it%d" % iters]
-        assert (got.view(np.uint32) == ref.view(np.uint32)).mean() >= 0.999, iters
+    ws = runtime.PN2Workspace(B, 4096, iters)
+    ws.plan_build(x0, dev(g["starts"][:iters], torch.int32), iters)
+    for t in (0, 1, 5, 9):
+        nxt = g["adv_color_final"] if t == iters - 1 else g["state_it%d" % (t + 1)]
+        _set_color(x0, g["state_it%d" % t])
+        got = _one_step(ws, gpu_model, x0, ori, None, t, g["alpha"], g["eps"], last=(t == iters - 1), mask=mask,
+                        target=int(g["target"]))
+        same = (np.ascontiguousarray(got).view(np.uint32) == nxt.view(np.uint32)).mean()
+        assert same >= 0.999, (t, same)
         m = g["mask"]
         assert np.array_equal(got[:, :, ~m], rooms.transpose(0, 2, 1)[:, 3:6][:, :, ~m])
+    # fused call: only masked colours may move, everything else bit-identical
+    images_np = np.ascontiguousarray(rooms.transpose(0, 2, 1))
+    adv = ws.nb_attack(gpu_model, dev(images_np), None, dev(g["starts"][:iters], torch.int32), float(g["eps"]),
+                       float(g["alpha"]), iters, mask=mask, target=int(g["target"]))
+    torch.cuda.synchronize()
+    out = adv.cpu().numpy()
+    assert np.array_equal(out[:, :, ~g["mask"]], images_np[:, :, ~g["mask"]])
+    same = (out[:, 3:6].view(np.uint32) == g["adv_color_final"].view(np.uint32)).mean()
+    assert same >= 0.99, same
 
 
 @pytest.mark.parametrize("n,s", [(4096, 1024), (1024, 256), (256, 64), (64, 16), (1000, 100), (77, 5)])
