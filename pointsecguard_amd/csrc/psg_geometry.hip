@@ -30,18 +30,40 @@ __device__ __forceinline__ float sqdist(float sx, float sy, float sz, float ssq,
     return __fadd_rn(__fadd_rn(__fmul_rn(-2.0f, dot), ssq), dsq);
 }
 
-__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m)
+// ---- wave-level max with DPP (no LDS round trips) --------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v)
 {
-    unsigned lo = __shfl_xor((unsigned)v, m);
-    unsigned hi = __shfl_xor((unsigned)(v >> 32), m);
-    return ((unsigned long long)hi << 32) | lo;
+    unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+    return o > v ? o : v;
+}
+// max over each row of 16 lanes, result in every lane of the row
+__device__ __forceinline__ unsigned row_max_u32(unsigned v)
+{
+    v = dpp_max_u32<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v = dpp_max_u32<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v = dpp_max_u32<0x141, 0xF>(v);  // row_half_mirror
+    v = dpp_max_u32<0x140, 0xF>(v);  // row_mirror
+    return v;
+}
+// max over the 64 lanes of the wave, returned wave-uniform
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    v = row_max_u32(v);
+    v = dpp_max_u32<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+    v = dpp_max_u32<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // ---------------------------------------------------------------------------------------------
-// FPS: one workgroup per problem, xyz in LDS (for the centroid broadcast) and in registers.
-// Per step: PPT distance updates per thread, wave argmax by shuffles, one LDS slot per wave, ONE
-// barrier (partials are double-buffered), every thread reduces the NW partials itself.
-// argmax key = (dist bits << 32) | ~index  ->  max distance, lowest index on ties (torch.max CPU).
+// FPS: one workgroup per problem; thread t owns the PPT consecutive points PPT*t .. PPT*t+PPT-1
+// (so a lower lane / lower wave always means a lower point index).  xyz stays in LDS for the centroid
+// broadcast and in registers for the distance update.  Per step:
+//   distance update + in-thread argmax  ->  wave max by DPP  ->  ballot picks the lowest lane holding
+//   it  ->  one LDS slot per wave, ONE barrier (slots double-buffered)  ->  16-lane DPP max over the
+//   wave partials, ballot picks the lowest wave.
+// Distances are non-negative floats, compared as their bit patterns (exact same order); ties resolve to
+// the lowest index like torch.max on CPU.
 // ---------------------------------------------------------------------------------------------
 template <int NT, int PPT>
 __global__ __launch_bounds__(NT) void fps_kernel(const float *__restrict__ xyz, int n_clouds, int N, int S,
@@ -49,23 +71,20 @@ __global__ __launch_bounds__(NT) void fps_kernel(const float *__restrict__ xyz, 
 {
     constexpr int NW = NT / 64;
     extern __shared__ float smem[];
-    float *s_xyz = smem;                                                        // [N*3]
-    unsigned long long *s_part = (unsigned long long *)(smem + ((N * 3 + 1) & ~1));  // [2][NW]
+    float *s_xyz = smem;                                 // [NT*PPT*3] (padded cloud)
+    uint2 *s_part = (uint2 *)(smem + NT * PPT * 3);      // [2][NW] (value bits, index)
 
     const int p = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *src = xyz + (size_t)(p % n_clouds) * N * 3;
-    for (int i = tid; i < N * 3; i += NT) s_xyz[i] = src[i];
+    for (int i = tid; i < NT * PPT * 3; i += NT) s_xyz[i] = i < N * 3 ? src[i] : 0.0f;
     __syncthreads();
 
     float px[PPT], py[PPT], pz[PPT], dist[PPT];
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
-        int i = tid + q * NT;
-        bool ok = i < N;
-        px[q] = ok ? s_xyz[3 * i] : 0.f;
-        py[q] = ok ? s_xyz[3 * i + 1] : 0.f;
-        pz[q] = ok ? s_xyz[3 * i + 2] : 0.f;
+        const int i = tid * PPT + q;
+        px[q] = s_xyz[3 * i]; py[q] = s_xyz[3 * i + 1]; pz[q] = s_xyz[3 * i + 2];
         dist[q] = 1e10f;
     }
     int far = start[p];
@@ -73,34 +92,31 @@ __global__ __launch_bounds__(NT) void fps_kernel(const float *__restrict__ xyz, 
     for (int s = 0; s < S; ++s) {
         if (tid == 0) o[s] = far;
         const float cx = s_xyz[3 * far], cy = s_xyz[3 * far + 1], cz = s_xyz[3 * far + 2];
-        unsigned long long best = 0ull;
+        unsigned best = 0u;
+        int bq = 0;
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
-            int i = tid + q * NT;
             float dx = __fsub_rn(px[q], cx), dy = __fsub_rn(py[q], cy), dz = __fsub_rn(pz[q], cz);
             float d = sumsq3(dx, dy, dz);
             dist[q] = d < dist[q] ? d : dist[q];
-            unsigned long long key =
-                ((unsigned long long)__float_as_uint(dist[q]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
-            key = i < N ? key : 0ull;
-            best = key > best ? key : best;
+            // points past N never win: their key is 0 and the real maximum is >= 0 at a lower index
+            unsigned key = (tid * PPT + q) < N ? __float_as_uint(dist[q]) : 0u;
+            if (key > best) { best = key; bq = q; }
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            unsigned long long o2 = shfl_xor_u64(best, m);
-            best = o2 > best ? o2 : best;
-        }
+        const unsigned wmax = wave_max_u32(best);
+        const unsigned long long hit = __ballot(best == wmax);
+        const int src_lane = __builtin_ctzll(hit);
+        int widx = __builtin_amdgcn_readlane(tid * PPT + bq, src_lane);
         if (NW > 1) {
-            unsigned long long *slot = s_part + (s & 1) * NW;
-            if ((tid & 63) == 0) slot[tid >> 6] = best;
+            uint2 *slot = s_part + (s & 1) * NW;
+            if (lane == 0) slot[wave] = make_uint2(wmax, (unsigned)widx);
             __syncthreads();
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                unsigned long long v = slot[w];
-                best = v > best ? v : best;
-            }
+            const uint2 part = slot[lane & (NW - 1)];
+            const unsigned gmax = row_max_u32(part.x);
+            const unsigned long long hw = __ballot(part.x == gmax) & ((1ull << NW) - 1ull);
+            widx = __builtin_amdgcn_readlane((int)part.y, __builtin_ctzll(hw));
         }
-        far = (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
+        far = widx;
     }
 }
 
@@ -123,8 +139,9 @@ __global__ void gather_rows_kernel(const float *__restrict__ pts, int n_clouds, 
 // scans it 64 points at a time in index order, compacting hits with ballot + prefix popcount and
 // stopping at K.  No [S,N] matrix, no sort (the reference materialises both).
 // ---------------------------------------------------------------------------------------------
-constexpr int BQ_THREADS = 256;
-constexpr int BQ_CPB = 64;  // centroids per workgroup
+constexpr int BQ_THREADS = 1024;
+constexpr int BQ_CPB = 128;  // centroids per workgroup (8 per wave)
+constexpr int BQ_UNROLL = 4; // 64-point chunks in flight per wave (hides the LDS latency of the scan)
 
 __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float *__restrict__ xyz, int n_clouds,
                                                                 const float *__restrict__ new_xyz, int N, int S,
@@ -147,24 +164,31 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float *__r
         const float csq = sumsq3(cx, cy, cz);
         int32_t *o = out + ((size_t)p * S + c) * K;
         int cnt = 0, first = N;
-        for (int base = 0; base < N && cnt < K; base += 64) {
-            int j = base + lane;
-            bool in = false;
-            if (j < N) {
-                float4 q = s_pts[j];
-                float d = sqdist(cx, cy, cz, csq, q.x, q.y, q.z, q.w);
-                in = !(d > r2);
+        for (int base = 0; base < N && cnt < K; base += 64 * BQ_UNROLL) {
+            bool in[BQ_UNROLL];
+#pragma unroll
+            for (int u = 0; u < BQ_UNROLL; ++u) {
+                const int j = base + u * 64 + lane;
+                in[u] = false;
+                if (j < N) {
+                    float4 q = s_pts[j];
+                    float d = sqdist(cx, cy, cz, csq, q.x, q.y, q.z, q.w);
+                    in[u] = !(d > r2);
+                }
             }
-            unsigned long long m = __ballot(in);
-            if (m) {
-                if (cnt == 0) first = base + __builtin_ctzll(m);
-                int pos = cnt + __popcll(m & lt_mask);
-                if (in && pos < K) o[pos] = j;
-                cnt += __popcll(m);
+#pragma unroll
+            for (int u = 0; u < BQ_UNROLL; ++u) {
+                unsigned long long m = __ballot(in[u]);
+                if (m) {
+                    if (cnt == 0) first = base + u * 64 + __builtin_ctzll(m);
+                    int pos = cnt + __popcll(m & lt_mask);
+                    if (in[u] && pos < K) o[pos] = base + u * 64 + lane;
+                    cnt += __popcll(m);
+                }
             }
         }
         // pad with the first hit (pointnet_util.py:104-106); an empty ball emits N (reference would fault)
-        for (int pos = cnt + lane; pos < K; pos += 64) o[pos] = first;
+        for (int pos = min(cnt, K) + lane; pos < K; pos += 64) o[pos] = first;
     }
 }
 
@@ -232,7 +256,7 @@ template <int NT, int PPT>
 int launch_fps(const float *xyz, int n_clouds, int P, int N, int S, const int32_t *start, int32_t *out,
                hipStream_t st)
 {
-    size_t lds = (size_t)((N * 3 + 1) & ~1) * 4 + 2 * (NT / 64) * 8;
+    size_t lds = (size_t)NT * PPT * 3 * 4 + 2 * (NT / 64) * 8;
     if (lds > 48 * 1024)
         PSG_CHECK_HIP(hipFuncSetAttribute((const void *)fps_kernel<NT, PPT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -36,22 +36,40 @@ struct BwdLayer {
 // accumulator register r of lane half h holds output row (r&3) + 8*(r>>2) + 4*h of the 32x32 tile
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-template <int LDP>
+// One 32x32 output tile: acc += sum_k A[.,k] B[k,.].  Weights stream from global/L2 with PF packed
+// float4 chunks in flight per lane (an L2 hit costs ~500 cycles, one chunk feeds 4 MFMAs = 256 cycles
+// of matrix pipe, so PF = 4 covers the latency with one wave and leaves slack with two per SIMD).
+// FLIP swaps the MFMA operands: D[point][channel] instead of D[channel][point].
+template <int LDP, bool FLIP>
 __device__ __forceinline__ f32x16 tile_mac(const float4 *__restrict__ w, int k8n, const float *__restrict__ bptr,
                                            f32x16 acc)
 {
     // w already offset to [mb][0][lane]; bptr = act + h*LDP + pb*32 + (lane&31)
-    float4 a = w[0];
-    for (int k8 = 0; k8 < k8n; ++k8) {
-        float4 an = a;
-        if (k8 + 1 < k8n) an = w[(size_t)(k8 + 1) * 64];
-        const float *bp = bptr + (size_t)k8 * 8 * LDP;
-        float b0 = bp[0], b1 = bp[2 * LDP], b2 = bp[4 * LDP], b3 = bp[6 * LDP];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b2, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b3, acc, 0, 0, 0);
-        a = an;
+    constexpr int PF = 4;
+    float4 buf[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) buf[i] = w[(size_t)min(i, k8n - 1) * 64];
+    for (int k8 = 0; k8 < k8n; k8 += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            if (k8 + i < k8n) {
+                const float4 a = buf[i];
+                buf[i] = w[(size_t)min(k8 + i + PF, k8n - 1) * 64];  // tail re-reads the last chunk (unused)
+                const float *bp = bptr + (size_t)(k8 + i) * 8 * LDP;
+                const float b0 = bp[0], b1 = bp[2 * LDP], b2 = bp[4 * LDP], b3 = bp[6 * LDP];
+                if (FLIP) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b2, a.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b3, a.w, acc, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b3, acc, 0, 0, 0);
+                }
+            }
+        }
     }
     return acc;
 }
@@ -70,7 +88,7 @@ __device__ __forceinline__ void layer_fwd(const FwdLayer &L, const float *__rest
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = L.bias[mb * 32 + acc_row(r, h)];
-        acc = tile_mac<LDP>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, in + h * LDP + pb * 32 + j, acc);
+        acc = tile_mac<LDP, false>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, in + h * LDP + pb * 32 + j, acc);
         unsigned m = 0;
         float *o = out + (size_t)(mb * 32) * LDP + pb * 32 + j;
 #pragma unroll
@@ -101,7 +119,7 @@ __device__ __forceinline__ void layer_bwd(const BwdLayer &L, const float *__rest
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        acc = tile_mac<LDP>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, in + h * LDP + pb * 32 + j, acc);
+        acc = tile_mac<LDP, false>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, in + h * LDP + pb * 32 + j, acc);
         unsigned m = 0xFFFFu;
         if (L.mask) m = L.mask[(wg_linear * ntask + task) * 64 + lane];
         float *o = out + (size_t)(mb * 32) * LDP + pb * 32 + j;

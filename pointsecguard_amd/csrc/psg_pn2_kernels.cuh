@@ -118,20 +118,7 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
         const float bias = a.b3[nb * 32 + jj];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = bias;
-        const float4 *w = a.w3 + (size_t)nb * a.k8_3 * 64 + lane;
-        const float *ap = buf0 + h * LDP + g * 32 + jj;
-        float4 wv = w[0];
-        for (int k8 = 0; k8 < a.k8_3; ++k8) {
-            float4 wn = wv;
-            if (k8 + 1 < a.k8_3) wn = w[(size_t)(k8 + 1) * 64];
-            const float *bp = ap + (size_t)k8 * 8 * LDP;
-            float x0 = bp[0], x1 = bp[2 * LDP], x2 = bp[4 * LDP], x3 = bp[6 * LDP];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, wv.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, wv.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x2, wv.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x3, wv.w, acc, 0, 0, 0);
-            wv = wn;
-        }
+        acc = tile_mac<LDP, true>(a.w3 + (size_t)nb * a.k8_3 * 64 + lane, a.k8_3, buf0 + h * LDP + g * 32 + jj, acc);
         float best = -1.0f;
         int bidx = 0;
 #pragma unroll
