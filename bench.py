@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--concurrency", type=int, default=4,
+                    help="independent attack steps in flight per GPU (one HIP stream + workspace each)")
     args = ap.parse_args()
 
     import torch
@@ -96,7 +98,10 @@ def main():
 
     sd = dict(np.load(os.path.join(ROOT, "tests", "golden", "pn2_weights.npz")))
     model = runtime.PN2Model(runtime.fold_state_dict(sd))
-    ws = runtime.PN2Workspace(BATCH, NPOINT, ITERS)
+    conc = max(1, min(args.concurrency, args.steps))
+    wss = [runtime.PN2Workspace(BATCH, NPOINT, ITERS) for _ in range(conc)]
+    streams = [torch.cuda.Stream() for _ in range(conc)]
+    ws = wss[0]
 
     n_steps = args.steps + args.warmup
     # each rank attacks its own shard of rooms (weak scaling: BATCH rooms per GPU per step)
@@ -111,7 +116,10 @@ def main():
     d_adv = [torch.empty_like(x) for x in d_images]
 
     def step(i):
-        ws.nb_attack(model, d_images[i], d_labels[i], d_starts[i], EPS, ALPHA, ITERS, out=d_adv[i])
+        # steps are independent batches: step i runs on stream i % conc with its own workspace, so
+        # small kernels of one attack overlap with kernels of the others (no cross-step dependency)
+        with torch.cuda.stream(streams[i % conc]):
+            wss[i % conc].nb_attack(model, d_images[i], d_labels[i], d_starts[i], EPS, ALPHA, ITERS, out=d_adv[i])
 
     for i in range(args.warmup):
         step(i)
@@ -157,7 +165,8 @@ def main():
         value = total_rooms / elapsed
         # ---- roofline of the dominant kernel: one extra attack with HIP-event timing of every launch
         ws.prof_enable(True)
-        step(args.warmup)
+        ws.nb_attack(model, d_images[args.warmup], d_labels[args.warmup], d_starts[args.warmup], EPS, ALPHA, ITERS,
+                     out=d_adv[args.warmup])
         torch.cuda.synchronize()
         prof = ws.prof_read()
         ws.prof_enable(False)
@@ -174,7 +183,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "NB non-targeted PGD (eps=0.05, alpha=2/255, 40 iters) on PointNet++ SSG sem_seg, "
                                    "batch=8 rooms x 4096 pts x 9 ch per GPU (BASELINE configs[1])",
-                       "rooms_per_step_per_gpu": BATCH, "weights": "tests/golden/pn2_weights.npz (fitted fixture)",
+                       "rooms_per_step_per_gpu": BATCH, "concurrent_steps_per_gpu": conc, "weights": "tests/golden/pn2_weights.npz (fitted fixture)",
                        "sharding": "rooms sharded by rank, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,

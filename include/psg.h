@@ -103,6 +103,11 @@ size_t psg_pn2_ws_bytes(const psg_pn2_ws *ws);
 int psg_pn2_prof_enable(psg_pn2_ws *ws, int on);
 int psg_pn2_prof_read(psg_pn2_ws *ws, int n_tags, double *total_ms, int *counts);
 
+/* Diagnostics (blocking): copies the in-kernel clock stamps written when the environment variable
+ * PSG_DIAG has bit 256 set -- per workgroup of the fp1+head forward kernel {s_memtime, s_memrealtime} at
+ * entry and exit -- used to report the shader clock the chip holds under this load. */
+int psg_pn2_debug_read(psg_pn2_ws *ws, unsigned long long *host_out, int n_words);
+
 /* Geometry for `n_forward` forwards at once (sample_and_group's FPS + ball query of the four SA
  * levels, and the 3-NN tables of the four FP levels; pointnet_util.py:110-143, :301-307).
  * x0 [batch][n_point][9] point-major rooms (only channels 0:3 are read);

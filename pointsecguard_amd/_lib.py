@@ -33,6 +33,7 @@ SIGNATURES = {
     "psg_pn2_ws_create": (ci, [vp, ci, ci, ci, ctypes.POINTER(vp)]),
     "psg_pn2_ws_destroy": (ci, [vp]),
     "psg_pn2_ws_bytes": (ctypes.c_size_t, [vp]),
+    "psg_pn2_debug_read": (ci, [vp, ctypes.POINTER(ctypes.c_ulonglong), ci]),
     "psg_pn2_prof_enable": (ci, [vp, ci]),
     "psg_pn2_prof_read": (ci, [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     "psg_pn2_plan_build": (ci, [vp, vp, vp, ci, vp]),

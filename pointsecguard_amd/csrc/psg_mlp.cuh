@@ -1,15 +1,21 @@
 // Device building blocks of the fused per-point MLP chains (shared 1x1-conv stacks) on gfx950.
 //
-// Activations of one workgroup's P points live in LDS as act[channel][point] (leading dimension
-// LDP = P+1 floats).  A layer is a sequence of 32x32 output tiles, one MFMA accumulator each:
+// Activations of one workgroup's P points live in LDS in "k8-block" layout
+//     act[c / 8][point][c % 8]        (block stride BLK = P*8 + 8 floats)
+// so that BOTH sides of a layer are 16-byte accesses that are contiguous across the wave:
+//   * MFMA operand read: lane (j = lane&31, h = lane>>5) reads the float4 at [k8][pb*32+j][4h..4h+3]
+//     (one ds_read_b128 feeds 4 MFMAs; the 64 lanes cover 1 KiB contiguous -> conflict free);
+//   * accumulator write-back: registers 4g..4g+3 of lane (j,h) are channels mb*32 + 8g + 4h + (0..3)
+//     of point j, i.e. one ds_write_b128 at [mb*4+g][pb*32+j][4h] (again 1 KiB contiguous per wave).
+// The extra 8 floats per block de-phase consecutive blocks by 8 banks so that row-wise epilogue reads
+// (lane = channel) are conflict free too.
+//
+// A layer is a sequence of 32x32 output tiles, one MFMA accumulator each:
 //     D[m = out channel][n = point] += A[m][k] * B[k][n]       v_mfma_f32_32x32x2_f32
 // A = weights, pre-packed on the host so that a wave reads one coalesced float4 per lane per four
-// MFMAs; B = the activation tile, one conflict-free ds_read_b32 per MFMA.  fp32 in / fp32
-// accumulate: the matrix pipe computes an exact fmaf chain, so results match a CPU fp32 GEMM to
-// rounding (no reduced-precision path exists or is wanted on this path).
-//
-// k-ordering inside an 8-wide k chunk: MFMA step t (0..3) consumes k = 8*k8 + 2*t + h from lane
-// half h, for A and B alike (any consistent k permutation is a valid dot product).
+// MFMAs (k = 8*k8 + 4*h + t for MFMA step t, matching the activation read above; any consistent k
+// permutation is a valid dot product).  fp32 in / fp32 accumulate: the matrix pipe computes an exact
+// fmaf chain, so results match a CPU fp32 GEMM to rounding (no reduced-precision path on this path).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,57 +27,230 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int MAX_LAYERS = 5;
 
 struct FwdLayer {
-    const float4 *w;    // packed [mb][k8][64] float4: lane (i,h) elem t = W[mb*32+i][8*k8+2*t+h]
+    const float4 *w;    // packed [mb][k8][64] float4: lane (i,h) elem t = W[mb*32+i][col(8*k8+4*h+t)]
     const float *bias;  // [mb*32], zero padded
     uint16_t *mask;     // ReLU mask out, [wg][mb][pb][64] (bit r of a lane = its accumulator r > 0), or null
     int k8, mb, relu;
 };
 
 struct BwdLayer {
-    const float4 *w;       // packed transpose: lane (i,h) elem t = W[8*k8+2*t+h][mb*32+i]
+    const float4 *w;       // packed transpose: lane (i,h) elem t = W[8*k8+4*h+t][col(mb*32+i)]
     const uint16_t *mask;  // mask of the activation this layer's OUTPUT is the gradient of, or null
     int k8, mb;
+};
+
+template <int P> struct Lds {
+    static constexpr int BLK = P * 8 + 8;  // floats per 8-channel block
+    __device__ static __forceinline__ int off(int c, int p) { return (c >> 3) * BLK + p * 8 + (c & 7); }
 };
 
 // accumulator register r of lane half h holds output row (r&3) + 8*(r>>2) + 4*h of the 32x32 tile
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// One 32x32 output tile: acc += sum_k A[.,k] B[k,.].  Weights stream from global/L2 with PF packed
-// float4 chunks in flight per lane (an L2 hit costs ~500 cycles, one chunk feeds 4 MFMAs = 256 cycles
-// of matrix pipe, so PF = 4 covers the latency with one wave and leaves slack with two per SIMD).
+template <bool FLIP>
+__device__ __forceinline__ f32x16 mfma4(const float4 a, const float4 b, f32x16 acc)
+{
+    if (FLIP) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// One 32x32 output tile: acc += sum_k A[.,k] B[k,.].  k8n is a multiple of 4 (K padded to 32 on the host,
+// pad rows of the activation block are zero).
+//
+// The k-loop is hand-scheduled in inline assembly.  hipcc cannot express this pipeline: left to itself it
+// sinks every weight re-load to just before its use, and with the order pinned by sched_barrier it still
+// drains vmcnt(0) at the loop head (its wait-count pass does not carry counted loads across the back
+// edge).  Steady state per iteration (16 MFMAs = 1024 matrix-pipe cycles):
+//   * four weight chunks (global_load_dwordx4, 1 KiB per wave) live in a static ring v[A0..A3]; a chunk
+//     is re-loaded right after its last use and waited for with a COUNTED s_waitcnt vmcnt(3), i.e. it
+//     has three younger loads and ~1000 cycles of MFMA behind it when it is needed;
+//   * the activation chunk (ds_read_b128) is fetched one step ahead (lgkmcnt(1)).
+// The last four chunks run in a peeled pass without re-loads, so nothing is fetched past the tile.  Fixed VGPRs v[64:87] are used for the operand ring and
+// declared as clobbers (keeps the kernels at <= 128 VGPRs = 4 waves per SIMD).
 // FLIP swaps the MFMA operands: D[point][channel] instead of D[channel][point].
-template <int LDP, bool FLIP>
+#ifdef PSG_DIAG_NOLOAD  // timing experiment only: the k-loop re-uses the first four weight chunks
+#define PSG_RELOAD(x) ""
+#else
+#define PSG_RELOAD(x) x
+#endif
+template <int BLK, bool FLIP>
 __device__ __forceinline__ f32x16 tile_mac(const float4 *__restrict__ w, int k8n, const float *__restrict__ bptr,
                                            f32x16 acc)
 {
-    // w already offset to [mb][0][lane]; bptr = act + h*LDP + pb*32 + (lane&31)
-    constexpr int PF = 4;
-    float4 buf[PF];
-#pragma unroll
-    for (int i = 0; i < PF; ++i) buf[i] = w[(size_t)min(i, k8n - 1) * 64];
-    for (int k8 = 0; k8 < k8n; k8 += PF) {
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            if (k8 + i < k8n) {
-                const float4 a = buf[i];
-                buf[i] = w[(size_t)min(k8 + i + PF, k8n - 1) * 64];  // tail re-reads the last chunk (unused)
-                const float *bp = bptr + (size_t)(k8 + i) * 8 * LDP;
-                const float b0 = bp[0], b1 = bp[2 * LDP], b2 = bp[4 * LDP], b3 = bp[6 * LDP];
-                if (FLIP) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b2, a.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b3, a.w, acc, 0, 0, 0);
-                } else {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b2, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b3, acc, 0, 0, 0);
-                }
-            }
-        }
+    // w already offset to [mb][0][lane]; bptr = act + (pb*32 + (lane&31))*8 + 4*(lane>>5)
+    unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)bptr;
+    const float4 *wp = w;
+    int n = (k8n >> 2) - 1;  // pipelined iterations; the last 4 chunks run without re-loads
+    const unsigned long long step = 4096ull;  // 4 chunks x 64 lanes x 16 B
+    constexpr int S1 = BLK * 4, S2 = 2 * BLK * 4, S3 = 3 * BLK * 4, S4 = 4 * BLK * 4;
+    if (FLIP) {
+        asm volatile(
+            "global_load_dwordx4 v[64:67], %[wp], off\n\t"
+            "global_load_dwordx4 v[68:71], %[wp], off offset:1024\n\t"
+            "global_load_dwordx4 v[72:75], %[wp], off offset:2048\n\t"
+            "global_load_dwordx4 v[76:79], %[wp], off offset:3072\n\t"
+            "ds_read_b128 v[80:83], %[lds]\n\t"
+            "s_cmp_eq_u32 %[n], 0\n\t"
+            "s_cbranch_scc1 L_psg_last_%=\n\t"
+            "L_psg_loop_%=:\n\t"
+            "v_lshl_add_u64 %[wp], %[wp], 0, %[step]\n\t"
+            "ds_read_b128 v[84:87], %[lds] offset:%[s1]\n\t"
+            "s_waitcnt vmcnt(3) lgkmcnt(1)\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v80, v64, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v81, v65, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v82, v66, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v83, v67, %[acc]\n\t"
+            PSG_RELOAD("global_load_dwordx4 v[64:67], %[wp], off\n\t")
+            "ds_read_b128 v[80:83], %[lds] offset:%[s2]\n\t"
+            "s_waitcnt vmcnt(3) lgkmcnt(1)\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v84, v68, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v85, v69, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v86, v70, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v87, v71, %[acc]\n\t"
+            PSG_RELOAD("global_load_dwordx4 v[68:71], %[wp], off offset:1024\n\t")
+            "ds_read_b128 v[84:87], %[lds] offset:%[s3]\n\t"
+            "s_waitcnt vmcnt(3) lgkmcnt(1)\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v80, v72, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v81, v73, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v82, v74, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v83, v75, %[acc]\n\t"
+            PSG_RELOAD("global_load_dwordx4 v[72:75], %[wp], off offset:2048\n\t")
+            "ds_read_b128 v[80:83], %[lds] offset:%[s4]\n\t"
+            "s_waitcnt vmcnt(3) lgkmcnt(1)\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v84, v76, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v85, v77, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v86, v78, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v87, v79, %[acc]\n\t"
+            PSG_RELOAD("global_load_dwordx4 v[76:79], %[wp], off offset:3072\n\t")
+            "v_add_u32 %[lds], %[s4], %[lds]\n\t"
+            "s_sub_u32 %[n], %[n], 1\n\t"
+            "s_cmp_lg_u32 %[n], 0\n\t"
+            "s_cbranch_scc1 L_psg_loop_%=\n\t"
+            "L_psg_last_%=:\n\t"
+            "ds_read_b128 v[84:87], %[lds] offset:%[s1]\n\t"
+            "s_waitcnt vmcnt(3) lgkmcnt(1)\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v80, v64, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v81, v65, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v82, v66, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v83, v67, %[acc]\n\t"
+            "ds_read_b128 v[80:83], %[lds] offset:%[s2]\n\t"
+            "s_waitcnt vmcnt(2) lgkmcnt(1)\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v84, v68, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v85, v69, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v86, v70, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v87, v71, %[acc]\n\t"
+            "ds_read_b128 v[84:87], %[lds] offset:%[s3]\n\t"
+            "s_waitcnt vmcnt(1) lgkmcnt(1)\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v80, v72, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v81, v73, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v82, v74, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v83, v75, %[acc]\n\t"
+            "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v84, v76, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v85, v77, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v86, v78, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v87, v79, %[acc]\n\t"
+            "s_nop 15\n\t"
+            "s_nop 3\n\t"
+            : [acc] "+a"(acc), [wp] "+v"(wp), [lds] "+v"(lds), [n] "+s"(n)
+            : [step] "s"(step), [s1] "n"(S1), [s2] "n"(S2), [s3] "n"(S3), [s4] "n"(S4)
+            : "memory", "scc", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
+              "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87");
+    } else {
+        asm volatile(
+            "global_load_dwordx4 v[64:67], %[wp], off\n\t"
+            "global_load_dwordx4 v[68:71], %[wp], off offset:1024\n\t"
+            "global_load_dwordx4 v[72:75], %[wp], off offset:2048\n\t"
+            "global_load_dwordx4 v[76:79], %[wp], off offset:3072\n\t"
+            "ds_read_b128 v[80:83], %[lds]\n\t"
+            "s_cmp_eq_u32 %[n], 0\n\t"
+            "s_cbranch_scc1 L_psg_last_%=\n\t"
+            "L_psg_loop_%=:\n\t"
+            "v_lshl_add_u64 %[wp], %[wp], 0, %[step]\n\t"
+            "ds_read_b128 v[84:87], %[lds] offset:%[s1]\n\t"
+            "s_waitcnt vmcnt(3) lgkmcnt(1)\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v64, v80, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v65, v81, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v66, v82, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v67, v83, %[acc]\n\t"
+            PSG_RELOAD("global_load_dwordx4 v[64:67], %[wp], off\n\t")
+            "ds_read_b128 v[80:83], %[lds] offset:%[s2]\n\t"
+            "s_waitcnt vmcnt(3) lgkmcnt(1)\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v68, v84, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v69, v85, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v70, v86, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v71, v87, %[acc]\n\t"
+            PSG_RELOAD("global_load_dwordx4 v[68:71], %[wp], off offset:1024\n\t")
+            "ds_read_b128 v[84:87], %[lds] offset:%[s3]\n\t"
+            "s_waitcnt vmcnt(3) lgkmcnt(1)\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v72, v80, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v73, v81, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v74, v82, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v75, v83, %[acc]\n\t"
+            PSG_RELOAD("global_load_dwordx4 v[72:75], %[wp], off offset:2048\n\t")
+            "ds_read_b128 v[80:83], %[lds] offset:%[s4]\n\t"
+            "s_waitcnt vmcnt(3) lgkmcnt(1)\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v76, v84, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v77, v85, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v78, v86, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v79, v87, %[acc]\n\t"
+            PSG_RELOAD("global_load_dwordx4 v[76:79], %[wp], off offset:3072\n\t")
+            "v_add_u32 %[lds], %[s4], %[lds]\n\t"
+            "s_sub_u32 %[n], %[n], 1\n\t"
+            "s_cmp_lg_u32 %[n], 0\n\t"
+            "s_cbranch_scc1 L_psg_loop_%=\n\t"
+            "L_psg_last_%=:\n\t"
+            "ds_read_b128 v[84:87], %[lds] offset:%[s1]\n\t"
+            "s_waitcnt vmcnt(3) lgkmcnt(1)\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v64, v80, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v65, v81, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v66, v82, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v67, v83, %[acc]\n\t"
+            "ds_read_b128 v[80:83], %[lds] offset:%[s2]\n\t"
+            "s_waitcnt vmcnt(2) lgkmcnt(1)\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v68, v84, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v69, v85, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v70, v86, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v71, v87, %[acc]\n\t"
+            "ds_read_b128 v[84:87], %[lds] offset:%[s3]\n\t"
+            "s_waitcnt vmcnt(1) lgkmcnt(1)\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v72, v80, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v73, v81, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v74, v82, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v75, v83, %[acc]\n\t"
+            "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v76, v84, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v77, v85, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v78, v86, %[acc]\n\t"
+            "v_mfma_f32_32x32x2_f32 %[acc], v79, v87, %[acc]\n\t"
+            "s_nop 15\n\t"
+            "s_nop 3\n\t"
+            : [acc] "+a"(acc), [wp] "+v"(wp), [lds] "+v"(lds), [n] "+s"(n)
+            : [step] "s"(step), [s1] "n"(S1), [s2] "n"(S2), [s3] "n"(S3), [s4] "n"(S4)
+            : "memory", "scc", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
+              "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87");
     }
     return acc;
+}
+
+// write a D[channel][point] accumulator tile back to LDS: 4 x ds_write_b128 per lane
+template <int P>
+__device__ __forceinline__ void store_tile(float *__restrict__ out, int mb, int pcol, int h, const f32x16 &v)
+{
+    float *o = out + (size_t)(mb * 4) * Lds<P>::BLK + pcol * 8 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *(float4 *)(o + (size_t)g * Lds<P>::BLK) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 }
 
 // Forward layer: out[m][p] = act(W in[:, p] + b).  Tiles (mb x P/32) are dealt round-robin to waves.
@@ -79,29 +258,34 @@ template <int P, int NW>
 __device__ __forceinline__ void layer_fwd(const FwdLayer &L, const float *__restrict__ in, float *__restrict__ out,
                                           size_t wg_linear)
 {
-    constexpr int LDP = P + 1, PB = P / 32;
+    constexpr int PB = P / 32, BLK = Lds<P>::BLK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int ntask = L.mb * PB;
     for (int task = wave; task < ntask; task += NW) {
         const int mb = task / PB, pb = task - mb * PB;
+        // bias: 4 x float4 issued before the k-loop, consumed after it (latency hidden behind the MFMAs)
+        const float4 *bp = (const float4 *)(L.bias + mb * 32 + 4 * h);
+        const float4 bq0 = bp[0], bq1 = bp[2], bq2 = bp[4], bq3 = bp[6];
         f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = L.bias[mb * 32 + acc_row(r, h)];
-        acc = tile_mac<LDP, false>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, in + h * LDP + pb * 32 + j, acc);
-        unsigned m = 0;
-        float *o = out + (size_t)(mb * 32) * LDP + pb * 32 + j;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        acc = tile_mac<BLK, false>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, in + (pb * 32 + j) * 8 + 4 * h, acc);
+        acc[0] += bq0.x; acc[1] += bq0.y; acc[2] += bq0.z; acc[3] += bq0.w;
+        acc[4] += bq1.x; acc[5] += bq1.y; acc[6] += bq1.z; acc[7] += bq1.w;
+        acc[8] += bq2.x; acc[9] += bq2.y; acc[10] += bq2.z; acc[11] += bq2.w;
+        acc[12] += bq3.x; acc[13] += bq3.y; acc[14] += bq3.z; acc[15] += bq3.w;
+        if (L.relu) {
+            unsigned m = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = acc[r];
-            if (L.relu) {
-                bool pos = v > 0.0f;
-                v = pos ? v : 0.0f;
+            for (int r = 0; r < 16; ++r) {
+                const bool pos = acc[r] > 0.0f;
+                acc[r] = pos ? acc[r] : 0.0f;
                 m |= (unsigned)pos << r;
             }
-            o[acc_row(r, h) * LDP] = v;
+            if (L.mask) L.mask[(wg_linear * ntask + task) * 64 + lane] = (uint16_t)m;
         }
-        if (L.mask) L.mask[(wg_linear * ntask + task) * 64 + lane] = (uint16_t)m;
+        store_tile<P>(out, mb, pb * 32 + j, h, acc);
     }
 }
 
@@ -110,21 +294,21 @@ template <int P, int NW>
 __device__ __forceinline__ void layer_bwd(const BwdLayer &L, const float *__restrict__ in, float *__restrict__ out,
                                           size_t wg_linear)
 {
-    constexpr int LDP = P + 1, PB = P / 32;
+    constexpr int PB = P / 32, BLK = Lds<P>::BLK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int ntask = L.mb * PB;
     for (int task = wave; task < ntask; task += NW) {
         const int mb = task / PB, pb = task - mb * PB;
+        unsigned m = 0xFFFFu;
+        if (L.mask) m = L.mask[(wg_linear * ntask + task) * 64 + lane];
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        acc = tile_mac<LDP, false>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, in + h * LDP + pb * 32 + j, acc);
-        unsigned m = 0xFFFFu;
-        if (L.mask) m = L.mask[(wg_linear * ntask + task) * 64 + lane];
-        float *o = out + (size_t)(mb * 32) * LDP + pb * 32 + j;
+        acc = tile_mac<BLK, false>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, in + (pb * 32 + j) * 8 + 4 * h, acc);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[acc_row(r, h) * LDP] = ((m >> r) & 1u) ? acc[r] : 0.0f;
+        for (int r = 0; r < 16; ++r) acc[r] = ((m >> r) & 1u) ? acc[r] : 0.0f;
+        store_tile<P>(out, mb, pb * 32 + j, h, acc);
     }
 }
 

@@ -8,6 +8,9 @@
 //   fp4 768->256,256   fp3 384->256,256    fp2 320->256,128    fp1 128->128,128,128
 //   conv1 128->128 (+bn1, ReLU, eval dropout = id), conv2 128->13, log_softmax
 #include <algorithm>
+#include <cstdlib>
+#include <mutex>
+#include <unordered_set>
 #include <vector>
 
 #include "psg_common.h"
@@ -36,9 +39,10 @@ struct PackedLayer {
     float4 *wb = nullptr;  // transposed packing [mb(cin)][k8(cout)][64]
     float *bias = nullptr; // [mb(cout)*32]
     int cin = 0, cout = 0;
-    int k8f() const { return ceil_div(cin, 8); }
+    // K is padded to a multiple of 32 (k8 multiple of 4: the MFMA loop is unrolled by 4 chunks)
+    int k8f() const { return round_up(ceil_div(cin, 8), 4); }
     int mbf() const { return ceil_div(cout, 32); }
-    int k8b() const { return ceil_div(cout, 8); }
+    int k8b() const { return round_up(ceil_div(cout, 8), 4); }
     int mbb() const { return ceil_div(cin, 32); }
 };
 
@@ -76,6 +80,7 @@ struct psg_pn2_ws {
     float *dx0;           // [B][N][9]
     // attack state
     float *x0, *ori;      // [B][N][9], [B][N][3]
+    unsigned long long *dbg;  // diagnostics scratch (PSG_DIAG=256), 4 words per workgroup
     int fwd_slot = -1;
     // optional per-launch HIP-event timing (psg_pn2_prof_enable); off in normal operation
     bool prof_on = false;
@@ -86,30 +91,42 @@ struct psg_pn2_ws {
 
 namespace {
 
-std::vector<float> pack_fwd(const float *w, int cin, int cout)
+// `perm` maps the packed (LDS-order) input-channel index to the reference's column: LDS order of an SA
+// module's grouped input is [feats(D), rel_xyz(3)], the reference concatenates [rel_xyz, feats].
+std::vector<int> sa_input_perm(int cin)
 {
-    const int k8 = ceil_div(cin, 8), mb = ceil_div(cout, 32);
-    std::vector<float> out((size_t)mb * k8 * 64 * 4, 0.0f);
+    std::vector<int> perm(cin);
+    const int D = cin - 3;
+    for (int c = 0; c < cin; ++c) perm[c] = c < D ? 3 + c : c - D;
+    return perm;
+}
+
+std::vector<float> pack_fwd(const float *w, int cin, int cout, const std::vector<int> *perm)
+{
+    const int k8 = round_up(ceil_div(cin, 8), 4), mb = ceil_div(cout, 32);
+    std::vector<float> out(((size_t)mb * k8 + 4) * 64 * 4, 0.0f);  // + 4 chunks: prefetch over-read slack
     for (int m = 0; m < mb; ++m)
         for (int k = 0; k < k8; ++k)
             for (int lane = 0; lane < 64; ++lane)
                 for (int t = 0; t < 4; ++t) {
-                    int o = m * 32 + (lane & 31), c = 8 * k + 2 * t + (lane >> 5);
-                    if (o < cout && c < cin) out[(((size_t)m * k8 + k) * 64 + lane) * 4 + t] = w[(size_t)o * cin + c];
+                    int o = m * 32 + (lane & 31), c = 8 * k + 4 * (lane >> 5) + t;
+                    if (o < cout && c < cin)
+                        out[(((size_t)m * k8 + k) * 64 + lane) * 4 + t] = w[(size_t)o * cin + (perm ? (*perm)[c] : c)];
                 }
     return out;
 }
 
-std::vector<float> pack_bwd(const float *w, int cin, int cout)
+std::vector<float> pack_bwd(const float *w, int cin, int cout, const std::vector<int> *perm)
 {
-    const int k8 = ceil_div(cout, 8), mb = ceil_div(cin, 32);
-    std::vector<float> out((size_t)mb * k8 * 64 * 4, 0.0f);
+    const int k8 = round_up(ceil_div(cout, 8), 4), mb = ceil_div(cin, 32);
+    std::vector<float> out(((size_t)mb * k8 + 4) * 64 * 4, 0.0f);  // + 4 chunks: prefetch over-read slack
     for (int m = 0; m < mb; ++m)
         for (int k = 0; k < k8; ++k)
             for (int lane = 0; lane < 64; ++lane)
                 for (int t = 0; t < 4; ++t) {
-                    int c = m * 32 + (lane & 31), o = 8 * k + 2 * t + (lane >> 5);
-                    if (o < cout && c < cin) out[(((size_t)m * k8 + k) * 64 + lane) * 4 + t] = w[(size_t)o * cin + c];
+                    int c = m * 32 + (lane & 31), o = 8 * k + 4 * (lane >> 5) + t;
+                    if (o < cout && c < cin)
+                        out[(((size_t)m * k8 + k) * 64 + lane) * 4 + t] = w[(size_t)o * cin + (perm ? (*perm)[c] : c)];
                 }
     return out;
 }
@@ -169,14 +186,25 @@ struct ProfScope {
     }
 };
 
+// opt a kernel into the full 160 KiB of dynamic LDS once (not per launch)
+hipError_t allow_big_lds(const void *kern)
+{
+    static std::mutex mu;
+    static std::unordered_set<const void *> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(kern)) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done.insert(kern);
+    return e;
+}
+
 template <typename KernelT, typename ArgsT>
-int launch_lds(psg_pn2_ws *ws, int tag, KernelT kern, dim3 grid, int threads, int rows, int ldp, const ArgsT &args,
+int launch_lds(psg_pn2_ws *ws, int tag, KernelT kern, dim3 grid, int threads, int blocks8, int blk, const ArgsT &args,
                hipStream_t st)
 {
-    size_t lds = (size_t)rows * ldp * sizeof(float);
+    size_t lds = (size_t)blocks8 * blk * sizeof(float);
     if (lds > 160 * 1024) { set_error("LDS request %zu exceeds 160 KiB", lds); return PSG_ERR_ARG; }
-    if (lds > 48 * 1024)
-        PSG_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 48 * 1024) PSG_CHECK_HIP(allow_big_lds((const void *)kern));
     ProfScope prof(ws, tag, st);
     hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, args);
     PSG_LAUNCH_CHECK();
@@ -190,7 +218,7 @@ template <> struct SaCfg<1> { static constexpr int P = 64, NW = 4; };
 template <> struct SaCfg<2> { static constexpr int P = 32, NW = 4; };
 template <> struct SaCfg<3> { static constexpr int P = 32, NW = 8; };
 template <int LVL> struct FpCfg { static constexpr int P = 32, NW = 8; };
-template <> struct FpCfg<0> { static constexpr int P = 64, NW = 8; };
+template <> struct FpCfg<0> { static constexpr int P = 32, NW = 4; };
 
 template <int LVL>
 int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *x0, hipStream_t st)
@@ -211,9 +239,10 @@ int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *x0, hipSt
     a.l2 = fwd_layer(L[1], true, ws->mask[3 * LVL + 1]);
     a.w3 = L[2].wf; a.b3 = L[2].bias; a.k8_3 = L[2].k8f(); a.nb3 = L[2].mbf();
     a.D = D; a.Np = Np; a.S = S; a.C3 = L[2].cout;
-    a.rows0 = std::max(a.l1.k8 * 8, a.l2.mb * 32);
-    a.rows1 = a.l1.mb * 32;
-    return launch_lds(ws, TAG_SA_FWD + LVL, sa_fwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, a.rows0 + a.rows1, P + 1, a, st);
+    a.rows0 = std::max(a.l1.k8, a.l2.mb * 4) + 1;   // + 1 spare block: the operand prefetch runs one chunk ahead
+    a.rows1 = std::max(a.l1.mb * 4, a.l2.k8) + 1;
+    return launch_lds(ws, TAG_SA_FWD + LVL, sa_fwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, a.rows0 + a.rows1,
+                      Lds<P>::BLK, a, st);
 }
 
 template <int LVL>
@@ -233,9 +262,10 @@ int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *dx0, int c_lo, 
     a.l1t = bwd_layer(L[0], nullptr);
     a.D = D; a.Np = Np; a.S = S; a.C3 = L[2].cout;
     a.c_lo = c_lo; a.c_hi = c_hi;
-    a.rows0 = std::max(a.C3, a.l2t.mb * 32);
-    a.rows1 = std::max(a.l3t.mb * 32, a.l1t.mb * 32);
-    return launch_lds(ws, TAG_SA_BWD + LVL, sa_bwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, a.rows0 + a.rows1, P + 1, a, st);
+    a.rows0 = std::max(std::max(a.l3t.k8, a.l2t.mb * 4), a.l1t.k8) + 1;
+    a.rows1 = std::max(std::max(a.l3t.mb * 4, a.l1t.mb * 4), a.l2t.k8) + 1;
+    return launch_lds(ws, TAG_SA_BWD + LVL, sa_bwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, a.rows0 + a.rows1,
+                      Lds<P>::BLK, a, st);
 }
 
 // FP module `LVL` (0 = fp1 ... 3 = fp4) upsamples level LVL+1 -> level LVL.
@@ -276,12 +306,21 @@ int run_fp_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *logp, hipStream
         a.Cout = m->L[kFpFirst[LVL] + nl - 1].cout;
     }
     a.n_layers = nl;
-    a.rows0 = a.layer[0].k8 * 8; a.rows1 = 0;
+    static const int diag = getenv("PSG_DIAG") ? atoi(getenv("PSG_DIAG")) : 0;
+    a.diag = diag;
+    a.dbg = ws->dbg;
+    if (diag & 2) for (int i = 0; i < nl; ++i) a.layer[i].mask = nullptr;
+    if (diag & 64) for (int i = 0; i < nl; ++i) a.layer[i].k8 = 4;    // timing only: 1/4 .. 1/24 of the MFMAs
+    if (diag & 128) for (int i = 0; i < nl; ++i) a.layer[i].relu = 0; // timing only: no ReLU/mask epilogue
+    a.rows0 = a.layer[0].k8; a.rows1 = 0;
     for (int i = 0; i < nl; ++i) {
-        int rows = a.layer[i].mb * 32;
+        int rows = a.layer[i].mb * 4;
+        if (i + 1 < nl) rows = std::max(rows, a.layer[i + 1].k8);
         if (i & 1) a.rows0 = std::max(a.rows0, rows); else a.rows1 = std::max(a.rows1, rows);
     }
-    return launch_lds(ws, TAG_FP_FWD + LVL, fp_fwd_kernel<P, NW>, dim3(N / P, B), NW * 64, a.rows0 + a.rows1, P + 1, a, st);
+    a.rows0 += 1; a.rows1 += 1;
+    return launch_lds(ws, TAG_FP_FWD + LVL, fp_fwd_kernel<P, NW>, dim3(N / P, B), NW * 64, a.rows0 + a.rows1,
+                      Lds<P>::BLK, a, st);
 }
 
 template <int LVL>
@@ -315,13 +354,16 @@ int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, con
     for (int i = cnt - 1; i >= 0; --i)
         a.layer[nl++] = bwd_layer(m->L[first + i], i > 0 ? ws->mask[first + i - 1] : nullptr);
     a.n_layers = nl;
-    a.rows0 = LVL == 0 ? a.layer[0].k8 * 8 : a.mb_last * 32;
+    a.rows0 = std::max(a.layer[0].k8, a.mb_last * 4);
     a.rows1 = 0;
     for (int i = 0; i < nl; ++i) {
-        int rows = a.layer[i].mb * 32;
+        int rows = a.layer[i].mb * 4;
+        if (i + 1 < nl) rows = std::max(rows, a.layer[i + 1].k8);
         if (i & 1) a.rows0 = std::max(a.rows0, rows); else a.rows1 = std::max(a.rows1, rows);
     }
-    return launch_lds(ws, TAG_FP_BWD + LVL, fp_bwd_kernel<P, NW>, dim3(N / P, B), NW * 64, a.rows0 + a.rows1, P + 1, a, st);
+    a.rows0 += 1; a.rows1 += 1;
+    return launch_lds(ws, TAG_FP_BWD + LVL, fp_bwd_kernel<P, NW>, dim3(N / P, B), NW * 64, a.rows0 + a.rows1,
+                      Lds<P>::BLK, a, st);
 }
 
 __global__ void extract_xyz_kernel(const float *__restrict__ x0, float *__restrict__ xyz, size_t rows)
@@ -383,6 +425,7 @@ size_t ws_layout(psg_pn2_ws *ws, char *base)
     ws->gzero_bytes = bp.off - g0;
     ws->x0 = bp.take<float>((size_t)B * ws->N * 9);
     ws->ori = bp.take<float>((size_t)B * ws->N * 3);
+    ws->dbg = bp.take<unsigned long long>(16 * 8192);
     return (bp.off + 255) & ~(size_t)255;
 }
 
@@ -400,8 +443,11 @@ extern "C" int psg_pn2_model_create(psg_ctx *ctx, const float *const *weights, c
     size_t total = 0;
     for (int i = 0; i < kNumReal; ++i) {
         if (!weights[i] || !biases[i]) { delete m; set_error("psg_pn2_model_create: layer %d is null", i); return PSG_ERR_ARG; }
-        wf[i] = pack_fwd(weights[i], kCin[i], kCout[i]);
-        wb[i] = pack_bwd(weights[i], kCin[i], kCout[i]);
+        std::vector<int> perm;
+        const bool sa_first = i < 12 && i % 3 == 0;
+        if (sa_first) perm = sa_input_perm(kCin[i]);
+        wf[i] = pack_fwd(weights[i], kCin[i], kCout[i], sa_first ? &perm : nullptr);
+        wb[i] = pack_bwd(weights[i], kCin[i], kCout[i], sa_first ? &perm : nullptr);
         bs[i].assign((size_t)ceil_div(kCout[i], 32) * 32, 0.0f);
         std::copy(biases[i], biases[i] + kCout[i], bs[i].begin());
         total += ((wf[i].size() + wb[i].size() + bs[i].size()) * 4 + 3 * 256);
@@ -465,6 +511,13 @@ extern "C" int psg_pn2_ws_destroy(psg_pn2_ws *ws)
 }
 
 extern "C" size_t psg_pn2_ws_bytes(const psg_pn2_ws *ws) { return ws ? ws->bytes : 0; }
+
+extern "C" int psg_pn2_debug_read(psg_pn2_ws *ws, unsigned long long *host_out, int n_words)
+{
+    PSG_REQUIRE(ws && host_out && n_words > 0 && n_words <= 16 * 8192, "psg_pn2_debug_read: bad argument");
+    PSG_CHECK_HIP(hipMemcpy(host_out, ws->dbg, (size_t)n_words * 8, hipMemcpyDeviceToHost));
+    return PSG_OK;
+}
 
 extern "C" int psg_pn2_prof_enable(psg_pn2_ws *ws, int on)
 {
@@ -593,9 +646,9 @@ static int backward_impl(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float 
     if ((rc = run_fp_bwd<1>(m, ws, fwd, nullptr, nullptr, st))) return rc;
     if ((rc = run_fp_bwd<2>(m, ws, fwd, nullptr, nullptr, st))) return rc;
     if ((rc = run_fp_bwd<3>(m, ws, fwd, nullptr, nullptr, st))) return rc;
-    if ((rc = run_sa_bwd<3>(m, ws, fwd, dx0, 3, 3 + kSaC[3], st))) return rc;
-    if ((rc = run_sa_bwd<2>(m, ws, fwd, dx0, 3, 3 + kSaC[2], st))) return rc;
-    if ((rc = run_sa_bwd<1>(m, ws, fwd, dx0, 3, 3 + kSaC[1], st))) return rc;
+    if ((rc = run_sa_bwd<3>(m, ws, fwd, dx0, 0, kSaC[3], st))) return rc;
+    if ((rc = run_sa_bwd<2>(m, ws, fwd, dx0, 0, kSaC[2], st))) return rc;
+    if ((rc = run_sa_bwd<1>(m, ws, fwd, dx0, 0, kSaC[1], st))) return rc;
     if ((rc = run_sa_bwd<0>(m, ws, fwd, dx0, c_lo, c_hi, st))) return rc;
     return PSG_OK;
 }
@@ -609,7 +662,7 @@ extern "C" int psg_pn2_backward(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const
         return PSG_ERR_STATE;
     }
     // the log_softmax backward reads the log-probs of the resident forward, kept in ws->logp
-    return backward_impl(m, ws, fwd, ws->logp, dlogp, dx0_out, 3, 12, (hipStream_t)stream);
+    return backward_impl(m, ws, fwd, ws->logp, dlogp, dx0_out, 0, 9, (hipStream_t)stream);
 }
 
 // ====================================================================================== NB attack
@@ -638,7 +691,7 @@ extern "C" int psg_pn2_nb_attack(psg_pn2_model *m, psg_pn2_ws *ws, const float *
                                        1.0f / (float)N, ws->dlogp, nullptr, st)))
                 return rc;
         }
-        if ((rc = backward_impl(m, ws, it, ws->logp, ws->dlogp, ws->dx0, 6, 9, st))) return rc;
+        if ((rc = backward_impl(m, ws, it, ws->logp, ws->dlogp, ws->dx0, 3, 6, st))) return rc;
         {
             ProfScope prof(ws, TAG_PGD, st);
             if ((rc = psg_pgd_step(ws->x0, ws->dx0, ws->ori, mask, B, N, alpha, eps, targeted ? -1.0f : 1.0f,

@@ -26,7 +26,7 @@ struct SaFwdArgs {
     const float *b3;
     int k8_3, nb3;
     int xyz_stride, D, Np, S, C3;
-    int rows0, rows1;
+    int rows0, rows1;      // LDS buffer sizes in 8-channel blocks
 };
 
 struct SaBwdArgs {
@@ -36,7 +36,7 @@ struct SaBwdArgs {
     float *dfeat;         // [B][Np][D]  (atomicAdd)
     BwdLayer l3t, l2t, l1t;
     int D, Np, S, C3;
-    int c_lo, c_hi;       // grouped-row channels [c_lo, c_hi) are scattered to feature c-3
+    int c_lo, c_hi;       // feature channels [c_lo, c_hi) of the grouped-input gradient are scattered
     int rows0, rows1;
 };
 
@@ -51,6 +51,8 @@ struct FpFwdArgs {
     int n_layers;
     int C1, C2, N, S, Cout, n_cls;
     int rows0, rows1;
+    int diag;               // timing diagnostics only (PSG_DIAG env): skip sections, results are then wrong
+    unsigned long long *dbg; // diag & 256: per-workgroup {memtime, memrealtime} at entry and exit
 };
 
 struct FpBwdArgs {
@@ -69,39 +71,50 @@ struct FpBwdArgs {
 };
 
 // ------------------------------------------------------------------------------------------ SA fwd
+// LDS channel order of the grouped input: [feats(D), rel_xyz(3), zero pad to a multiple of 8]; the
+// first layer's weight columns are permuted accordingly at pack time (reference order is
+// [rel_xyz, feats], pointnet_util.py:137).
 template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
 {
-    constexpr int LDP = P + 1, G = P / 32, NT = NW * 64, NPART = NT / P;
+    using L = Lds<P>;
+    constexpr int G = P / 32, NT = NW * 64, NPART = NT / P;
     extern __shared__ float lds[];
-    float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * LDP;
+    float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * L::BLK;   // rows0/rows1 are counted in 8-channel blocks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, s0 = blockIdx.x * G;
     const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
 
-    {   // gather [rel_xyz(3), feats(D)] of the P grouped points into buf0[channel][point]
+    {   // gather the P grouped points
         const int j = tid % P, part = tid / P;
         const int s = s0 + (j >> 5);
         const int src = a.gidx[((size_t)b * a.S + s) * 32 + (j & 31)];
         const float *frow = a.feat + ((size_t)b * a.Np + src) * a.D;
-        if (part == 0) {
-            const float *xr = a.xyz + ((size_t)b * a.Np + src) * a.xyz_stride;
-            const float *cr = a.new_xyz + ((size_t)b * a.S + s) * 3;
-            buf0[0 * LDP + j] = xr[0] - cr[0];
-            buf0[1 * LDP + j] = xr[1] - cr[1];
-            buf0[2 * LDP + j] = xr[2] - cr[2];
-        }
+        const float *xr = a.xyz + ((size_t)b * a.Np + src) * a.xyz_stride;
+        const float *cr = a.new_xyz + ((size_t)b * a.S + s) * 3;
         if ((a.D & 3) == 0) {
             const float4 *f4 = (const float4 *)frow;
-            for (int q = part; q < (a.D >> 2); q += NPART) {
-                float4 v = f4[q];
-                float *o = buf0 + (size_t)(3 + 4 * q) * LDP + j;
-                o[0] = v.x; o[LDP] = v.y; o[2 * LDP] = v.z; o[3 * LDP] = v.w;
+            for (int q = part; q < (a.D >> 2); q += NPART) *(float4 *)(buf0 + L::off(4 * q, j)) = f4[q];
+            if (part == 0) {
+                *(float4 *)(buf0 + L::off(a.D, j)) = make_float4(xr[0] - cr[0], xr[1] - cr[1], xr[2] - cr[2], 0.0f);
+                if ((a.D & 7) == 0) *(float4 *)(buf0 + L::off(a.D + 4, j)) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        } else {
-            for (int c = part; c < a.D; c += NPART) buf0[(size_t)(3 + c) * LDP + j] = frow[c];
+        } else if (part == 0) {
+            // sa1: D = 9 -> [f0..f8, rx, ry, rz, 0, 0, 0, 0] (two 8-channel blocks)
+            float f[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) f[c] = frow[c];
+            *(float4 *)(buf0 + L::off(0, j)) = make_float4(f[0], f[1], f[2], f[3]);
+            *(float4 *)(buf0 + L::off(4, j)) = make_float4(f[4], f[5], f[6], f[7]);
+            *(float4 *)(buf0 + L::off(8, j)) = make_float4(f[8], xr[0] - cr[0], xr[1] - cr[1], xr[2] - cr[2]);
+            *(float4 *)(buf0 + L::off(12, j)) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        for (int c = 3 + a.D + part; c < a.l1.k8 * 8; c += NPART) buf0[(size_t)c * LDP + j] = 0.0f;
+        // zero the K-padding blocks of the first layer (K is padded to a multiple of 32)
+        for (int blk = ((a.D + 3) >> 3) + 1 + part; blk < a.l1.k8; blk += NPART) {
+            float *z = buf0 + (size_t)blk * L::BLK + j * 8;
+            *(float4 *)z = make_float4(0.f, 0.f, 0.f, 0.f);
+            *(float4 *)(z + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     __syncthreads();
     layer_fwd<P, NW>(a.l1, buf0, buf1, wg);
@@ -118,7 +131,8 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
         const float bias = a.b3[nb * 32 + jj];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = bias;
-        acc = tile_mac<LDP, true>(a.w3 + (size_t)nb * a.k8_3 * 64 + lane, a.k8_3, buf0 + h * LDP + g * 32 + jj, acc);
+        acc = tile_mac<L::BLK, true>(a.w3 + (size_t)nb * a.k8_3 * 64 + lane, a.k8_3, buf0 + (g * 32 + jj) * 8 + 4 * h,
+                                     acc);
         float best = -1.0f;
         int bidx = 0;
 #pragma unroll
@@ -141,20 +155,35 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
 template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
 {
-    constexpr int LDP = P + 1, G = P / 32, NT = NW * 64;
+    using L = Lds<P>;
+    constexpr int G = P / 32, NT = NW * 64;
     extern __shared__ float lds[];
-    float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * LDP;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * L::BLK;
+    const int tid = threadIdx.x;
     const int b = blockIdx.y, s0 = blockIdx.x * G;
     const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
 
-    // max-pool backward: dZ3[c][g*32+k] = dout[g][c] if k == arg[g][c] else 0
-    for (int pair = wave * 2 + (lane >> 5); pair < a.C3 * G; pair += NW * 2) {
-        const int g = pair / a.C3, c = pair - g * a.C3;
-        const size_t o = ((size_t)b * a.S + s0 + g) * a.C3 + c;
-        const int am = a.arg[o];
-        const float v = a.dout[o];
-        buf0[(size_t)c * LDP + g * 32 + (lane & 31)] = ((lane & 31) == am) ? v : 0.0f;
+    // max-pool backward: dZ3[c][g*32+k] = dout[g][c] if k == arg[g][c] else 0.
+    // One (point, 8-channel block) per thread; arg/dout reads are broadcasts across the 32 samples.
+    const int nblk = a.C3 >> 3;
+    for (int t = tid; t < P * nblk; t += NT) {
+        const int pnt = t % P, blk = t / P;
+        const int g = pnt >> 5, k = pnt & 31;
+        const size_t o = ((size_t)b * a.S + s0 + g) * a.C3 + blk * 8;
+        const uint2 am = *(const uint2 *)(a.arg + o);
+        const float4 d0 = *(const float4 *)(a.dout + o), d1 = *(const float4 *)(a.dout + o + 4);
+        float4 v0, v1;
+        v0.x = (int)(am.x & 0xFF) == k ? d0.x : 0.f;
+        v0.y = (int)((am.x >> 8) & 0xFF) == k ? d0.y : 0.f;
+        v0.z = (int)((am.x >> 16) & 0xFF) == k ? d0.z : 0.f;
+        v0.w = (int)(am.x >> 24) == k ? d0.w : 0.f;
+        v1.x = (int)(am.y & 0xFF) == k ? d1.x : 0.f;
+        v1.y = (int)((am.y >> 8) & 0xFF) == k ? d1.y : 0.f;
+        v1.z = (int)((am.y >> 16) & 0xFF) == k ? d1.z : 0.f;
+        v1.w = (int)(am.y >> 24) == k ? d1.w : 0.f;
+        float *dst = buf0 + (size_t)blk * L::BLK + pnt * 8;
+        *(float4 *)dst = v0;
+        *(float4 *)(dst + 4) = v1;
     }
     __syncthreads();
     layer_bwd<P, NW>(a.l3t, buf0, buf1, wg);
@@ -163,14 +192,15 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     __syncthreads();
     layer_bwd<P, NW>(a.l1t, buf0, buf1, wg);
     __syncthreads();
-    // index_points backward: scatter-add the feature rows of the grouped-input gradient
+    // index_points backward: scatter-add the feature rows [c_lo, c_hi) of the grouped-input gradient
+    // (LDS channel order is [feats, rel_xyz]: LDS channel c is feature channel c)
     const int nc = a.c_hi - a.c_lo;
     for (int t = tid; t < P * nc; t += NT) {
         const int j = t / nc, c = a.c_lo + (t - j * nc);
-        const float v = buf1[(size_t)c * LDP + j];
+        const float v = buf1[L::off(c, j)];
         if (v != 0.0f) {
             const int src = a.gidx[((size_t)b * a.S + s0 + (j >> 5)) * 32 + (j & 31)];
-            atomicAdd(a.dfeat + ((size_t)b * a.Np + src) * a.D + (c - 3), v);
+            atomicAdd(a.dfeat + ((size_t)b * a.Np + src) * a.D + c, v);
         }
     }
 }
@@ -179,22 +209,23 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
 template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
 {
-    constexpr int LDP = P + 1, NT = NW * 64, NPART = NT / P;
+    using L = Lds<P>;
+    constexpr int NT = NW * 64, NPART = NT / P;
     extern __shared__ float lds[];
-    float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * LDP;
+    float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * L::BLK;
     const int tid = threadIdx.x;
     const int b = blockIdx.y, n0 = blockIdx.x * P;
     const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    {
+    if ((a.diag & 256) && tid == 0) {
+        a.dbg[wg * 4 + 0] = __builtin_amdgcn_s_memtime();
+        a.dbg[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (!(a.diag & 1)) {
         const int j = tid % P, part = tid / P;
         const size_t n = (size_t)b * a.N + n0 + j;
         if (a.feat1) {
             const float4 *f4 = (const float4 *)(a.feat1 + n * a.C1);
-            for (int q = part; q < (a.C1 >> 2); q += NPART) {
-                float4 v = f4[q];
-                float *o = buf0 + (size_t)(4 * q) * LDP + j;
-                o[0] = v.x; o[LDP] = v.y; o[2 * LDP] = v.z; o[3 * LDP] = v.w;
-            }
+            for (int q = part; q < (a.C1 >> 2); q += NPART) *(float4 *)(buf0 + L::off(4 * q, j)) = f4[q];
         }
         const int i0 = a.nn_idx[n * 3], i1 = a.nn_idx[n * 3 + 1], i2 = a.nn_idx[n * 3 + 2];
         const float w0 = a.nn_w[n * 3], w1 = a.nn_w[n * 3 + 1], w2 = a.nn_w[n * 3 + 2];
@@ -202,38 +233,55 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
         const float4 *g1 = (const float4 *)(a.feat2 + ((size_t)b * a.S + i1) * a.C2);
         const float4 *g2 = (const float4 *)(a.feat2 + ((size_t)b * a.S + i2) * a.C2);
         for (int q = part; q < (a.C2 >> 2); q += NPART) {
-            float4 u0 = g0[q], u1 = g1[q], u2 = g2[q];
-            float *o = buf0 + (size_t)(a.C1 + 4 * q) * LDP + j;
-            o[0] = u0.x * w0 + u1.x * w1 + u2.x * w2;
-            o[LDP] = u0.y * w0 + u1.y * w1 + u2.y * w2;
-            o[2 * LDP] = u0.z * w0 + u1.z * w1 + u2.z * w2;
-            o[3 * LDP] = u0.w * w0 + u1.w * w1 + u2.w * w2;
+            const float4 u0 = g0[q], u1 = g1[q], u2 = g2[q];
+            float4 r;
+            r.x = u0.x * w0 + u1.x * w1 + u2.x * w2;
+            r.y = u0.y * w0 + u1.y * w1 + u2.y * w2;
+            r.z = u0.z * w0 + u1.z * w1 + u2.z * w2;
+            r.w = u0.w * w0 + u1.w * w1 + u2.w * w2;
+            *(float4 *)(buf0 + L::off(a.C1 + 4 * q, j)) = r;
         }
     }
     __syncthreads();
     float *in = buf0, *out = buf1;
+    if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 4 + (tid >> 6)) * 16 + 0] = __builtin_amdgcn_s_memtime();
     for (int l = 0; l < a.n_layers; ++l) {
-        layer_fwd<P, NW>(a.layer[l], in, out, wg);
-        __syncthreads();
+        if (!(a.diag & 8)) layer_fwd<P, NW>(a.layer[l], in, out, wg);
+        if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 4 + (tid >> 6)) * 16 + 1 + 2 * l] = __builtin_amdgcn_s_memtime();
+        if (!(a.diag & 16)) __syncthreads();
+        if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 4 + (tid >> 6)) * 16 + 2 + 2 * l] = __builtin_amdgcn_s_memtime();
         float *t = in; in = out; out = t;
     }
-    // `in` now holds the last layer's output [channel][point]
+    // `in` now holds the last layer's output
     if (a.out) {
         for (int t = tid; t < P * a.Cout; t += NT) {
             const int j = t / a.Cout, c = t - j * a.Cout;
-            a.out[((size_t)b * a.N + n0 + j) * a.Cout + c] = in[(size_t)c * LDP + j];
+            a.out[((size_t)b * a.N + n0 + j) * a.Cout + c] = in[L::off(c, j)];
         }
     }
-    if (a.logp && tid < P) {
+    if (a.logp && tid < P && !(a.diag & 4)) {
         const int j = tid;
         float z[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *(const float4 *)(in + L::off(4 * q, j));
+            z[4 * q] = v.x; z[4 * q + 1] = v.y; z[4 * q + 2] = v.z; z[4 * q + 3] = v.w;
+        }
         float m = -INFINITY;
-        for (int c = 0; c < a.n_cls; ++c) { z[c] = in[(size_t)c * LDP + j]; m = fmaxf(m, z[c]); }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) m = c < a.n_cls ? fmaxf(m, z[c]) : m;
         float s = 0.0f;
-        for (int c = 0; c < a.n_cls; ++c) s += expf(z[c] - m);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s += c < a.n_cls ? expf(z[c] - m) : 0.0f;
         const float lse = logf(s);
         float *o = a.logp + ((size_t)b * a.N + n0 + j) * a.n_cls;
-        for (int c = 0; c < a.n_cls; ++c) o[c] = (z[c] - m) - lse;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < a.n_cls) o[c] = (z[c] - m) - lse;
+    }
+    if ((a.diag & 256) && tid == 0) {
+        a.dbg[wg * 4 + 2] = __builtin_amdgcn_s_memtime();
+        a.dbg[wg * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -241,9 +289,10 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
 template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
 {
-    constexpr int LDP = P + 1, PB = P / 32, NT = NW * 64;
+    using L = Lds<P>;
+    constexpr int PB = P / 32, NT = NW * 64;
     extern __shared__ float lds[];
-    float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * LDP;
+    float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * L::BLK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, n0 = blockIdx.x * P;
     const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
@@ -256,15 +305,16 @@ __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
             const int mb = task / PB, pb = task - mb * PB;
             const unsigned m = a.mask_last[(wg * ntask + task) * 64 + lane];
             const float *row = a.dout + ((size_t)b * a.N + n0 + pb * 32 + j) * a.Cout + mb * 32 + 4 * h;
+            f32x16 v;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float4 v = *(const float4 *)(row + 8 * g);
-                float *o = buf0 + (size_t)(mb * 32 + 8 * g + 4 * h) * LDP + pb * 32 + j;
-                o[0] = ((m >> (4 * g)) & 1u) ? v.x : 0.0f;
-                o[LDP] = ((m >> (4 * g + 1)) & 1u) ? v.y : 0.0f;
-                o[2 * LDP] = ((m >> (4 * g + 2)) & 1u) ? v.z : 0.0f;
-                o[3 * LDP] = ((m >> (4 * g + 3)) & 1u) ? v.w : 0.0f;
+                const float4 d = *(const float4 *)(row + 8 * g);
+                v[4 * g] = ((m >> (4 * g)) & 1u) ? d.x : 0.0f;
+                v[4 * g + 1] = ((m >> (4 * g + 1)) & 1u) ? d.y : 0.0f;
+                v[4 * g + 2] = ((m >> (4 * g + 2)) & 1u) ? d.z : 0.0f;
+                v[4 * g + 3] = ((m >> (4 * g + 3)) & 1u) ? d.w : 0.0f;
             }
+            store_tile<P>(buf0, mb, pb * 32 + j, h, v);
         }
     } else if (tid < P) {
         // log_softmax backward: dz = dlogp - exp(logp) * sum(dlogp)   (pointnet2_sem_seg.py:38)
@@ -273,8 +323,17 @@ __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
         const float *lp = a.logp + n * a.n_cls, *dl = a.dlogp + n * a.n_cls;
         float s = 0.0f;
         for (int c = 0; c < a.n_cls; ++c) s += dl[c];
-        for (int c = 0; c < a.n_cls; ++c) buf0[(size_t)c * LDP + j] = dl[c] - expf(lp[c]) * s;
-        for (int c = a.n_cls; c < a.layer[0].k8 * 8; ++c) buf0[(size_t)c * LDP + j] = 0.0f;
+        float z[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) z[c] = c < a.n_cls ? dl[c] - expf(lp[c]) * s : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *(float4 *)(buf0 + L::off(4 * q, j)) = make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
+        for (int blk = 2; blk < a.layer[0].k8; ++blk) {  // K-padding blocks of conv2^T
+            float *zp = buf0 + (size_t)blk * L::BLK + j * 8;
+            *(float4 *)zp = make_float4(0.f, 0.f, 0.f, 0.f);
+            *(float4 *)(zp + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     __syncthreads();
     float *in = buf0, *out = buf1;
@@ -287,13 +346,13 @@ __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
     if (a.dfeat1) {
         for (int t = tid; t < P * a.C1; t += NT) {
             const int j = t / a.C1, c = t - j * a.C1;
-            const float v = in[(size_t)c * LDP + j];
+            const float v = in[L::off(c, j)];
             if (v != 0.0f) atomicAdd(a.dfeat1 + ((size_t)b * a.N + n0 + j) * a.C1 + c, v);
         }
     }
     for (int t = tid; t < P * a.C2; t += NT) {
         const int j = t / a.C2, c = t - j * a.C2;
-        const float v = in[(size_t)(a.C1 + c) * LDP + j];
+        const float v = in[L::off(a.C1 + c, j)];
         if (v != 0.0f) {
             const size_t n = (size_t)b * a.N + n0 + j;
 #pragma unroll
