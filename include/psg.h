@@ -171,6 +171,36 @@ int psg_pn2_nb_attack(psg_pn2_model *model, psg_pn2_ws *ws, const float *images,
                       const int32_t *starts, const uint8_t *mask, float eps, float alpha, int iters, int targeted,
                       int target, float *adv_out, psg_stream stream);
 
+/* ---- NU (Adam in tanh space) attack arithmetic: nontarget.py:52-135, target.py:62-175 -------------
+ * w / m / v are [B][N][3] fp32 (the attack variable and its Adam moments); colours live in channels 3:6
+ * of the point-major rooms x0 [B][N][9]; `mask` (nullable, [N] uint8) restricts every op to masked points. */
+
+/* w = 0.5*log((1+x)/(1-x)), x = 2c-1 (inverse_tanh_space, nontarget.py:110-116). */
+int psg_nu_inverse_tanh(const float *x0, int B, int N, float *w_out, psg_stream stream);
+
+/* colour = 1/2*(tanh(w)+1) written into x0 (tanh_space, nontarget.py:107-108). */
+int psg_nu_tanh_color(const float *w, const uint8_t *mask, int B, int N, float *x0, psg_stream stream);
+
+/* f-loss (nontarget.py:119-128 / target.py:148-168): per point clamp(tsign*(p_y - max_{k!=y} p_k), min=-kappa)
+ * on p = softmax(log-probs); y = labels[row] or `target` when labels == NULL.  Writes d(sum f)/d(logp),
+ * adds the sum to *f_sum (nullable) and the arg-max class to pred_out (nullable). */
+int psg_nu_f_loss_grad(const float *logp, const int32_t *labels, int target, int rows, int n_cls, float kappa,
+                       float tsign, float *dlogp_out, float *f_sum, int32_t *pred_out, psg_stream stream);
+
+/* Smooth loss (nontarget.py:131-135): for each of the N adversarial colours (rows of `adv_color`, stride
+ * in floats) the nb smallest Euclidean distances to the N reference colours; adds their total to *dist_sum
+ * and writes d(total)/d(adv colour) to grad_out [N][3].  Distances are evaluated directly (the reference's
+ * cdist uses the matmul expansion; values agree to ~1e-4 absolute).  nb <= 16, N <= 8192. */
+int psg_smooth_knn(const float *adv_color, int adv_stride, const float *ref_color, int ref_stride, int N, int nb,
+                   float *dist_sum, float *grad_out, psg_stream stream);
+
+/* One optimiser step: g = dx0[colour] + 2*c_l2*(colour - ori) (+ c_smooth*smooth_grad on room 0), chained
+ * through tanh_space, then torch.optim.Adam's single-tensor update (betas, eps, bias correction for `step`
+ * >= 1) on w/m/v in place.  Adds sum((colour-ori)^2) to *l2_sum (nullable). */
+int psg_nu_adam_step(float *w, float *m, float *v, const uint8_t *mask, const float *dx0, const float *x0,
+                     const float *ori, const float *smooth_grad, float c_smooth, float c_l2, float lr, float beta1,
+                     float beta2, float eps, int step, int B, int N, float *l2_sum, psg_stream stream);
+
 /* Segmentation statistics of NB_nontarget_test_semseg.py:199-205: for every class l accumulates
  * seen[l] += #(gt==l), inter[l] += #(pred==l & gt==l), uni[l] += #(pred==l | gt==l) where
  * pred = argmax(logp) (first index on ties).  counters: int64 [3][n_cls] = seen, inter, uni.

@@ -261,10 +261,16 @@ void orc_smooth_knn(const float *a, const float *b, int n, int nb, float *dist, 
         float bd[16];
         int bi[16];
         for (int t = 0; t < nb; ++t) { bd[t] = INFINITY; bi[t] = 0; }
+        /* torch.cdist = sqrt(clamp_min(|a|^2 + |b|^2 - 2 a.b, 0)) evaluated in fp32 through a matmul: the
+         * cancellation noise is part of the reference's loss surface (see psg_attack.hip: smooth_knn_kernel) */
+        const float ax = a[3 * i], ay = a[3 * i + 1], az = a[3 * i + 2];
+        const float asq = (ax * ax + ay * ay) + az * az;
         for (int j = 0; j < n; ++j) {
-            double dx = (double)a[3 * i] - b[3 * j], dy = (double)a[3 * i + 1] - b[3 * j + 1],
-                   dz = (double)a[3 * i + 2] - b[3 * j + 2];
-            float d = (float)sqrt(dx * dx + dy * dy + dz * dz);
+            const float bx = b[3 * j], by = b[3 * j + 1], bz = b[3 * j + 2];
+            float d2 = fmaf(-2.0f * az, bz, fmaf(-2.0f * ay, by, (-2.0f * ax) * bx));
+            d2 = (d2 + asq) + ((bx * bx + by * by) + bz * bz);
+            if (d2 < 0.0f) d2 = 0.0f;
+            float d = sqrtf(d2);
             if (d < bd[nb - 1]) {
                 int t = nb - 1;
                 while (t > 0 && d < bd[t - 1]) { bd[t] = bd[t - 1]; bi[t] = bi[t - 1]; --t; }

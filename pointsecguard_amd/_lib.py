@@ -46,6 +46,11 @@ SIGNATURES = {
     "psg_ce_logp_grad": (ci, [vp, vp, ci, ci, ci, ci, cf, vp, vp, vp]),
     "psg_pgd_step": (ci, [vp, vp, vp, vp, ci, ci, cf, cf, cf, ci, vp]),
     "psg_pn2_nb_attack": (ci, [vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, vp, vp]),
+    "psg_nu_inverse_tanh": (ci, [vp, ci, ci, vp, vp]),
+    "psg_nu_tanh_color": (ci, [vp, vp, ci, ci, vp, vp]),
+    "psg_nu_f_loss_grad": (ci, [vp, vp, ci, ci, ci, cf, cf, vp, vp, vp, vp]),
+    "psg_smooth_knn": (ci, [vp, ci, vp, ci, ci, ci, vp, vp, vp]),
+    "psg_nu_adam_step": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, cf, ci, ci, ci, vp, vp]),
     "psg_seg_stats": (ci, [vp, vp, ci, ci, vp, vp, vp]),
 }
 

@@ -165,3 +165,234 @@ extern "C" int psg_seg_stats(const float *logp, const int32_t *labels, int rows,
     PSG_LAUNCH_CHECK();
     return PSG_OK;
 }
+
+// =============================================================================================
+// NU (norm-unbounded, Adam in tanh space) attack arithmetic.
+// Reference: PointNet/attacks/torchattacks/attacks/nontarget.py:52-135 (NU_attack),
+//            PointNet/attacks/torchattacks/attacks/target.py:62-175 (tar_NU_attack).
+// =============================================================================================
+namespace {
+
+// w = atanh(2c - 1) written the reference's way: 0.5*log((1+x)/(1-x))  (nontarget.py:110-116)
+__global__ void nu_inverse_tanh_kernel(const float *__restrict__ x0, float *__restrict__ w, size_t rows)
+{
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < rows * 3; t += (size_t)gridDim.x * blockDim.x) {
+        float c = x0[(t / 3) * 9 + 3 + (t % 3)];
+        float x = __fsub_rn(__fmul_rn(c, 2.0f), 1.0f);
+        w[t] = __fmul_rn(0.5f, logf(__fdiv_rn(__fadd_rn(1.0f, x), __fsub_rn(1.0f, x))));
+    }
+}
+
+// colour = 1/2 * (tanh(w) + 1)  (nontarget.py:107-108) written into channels 3:6 of x0, masked points only
+__global__ void nu_tanh_color_kernel(const float *__restrict__ w, const uint8_t *__restrict__ mask, float *__restrict__ x0,
+                                     int N, size_t rows)
+{
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < rows * 3; t += (size_t)gridDim.x * blockDim.x) {
+        size_t pt = t / 3;
+        if (mask && !mask[pt % N]) continue;
+        x0[pt * 9 + 3 + (t % 3)] = __fmul_rn(0.5f, __fadd_rn(tanhf(w[t]), 1.0f));
+    }
+}
+
+// f-loss of the paper on softmax(log-probs) + its gradient w.r.t. the log-probs (nontarget.py:119-128,
+// target.py:148-168): f = clamp(tsign * (p_y - max_{k != y} p_k), min = -kappa), summed over points.
+__global__ void nu_f_loss_grad_kernel(const float *__restrict__ logp, const int32_t *__restrict__ labels, int target,
+                                      int rows, int n_cls, float kappa, float tsign, float *__restrict__ dlogp,
+                                      float *__restrict__ f_sum, int32_t *__restrict__ pred)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    float fval = 0.0f;
+    if (r < rows) {
+        const float *lp = logp + (size_t)r * n_cls;
+        float p[MAXC];
+        float m = -INFINITY;
+        int am = 0;
+        for (int c = 0; c < n_cls; ++c) {
+            p[c] = lp[c];
+            if (p[c] > m) { m = p[c]; am = c; }
+        }
+        if (pred) pred[r] = am;
+        float s = 0.0f;
+        for (int c = 0; c < n_cls; ++c) { p[c] = expf(p[c] - m); s += p[c]; }
+        for (int c = 0; c < n_cls; ++c) p[c] = p[c] / s;
+        const int y = labels ? labels[r] : target;
+        float oth = -1.0f;
+        int oi = 0;
+        for (int c = 0; c < n_cls; ++c)
+            if (c != y && p[c] > oth) { oth = p[c]; oi = c; }
+        if (oth < 0.0f) oth = 0.0f;  // (1 - onehot) * p is 0 at the true class: the max is never below 0
+        const float val = tsign * (p[y] - oth);
+        const bool pass = val >= -kappa;
+        fval = pass ? val : -kappa;
+        const float gy = pass ? tsign : 0.0f, go = pass ? -tsign : 0.0f;
+        const float dot = gy * p[y] + go * p[oi];
+        float *g = dlogp + (size_t)r * n_cls;
+        for (int c = 0; c < n_cls; ++c) {
+            float gc = c == y ? gy : (c == oi ? go : 0.0f);
+            g[c] = p[c] * (gc - dot);
+        }
+    }
+    // block reduction of the f values, one atomic per wave
+    for (int o = 32; o >= 1; o >>= 1) fval += __shfl_xor(fval, o);
+    if ((threadIdx.x & 63) == 0 && f_sum) atomicAdd(f_sum, fval);
+}
+
+// Smooth loss (nontarget.py:131-135): for every adversarial colour of room 0 the `nb` smallest
+// Euclidean distances to the reference colours; returns their sum and d(sum)/d(adv colour).
+constexpr int SM_MAX_NB = 16;
+__global__ __launch_bounds__(256) void smooth_knn_kernel(const float *__restrict__ adv, int adv_stride,
+                                                         const float *__restrict__ ref, int ref_stride, int N, int nb,
+                                                         float *__restrict__ dist_sum, float *__restrict__ grad)
+{
+    extern __shared__ float4 s_ref[];
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const float x = ref[(size_t)i * ref_stride], y = ref[(size_t)i * ref_stride + 1], z = ref[(size_t)i * ref_stride + 2];
+        s_ref[i] = make_float4(x, y, z, x * x + y * y + z * z);
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float local = 0.0f;
+    if (i < N) {
+        const float ax = adv[(size_t)i * adv_stride], ay = adv[(size_t)i * adv_stride + 1], az = adv[(size_t)i * adv_stride + 2];
+        float bd[SM_MAX_NB];
+        int bi[SM_MAX_NB];
+#pragma unroll
+        for (int t = 0; t < SM_MAX_NB; ++t) { bd[t] = INFINITY; bi[t] = 0; }
+        // torch.cdist evaluates |a|^2 + |r|^2 - 2 a.r through a matmul (euclid_dist, clamp_min(0), sqrt): the
+        // cancellation noise (~1e-7 in d^2, ~3e-4 in d) is part of the reference's loss surface -- it is what
+        // keeps the gradient of a colour that has barely moved from its original near 0 instead of a unit
+        // vector of rounding noise -- so the same expansion is used here (not bit-identical to MKL's order).
+        const float asq = ax * ax + ay * ay + az * az;
+        const float m2x = -2.0f * ax, m2y = -2.0f * ay, m2z = -2.0f * az;
+        for (int j = 0; j < N; ++j) {
+            const float4 q = s_ref[j];
+            float d2 = __fmaf_rn(m2z, q.z, __fmaf_rn(m2y, q.y, __fmul_rn(m2x, q.x)));
+            d2 = __fadd_rn(__fadd_rn(d2, asq), q.w);
+            d2 = fmaxf(d2, 0.0f);
+            if (d2 < bd[SM_MAX_NB - 1]) {
+                // sorted insertion with static indexing (keeps the arrays in registers)
+                float cd = d2;
+                int ci = j;
+#pragma unroll
+                for (int t = 0; t < SM_MAX_NB; ++t) {
+                    if (cd < bd[t]) {
+                        float td = bd[t]; int ti = bi[t];
+                        bd[t] = cd; bi[t] = ci;
+                        cd = td; ci = ti;
+                    }
+                }
+            }
+        }
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int t = 0; t < SM_MAX_NB; ++t) {
+            if (t < nb) {
+                const float d = sqrtf(bd[t]);
+                local += d;
+                if (d > 0.0f) {
+                    const float4 q = s_ref[bi[t]];
+                    gx += (ax - q.x) / d; gy += (ay - q.y) / d; gz += (az - q.z) / d;
+                }
+            }
+        }
+        grad[(size_t)i * 3] = gx; grad[(size_t)i * 3 + 1] = gy; grad[(size_t)i * 3 + 2] = gz;
+    }
+    for (int o = 32; o >= 1; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0 && dist_sum) atomicAdd(dist_sum, local);
+}
+
+// Gradient assembly + torch.optim.Adam single-tensor update on w (fp32, torch's operation order).
+__global__ void nu_adam_step_kernel(float *__restrict__ w, float *__restrict__ m, float *__restrict__ v,
+                                    const uint8_t *__restrict__ mask, const float *__restrict__ dx0,
+                                    const float *__restrict__ x0, const float *__restrict__ ori,
+                                    const float *__restrict__ smooth_grad, float c_smooth, float c_l2, float beta1,
+                                    float beta2, float eps, float step_size, float bc2_sqrt, int N, size_t rows,
+                                    float *__restrict__ l2_sum)
+{
+    float l2 = 0.0f;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < rows * 3; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t pt = t / 3;
+        const int ch = (int)(t % 3);
+        if (mask && !mask[pt % N]) continue;
+        const float color = x0[pt * 9 + 3 + ch];
+        const float diff = color - ori[t];
+        l2 += diff * diff;
+        float g = dx0[pt * 9 + 3 + ch] + c_l2 * 2.0f * diff;
+        if (smooth_grad && pt < (size_t)N) g += c_smooth * smooth_grad[t];
+        const float th = tanhf(w[t]);
+        g = g * 0.5f * (1.0f - th * th);
+        const float mm = __fadd_rn(m[t], __fmul_rn(__fsub_rn(g, m[t]), 1.0f - beta1));
+        const float vv = __fadd_rn(__fmul_rn(v[t], beta2), __fmul_rn(1.0f - beta2, __fmul_rn(g, g)));
+        m[t] = mm;
+        v[t] = vv;
+        const float denom = __fadd_rn(__fdiv_rn(sqrtf(vv), bc2_sqrt), eps);
+        w[t] = __fadd_rn(w[t], __fmul_rn(-step_size, __fdiv_rn(mm, denom)));
+    }
+    for (int o = 32; o >= 1; o >>= 1) l2 += __shfl_xor(l2, o);
+    if ((threadIdx.x & 63) == 0 && l2_sum) atomicAdd(l2_sum, l2);
+}
+
+}  // namespace
+
+extern "C" int psg_nu_inverse_tanh(const float *x0, int B, int N, float *w_out, psg_stream stream)
+{
+    PSG_REQUIRE(x0 && w_out && B > 0 && N > 0, "psg_nu_inverse_tanh: bad argument");
+    size_t rows = (size_t)B * N;
+    hipLaunchKernelGGL(nu_inverse_tanh_kernel, dim3(grid_for(rows * 3)), dim3(256), 0, (hipStream_t)stream, x0, w_out, rows);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+extern "C" int psg_nu_tanh_color(const float *w, const uint8_t *mask, int B, int N, float *x0, psg_stream stream)
+{
+    PSG_REQUIRE(w && x0 && B > 0 && N > 0, "psg_nu_tanh_color: bad argument");
+    size_t rows = (size_t)B * N;
+    hipLaunchKernelGGL(nu_tanh_color_kernel, dim3(grid_for(rows * 3)), dim3(256), 0, (hipStream_t)stream, w, mask, x0, N,
+                       rows);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+extern "C" int psg_nu_f_loss_grad(const float *logp, const int32_t *labels, int target, int rows, int n_cls, float kappa,
+                                  float tsign, float *dlogp_out, float *f_sum, int32_t *pred_out, psg_stream stream)
+{
+    PSG_REQUIRE(logp && dlogp_out && rows > 0, "psg_nu_f_loss_grad: bad argument");
+    PSG_REQUIRE(n_cls > 1 && n_cls <= MAXC, "psg_nu_f_loss_grad: n_cls=%d out of range", n_cls);
+    PSG_REQUIRE(labels || (target >= 0 && target < n_cls), "psg_nu_f_loss_grad: target class %d out of range", target);
+    hipLaunchKernelGGL(nu_f_loss_grad_kernel, dim3(psg::ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream, logp,
+                       labels, target, rows, n_cls, kappa, tsign, dlogp_out, f_sum, pred_out);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+extern "C" int psg_smooth_knn(const float *adv_color, int adv_stride, const float *ref_color, int ref_stride, int N,
+                              int nb, float *dist_sum, float *grad_out, psg_stream stream)
+{
+    PSG_REQUIRE(adv_color && ref_color && grad_out && N > 0, "psg_smooth_knn: bad argument");
+    PSG_REQUIRE(nb > 0 && nb <= SM_MAX_NB, "psg_smooth_knn: neighbour count %d out of range (1..%d)", nb, SM_MAX_NB);
+    PSG_REQUIRE(N <= 8192, "psg_smooth_knn: N=%d exceeds the LDS-resident limit 8192", N);
+    size_t lds = (size_t)N * sizeof(float4);
+    if (lds > 48 * 1024)
+        PSG_CHECK_HIP(hipFuncSetAttribute((const void *)smooth_knn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds));
+    hipLaunchKernelGGL(smooth_knn_kernel, dim3(psg::ceil_div(N, 256)), dim3(256), lds, (hipStream_t)stream, adv_color,
+                       adv_stride, ref_color, ref_stride, N, nb, dist_sum, grad_out);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+extern "C" int psg_nu_adam_step(float *w, float *m, float *v, const uint8_t *mask, const float *dx0, const float *x0,
+                                const float *ori, const float *smooth_grad, float c_smooth, float c_l2, float lr,
+                                float beta1, float beta2, float eps, int step, int B, int N, float *l2_sum,
+                                psg_stream stream)
+{
+    PSG_REQUIRE(w && m && v && dx0 && x0 && ori && B > 0 && N > 0 && step >= 1, "psg_nu_adam_step: bad argument");
+    // torch.optim.Adam (single tensor): step_size = lr / (1 - beta1^t), denom = sqrt(v)/sqrt(1 - beta2^t) + eps
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    size_t rows = (size_t)B * N;
+    hipLaunchKernelGGL(nu_adam_step_kernel, dim3(grid_for(rows * 3)), dim3(256), 0, (hipStream_t)stream, w, m, v, mask,
+                       dx0, x0, ori, smooth_grad, c_smooth, c_l2, beta1, beta2, eps, step_size, bc2_sqrt, N, rows, l2_sum);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}

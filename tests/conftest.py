@@ -46,3 +46,13 @@ def gpu_model(weights_sd):
     assert torch.cuda.is_available(), "GPU tests need an MI355X"
     from pointsecguard_amd import runtime
     return runtime.PN2Model(runtime.fold_state_dict(weights_sd))
+
+
+@pytest.fixture(scope="session")
+def golden_nu():
+    return dict(np.load(os.path.join(GOLDEN, "pn2_nu.npz")))
+
+
+@pytest.fixture(scope="session")
+def golden_tarnu():
+    return dict(np.load(os.path.join(GOLDEN, "pn2_tarnu.npz")))

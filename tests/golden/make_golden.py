@@ -13,6 +13,10 @@ Outputs are plain numeric .npz files (inputs + expected outputs); no reference s
                     argument; the attack code itself is unmodified), the returned adversarial colours,
                     the recorded torch.randint stream, clean/adv log-probs and metrics
   pn2_tarnb.npz     tar_NB_attack(eps=.5, alpha=.1, iters=10, target=6, mask=label==11), B=2, same layout
+  pn2_nu.npz        NU_attack(c=.1, lr=.01, 6 steps), B=1: per Adam step w before, gradient, w/m/v after, cost
+                    (recorded by instrumenting torch.optim.Adam.step / Tensor.backward / torch.randint)
+  pn2_tarnu.npz     tar_NU_attack(c=1, lr=.01, 23 steps, target=6, mask=label==11): same, steps 0-2 and 19-22
+                    (around the first restart at step 20)
 """
 import os
 import sys
@@ -157,9 +161,11 @@ class Recorder(torch.nn.Module):
         super().__init__()
         self.inner = inner
         self.seen = []
+        self.seen_full = []
 
     def forward(self, x):
         self.seen.append(x.detach()[:, 3:6].clone().numpy())
+        self.seen_full.append(x.detach().clone().numpy())
         return self.inner(x)
 
 
@@ -229,6 +235,105 @@ def gen_tarnb():
     print("tarnb: mask count", int(mask.sum()), "target_acc", out["target_acc"])
 
 
+class Instrument:
+    """Records, around the UNMODIFIED reference NU attacks, what their internals compute: every
+    torch.randint draw (FPS starts), every Adam step (w before, grad, w/m/v after) and the scalar
+    each .backward() is called on (the attack cost).  Only torch itself is patched."""
+
+    def __init__(self):
+        self.randints, self.adam, self.costs = [], [], []
+
+    def __enter__(self):
+        self._randint, self._step, self._backward = torch.randint, torch.optim.Adam.step, torch.Tensor.backward
+        inst = self
+
+        def randint(*a, **k):
+            out = inst._randint(*a, **k)
+            inst.randints.append(out.numpy().copy())
+            return out
+
+        def step(opt, *a, **k):
+            p = opt.param_groups[0]["params"][0]
+            rec = {"w_before": p.detach().numpy().copy(), "grad": p.grad.detach().numpy().copy(),
+                   "lr": opt.param_groups[0]["lr"]}
+            r = inst._step(opt, *a, **k)
+            st = opt.state[p]
+            rec.update(w_after=p.detach().numpy().copy(), m=st["exp_avg"].numpy().copy(),
+                       v=st["exp_avg_sq"].numpy().copy(), t=int(st["step"]))
+            inst.adam.append(rec)
+            return r
+
+        def backward(t, *a, **k):
+            if t.dim() == 0:
+                inst.costs.append(float(t.item()))
+            return inst._backward(t, *a, **k)
+
+        torch.randint, torch.optim.Adam.step, torch.Tensor.backward = randint, step, backward
+        return self
+
+    def __exit__(self, *exc):
+        torch.randint, torch.optim.Adam.step, torch.Tensor.backward = self._randint, self._step, self._backward
+
+    def starts(self, batch):
+        """[n_forward][4][batch] from the recorded randint stream."""
+        r = [x for x in self.randints if x.shape == (batch,)]
+        n = len(r) // 4
+        return np.stack([np.stack(r[4 * f:4 * f + 4]) for f in range(n)]).astype(np.int32)
+
+
+def _pack_adam(out, inst, keep):
+    for t in keep:
+        rec = inst.adam[t]
+        for k in ("w_before", "grad", "w_after", "m", "v"):
+            out["s%d_%s" % (t, k)] = rec[k]
+        out["s%d_lr" % t] = rec["lr"]
+        out["s%d_t" % t] = rec["t"]
+    out["costs"] = np.array(inst.costs, np.float64)
+
+
+def gen_nu():
+    torch.set_num_threads(1)
+    m = load_model()
+    seed_room, seed_rng, steps = 41, 8, 6
+    c, kappa, lr = 0.1, 0, 0.01
+    room = make_rooms(1, seed_room)
+    labels = rule_labels(room)
+    x = torch.from_numpy(room).transpose(2, 1).contiguous()
+    torch.manual_seed(seed_rng)
+    rec = Recorder(m).eval()
+    with Instrument() as inst:
+        adv = torchattacks.NU_attack(rec, c=c, kappa=kappa, steps=steps, lr=lr)(x, labels.astype(np.float64)).detach()
+    out = {"rooms": room, "labels": labels.astype(np.int16), "c": c, "kappa": kappa, "lr": lr, "steps": steps,
+           "starts": inst.starts(1), "adv_final": adv.numpy(), "n_steps_run": len(inst.adam)}
+    _pack_adam(out, inst, range(len(inst.adam)))
+    np.savez_compressed(os.path.join(HERE, "pn2_nu.npz"), **out)
+    print("nu: steps run", len(inst.adam), "costs", inst.costs)
+
+
+def gen_tarnu():
+    torch.set_num_threads(1)
+    m = load_model()
+    seed_room, seed_rng, steps = 33, 6, 43
+    c, kappa, lr, target, origin = 1, 0, 0.01, 6, 11
+    room = make_rooms(1, seed_room)
+    labels = rule_labels(room)
+    mask = labels[0] == origin
+    x = torch.from_numpy(room).transpose(2, 1).contiguous()
+    torch.manual_seed(seed_rng)
+    rec = Recorder(m).eval()
+    with Instrument() as inst:
+        atk = torchattacks.tar_NU_attack(rec, c=c, kappa=kappa, steps=steps, lr=lr, target=target, mask=mask)
+        adv = atk(x, labels.astype(np.float64)).detach()
+    keep = [t for t in (0, 1, 2, 19, 20, 21, 29, 30, 31, 39, 40, 41) if t < len(inst.adam)]
+    out = {"rooms": room, "labels": labels.astype(np.int16), "mask": mask, "c": c, "kappa": kappa, "lr": lr,
+           "steps": steps, "target": target, "starts": inst.starts(1), "adv_final": adv.numpy(),
+           "n_steps_run": len(inst.adam), "keep": np.array(keep),
+           "xyz_step21": rec.seen_full[21] if len(rec.seen_full) > 21 else np.zeros(0)}
+    _pack_adam(out, inst, keep)
+    np.savez_compressed(os.path.join(HERE, "pn2_tarnu.npz"), **out)
+    print("tarnu: steps run", len(inst.adam), "mask", int(mask.sum()), "costs", np.round(inst.costs, 2).tolist())
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("weights", "all"):
@@ -239,3 +344,7 @@ if __name__ == "__main__":
         gen_nb()
     if what in ("tarnb", "all"):
         gen_tarnb()
+    if what in ("nu", "all"):
+        gen_nu()
+    if what in ("tarnu", "all"):
+        gen_tarnu()

@@ -117,3 +117,46 @@ def test_nb_attack_loop_matches_steps(golden_nb, oracle_net):
     oatk.nb_attack(oracle_net, images, g["labels"].astype(np.int64), float(g["eps"]), float(g["alpha"]), 1,
                    g["starts"][1:2], record=lambda it, a, c, gr, lp: rec.update(color=c.copy()))
     assert (rec["color"].view(np.uint32) == g["state_it1"].view(np.uint32)).mean() >= 0.999
+
+
+def _nu_check(orc, g, t, nb, mask, target):
+    images = np.ascontiguousarray(g["rooms"].transpose(0, 2, 1))
+    w = g["s%d_w_before" % t]
+    if t == 0:
+        m, v = np.zeros_like(w), np.zeros_like(w)
+    else:
+        m, v = g["s%d_m" % (t - 1)], g["s%d_v" % (t - 1)]
+    r = oatk.nu_step(orc, images, images, w, m, v, int(g["s%d_t" % t]), g["labels"].astype(np.int64), g["starts"][t],
+                     float(g["c"]), float(g["kappa"]), float(g["s%d_lr" % t]), nb, mask=mask, target=target)
+    ref = g["s%d_grad" % t]
+    assert abs(r["cost"] - g["costs"][t]) <= 1e-4 * abs(g["costs"][t]) + 0.02
+    assert np.median(np.abs(r["grad_w"] - ref) / (np.abs(ref) + 1e-12)) < 1e-3
+    assert (np.abs(r["grad_w"] - ref) <= 1e-2 * np.abs(ref).max()).mean() >= 0.99
+    assert (np.abs(r["w"] - g["s%d_w_after" % t]) <= 1e-4).mean() >= 0.995
+    assert (np.abs(r["m"] - g["s%d_m" % t]) <= 1e-3 * np.abs(ref).max()).mean() >= 0.99
+
+
+@pytest.mark.parametrize("t", [0, 1, 5])
+def test_nu_attack_step(golden_nu, oracle_net, t):
+    """NU_attack (nontarget.py:52-135): f-loss + c*Smooth + c*L2, tanh space, torch Adam -- one
+    teacher-forced optimiser step from the state recorded inside the reference."""
+    _nu_check(oracle_net, golden_nu, t, 10, None, None)
+
+
+@pytest.mark.parametrize("t", [0, 20, 30])
+def test_tar_nu_attack_step(golden_tarnu, oracle_net, t):
+    """tar_NU_attack (target.py:62-175), masked colours, lr halved + fresh Adam after step 50 not reached;
+    steps 20/30 sit on the restart check boundary."""
+    g = golden_tarnu
+    _nu_check(oracle_net, g, t, 5, g["mask"], int(g["target"]))
+
+
+def test_tar_nu_restart_clamps_xyz(golden_tarnu):
+    """Known answer from the recorded reference run: the restart after step 40 (cost[40] >= cost[30])
+    clamps ALL channels to [0,1]; the L2 term then carries sum((clamp(xyz)-xyz)^2) (cost jump)."""
+    g = golden_tarnu
+    c = g["costs"]
+    assert c[40] >= c[30] and c[20] < c[10] and c[30] < c[20]
+    x = g["rooms"][0]
+    moved = ((np.clip(x, 0, 1) - x) ** 2).sum()
+    assert abs((c[41] - c[39]) - float(g["c"]) * moved) <= 0.03 * moved  # + the f/Smooth change of the moved geometry
