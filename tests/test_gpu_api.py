@@ -1,0 +1,102 @@
+"""GPU tests of the drop-in Python surface (pointsecguard_amd.models / .attacks.torchattacks) used the way
+the reference harness uses it (PointNet/NB_nontarget_test_semseg.py:100-106,163-173)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def net(weights_sd):
+    from pointsecguard_amd.models.pointnet2_sem_seg import get_model
+    m = get_model(13)
+    missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in weights_sd.items()})
+    assert not missing.missing_keys and not missing.unexpected_keys   # reference checkpoints load as-is
+    return m.cuda().eval()
+
+
+def test_harness_sequence_matches_reference_stream(net, golden_nb):
+    """torch.manual_seed -> clean forward -> NB_attack: the FPS draws come from the CPU generator in the
+    reference's order, so the clean log-probs and the first attack iterations match the golden run."""
+    from pointsecguard_amd.attacks import torchattacks
+    g = golden_nb
+    x = torch.from_numpy(np.ascontiguousarray(g["rooms"].transpose(0, 2, 1))).cuda()
+    torch.manual_seed(int(g["seed_rng"]))
+    logp, l4 = net(x)
+    assert logp.shape == (2, 4096, 13) and l4.shape == (2, 512, 16)
+    assert np.abs(logp.detach().cpu().numpy() - g["clean_logp"]).max() <= 1e-4
+    atk = torchattacks.NB_attack(net, eps=float(g["eps"]), alpha=float(g["alpha"]), iters=2)
+    adv = atk(x, g["labels"].astype(np.float64))           # labels as float64 numpy, like the harness
+    assert adv.shape == x.shape and not adv.requires_grad
+    ori = x[:, 3:6].cpu().numpy()
+    got = adv[:, 3:6].cpu().numpy()
+    proj = np.clip(ori + np.clip(got - ori, -np.float32(g["eps"]), np.float32(g["eps"])), 0, 1).astype(np.float32)
+    assert (proj.view(np.uint32) == g["state_it2"].view(np.uint32)).mean() >= 0.999
+    assert str(atk).startswith("NB_attack(")
+    assert net.training is False
+
+
+def test_autograd_colour_leaf(net, golden_room):
+    """A leaf on the colour channels gets its .grad from the HIP backward (nontarget.py:29-35 pattern)."""
+    g = golden_room
+    x = torch.from_numpy(np.ascontiguousarray(g["room"].T[None])).cuda()
+    color = x[:, 3:6].clone().requires_grad_(True)
+    adv = x.clone()
+    adv[:, 3:6] = color
+    torch.manual_seed(0)
+    outputs, _ = net(adv)
+    y = torch.from_numpy(g["labels"].astype(np.int64)).cuda()
+    cost = torch.nn.CrossEntropyLoss(reduction="sum")(outputs.reshape(-1, 13), y.view(-1)) / outputs.size(1)
+    net.zero_grad()
+    cost.backward()
+    assert abs(cost.item() - float(g["cost"])) < 1e-4
+    got = color.grad[0].T.cpu().numpy()
+    ref = g["dcolor"]
+    nz = ref != 0
+    assert np.array_equal(got != 0, nz)
+    assert (np.sign(got[nz]) == np.sign(ref[nz])).mean() >= 0.999
+
+
+def test_tar_nb_attack_api(net, golden_tarnb):
+    from pointsecguard_amd.attacks import torchattacks
+    g = golden_tarnb
+    x = torch.from_numpy(np.ascontiguousarray(g["rooms"].transpose(0, 2, 1))).cuda()
+    torch.manual_seed(int(g["seed_rng"]))
+    atk = torchattacks.tar_NB_attack(net, eps=float(g["eps"]), alpha=float(g["alpha"]), iters=2,
+                                     target=int(g["target"]), mask=g["mask"])
+    adv = atk(x, g["labels"].astype(np.float64)).cpu().numpy()
+    ori = x[:, 3:6].cpu().numpy()
+    proj = np.clip(ori + np.clip(adv[:, 3:6] - ori, -np.float32(g["eps"]), np.float32(g["eps"])), 0, 1).astype(np.float32)
+    assert (proj.view(np.uint32) == g["state_it2"].view(np.uint32)).mean() >= 0.999
+
+
+def test_errors_are_loud(net):
+    from pointsecguard_amd import _lib
+    with pytest.raises(_lib.PsgError):
+        net(torch.zeros(1, 9, 4096))                      # CPU tensor: no fallback
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(1, 9, 4096, device="cuda"))
+    net.eval()
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 6, 4096, device="cuda"))
+
+
+def test_pointnet_util_functions(golden_room):
+    """Public helpers of models/pointnet_util.py on CUDA tensors, against the reference's outputs."""
+    from pointsecguard_amd.models import pointnet_util as pu
+    g = golden_room
+    xyz = torch.from_numpy(g["room"][None, :, :3].copy()).cuda()
+    torch.manual_seed(0)
+    fi = pu.farthest_point_sample(xyz, 1024)
+    assert fi.dtype == torch.int64 and np.array_equal(fi[0].cpu().numpy(), g["fps0"].astype(np.int64))
+    new_xyz = pu.index_points(xyz, fi)
+    gi = pu.query_ball_point(0.1, 32, xyz, new_xyz)
+    assert np.array_equal(gi[0].cpu().numpy(), g["group0"].astype(np.int64))
+    d = pu.square_distance(torch.from_numpy(g["sqd_src"][None]).cuda(), torch.from_numpy(g["sqd_dst"][None]).cuda())
+    assert np.array_equal(d[0].cpu().numpy().view(np.uint32), g["sqd_bits"])
+    torch.manual_seed(0)
+    nx, npnts = pu.sample_and_group(1024, 0.1, 32, xyz, torch.from_numpy(g["room"][None]).cuda())
+    assert nx.shape == (1, 1024, 3) and npnts.shape == (1, 1024, 32, 12)
+    assert torch.equal(npnts[0, :, 0, 3:], torch.from_numpy(g["room"]).cuda()[gi[0, :, 0]])
