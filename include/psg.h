@@ -208,6 +208,51 @@ int psg_nu_adam_step(float *w, float *m, float *v, const uint8_t *mask, const fl
 int psg_seg_stats(const float *logp, const int32_t *labels, int rows, int n_cls, long long *counters,
                   int32_t *pred_out, psg_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * ResGCN-28 dense DeepGCN sem-seg network (ResGCN/sem_seg_dense/architecture.py:6-68), eval mode:
+ * head EdgeConv(9->64) on the xyz kNN graph, n_blocks-1 residual dynamic EdgeConv blocks (feature-space
+ * kNN, k = 16, dilation 1..n_blocks-1), fusion 1x1 conv + global max, prediction MLP.  BasicConv order is
+ * Conv -> ReLU -> BatchNorm (ResGCN/gcn_lib/dense/torch_nn.py:55-66).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct psg_gcn_model psg_gcn_model;
+typedef struct psg_gcn_ws psg_gcn_ws;
+
+/* tensors: HOST fp32 pointers in the order documented in csrc/psg_resgcn.hip (per EdgeConv: conv weight
+ * [64][2C], bias, BN weight/bias/running_mean/running_var; fusion_block; prediction.0/.1 with BN; prediction.3).
+ * n_tensors must equal 6*n_blocks + 20.  Blocking. */
+int psg_gcn_model_create(psg_ctx *ctx, const float *const *tensors, int n_tensors, int n_blocks, psg_gcn_model **out);
+int psg_gcn_model_destroy(psg_gcn_model *model);
+int psg_gcn_ws_create(psg_ctx *ctx, int batch, int n_point, int n_blocks, psg_gcn_ws **out);
+int psg_gcn_ws_destroy(psg_gcn_ws *ws);
+size_t psg_gcn_ws_bytes(const psg_gcn_ws *ws);
+
+/* DenseDilatedKnnGraph (torch_edge.py:45-79) on point-major features x [batch][n_point][C]: neighbours at
+ * ranks 0, d, 2d, ... of the ascending pairwise_distance row, k = 16; out_idx [batch][n_point][16].
+ * Distances follow the reference's fp32 order (ascending-k fmaf dot, (|xi|^2 + -2 xi.xj) + |xj|^2);
+ * equal distances resolve to the lowest index (torch.topk leaves that order unspecified). */
+int psg_gcn_knn(psg_gcn_ws *ws, const float *x, int C, int dilation, int32_t *out_idx, psg_stream stream);
+
+/* DenseDeepGCN.forward (architecture.py:58-68): x0 [batch][n_point][9] point-major -> logits [batch][n_point][13]. */
+int psg_gcn_forward(psg_gcn_model *model, psg_gcn_ws *ws, const float *x0, float *logits_out, psg_stream stream);
+
+/* Input-gradient backward of the resident forward (kNN graphs are constants, as under torch.no_grad in the
+ * reference): dlogits [batch][n_point][13] -> dx0_out [batch][n_point][9]. */
+int psg_gcn_backward(psg_gcn_model *model, psg_gcn_ws *ws, const float *dlogits, float *dx0_out, psg_stream stream);
+
+/* colper.NB_attack (ResGCN/sem_seg_dense/attacks/torchattacks/attacks/colper.py:17-39): CrossEntropyLoss (mean)
+ * on logits, sign ascent on colour, L-inf projection; images/adv_out [batch][9][n_point]. */
+int psg_gcn_nb_attack(psg_gcn_model *model, psg_gcn_ws *ws, const float *images, const int32_t *labels, float eps,
+                      float alpha, int iters, float *adv_out, psg_stream stream);
+
+/* Teacher forcing for parity tests: nbr (device, [n_blocks][batch][n_point][16]) replaces the kNN graphs of
+ * every following forward; NULL restores the dynamic graphs.  (Feature-space kNN has near-ties that no two
+ * fp32 pipelines break alike, so value parity is checked on identical graphs and graph parity by overlap.) */
+int psg_gcn_set_graphs(psg_gcn_ws *ws, const int32_t *nbr, psg_stream stream);
+
+/* parity-test read-back: neighbour table of EdgeConv `block` [batch][n_point][16]; block outputs [batch][n_point][64*n_blocks] */
+const int32_t *psg_gcn_edge_ptr(const psg_gcn_ws *ws, int block);
+const float *psg_gcn_feats_ptr(const psg_gcn_ws *ws);
+
 #ifdef __cplusplus
 }
 #endif

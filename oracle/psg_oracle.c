@@ -280,3 +280,78 @@ void orc_smooth_knn(const float *a, const float *b, int n, int nb, float *dist, 
         for (int t = 0; t < nb; ++t) { dist[(size_t)i * nb + t] = bd[t]; idx[(size_t)i * nb + t] = bi[t]; }
     }
 }
+
+/* ---- G1/G2: dense dilated kNN graph, ResGCN/gcn_lib/dense/torch_edge.py:32-79 ----------------
+ * pairwise_distance: (|x_i|^2 + (-2 x_i.x_j)) + |x_j|^2 with the fp32 orders pinned in SURVEY 8(a'):
+ *   dot    = single ascending-k fmaf chain starting from 0 (first product rounded)
+ *   |x|^2  = for C == 64: 8 lanes x 4 accumulators over two passes of 32, lane-wise ((a0+a1)+a2)+a3, lanes
+ *            summed left to right; otherwise left-to-right
+ * topk(-dist, k*d) sorted, then every d-th; equal distances -> lowest index first (policy). */
+static float sumsq_row(const float *p, int c)
+{
+    if (c == 64) {
+        float acc[4][8];
+        for (int j = 0; j < 4; ++j) for (int l = 0; l < 8; ++l) acc[j][l] = 0.0f;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int j = 0; j < 4; ++j)
+                for (int l = 0; l < 8; ++l) { float v = p[32 * pass + 8 * j + l]; acc[j][l] = acc[j][l] + v * v; }
+        float s = 0.0f;
+        for (int l = 0; l < 8; ++l) {
+            float t = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l];
+            s = l ? s + t : t;
+        }
+        return s;
+    }
+    float s = p[0] * p[0];
+    for (int i = 1; i < c; ++i) s = s + p[i] * p[i];
+    return s;
+}
+
+void orc_pairwise_distance(const float *x, int n, int c, float *out)
+{
+    float *sq = (float *)malloc(sizeof(float) * (size_t)n);
+    for (int i = 0; i < n; ++i) sq[i] = sumsq_row(x + (size_t)i * c, c);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const float *a = x + (size_t)i * c, *b = x + (size_t)j * c;
+            float dot = a[0] * b[0];
+            for (int t = 1; t < c; ++t) dot = fmaf(a[t], b[t], dot);
+            out[(size_t)i * n + j] = (sq[i] + (-2.0f * dot)) + sq[j];
+        }
+    free(sq);
+}
+
+typedef struct { float d; int32_t i; } orc_pair;
+static int orc_pair_cmp(const void *pa, const void *pb)
+{
+    const orc_pair *a = (const orc_pair *)pa, *b = (const orc_pair *)pb;
+    if (a->d < b->d) return -1;
+    if (a->d > b->d) return 1;
+    return a->i < b->i ? -1 : (a->i > b->i ? 1 : 0);
+}
+
+void orc_knn_dilated(const float *x, int n, int c, int k, int d, int32_t *out)
+{
+    float *sq = (float *)malloc(sizeof(float) * (size_t)n);
+    for (int i = 0; i < n; ++i) sq[i] = sumsq_row(x + (size_t)i * c, c);
+#pragma omp parallel
+    {
+        orc_pair *row = (orc_pair *)malloc(sizeof(orc_pair) * (size_t)n);
+#pragma omp for schedule(static)
+        for (int i = 0; i < n; ++i) {
+            const float *a = x + (size_t)i * c;
+            for (int j = 0; j < n; ++j) {
+                const float *b = x + (size_t)j * c;
+                float dot = a[0] * b[0];
+                for (int t = 1; t < c; ++t) dot = fmaf(a[t], b[t], dot);
+                row[j].d = (sq[i] + (-2.0f * dot)) + sq[j];
+                row[j].i = j;
+            }
+            qsort(row, (size_t)n, sizeof(orc_pair), orc_pair_cmp);
+            for (int t = 0; t < k; ++t) out[(size_t)i * k + t] = row[(size_t)t * d].i;
+        }
+        free(row);
+    }
+    free(sq);
+}

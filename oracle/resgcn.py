@@ -1,0 +1,173 @@
+"""CPU oracle for the ResGCN-28 (dense DeepGCN) sem-seg attack path (numpy driver over oracle/psg_oracle.c).
+
+TEST INFRASTRUCTURE ONLY (see oracle/pn2.py).  Restates, relative to /root/reference/ResGCN:
+  gcn_lib/dense/torch_edge.py:32-79    pairwise_distance, dense_knn_matrix, DenseDilatedKnnGraph
+  gcn_lib/dense/torch_nn.py:55-98      BasicConv (Conv -> ReLU -> BatchNorm), batched_index_select
+  gcn_lib/dense/torch_vertex.py:23-100 EdgeConv2d (cat[x_i, x_j - x_i] -> conv -> max over k), ResDynBlock2d
+  sem_seg_dense/architecture.py:58-68  DenseDeepGCN.forward
+  sem_seg_dense/attacks/torchattacks/attacks/colper.py:17-39  NB_attack
+and the input-gradient backward autograd derives (kNN graphs are constants: computed under no_grad).
+EdgeConv is evaluated edge by edge exactly as the reference writes it (no algebraic split), so the HIP
+path's split-GEMM identity is checked against the un-split form.
+Parity status: pinned by tests/golden/gcn_*.npz (generated from the reference, tests/golden/make_golden.py).
+"""
+import ctypes
+
+import numpy as np
+
+from . import pn2
+from .pn2 import _c, _fp, _ip, lib, linear_bwd, linear_fwd
+
+F = np.float32
+BN_EPS = 1e-5
+K = 16
+
+
+def knn_dilated(x, d, k=K):
+    x = _c(x)
+    out = np.empty((x.shape[0], k), np.int32)
+    lib().orc_knn_dilated(_fp(x), x.shape[0], x.shape[1], k, int(d), _ip(out))
+    return out
+
+
+def pairwise_distance(x):
+    x = _c(x)
+    out = np.empty((x.shape[0], x.shape[0]), np.float32)
+    lib().orc_pairwise_distance(_fp(x), x.shape[0], x.shape[1], _fp(out))
+    return out
+
+
+def _bn(sd, name):
+    s = np.asarray(sd[name + ".weight"], np.float64) / np.sqrt(np.asarray(sd[name + ".running_var"], np.float64) + BN_EPS)
+    t = np.asarray(sd[name + ".bias"], np.float64) - np.asarray(sd[name + ".running_mean"], np.float64) * s
+    return s.astype(F), t.astype(F)
+
+
+def _conv(sd, name):
+    w = np.asarray(sd[name + ".weight"], F)
+    return _c(w.reshape(w.shape[0], -1)), _c(np.asarray(sd[name + ".bias"], F))
+
+
+class GCNOracle:
+    def __init__(self, sd, n_blocks=28):
+        self.n_blocks = n_blocks
+        self.edge = []
+        for e in range(n_blocks):
+            base = "head.gconv.nn" if e == 0 else "backbone.%d.body.gconv.nn" % (e - 1)
+            w, b = _conv(sd, base + ".0")
+            s, t = _bn(sd, base + ".2")
+            self.edge.append((w, b, s, t))
+        self.fusion = _conv(sd, "fusion_block.0") + _bn(sd, "fusion_block.2")
+        self.p1 = _conv(sd, "prediction.0.0") + _bn(sd, "prediction.0.2")
+        self.p2 = _conv(sd, "prediction.1.0") + _bn(sd, "prediction.1.2")
+        self.p3 = _conv(sd, "prediction.3.0")
+
+    @staticmethod
+    def _basic(x, w, b, s, t):
+        z = linear_fwd(x, w, b, False)                 # Conv
+        act = z > 0
+        return (np.where(act, z, F(0)) * s + t).astype(F), act   # ReLU -> BatchNorm (torch_nn.py:57-63)
+
+    def edge_conv(self, x, nbr, e):
+        """EdgeConv2d.forward (torch_vertex.py:31-35): max_k BasicConv(cat[x_i, x_j - x_i])."""
+        w, b, s, t = self.edge[e]
+        n, c = x.shape
+        xi = np.repeat(x[:, None, :], K, axis=1)
+        xj = x[nbr]
+        rows = _c(np.concatenate([xi, xj - xi], axis=2).reshape(n * K, 2 * c))
+        y, act = self._basic(rows, w, b, s, t)
+        y = y.reshape(n, K, -1)
+        arg = y.argmax(axis=1)                          # first index on ties, like torch.max
+        out = np.take_along_axis(y, arg[:, None, :], axis=1)[:, 0, :]
+        return out.astype(F), (arg, act.reshape(n, K, -1))
+
+    def forward(self, x, graphs=None):
+        """x [N,9] -> (logits [N,13], cache).  `graphs`: optional precomputed neighbour tables (teacher forcing)."""
+        x = _c(x)
+        cache = {"x": x, "nbr": [], "ec": []}
+        feats = []
+        cur = None
+        for e in range(self.n_blocks):
+            inp = x if e == 0 else cur
+            if graphs is not None:
+                nbr = graphs[e]
+            else:
+                nbr = knn_dilated(x[:, :3] if e == 0 else cur, 1 if e == 0 else e)
+            y, aux = self.edge_conv(inp, nbr, e)
+            cur = y if e == 0 else (y + cur).astype(F)   # ResDynBlock2d: body(x) + x (torch_vertex.py:99-100)
+            cache["nbr"].append(nbr)
+            cache["ec"].append(aux)
+            feats.append(cur)
+        feats = _c(np.concatenate(feats, axis=1))
+        fused, fact = self._basic(feats, *self.fusion)
+        farg = fused.argmax(axis=0)
+        fmax = fused[farg, np.arange(fused.shape[1])]
+        cat = _c(np.concatenate([np.repeat(fmax[None, :], x.shape[0], axis=0), feats], axis=1))
+        h1, a1 = self._basic(cat, *self.p1)
+        h2, a2 = self._basic(h1, *self.p2)
+        logits = linear_fwd(h2, self.p3[0], self.p3[1], False)
+        cache.update(feats=feats, fact=fact, farg=farg, a1=a1, a2=a2, n=x.shape[0])
+        return logits, cache
+
+    def backward(self, cache, dlogits):
+        """d loss / d x [N,9] given d loss / d logits [N,13]."""
+        n = cache["n"]
+        g2 = linear_bwd(_c(dlogits), None, self.p3[0], False) if False else (_c(dlogits) @ self.p3[0]).astype(F)
+        g2 = (g2 * self.p2[2] * cache["a2"]).astype(F)
+        g1 = (g2.astype(np.float64) @ self.p2[0].astype(np.float64)).astype(F)
+        g1 = (g1 * self.p1[2] * cache["a1"]).astype(F)
+        dcat = (g1.astype(np.float64) @ self.p1[0].astype(np.float64)).astype(F)
+        dfeats = dcat[:, 1024:].copy()
+        gf = dcat[:, :1024].sum(axis=0, dtype=np.float64).astype(F)
+        farg, fact = cache["farg"], cache["fact"]
+        cols = np.arange(1024)
+        gz = np.where(fact[farg, cols], gf * self.fusion[2], F(0)).astype(np.float64)
+        np.add.at(dfeats, farg, (gz[:, None] * self.fusion[0].astype(np.float64)).astype(F))
+        G = dfeats[:, -64:].copy()
+        dx = None
+        for e in range(self.n_blocks - 1, -1, -1):
+            w, b, s, t = self.edge[e]
+            arg, act = cache["ec"][e]
+            nbr = cache["nbr"][e]
+            c = 9 if e == 0 else 64
+            win_act = np.take_along_axis(act, arg[:, None, :], axis=1)[:, 0, :]
+            gz = np.where(win_act, G * s, F(0)).astype(np.float64)            # [N,64] at the winning edge
+            # d/d(cat[x_i, x_j - x_i]) of the winning edge of every (vertex, channel)
+            dxi = np.zeros((n, c), np.float64)
+            dxj = np.zeros((n, c), np.float64)
+            w1, w2 = w[:, :c].astype(np.float64), w[:, c:].astype(np.float64)
+            for k in range(K):
+                gk = np.where(arg == k, gz, 0.0)                                # [N,64]
+                if not gk.any():
+                    continue
+                d1, d2 = gk @ w1, gk @ w2
+                dxi += d1 - d2
+                np.add.at(dxj, nbr[:, k], d2)
+            dprev = (dxi + dxj).astype(F)
+            if e > 0:
+                G = (dfeats[:, 64 * (e - 1):64 * e] + G + dprev).astype(F)
+            else:
+                dx = dprev
+        return dx
+
+
+def ce_mean_grad(logits, labels):
+    """nn.CrossEntropyLoss() (mean) on logits (colper.py:24,32): returns (d/dlogits, cost)."""
+    z = logits - logits.max(axis=1, keepdims=True)
+    lp = z - np.log(np.exp(z).sum(axis=1, keepdims=True, dtype=F))
+    n = logits.shape[0]
+    g = np.exp(lp).astype(F)
+    g[np.arange(n), labels] -= F(1)
+    return (g / F(n)).astype(F), float(-lp[np.arange(n), labels].mean(dtype=np.float64))
+
+
+def nb_step(orc, x, state, ori, labels, alpha, eps, last, graphs=None):
+    """One colper.NB_attack iteration for a single room: x [N,9] (colour replaced by `state` [N,3])."""
+    xa = x.copy()
+    xa[:, 3:6] = state
+    logits, cache = orc.forward(xa, graphs=graphs)
+    dl, cost = ce_mean_grad(logits, labels)
+    g = orc.backward(cache, dl)[:, 3:6]
+    stepped = (state + F(alpha) * np.sign(g)).astype(F)
+    proj = np.clip(ori + np.clip(stepped - ori, -F(eps), F(eps)), 0, 1).astype(F)
+    return (stepped if last else proj), g, logits, cost

@@ -51,6 +51,18 @@ SIGNATURES = {
     "psg_nu_f_loss_grad": (ci, [vp, vp, ci, ci, ci, cf, cf, vp, vp, vp, vp]),
     "psg_smooth_knn": (ci, [vp, ci, vp, ci, ci, ci, vp, vp, vp]),
     "psg_nu_adam_step": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, cf, ci, ci, ci, vp, vp]),
+    "psg_gcn_model_create": (ci, [vp, ctypes.POINTER(vp), ci, ci, ctypes.POINTER(vp)]),
+    "psg_gcn_model_destroy": (ci, [vp]),
+    "psg_gcn_ws_create": (ci, [vp, ci, ci, ci, ctypes.POINTER(vp)]),
+    "psg_gcn_ws_destroy": (ci, [vp]),
+    "psg_gcn_ws_bytes": (ctypes.c_size_t, [vp]),
+    "psg_gcn_knn": (ci, [vp, vp, ci, ci, vp, vp]),
+    "psg_gcn_forward": (ci, [vp, vp, vp, vp, vp]),
+    "psg_gcn_backward": (ci, [vp, vp, vp, vp, vp]),
+    "psg_gcn_nb_attack": (ci, [vp, vp, vp, vp, cf, cf, ci, vp, vp]),
+    "psg_gcn_set_graphs": (ci, [vp, vp, vp]),
+    "psg_gcn_edge_ptr": (vp, [vp, ci]),
+    "psg_gcn_feats_ptr": (vp, [vp]),
     "psg_seg_stats": (ci, [vp, vp, ci, ci, vp, vp, vp]),
 }
 

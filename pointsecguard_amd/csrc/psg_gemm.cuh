@@ -1,0 +1,189 @@
+// Generic row-major fp32 GEMM on the gfx950 matrix cores with fused epilogues:
+//     out[r][m] = epi( sum_k in[r][k] * w[m][k] )          r < rows, m < M, k < K
+// (1x1 convolution over point-major rows).  Used by the ResGCN path (EdgeConv vertex products, fusion and
+// prediction layers and their input-gradient transposes, and the feature-space kNN distance matrix).
+//
+// Tiling: a workgroup of 4 waves owns BR rows x BN output channels; every wave owns a 64x64 sub-tile as
+// 2x2 MFMA tiles (v_mfma_f32_32x32x2_f32, 4 accumulators = 64 AGPRs), so one ds_read_b128 per operand block
+// feeds 8 MFMAs.  K advances in steps of 32 through LDS in the k8-block layout [k/8][row][8] (see
+// psg_mlp.cuh), both operands staged by all 256 threads with 16-byte global loads.
+// D orientation: D[m = channel][n = row]: lane = row, registers = channels, so the epilogue stores one
+// float4 (4 consecutive channels of one row) per lane per 4 accumulator registers.
+//
+// ASC_K = true stores each 8-chunk permuted so that MFMA step t consumes k = 8*k8 + 2*t + h: the
+// accumulation is then the ascending-k fmaf chain starting from 0 that a CPU sgemm produces
+// (SURVEY.md section 8a': needed for bit-exact feature-space kNN graphs, ResGCN/gcn_lib/dense/torch_edge.py:41).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "psg_mlp.cuh"
+
+namespace psg {
+
+enum GemmEpi { EPI_LINEAR = 0, EPI_RELU_AFFINE = 1, EPI_KNN_DIST = 2 };
+
+struct GemmArgs {
+    const float *in;      // [rows][ld_in]
+    const float *w;       // [M][ld_w]
+    const float *bias;    // [M] or null
+    const float *gbias;   // per-group bias [rows / group_rows][M] or null (broadcast concat term)
+    const float *scale;   // [M] affine applied AFTER the ReLU (Conv -> ReLU -> BatchNorm order), or null
+    const float *shift;   // [M]
+    const float *sq;      // EPI_KNN_DIST: [rows] squared norms (same array indexes rows and columns)
+    float *out;           // [rows][ld_out]
+    uint32_t *mask_out;   // ReLU bits out: [rows][ceil(M/32)] words, or null
+    const uint32_t *mask_in;  // multiply the result by these bits (backward through the producer's ReLU), or null
+    int rows, K, M, ld_in, ld_w, ld_out, group_rows;
+    int accumulate;       // out += result
+};
+
+template <int WM, int WN, int EPI, bool ASC_K>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
+{
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int BR = 64 * WM, BN = 64 * WN;
+    constexpr int BLK_R = BR * 8 + 8, BLK_N = BN * 8 + 8;  // floats per 8-k block (+8: bank de-phasing)
+    __shared__ float s_in[4 * BLK_R];
+    __shared__ float s_w[4 * BLK_N];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int wr = wave / WN, wc = wave % WN;
+    const int row0 = blockIdx.x * BR, col0 = blockIdx.y * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.0f;
+
+    for (int k0 = 0; k0 < a.K; k0 += 32) {
+        // ---- stage in[row0.., k0..k0+31] and w[col0.., k0..k0+31] (zero filled outside the matrices)
+        for (int t = tid; t < BR * 8; t += 256) {
+            const int r = t >> 3, q = t & 7, k = k0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + r < a.rows) {
+                const float *p = a.in + (size_t)(row0 + r) * a.ld_in + k;
+                if (k + 3 < a.K && ((a.ld_in & 3) == 0)) v = *(const float4 *)p;
+                else {
+                    if (k < a.K) v.x = p[0];
+                    if (k + 1 < a.K) v.y = p[1];
+                    if (k + 2 < a.K) v.z = p[2];
+                    if (k + 3 < a.K) v.w = p[3];
+                }
+            }
+            float *d = s_in + (q >> 1) * BLK_R + r * 8;
+            if (ASC_K) {  // element k%8 = 2t+h goes to slot 4h+t
+                const int e = (q & 1) * 4;
+                d[((e + 0) & 1) * 4 + ((e + 0) >> 1)] = v.x;
+                d[((e + 1) & 1) * 4 + ((e + 1) >> 1)] = v.y;
+                d[((e + 2) & 1) * 4 + ((e + 2) >> 1)] = v.z;
+                d[((e + 3) & 1) * 4 + ((e + 3) >> 1)] = v.w;
+            } else {
+                *(float4 *)(d + (q & 1) * 4) = v;
+            }
+        }
+        for (int t = tid; t < BN * 8; t += 256) {
+            const int r = t >> 3, q = t & 7, k = k0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col0 + r < a.M) {
+                const float *p = a.w + (size_t)(col0 + r) * a.ld_w + k;
+                if (k + 3 < a.K && ((a.ld_w & 3) == 0)) v = *(const float4 *)p;
+                else {
+                    if (k < a.K) v.x = p[0];
+                    if (k + 1 < a.K) v.y = p[1];
+                    if (k + 2 < a.K) v.z = p[2];
+                    if (k + 3 < a.K) v.w = p[3];
+                }
+            }
+            float *d = s_w + (q >> 1) * BLK_N + r * 8;
+            if (ASC_K) {
+                const int e = (q & 1) * 4;
+                d[((e + 0) & 1) * 4 + ((e + 0) >> 1)] = v.x;
+                d[((e + 1) & 1) * 4 + ((e + 1) >> 1)] = v.y;
+                d[((e + 2) & 1) * 4 + ((e + 2) >> 1)] = v.z;
+                d[((e + 3) & 1) * 4 + ((e + 3) >> 1)] = v.w;
+            } else {
+                *(float4 *)(d + (q & 1) * 4) = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) {
+            float4 wa[2], xb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wa[i] = *(const float4 *)(s_w + k8 * BLK_N + (wc * 64 + i * 32 + j) * 8 + 4 * h);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) xb[q] = *(const float4 *)(s_in + k8 * BLK_R + (wr * 64 + q * 32 + j) * 8 + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[i][q] = mfma4<false>(wa[i], xb[q], acc[i][q]);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane (j,h) of tile (i,q) holds channels cbase + 8g + 4h + (0..3) of row rbase + j
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = row0 + wr * 64 + q * 32 + j;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cbase = col0 + wc * 64 + i * 32;
+            unsigned mbits = 0;
+            unsigned min_bits = 0xFFFFFFFFu;
+            if (a.mask_in && row < a.rows && cbase < a.M) min_bits = a.mask_in[(size_t)row * ((a.M + 31) >> 5) + (cbase >> 5)];
+            float vals[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = acc_row(r, h);  // channel within the 32-tile
+                const int c = cbase + cl;
+                float z = acc[i][q][r];
+                if (EPI == EPI_KNN_DIST) {
+                    // (|x_i|^2 + (-2 x_i.x_j)) + |x_j|^2, torch_edge.py:41-43 (i = row, j = column)
+                    const float si = row < a.rows ? a.sq[row] : 0.f, sj = c < a.M ? a.sq[c] : 0.f;
+                    z = __fadd_rn(__fadd_rn(si, __fmul_rn(-2.0f, z)), sj);
+                } else {
+                    if (a.bias && c < a.M) z += a.bias[c];
+                    if (a.gbias && c < a.M && row < a.rows) z += a.gbias[(size_t)(row / a.group_rows) * a.M + c];
+                    if (EPI == EPI_RELU_AFFINE) {
+                        const bool pos = z > 0.0f;
+                        mbits |= (unsigned)pos << cl;
+                        z = pos ? z : 0.0f;
+                        if (a.scale && c < a.M) z = z * a.scale[c] + a.shift[c];
+                    }
+                    if (!((min_bits >> cl) & 1u)) z = 0.0f;
+                }
+                vals[r] = z;
+            }
+            if (EPI == EPI_RELU_AFFINE && a.mask_out) {
+                const unsigned other = __shfl_xor(mbits, 32);
+                if (h == 0 && row < a.rows && cbase < a.M) a.mask_out[(size_t)row * ((a.M + 31) >> 5) + (cbase >> 5)] = mbits | other;
+            }
+            if (row < a.rows) {
+                float *o = a.out + (size_t)row * a.ld_out + cbase + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = cbase + 8 * g + 4 * h;
+                    if (c + 3 < a.M && ((a.ld_out & 3) == 0)) {
+                        float4 v = make_float4(vals[4 * g], vals[4 * g + 1], vals[4 * g + 2], vals[4 * g + 3]);
+                        float4 *dst = (float4 *)(o + 8 * g);
+                        if (a.accumulate) { float4 old = *dst; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+                        *dst = v;
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (c + u < a.M) {
+                                float *dst = o + 8 * g + u;
+                                *dst = a.accumulate ? *dst + vals[4 * g + u] : vals[4 * g + u];
+                            }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace psg

@@ -1,0 +1,697 @@
+// ResGCN-28 (dense DeepGCN) semantic-segmentation network on gfx950: forward, input-gradient backward
+// and the NB colour attack loop.  Reference (paths relative to /root/reference/ResGCN):
+//   gcn_lib/dense/torch_edge.py:32-79   pairwise_distance, dense_knn_matrix, DenseDilated(KnnGraph)
+//   gcn_lib/dense/torch_nn.py:55-98     BasicConv (Conv -> ReLU -> BatchNorm), batched_index_select
+//   gcn_lib/dense/torch_vertex.py:23-100 EdgeConv2d, DynConv2d, ResDynBlock2d
+//   sem_seg_dense/architecture.py:58-68  DenseDeepGCN.forward
+//   sem_seg_dense/attacks/torchattacks/attacks/colper.py:17-39  NB_attack
+//
+// MI355X-first choices:
+//   * EdgeConv uses the split identity W.[x_i, x_j - x_i] = (W1 - W2) x_i + W2 x_j: one 64->128 GEMM per
+//     vertex ([P | Q]) instead of a 128->64 GEMM per EDGE (16x fewer MACs), then a gather kernel does
+//     relu(P_i + Q_j) -> BatchNorm affine -> max over the 16 neighbours (+ residual) in one pass.
+//   * the feature-space kNN distance matrix is an fp32 MFMA GEMM whose accumulation order is the
+//     ascending-k fmaf chain of a CPU sgemm (bit-identical distances for bit-identical features); the
+//     top-(k*d) selection is an in-LDS bitonic sort of (distance, index) keys per row, ties -> lowest index.
+//   * backward exploits structure: the global max-pool makes the fusion layer's gradient 1024-sparse
+//     (one point per channel), so its 1792x1024 transpose GEMM collapses to 1024 scaled row additions;
+//     the broadcast fusion term of the first prediction layer becomes a per-room bias (forward) and a
+//     column sum + mat-vec (backward).
+#include <algorithm>
+#include <vector>
+
+#include "psg_common.h"
+#include "psg_gemm.cuh"
+
+using namespace psg;
+
+namespace {
+
+constexpr int GC = 64;      // n_filters
+constexpr int NCLS = 13;
+constexpr int KNB = 16;     // k
+
+template <int WM, int WN, int EPI, bool ASC>
+int launch_gemm(const GemmArgs &a, hipStream_t st)
+{
+    constexpr int BR = 64 * WM, BN = 64 * WN;
+    dim3 grid(ceil_div(a.rows, BR), ceil_div(a.M, BN));
+    hipLaunchKernelGGL((gemm_rows_kernel<WM, WN, EPI, ASC>), grid, dim3(256), 0, st, a);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+GemmArgs gemm_args(const float *in, int ld_in, const float *w, int ld_w, float *out, int ld_out, int rows, int K, int M)
+{
+    GemmArgs a;
+    a.in = in; a.w = w; a.bias = nullptr; a.gbias = nullptr; a.scale = nullptr; a.shift = nullptr; a.sq = nullptr;
+    a.out = out; a.mask_out = nullptr; a.mask_in = nullptr;
+    a.rows = rows; a.K = K; a.M = M; a.ld_in = ld_in; a.ld_w = ld_w; a.ld_out = ld_out; a.group_rows = 1; a.accumulate = 0;
+    return a;
+}
+
+// ---- squared norms with the reference's summation order (SURVEY 8a'): for C = 64 torch.sum(x*x, -1) uses
+// 8 lanes x 4 accumulators (two passes of 32), lane-wise ((a0+a1)+a2)+a3, then the 8 lanes left to right.
+__global__ void sumsq_rows_kernel(const float *__restrict__ x, int ld, int C, size_t rows, float *__restrict__ out)
+{
+    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float *p = x + r * ld;
+    float s;
+    if (C == 64) {
+        float acc[4][8];
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[jq][l] = 0.0f;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq)
+#pragma unroll
+                for (int l = 0; l < 8; ++l) {
+                    const float v = p[32 * pass + 8 * jq + l];
+                    acc[jq][l] = __fadd_rn(acc[jq][l], __fmul_rn(v, v));
+                }
+        s = 0.0f;
+        bool first = true;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const float t = __fadd_rn(__fadd_rn(__fadd_rn(acc[0][l], acc[1][l]), acc[2][l]), acc[3][l]);
+            s = first ? t : __fadd_rn(s, t);
+            first = false;
+        }
+    } else {
+        s = __fmul_rn(p[0], p[0]);
+        for (int c = 1; c < C; ++c) s = __fadd_rn(s, __fmul_rn(p[c], p[c]));
+    }
+    out[r] = s;
+}
+
+// ---- dilated kNN selection: one workgroup per query row sorts (distance, index) keys of its distance-matrix
+// row in LDS (bitonic, 64-bit keys: order-preserving float bits << 32 | index => ascending distance, lowest
+// index on ties) and emits the neighbours at ranks 0, d, 2d, ... (torch.topk(-dist, k*d)[..., ::d]).
+__global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict__ dist, int N, int NP2, int k, int d,
+                                                         int32_t *__restrict__ out)
+{
+    extern __shared__ unsigned long long keys[];  // [NP2]
+    const size_t row = blockIdx.x;                 // global row over all rooms
+    const float *drow = dist + row * (size_t)N;
+    for (int t = threadIdx.x; t < NP2; t += 256) {
+        unsigned long long key = ~0ull;
+        if (t < N) {
+            unsigned u = __float_as_uint(drow[t]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // total order of floats as unsigned
+            key = ((unsigned long long)u << 32) | (unsigned)t;
+        }
+        keys[t] = key;
+    }
+    __syncthreads();
+    for (int size = 2; size <= NP2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < NP2 / 2; t += 256) {
+                const int lo = ((t / stride) * stride * 2) + (t % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int t = threadIdx.x; t < k; t += 256) out[row * k + t] = (int32_t)(keys[(size_t)t * d] & 0xFFFFFFFFull);
+}
+
+// ---- EdgeConv edge pass (forward): y[i][c] = max_k ( s_c * relu(P[i][c] + Q[nbr(i,k)][c]) + t_c ) (+ residual)
+// One thread per (vertex, channel), channel fastest: the 64 lanes of a wave read one 256-byte Q row.
+__global__ void edge_max_fwd_kernel(const float *__restrict__ pq, const int32_t *__restrict__ nbr,
+                                    const float *__restrict__ scale, const float *__restrict__ shift,
+                                    const float *__restrict__ resid, int ld_res, float *__restrict__ out, int ld_out,
+                                    uint8_t *__restrict__ arg, int N, size_t total)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c = (int)(t % GC);
+    const size_t v = t / GC;                 // global vertex (room * N + i)
+    const size_t room_base = (v / N) * N;
+    const float p = pq[v * 2 * GC + c];
+    const float s = scale[c], sh = shift[c];
+    float best = -INFINITY;
+    int bk = 0;
+    bool bact = false;
+    const int32_t *nb = nbr + v * KNB;
+#pragma unroll 4
+    for (int k = 0; k < KNB; ++k) {
+        const float z = p + pq[(room_base + nb[k]) * 2 * GC + GC + c];
+        const bool act = z > 0.0f;
+        const float y = (act ? z : 0.0f) * s + sh;
+        if (y > best) { best = y; bk = k; bact = act; }
+    }
+    if (resid) best += resid[v * ld_res + c];
+    out[v * ld_out + c] = best;
+    arg[t] = (uint8_t)(bk | (bact ? 0x80 : 0));
+}
+
+// ---- EdgeConv edge pass (backward): g = dY * s_c where the winning edge was active;  dP[i][c] = g,
+// dQ[nbr(i,k*)][c] += g.  dpq must be zeroed (Q half) before the launch.
+__global__ void edge_max_bwd_kernel(const float *__restrict__ dy, int ld_dy, const int32_t *__restrict__ nbr,
+                                    const uint8_t *__restrict__ arg, const float *__restrict__ scale,
+                                    float *__restrict__ dpq, int N, size_t total)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c = (int)(t % GC);
+    const size_t v = t / GC;
+    const uint8_t a = arg[t];
+    float g = 0.0f;
+    if (a & 0x80) g = dy[v * ld_dy + c] * scale[c];
+    dpq[v * 2 * GC + c] = g;
+    if (g != 0.0f) {
+        const size_t j = (v / N) * N + nbr[v * KNB + (a & 0x7F)];
+        atomicAdd(dpq + j * 2 * GC + GC + c, g);
+    }
+}
+
+__global__ void add_slice_kernel(float *__restrict__ g, const float *__restrict__ src, int ld_src, size_t rows)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < rows * GC) g[t] += src[(t / GC) * ld_src + (t % GC)];
+}
+
+// ---- global max over the N points of a room, per channel (torch.max_pool2d over [N,1], architecture.py:64)
+__global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ x, int N, int C, float *__restrict__ mx,
+                                                     int32_t *__restrict__ arg)
+{
+    // grid (C/64, rooms); thread (cc = tid&63, part = tid>>6) scans rows part, part+4, ...
+    __shared__ float s_v[4][64];
+    __shared__ int s_i[4][64];
+    const int cc = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cc;
+    const size_t room = blockIdx.y;
+    float best = -INFINITY;
+    int bi = 0;
+    for (int i = part; i < N; i += 4) {
+        const float v = x[(room * N + i) * C + c];
+        if (v > best) { best = v; bi = i; }
+    }
+    s_v[part][cc] = best; s_i[part][cc] = bi;
+    __syncthreads();
+    if (part == 0) {
+        for (int q = 1; q < 4; ++q)
+            if (s_v[q][cc] > best || (s_v[q][cc] == best && s_i[q][cc] < bi)) { best = s_v[q][cc]; bi = s_i[q][cc]; }
+        mx[room * C + c] = best;
+        arg[room * C + c] = bi;
+    }
+}
+
+// out[room][m] = sum_k w[m][k] * v[room][k]   (small mat-vec; w row-major with leading dimension ld_w)
+__global__ void matvec_kernel(const float *__restrict__ w, int ld_w, const float *__restrict__ v, int K, int M,
+                              float *__restrict__ out)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t room = blockIdx.y;
+    if (m >= M) return;
+    float acc = 0.0f;
+    for (int k = 0; k < K; ++k) acc += w[(size_t)m * ld_w + k] * v[room * K + k];
+    out[room * M + m] = acc;
+}
+
+// column sums over the N rows of each room: out[room][c] = sum_i x[room*N+i][c]
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, int N, int C, float *__restrict__ out)
+{
+    __shared__ float s_v[4][64];
+    const int cc = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cc;
+    const size_t room = blockIdx.y;
+    float acc = 0.0f;
+    for (int i = part; i < N; i += 4) acc += x[(room * N + i) * C + c];
+    s_v[part][cc] = acc;
+    __syncthreads();
+    if (part == 0) out[room * C + c] = ((s_v[0][cc] + s_v[1][cc]) + s_v[2][cc]) + s_v[3][cc];
+}
+
+// fusion backward: dfeats[argmax point of channel c][:] += gvec[c] * s_c[active] * Wf[c][:]
+__global__ void fusion_bwd_kernel(const float *__restrict__ gvec, const int32_t *__restrict__ arg,
+                                  const uint32_t *__restrict__ mask, const float *__restrict__ scale,
+                                  const float *__restrict__ wf, int Cin, int Cout, int N, float *__restrict__ dfeats)
+{
+    // grid (Cout, rooms), block 256 threads over the Cin input channels
+    const int c = blockIdx.x;
+    const size_t room = blockIdx.y;
+    const int i = arg[room * Cout + c];
+    const size_t row = room * N + i;
+    const bool act = (mask[row * (Cout / 32) + (c >> 5)] >> (c & 31)) & 1u;
+    const float g = act ? gvec[room * Cout + c] * scale[c] : 0.0f;
+    if (g == 0.0f) return;
+    for (int k = threadIdx.x; k < Cin; k += blockDim.x) atomicAdd(dfeats + row * Cin + k, g * wf[(size_t)c * Cin + k]);
+}
+
+__global__ void scale_rows_kernel(const float *__restrict__ w, int M, int K, const float *__restrict__ s_by_k,
+                                  float *__restrict__ out)
+{
+    // out[m][k] = w[m][k] * s_by_k[k]
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (size_t)M * K) out[t] = w[t] * s_by_k[t % K];
+}
+
+struct EdgeLayer {
+    float *wcat;    // [128][C]: rows 0..63 = W1 - W2, rows 64..127 = W2
+    float *bcat;    // [128] = [b, 0]
+    float *wcat_t;  // [C][128] (transpose, for the input gradient)
+    float *scale, *shift;  // eval BatchNorm after the ReLU
+    int C;
+};
+
+}  // namespace
+
+struct psg_gcn_model {
+    psg_ctx *ctx;
+    int n_blocks;
+    std::vector<EdgeLayer> edge;
+    float *wf, *bf, *sf, *tf;             // fusion 1792 -> 1024
+    float *wp1, *bp1, *s1, *t1;           // prediction.0: 2816 -> 512 (columns: [fusion 1024 | feats 1792])
+    float *wp2, *bp2, *s2, *t2;           // 512 -> 256
+    float *wp3, *bp3;                     // 256 -> 13
+    float *wp3_t;                         // [256][13]
+    float *wp2_st;                        // [512][256]: W2^T with BatchNorm scale s2 folded (by W2's output row)
+    float *wp1b_st;                       // [1792][512]: W1b^T with s1 folded
+    float *wp1a_st;                       // [1024][512]: (s1 * W1a)^T (for the fusion-vector gradient)
+    int fdim;                             // 64 * n_blocks
+    std::vector<void *> allocs;
+};
+
+struct psg_gcn_ws {
+    psg_ctx *ctx;
+    int B, N, NP2, n_blocks, fdim;
+    void *arena = nullptr;
+    size_t bytes = 0;
+    float *feats, *dfeats;     // [B*N][fdim]
+    float *dist;               // [B*N][N]
+    float *sq;                 // [B*N]
+    float *pq, *dpq;           // [B*N][128]
+    int32_t *nbr;              // [n_blocks][B*N][16]
+    uint8_t *arg;              // [n_blocks][B*N][64]
+    float *fused;              // [B*N][1024]
+    uint32_t *mask_f, *mask1, *mask2;
+    float *fmax; int32_t *farg; // [B][1024]
+    float *gb1;                // [B][512]
+    float *h1, *h2;            // [B*N][512], [B*N][256]
+    float *g2, *g1;            // backward buffers [B*N][256], [B*N][512]
+    float *g1sum, *gfvec;      // [B][512], [B][1024]
+    float *gcur;               // [B*N][64]
+    float *logits, *dlogits;   // [B*N][13]
+    float *x0, *ori, *dx0;     // attack state [B*N][9], [B*N][3], [B*N][9]
+    float *xyz;                // [B*N][3]
+    bool have_fwd = false;
+    bool fixed_graphs = false;  // psg_gcn_set_graphs: forward uses the supplied neighbour tables
+};
+
+namespace {
+
+template <typename T> T *dev_upload(psg_gcn_model *m, const std::vector<T> &h)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, h.size() * sizeof(T)) != hipSuccess) return nullptr;
+    (void)hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    m->allocs.push_back(p);
+    return (T *)p;
+}
+
+void bn_affine(const float *g, const float *b, const float *mu, const float *var, int n, std::vector<float> &s,
+               std::vector<float> &t)
+{
+    s.resize(n); t.resize(n);
+    for (int i = 0; i < n; ++i) {
+        double sc = (double)g[i] / sqrt((double)var[i] + 1e-5);
+        s[i] = (float)sc;
+        t[i] = (float)((double)b[i] - (double)mu[i] * sc);
+    }
+}
+
+__global__ void extract3_kernel(const float *__restrict__ x0, float *__restrict__ xyz, size_t rows)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < rows * 3) xyz[t] = x0[(t / 3) * 9 + (t % 3)];
+}
+
+__global__ void extract_color3_kernel(const float *__restrict__ x0, float *__restrict__ ori, size_t rows)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < rows * 3) ori[t] = x0[(t / 3) * 9 + 3 + (t % 3)];
+}
+
+int knn_graph(psg_gcn_ws *ws, const float *x, int ld, int C, int d, int32_t *out, hipStream_t st)
+{
+    const size_t rows = (size_t)ws->B * ws->N;
+    hipLaunchKernelGGL(sumsq_rows_kernel, dim3(ceil_div((int)rows, 256)), dim3(256), 0, st, x, ld, C, rows, ws->sq);
+    PSG_LAUNCH_CHECK();
+    for (int b = 0; b < ws->B; ++b) {  // distances never cross rooms
+        GemmArgs a = gemm_args(x + (size_t)b * ws->N * ld, ld, x + (size_t)b * ws->N * ld, ld,
+                               ws->dist + (size_t)b * ws->N * ws->N, ws->N, ws->N, C, ws->N);
+        a.sq = ws->sq + (size_t)b * ws->N;
+        int rc = launch_gemm<2, 2, EPI_KNN_DIST, true>(a, st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)rows), dim3(256), (size_t)ws->NP2 * 8, st, ws->dist, ws->N,
+                       ws->NP2, KNB, d, out);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+}  // namespace
+
+// ============================================================================================ model
+// tensors (host pointers, fp32), in this order:
+//   for each EdgeConv e = 0 (head) .. n_blocks-1:  conv.weight [64][2C], conv.bias [64], bn.weight, bn.bias,
+//                                                 bn.running_mean, bn.running_var [64]      (C = 9 for e = 0, else 64)
+//   fusion_block: weight [1024][64*n_blocks], bias, bn x4 [1024]
+//   prediction.0: weight [512][1024 + 64*n_blocks], bias, bn x4 [512]
+//   prediction.1: weight [256][512], bias, bn x4 [256]
+//   prediction.3: weight [13][256], bias [13]
+extern "C" int psg_gcn_model_create(psg_ctx *ctx, const float *const *tensors, int n_tensors, int n_blocks,
+                                    psg_gcn_model **out)
+{
+    PSG_REQUIRE(ctx && tensors && out, "psg_gcn_model_create: null argument");
+    PSG_REQUIRE(n_blocks >= 1 && n_blocks <= 64, "psg_gcn_model_create: n_blocks out of range");
+    PSG_REQUIRE(n_tensors == 6 * n_blocks + 6 + 6 + 6 + 2, "psg_gcn_model_create: expected %d tensors, got %d",
+                6 * n_blocks + 20, n_tensors);
+    for (int i = 0; i < n_tensors; ++i) PSG_REQUIRE(tensors[i], "psg_gcn_model_create: tensor %d is null", i);
+    PSG_CHECK_HIP(hipSetDevice(ctx->device));
+    auto *m = new psg_gcn_model();
+    m->ctx = ctx; m->n_blocks = n_blocks; m->fdim = GC * n_blocks;
+    int ti = 0;
+    for (int e = 0; e < n_blocks; ++e) {
+        const int C = e == 0 ? 9 : GC;
+        const float *W = tensors[ti], *b = tensors[ti + 1];
+        std::vector<float> s, t;
+        bn_affine(tensors[ti + 2], tensors[ti + 3], tensors[ti + 4], tensors[ti + 5], GC, s, t);
+        ti += 6;
+        std::vector<float> wcat((size_t)2 * GC * C), wt((size_t)C * 2 * GC), bcat(2 * GC, 0.0f);
+        for (int o = 0; o < GC; ++o) {
+            bcat[o] = b[o];
+            for (int c = 0; c < C; ++c) {
+                const float w1 = W[(size_t)o * 2 * C + c], w2 = W[(size_t)o * 2 * C + C + c];
+                wcat[(size_t)o * C + c] = w1 - w2;
+                wcat[(size_t)(GC + o) * C + c] = w2;
+            }
+        }
+        for (int r = 0; r < 2 * GC; ++r)
+            for (int c = 0; c < C; ++c) wt[(size_t)c * 2 * GC + r] = wcat[(size_t)r * C + c];
+        EdgeLayer L;
+        L.C = C;
+        L.wcat = dev_upload(m, wcat); L.bcat = dev_upload(m, bcat); L.wcat_t = dev_upload(m, wt);
+        L.scale = dev_upload(m, s); L.shift = dev_upload(m, t);
+        m->edge.push_back(L);
+    }
+    const int F = m->fdim;
+    auto up = [&](const float *p, size_t n) { return dev_upload(m, std::vector<float>(p, p + n)); };
+    std::vector<float> s, t;
+    m->wf = up(tensors[ti], (size_t)1024 * F); m->bf = up(tensors[ti + 1], 1024);
+    bn_affine(tensors[ti + 2], tensors[ti + 3], tensors[ti + 4], tensors[ti + 5], 1024, s, t);
+    m->sf = dev_upload(m, s); m->tf = dev_upload(m, t); ti += 6;
+    const float *W1 = tensors[ti];
+    m->wp1 = up(W1, (size_t)512 * (1024 + F)); m->bp1 = up(tensors[ti + 1], 512);
+    std::vector<float> s1v, t1v;
+    bn_affine(tensors[ti + 2], tensors[ti + 3], tensors[ti + 4], tensors[ti + 5], 512, s1v, t1v);
+    m->s1 = dev_upload(m, s1v); m->t1 = dev_upload(m, t1v); ti += 6;
+    const float *W2 = tensors[ti];
+    m->wp2 = up(W2, (size_t)256 * 512); m->bp2 = up(tensors[ti + 1], 256);
+    std::vector<float> s2v, t2v;
+    bn_affine(tensors[ti + 2], tensors[ti + 3], tensors[ti + 4], tensors[ti + 5], 256, s2v, t2v);
+    m->s2 = dev_upload(m, s2v); m->t2 = dev_upload(m, t2v); ti += 6;
+    const float *W3 = tensors[ti];
+    m->wp3 = up(W3, (size_t)NCLS * 256); m->bp3 = up(tensors[ti + 1], NCLS);
+    // transposes for the input-gradient pass, BatchNorm scales folded in
+    std::vector<float> w3t((size_t)256 * NCLS), w2st((size_t)512 * 256), w1bst((size_t)F * 512), w1ast((size_t)1024 * 512);
+    for (int o = 0; o < NCLS; ++o)
+        for (int k = 0; k < 256; ++k) w3t[(size_t)k * NCLS + o] = W3[(size_t)o * 256 + k];
+    for (int o = 0; o < 256; ++o)
+        for (int k = 0; k < 512; ++k) w2st[(size_t)k * 256 + o] = W2[(size_t)o * 512 + k] * s2v[o];
+    for (int o = 0; o < 512; ++o) {
+        for (int k = 0; k < F; ++k) w1bst[(size_t)k * 512 + o] = W1[(size_t)o * (1024 + F) + 1024 + k] * s1v[o];
+        for (int k = 0; k < 1024; ++k) w1ast[(size_t)k * 512 + o] = W1[(size_t)o * (1024 + F) + k] * s1v[o];
+    }
+    m->wp3_t = dev_upload(m, w3t); m->wp2_st = dev_upload(m, w2st); m->wp1b_st = dev_upload(m, w1bst);
+    m->wp1a_st = dev_upload(m, w1ast);
+    for (void *p : m->allocs)
+        if (!p) { set_error("psg_gcn_model_create: device allocation failed"); return PSG_ERR_HIP; }
+    *out = m;
+    return PSG_OK;
+}
+
+extern "C" int psg_gcn_model_destroy(psg_gcn_model *m)
+{
+    if (!m) return PSG_OK;
+    for (void *p : m->allocs) (void)hipFree(p);
+    delete m;
+    return PSG_OK;
+}
+
+// ======================================================================================== workspace
+extern "C" int psg_gcn_ws_create(psg_ctx *ctx, int batch, int n_point, int n_blocks, psg_gcn_ws **out)
+{
+    PSG_REQUIRE(ctx && out, "psg_gcn_ws_create: null argument");
+    PSG_REQUIRE(batch > 0 && n_blocks >= 1, "psg_gcn_ws_create: bad sizes");
+    PSG_REQUIRE(n_point >= 16 * n_blocks && n_point <= 4096,
+                "psg_gcn_ws_create: n_point=%d must be in [k*max dilation = %d, 4096]", n_point, 16 * n_blocks);
+    PSG_CHECK_HIP(hipSetDevice(ctx->device));
+    auto *ws = new psg_gcn_ws();
+    ws->ctx = ctx; ws->B = batch; ws->N = n_point; ws->n_blocks = n_blocks; ws->fdim = GC * n_blocks;
+    ws->NP2 = 1;
+    while (ws->NP2 < n_point) ws->NP2 <<= 1;
+    const size_t R = (size_t)batch * n_point;
+    for (int pass = 0; pass < 2; ++pass) {
+        size_t off = 0;
+        auto take = [&](size_t bytes) {
+            off = (off + 255) & ~(size_t)255;
+            char *p = pass ? (char *)ws->arena + off : nullptr;
+            off += bytes;
+            return (void *)p;
+        };
+        ws->feats = (float *)take(R * ws->fdim * 4);
+        ws->dfeats = (float *)take(R * ws->fdim * 4);
+        ws->dist = (float *)take(R * n_point * 4);
+        ws->sq = (float *)take(R * 4);
+        ws->pq = (float *)take(R * 128 * 4);
+        ws->dpq = (float *)take(R * 128 * 4);
+        ws->nbr = (int32_t *)take((size_t)n_blocks * R * KNB * 4);
+        ws->arg = (uint8_t *)take((size_t)n_blocks * R * GC);
+        ws->fused = (float *)take(R * 1024 * 4);
+        ws->mask_f = (uint32_t *)take(R * 32 * 4);
+        ws->mask1 = (uint32_t *)take(R * 16 * 4);
+        ws->mask2 = (uint32_t *)take(R * 8 * 4);
+        ws->fmax = (float *)take((size_t)batch * 1024 * 4);
+        ws->farg = (int32_t *)take((size_t)batch * 1024 * 4);
+        ws->gb1 = (float *)take((size_t)batch * 512 * 4);
+        ws->h1 = (float *)take(R * 512 * 4);
+        ws->h2 = (float *)take(R * 256 * 4);
+        ws->g2 = (float *)take(R * 256 * 4);
+        ws->g1 = (float *)take(R * 512 * 4);
+        ws->g1sum = (float *)take((size_t)batch * 512 * 4);
+        ws->gfvec = (float *)take((size_t)batch * 1024 * 4);
+        ws->gcur = (float *)take(R * GC * 4);
+        ws->logits = (float *)take(R * NCLS * 4);
+        ws->dlogits = (float *)take(R * NCLS * 4);
+        ws->x0 = (float *)take(R * 9 * 4);
+        ws->ori = (float *)take(R * 3 * 4);
+        ws->dx0 = (float *)take(R * 9 * 4);
+        ws->xyz = (float *)take(R * 3 * 4);
+        if (!pass) {
+            ws->bytes = (off + 255) & ~(size_t)255;
+            hipError_t e = hipMalloc(&ws->arena, ws->bytes);
+            if (e != hipSuccess) {
+                set_error("psg_gcn_ws_create: hipMalloc(%zu) failed: %s", ws->bytes, hipGetErrorString(e));
+                delete ws;
+                return PSG_ERR_HIP;
+            }
+        }
+    }
+    *out = ws;
+    return PSG_OK;
+}
+
+extern "C" int psg_gcn_ws_destroy(psg_gcn_ws *ws)
+{
+    if (!ws) return PSG_OK;
+    if (ws->arena) (void)hipFree(ws->arena);
+    delete ws;
+    return PSG_OK;
+}
+
+extern "C" size_t psg_gcn_ws_bytes(const psg_gcn_ws *ws) { return ws ? ws->bytes : 0; }
+
+extern "C" const int32_t *psg_gcn_edge_ptr(const psg_gcn_ws *ws, int block)
+{
+    if (!ws || block < 0 || block >= ws->n_blocks) return nullptr;
+    return ws->nbr + (size_t)block * ws->B * ws->N * KNB;
+}
+
+extern "C" int psg_gcn_set_graphs(psg_gcn_ws *ws, const int32_t *nbr, psg_stream stream)
+{
+    PSG_REQUIRE(ws, "psg_gcn_set_graphs: null workspace");
+    if (!nbr) { ws->fixed_graphs = false; return PSG_OK; }
+    PSG_CHECK_HIP(hipMemcpyAsync(ws->nbr, nbr, (size_t)ws->n_blocks * ws->B * ws->N * KNB * 4, hipMemcpyDeviceToDevice,
+                                 (hipStream_t)stream));
+    ws->fixed_graphs = true;
+    return PSG_OK;
+}
+
+extern "C" const float *psg_gcn_feats_ptr(const psg_gcn_ws *ws) { return ws ? ws->feats : nullptr; }
+
+// unit op: dilated dense kNN graph of point-major features x [B][N][C] (torch_edge.py:45-79)
+extern "C" int psg_gcn_knn(psg_gcn_ws *ws, const float *x, int C, int dilation, int32_t *out_idx, psg_stream stream)
+{
+    PSG_REQUIRE(ws && x && out_idx, "psg_gcn_knn: null argument");
+    PSG_REQUIRE(C >= 1 && dilation >= 1 && KNB * dilation <= ws->N, "psg_gcn_knn: k*dilation=%d exceeds N=%d",
+                KNB * dilation, ws->N);
+    return knn_graph(ws, x, C, C, dilation, out_idx, (hipStream_t)stream);
+}
+
+// ==================================================================================== forward / backward
+extern "C" int psg_gcn_forward(psg_gcn_model *m, psg_gcn_ws *ws, const float *x0, float *logits_out, psg_stream stream)
+{
+    PSG_REQUIRE(m && ws && x0 && logits_out, "psg_gcn_forward: null argument");
+    PSG_REQUIRE(m->n_blocks == ws->n_blocks, "psg_gcn_forward: model/workspace block count mismatch");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = ws->B, N = ws->N, F = ws->fdim;
+    const size_t R = (size_t)B * N;
+    const int g256 = ceil_div((int)(R * GC), 256);
+    int rc;
+    hipLaunchKernelGGL(extract3_kernel, dim3(ceil_div((int)(R * 3), 256)), dim3(256), 0, st, x0, ws->xyz, R);
+    PSG_LAUNCH_CHECK();
+    for (int e = 0; e < m->n_blocks; ++e) {
+        const EdgeLayer &L = m->edge[e];
+        int32_t *nbr = ws->nbr + (size_t)e * R * KNB;
+        const float *xin = e == 0 ? x0 : ws->feats + (size_t)(e - 1) * GC;
+        const int ld = e == 0 ? 9 : F;
+        // graph: xyz kNN for the head (architecture.py:59), feature-space kNN with dilation e for block e (:61-62)
+        if (!ws->fixed_graphs &&
+            (rc = knn_graph(ws, e == 0 ? ws->xyz : xin, e == 0 ? 3 : ld, e == 0 ? 3 : GC, e == 0 ? 1 : e, nbr, st)))
+            return rc;
+        // [P | Q] = x . [W1 - W2 ; W2]^T + [b, 0]
+        GemmArgs a = gemm_args(xin, ld, L.wcat, L.C, ws->pq, 2 * GC, (int)R, L.C, 2 * GC);
+        a.bias = L.bcat;
+        if ((rc = launch_gemm<2, 2, EPI_LINEAR, false>(a, st))) return rc;
+        hipLaunchKernelGGL(edge_max_fwd_kernel, dim3(g256), dim3(256), 0, st, ws->pq, nbr, L.scale, L.shift,
+                           e == 0 ? nullptr : xin, F, ws->feats + (size_t)e * GC, F, ws->arg + (size_t)e * R * GC, N,
+                           R * GC);
+        PSG_LAUNCH_CHECK();
+    }
+    // fusion: Conv(F -> 1024) + ReLU + BN, global max over the room
+    {
+        GemmArgs a = gemm_args(ws->feats, F, m->wf, F, ws->fused, 1024, (int)R, F, 1024);
+        a.bias = m->bf; a.scale = m->sf; a.shift = m->tf; a.mask_out = ws->mask_f;
+        if ((rc = launch_gemm<2, 2, EPI_RELU_AFFINE, false>(a, st))) return rc;
+        hipLaunchKernelGGL(colmax_kernel, dim3(1024 / 64, B), dim3(256), 0, st, ws->fused, N, 1024, ws->fmax, ws->farg);
+        PSG_LAUNCH_CHECK();
+    }
+    // prediction.0 on cat(fusion broadcast, feats): the broadcast half is a per-room bias W1a . fmax
+    hipLaunchKernelGGL(matvec_kernel, dim3(ceil_div(512, 256), B), dim3(256), 0, st, m->wp1, 1024 + F, ws->fmax, 1024, 512,
+                       ws->gb1);
+    PSG_LAUNCH_CHECK();
+    {
+        GemmArgs a = gemm_args(ws->feats, F, m->wp1 + 1024, 1024 + F, ws->h1, 512, (int)R, F, 512);
+        a.bias = m->bp1; a.gbias = ws->gb1; a.group_rows = N; a.scale = m->s1; a.shift = m->t1; a.mask_out = ws->mask1;
+        if ((rc = launch_gemm<2, 2, EPI_RELU_AFFINE, false>(a, st))) return rc;
+    }
+    {
+        GemmArgs a = gemm_args(ws->h1, 512, m->wp2, 512, ws->h2, 256, (int)R, 512, 256);
+        a.bias = m->bp2; a.scale = m->s2; a.shift = m->t2; a.mask_out = ws->mask2;
+        if ((rc = launch_gemm<2, 2, EPI_RELU_AFFINE, false>(a, st))) return rc;
+    }
+    {
+        GemmArgs a = gemm_args(ws->h2, 256, m->wp3, 256, ws->logits, NCLS, (int)R, 256, NCLS);
+        a.bias = m->bp3;
+        if ((rc = launch_gemm<4, 1, EPI_LINEAR, false>(a, st))) return rc;
+    }
+    if (logits_out != ws->logits)
+        PSG_CHECK_HIP(hipMemcpyAsync(logits_out, ws->logits, R * NCLS * 4, hipMemcpyDeviceToDevice, st));
+    ws->have_fwd = true;
+    return PSG_OK;
+}
+
+extern "C" int psg_gcn_backward(psg_gcn_model *m, psg_gcn_ws *ws, const float *dlogits, float *dx0_out,
+                                psg_stream stream)
+{
+    PSG_REQUIRE(m && ws && dlogits && dx0_out, "psg_gcn_backward: null argument");
+    if (!ws->have_fwd) { set_error("psg_gcn_backward: no forward is resident in the workspace"); return PSG_ERR_STATE; }
+    hipStream_t st = (hipStream_t)stream;
+    const int B = ws->B, N = ws->N, F = ws->fdim;
+    const size_t R = (size_t)B * N;
+    const int g256 = ceil_div((int)(R * GC), 256);
+    int rc;
+    // prediction.3^T, then through ReLU/BN of prediction.1 (mask2; its scale s2 is folded into wp2_st)
+    {
+        GemmArgs a = gemm_args(dlogits, NCLS, m->wp3_t, NCLS, ws->g2, 256, (int)R, NCLS, 256);
+        a.mask_in = ws->mask2;
+        if ((rc = launch_gemm<2, 2, EPI_LINEAR, false>(a, st))) return rc;
+    }
+    {
+        GemmArgs a = gemm_args(ws->g2, 256, m->wp2_st, 256, ws->g1, 512, (int)R, 256, 512);
+        a.mask_in = ws->mask1;
+        if ((rc = launch_gemm<2, 2, EPI_LINEAR, false>(a, st))) return rc;
+    }
+    // feats half of prediction.0^T
+    {
+        GemmArgs a = gemm_args(ws->g1, 512, m->wp1b_st, 512, ws->dfeats, F, (int)R, 512, F);
+        if ((rc = launch_gemm<2, 2, EPI_LINEAR, false>(a, st))) return rc;
+    }
+    // fusion half: gradient of the broadcast vector = (s1 * W1a)^T . (column sum of g1), then back through the
+    // global max (one point per channel), ReLU/BN of the fusion block and its 1x1 conv: 1024 scaled row adds
+    hipLaunchKernelGGL(colsum_kernel, dim3(512 / 64, B), dim3(256), 0, st, ws->g1, N, 512, ws->g1sum);
+    PSG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(matvec_kernel, dim3(ceil_div(1024, 256), B), dim3(256), 0, st, m->wp1a_st, 512, ws->g1sum, 512, 1024,
+                       ws->gfvec);
+    PSG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fusion_bwd_kernel, dim3(1024, B), dim3(256), 0, st, ws->gfvec, ws->farg, ws->mask_f, m->sf, m->wf, F,
+                       1024, N, ws->dfeats);
+    PSG_LAUNCH_CHECK();
+    // backbone in reverse: G_e = d/d x_e
+    PSG_CHECK_HIP(hipMemcpy2DAsync(ws->gcur, GC * 4, ws->dfeats + (size_t)(m->n_blocks - 1) * GC, (size_t)F * 4, GC * 4, R,
+                                   hipMemcpyDeviceToDevice, st));
+    for (int e = m->n_blocks - 1; e >= 0; --e) {
+        const EdgeLayer &L = m->edge[e];
+        PSG_CHECK_HIP(hipMemsetAsync(ws->dpq, 0, R * 2 * GC * 4, st));
+        hipLaunchKernelGGL(edge_max_bwd_kernel, dim3(g256), dim3(256), 0, st, ws->gcur, GC, ws->nbr + (size_t)e * R * KNB,
+                           ws->arg + (size_t)e * R * GC, L.scale, ws->dpq, N, R * GC);
+        PSG_LAUNCH_CHECK();
+        if (e > 0) {
+            // x_e = EdgeConv_e(x_{e-1}) + x_{e-1}:  G_{e-1} = dfeats[e-1] + G_e + [dP | dQ] . [W1-W2 ; W2]
+            hipLaunchKernelGGL(add_slice_kernel, dim3(g256), dim3(256), 0, st, ws->gcur, ws->dfeats + (size_t)(e - 1) * GC, F, R);
+            PSG_LAUNCH_CHECK();
+            GemmArgs a = gemm_args(ws->dpq, 2 * GC, L.wcat_t, 2 * GC, ws->gcur, GC, (int)R, 2 * GC, GC);
+            a.accumulate = 1;
+            if ((rc = launch_gemm<4, 1, EPI_LINEAR, false>(a, st))) return rc;
+        } else {
+            GemmArgs a = gemm_args(ws->dpq, 2 * GC, L.wcat_t, 2 * GC, dx0_out, 9, (int)R, 2 * GC, 9);
+            if ((rc = launch_gemm<4, 1, EPI_LINEAR, false>(a, st))) return rc;
+        }
+    }
+    return PSG_OK;
+}
+
+// ====================================================================================== NB attack
+// colper.NB_attack (ResGCN/sem_seg_dense/attacks/torchattacks/attacks/colper.py:17-39): CrossEntropyLoss()
+// (mean over all B*N points) on the logits, sign ascent on the colour channels, L-inf projection; the
+// returned colours are the un-projected last step (the projection is not written back after the loop).
+extern "C" int psg_gcn_nb_attack(psg_gcn_model *m, psg_gcn_ws *ws, const float *images, const int32_t *labels,
+                                 float eps, float alpha, int iters, float *adv_out, psg_stream stream)
+{
+    PSG_REQUIRE(m && ws && images && labels && adv_out, "psg_gcn_nb_attack: null argument");
+    PSG_REQUIRE(iters > 0, "psg_gcn_nb_attack: iters must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = ws->B, N = ws->N;
+    const size_t R = (size_t)B * N;
+    int rc;
+    if ((rc = psg_to_point_major(images, B, 9, N, ws->x0, st))) return rc;
+    hipLaunchKernelGGL(extract_color3_kernel, dim3(ceil_div((int)(R * 3), 256)), dim3(256), 0, st, ws->x0, ws->ori, R);
+    PSG_LAUNCH_CHECK();
+    for (int it = 0; it < iters; ++it) {
+        if ((rc = psg_gcn_forward(m, ws, ws->x0, ws->logits, st))) return rc;
+        if ((rc = psg_ce_logp_grad(ws->logits, labels, 0, (int)R, (int)R, NCLS, 1.0f / (float)R, ws->dlogits, nullptr, st)))
+            return rc;
+        if ((rc = psg_gcn_backward(m, ws, ws->dlogits, ws->dx0, st))) return rc;
+        if ((rc = psg_pgd_step(ws->x0, ws->dx0, ws->ori, nullptr, B, N, alpha, eps, 1.0f, it == iters - 1, st))) return rc;
+    }
+    return psg_to_channel_major(ws->x0, B, 9, N, adv_out, st);
+}

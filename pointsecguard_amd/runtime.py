@@ -273,3 +273,110 @@ def seg_stats(logp, labels, n_cls=NUM_CLASSES, counters=None):
     pred = torch.empty(rows, dtype=torch.int32, device=logp.device)
     _lib.call("psg_seg_stats", ptr(logp), ptr(labels), rows, n_cls, ptr(counters), ptr(pred), stream())
     return counters, pred.view(labels.shape)
+
+
+# ---- ResGCN (dense DeepGCN) ------------------------------------------------------------------------
+def gcn_tensor_list(sd, n_blocks):
+    """state_dict (reference key names, ResGCN/sem_seg_dense/architecture.py) -> the flat fp32 tensor list of
+    psg_gcn_model_create."""
+    def a(k):
+        v = sd[k]
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        v = np.ascontiguousarray(v, np.float32)
+        return v.reshape(v.shape[0], -1) if v.ndim > 1 else v
+
+    out = []
+    for e in range(n_blocks):
+        base = "head.gconv.nn" if e == 0 else "backbone.%d.body.gconv.nn" % (e - 1)
+        out += [a(base + ".0.weight"), a(base + ".0.bias")]
+        out += [a(base + ".2." + k) for k in ("weight", "bias", "running_mean", "running_var")]
+    for conv, bn in (("fusion_block.0", "fusion_block.2"), ("prediction.0.0", "prediction.0.2"),
+                     ("prediction.1.0", "prediction.1.2")):
+        out += [a(conv + ".weight"), a(conv + ".bias")] + [a(bn + "." + k) for k in ("weight", "bias", "running_mean", "running_var")]
+    out += [a("prediction.3.0.weight"), a("prediction.3.0.bias")]
+    return out
+
+
+class GCNModel:
+    def __init__(self, sd, n_blocks, device=None):
+        self.ctx = context(device)
+        self.n_blocks = n_blocks
+        self._keep = gcn_tensor_list(sd, n_blocks)
+        arr = (ctypes.c_void_p * len(self._keep))(*[t.ctypes.data_as(ctypes.c_void_p) for t in self._keep])
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.load().psg_gcn_model_create(self.ctx, arr, len(self._keep), n_blocks, ctypes.byref(self.handle)),
+                   "psg_gcn_model_create")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().psg_gcn_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class GCNWorkspace:
+    def __init__(self, batch, n_point, n_blocks, device=None):
+        self.ctx = context(device)
+        self.batch, self.n_point, self.n_blocks = batch, n_point, n_blocks
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.load().psg_gcn_ws_create(self.ctx, batch, n_point, n_blocks, ctypes.byref(self.handle)),
+                   "psg_gcn_ws_create")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().psg_gcn_ws_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def knn(self, x, dilation):
+        require_cuda(x, "x", torch.float32)
+        B, N, C = x.shape
+        out = torch.empty(B, N, 16, dtype=torch.int32, device=x.device)
+        _lib.call("psg_gcn_knn", self.handle, ptr(x), C, int(dilation), ptr(out), stream())
+        return out
+
+    def set_graphs(self, nbr):
+        if nbr is not None:
+            require_cuda(nbr, "nbr", torch.int32)
+        _lib.call("psg_gcn_set_graphs", self.handle, ptr(nbr), stream())
+
+    def forward(self, model, x0, logits=None):
+        require_cuda(x0, "x0", torch.float32)
+        if logits is None:
+            logits = torch.empty(self.batch, self.n_point, NUM_CLASSES, device=x0.device, dtype=torch.float32)
+        _lib.call("psg_gcn_forward", model.handle, self.handle, ptr(x0), ptr(logits), stream())
+        return logits
+
+    def backward(self, model, dlogits, dx0=None):
+        require_cuda(dlogits, "dlogits", torch.float32)
+        if dx0 is None:
+            dx0 = torch.empty(self.batch, self.n_point, 9, device=dlogits.device, dtype=torch.float32)
+        _lib.call("psg_gcn_backward", model.handle, self.handle, ptr(dlogits), ptr(dx0), stream())
+        return dx0
+
+    def nb_attack(self, model, images, labels, eps, alpha, iters, out=None):
+        require_cuda(images, "images", torch.float32)
+        require_cuda(labels, "labels", torch.int32)
+        if out is None:
+            out = torch.empty_like(images)
+        _lib.call("psg_gcn_nb_attack", model.handle, self.handle, ptr(images), ptr(labels), float(eps), float(alpha),
+                  int(iters), ptr(out), stream())
+        return out
+
+    def edges(self, block):
+        src = _lib.load().psg_gcn_edge_ptr(self.handle, block)
+        out = torch.empty(self.batch, self.n_point, 16, dtype=torch.int32, device=self.device)
+        _hip_memcpy_d2d(out.data_ptr(), src, out.numel() * 4)
+        return out
+
+    def feats(self):
+        src = _lib.load().psg_gcn_feats_ptr(self.handle)
+        out = torch.empty(self.batch, self.n_point, 64 * self.n_blocks, dtype=torch.float32, device=self.device)
+        _hip_memcpy_d2d(out.data_ptr(), src, out.numel() * 4)
+        return out

@@ -56,3 +56,24 @@ def golden_nu():
 @pytest.fixture(scope="session")
 def golden_tarnu():
     return dict(np.load(os.path.join(GOLDEN, "pn2_tarnu.npz")))
+
+
+@pytest.fixture(scope="session")
+def gcn_weights_sd():
+    return dict(np.load(os.path.join(GOLDEN, "gcn_weights.npz")))
+
+
+@pytest.fixture(scope="session")
+def golden_gcn_room():
+    return dict(np.load(os.path.join(GOLDEN, "gcn_room.npz")))
+
+
+@pytest.fixture(scope="session")
+def golden_gcn_nb():
+    return dict(np.load(os.path.join(GOLDEN, "gcn_nb.npz")))
+
+
+@pytest.fixture(scope="session")
+def gcn_oracle(gcn_weights_sd):
+    from oracle import resgcn
+    return resgcn.GCNOracle(gcn_weights_sd, n_blocks=5)

@@ -1,0 +1,173 @@
+"""Generate the ResGCN golden fixtures by running the REFERENCE itself (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_gcn.py [weights|room|nb|all]
+
+The reference's gcn_lib imports `torch_cluster.knn_graph` at module scope (gcn_lib/dense/torch_edge.py:3) but
+only the non-default DilatedKnnGraph uses it; torch_cluster is not installed here, so an empty stand-in
+module is registered before the import.  Outputs (numbers only):
+  gcn_weights.npz  state_dict of DenseDeepGCN (n_blocks=5, k=16, res/edge/batch/relu) after a short supervised
+                   fit on rule-labelled synthetic rooms of 1024 points (5 blocks keep the fixture at ~4 MB; the
+                   kernels are generic in n_blocks and the 28-block net is what bench.py times)
+  gcn_room.npz     one 1024-point room: neighbour tables of every EdgeConv, block outputs, logits, cost and
+                   d cost / d input; plus a dilation-27 kNN table on the head features (k*d = 432)
+  gcn_nb.npz       colper.NB_attack(eps=.3, alpha=2/255, iters=4): colour state fed to the model at every
+                   iteration + returned colours
+"""
+import os
+import sys
+import time
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/ResGCN"
+sys.modules.setdefault("torch_cluster", types.ModuleType("torch_cluster"))
+sys.modules["torch_cluster"].knn_graph = None
+sys.path[:0] = [ROOT, REF, REF + "/sem_seg_dense", REF + "/sem_seg_dense/attacks"]
+sys.dont_write_bytecode = True
+
+from pointsecguard_amd.synthetic import make_rooms, rule_labels  # noqa: E402
+
+from architecture import DenseDeepGCN  # noqa: E402  (reference)
+import torchattacks  # noqa: E402  (reference, ResGCN variant)
+from gcn_lib.dense import torch_edge  # noqa: E402
+
+N_BLOCKS, NPT = 5, 1024
+OPT = SimpleNamespace(n_filters=64, k=16, act="relu", norm="batch", bias=True, epsilon=0.0, stochastic=True,
+                      conv="edge", n_blocks=N_BLOCKS, block="res", in_channels=9, dropout=0.0, n_classes=13)
+
+
+def rooms(batch, seed):
+    r = make_rooms(batch, seed)[:, :NPT].copy()
+    return r, rule_labels(r)
+
+
+def to_input(r):
+    return torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 1))).unsqueeze(-1)   # [B,9,N,1]
+
+
+def load_model():
+    sd = np.load(os.path.join(HERE, "gcn_weights.npz"))
+    m = DenseDeepGCN(OPT)
+    m.load_state_dict({k: torch.from_numpy(sd[k]) for k in sd.files})
+    return m.eval()
+
+
+def fit_weights(steps=150):
+    torch.manual_seed(4321)
+    torch.set_num_threads(8)
+    m = DenseDeepGCN(OPT).train()
+    opt = torch.optim.Adam(m.parameters(), lr=2e-3)
+    t0 = time.time()
+    for step in range(steps):
+        r, y = rooms(4, 20_000 + step)
+        out = m(to_input(r))
+        loss = torch.nn.functional.cross_entropy(out, torch.from_numpy(y))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if step % 10 == 0 or step == steps - 1:
+            acc = (out.argmax(1) == torch.from_numpy(y)).float().mean().item()
+            print("fit step %d loss %.4f acc %.3f ncls %d %.0fs" % (step, loss.item(), acc, out.argmax(1).unique().numel(),
+                                                                   time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(HERE, "gcn_weights.npz"), **{k: v.detach().numpy() for k, v in m.state_dict().items()})
+
+
+def gen_room():
+    torch.set_num_threads(1)
+    m = load_model()
+    r, y = rooms(1, 77)
+    x = to_input(r)
+    out = {"room": r[0], "labels": y[0].astype(np.int16)}
+    graphs, feats = [], []
+    hooks = []
+    # neighbour tables: every DenseDilatedKnnGraph output (the head's module is called twice; keep the first)
+    seen = {}
+
+    def knn_hook(mod, inp, res):
+        seen.setdefault(id(mod), res[0, 0].numpy().copy())   # edge_index[0] = nn_idx, batch 0
+    hooks.append(m.knn.register_forward_hook(knn_hook))
+    for blk in m.backbone:
+        hooks.append(blk.body.dilated_knn_graph.register_forward_hook(knn_hook))
+    hooks.append(m.head.register_forward_hook(lambda mod, i, o: feats.append(o.detach()[0, :, :, 0].T.contiguous().numpy())))
+    for blk in m.backbone:
+        hooks.append(blk.register_forward_hook(lambda mod, i, o: feats.append(o.detach()[0, :, :, 0].T.contiguous().numpy())))
+    xin = x.clone().requires_grad_(True)
+    logits = m(xin)
+    cost = torch.nn.CrossEntropyLoss()(logits, torch.from_numpy(y))
+    cost.backward()
+    for h in hooks:
+        h.remove()
+    mods = [m.knn] + [blk.body.dilated_knn_graph for blk in m.backbone]
+    for e, mod in enumerate(mods):
+        out["nbr%d" % e] = seen[id(mod)].astype(np.int16)
+    for e, f in enumerate(feats):
+        out["feat%d" % e] = f
+    out["logits"] = logits.detach()[0].T.contiguous().numpy()
+    out["cost"] = np.float64(cost.item())
+    out["dx"] = xin.grad[0, :, :, 0].T.contiguous().numpy()
+    # feature-space kNN at the largest dilation of the 28-block net (k*d = 432) on the head features
+    f0 = torch.from_numpy(feats[0]).T.unsqueeze(0).unsqueeze(-1)     # [1,64,N,1]
+    ei = torch_edge.dense_knn_matrix(f0, 16 * 27)
+    out["nbr_d27"] = ei[0, 0, :, ::27].numpy().astype(np.int16)
+    d = torch_edge.pairwise_distance(torch.from_numpy(feats[0][:64]).unsqueeze(0))
+    out["pd_bits"] = d[0].numpy().view(np.uint32)
+    np.savez_compressed(os.path.join(HERE, "gcn_room.npz"), **out)
+    print("gcn room: cost %.6f |dx|max %.3e" % (cost.item(), xin.grad.abs().max().item()))
+
+
+class Recorder(torch.nn.Module):
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+        self.seen = []
+
+    def forward(self, x):
+        self.seen.append(x.detach()[:, 3:6, :, 0].clone().numpy())
+        return self.inner(x)
+
+
+def gen_nb():
+    torch.set_num_threads(1)
+    m = load_model()
+    iters, eps, alpha = 4, 0.3, 2 / 255
+    r, y = rooms(1, 78)
+    x = to_input(r)
+    rec = Recorder(m).eval()
+    # neighbour tables of every forward (feature-space kNN has near-ties that no two fp32 pipelines break alike:
+    # parity tests teacher-force the reference's graphs)
+    graphs = []
+    mods = [m.knn] + [blk.body.dilated_knn_graph for blk in m.backbone]
+    hooks = [mod.register_forward_hook(lambda mod_, i, res, e=e: graphs.append((e, res[0, 0].numpy().astype(np.int16))))
+             for e, mod in enumerate(mods)]
+    atk = torchattacks.NB_attack(rec, eps=eps, alpha=alpha, iters=iters)
+    adv = atk(x, torch.from_numpy(y)).detach()
+    for h in hooks:
+        h.remove()
+    out = {"rooms": r, "labels": y.astype(np.int16), "eps": eps, "alpha": alpha, "iters": iters,
+           "adv_color_final": adv[:, 3:6, :, 0].numpy()}
+    per_fwd = len(mods) + 1   # the head's module is called twice per forward (architecture.py:59-60)
+    assert len(graphs) == per_fwd * iters
+    for t in range(iters):
+        out["state_it%d" % t] = rec.seen[t]
+        chunk = graphs[t * per_fwd:(t + 1) * per_fwd]
+        first = {}
+        for e, tab in chunk:
+            first.setdefault(e, tab)
+        out["graphs_it%d" % t] = np.stack([first[e] for e in range(len(mods))])
+    np.savez_compressed(os.path.join(HERE, "gcn_nb.npz"), **out)
+    print("gcn nb done")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("weights", "all"):
+        fit_weights()
+    if what in ("room", "all"):
+        gen_room()
+    if what in ("nb", "all"):
+        gen_nb()

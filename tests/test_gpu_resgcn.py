@@ -1,0 +1,137 @@
+"""GPU parity of the ResGCN (dense DeepGCN) path against the reference-generated fixtures
+(tests/golden/gcn_*.npz, 5-block net, 1024-point rooms) and the CPU oracle.
+
+Bars: pairwise-distance / kNN graphs bit-exact on fixture features except exact-distance ties (>= 99.98 % of
+entries); dynamic graphs of a free-running forward overlap the reference's by >= 99.5 % per block; with the
+reference's graphs teacher-forced: block outputs and logits within 1e-4, gradient sign agreement >= 99.9 %,
+NB_attack iterations bit-equal on >= 99.9 % of entries."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+NB = 5
+
+
+def dev(a, dt=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dt is not None:
+        t = t.to(dt)
+    return t.cuda().contiguous()
+
+
+@pytest.fixture(scope="module")
+def gcn(gcn_weights_sd):
+    from pointsecguard_amd import runtime
+    return runtime.GCNModel(gcn_weights_sd, NB), runtime.GCNWorkspace(1, 1024, NB)
+
+
+def test_knn_graphs_on_fixture_features(gcn, golden_gcn_room):
+    from oracle import resgcn
+    _, ws = gcn
+    g = golden_gcn_room
+    f0 = dev(g["feat0"][None])
+    got = ws.knn(f0, 27)[0].cpu().numpy()
+    assert np.array_equal(got, resgcn.knn_dilated(g["feat0"], 27))        # bit-exact vs the oracle
+    assert (got == g["nbr_d27"]).mean() >= 0.9998                           # reference (ties: see DESIGN.md)
+    xyz = dev(g["room"][None, :, :3].copy())
+    got = ws.knn(xyz, 1)[0].cpu().numpy()
+    assert np.array_equal(got, resgcn.knn_dilated(g["room"][:, :3], 1))
+    assert (got == g["nbr0"]).mean() >= 0.9998
+
+
+def test_forward_dynamic_graphs(gcn, golden_gcn_room):
+    """Free-running forward: every dynamic graph must be EXACTLY the oracle's kNN of the features the GPU itself
+    produced for the previous block (kernel correctness in situ, dilation 1..4), and stay close to the
+    reference's graphs (near-ties cascade: one different neighbour changes a vertex feature by O(1), which
+    re-ranks its whole neighbourhood in the next, more dilated, block)."""
+    from oracle import resgcn
+    model, ws = gcn
+    g = golden_gcn_room
+    ws.set_graphs(None)
+    ws.forward(model, dev(g["room"][None]))
+    torch.cuda.synchronize()
+    feats = ws.feats()[0].cpu().numpy()
+    for e in range(NB):
+        got = ws.edges(e)[0].cpu().numpy()
+        src = g["room"][:, :3] if e == 0 else np.ascontiguousarray(feats[:, 64 * (e - 1):64 * e])
+        assert np.array_equal(got, resgcn.knn_dilated(src, 1 if e == 0 else e)), e
+        ref = g["nbr%d" % e]
+        overlap = np.mean([len(set(a) & set(b)) / 16.0 for a, b in zip(got, ref)])
+        assert overlap >= (0.995 if e <= 2 else 0.85), (e, overlap)
+
+
+def test_forward_backward_with_reference_graphs(gcn, golden_gcn_room):
+    from pointsecguard_amd import _lib, runtime
+    model, ws = gcn
+    g = golden_gcn_room
+    graphs = dev(np.stack([g["nbr%d" % e].astype(np.int32)[None] for e in range(NB)]))
+    ws.set_graphs(graphs)
+    x0 = dev(g["room"][None])
+    logits = ws.forward(model, x0)
+    feats = ws.feats()[0].cpu().numpy()
+    for e in range(NB):
+        assert np.abs(feats[:, 64 * e:64 * e + 64] - g["feat%d" % e]).max() <= 1e-4, e
+    assert np.abs(logits[0].cpu().numpy() - g["logits"]).max() <= 1e-4
+    labels = dev(g["labels"].astype(np.int32)[None])
+    dl = torch.empty_like(logits)
+    cost = torch.zeros(1, device="cuda")
+    _lib.call("psg_ce_logp_grad", runtime.ptr(logits), runtime.ptr(labels), 0, 1024, 1024, 13, 1.0 / 1024,
+              runtime.ptr(dl), runtime.ptr(cost), runtime.stream())
+    dx = ws.backward(model, dl)[0].cpu().numpy()
+    ws.set_graphs(None)
+    assert abs(cost.item() - float(g["cost"])) <= 1e-4
+    ref = g["dx"]
+    assert (np.sign(dx[:, 3:6]) == np.sign(ref[:, 3:6])).mean() >= 0.999
+    assert np.median(np.abs(dx - ref)[ref != 0] / np.abs(ref[ref != 0])) < 1e-3
+    assert np.abs(dx - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-6
+
+
+def test_nb_attack_steps_with_reference_graphs(gcn, golden_gcn_nb):
+    from pointsecguard_amd import _lib, runtime
+    model, ws = gcn
+    g = golden_gcn_nb
+    iters = int(g["iters"])
+    x0 = dev(g["rooms"])
+    ori = x0[:, :, 3:6].contiguous()
+    labels = dev(g["labels"].astype(np.int32))
+    for t in range(iters):
+        ws.set_graphs(dev(g["graphs_it%d" % t].astype(np.int32)[:, None]))
+        x0[:, :, 3:6] = dev(np.ascontiguousarray(g["state_it%d" % t].transpose(0, 2, 1)))
+        logits = ws.forward(model, x0)
+        dl = torch.empty_like(logits)
+        _lib.call("psg_ce_logp_grad", runtime.ptr(logits), runtime.ptr(labels), 0, 1024, 1024, 13, 1.0 / 1024,
+                  runtime.ptr(dl), None, runtime.stream())
+        dx = ws.backward(model, dl)
+        _lib.call("psg_pgd_step", runtime.ptr(x0), runtime.ptr(dx), runtime.ptr(ori), None, 1, 1024, float(g["alpha"]),
+                  float(g["eps"]), 1.0, 1 if t == iters - 1 else 0, runtime.stream())
+        torch.cuda.synchronize()
+        got = np.ascontiguousarray(x0[:, :, 3:6].cpu().numpy().transpose(0, 2, 1))
+        nxt = g["adv_color_final"] if t == iters - 1 else g["state_it%d" % (t + 1)]
+        assert (got.view(np.uint32) == nxt.view(np.uint32)).mean() >= 0.999, t
+    ws.set_graphs(None)
+
+
+def test_fused_nb_attack_vs_oracle(gcn, gcn_oracle, golden_gcn_nb):
+    """Fused psg_gcn_nb_attack (dynamic graphs) against the oracle loop on the same room: the first iteration
+    must agree wherever the two graph sets agree; invariants hold for the whole run."""
+    from oracle import resgcn
+    model, ws = gcn
+    g = golden_gcn_nb
+    images_np = np.ascontiguousarray(g["rooms"].transpose(0, 2, 1))
+    adv = ws.nb_attack(model, dev(images_np), dev(g["labels"].astype(np.int32)), float(g["eps"]), float(g["alpha"]), 1)
+    torch.cuda.synchronize()
+    out = adv.cpu().numpy()
+    assert np.array_equal(out[:, :3], images_np[:, :3]) and np.array_equal(out[:, 6:], images_np[:, 6:])
+    xr = g["rooms"][0]
+    got1, _, _, _ = resgcn.nb_step(gcn_oracle, xr, xr[:, 3:6].copy(), xr[:, 3:6].copy(), g["labels"][0].astype(np.int64),
+                                   float(g["alpha"]), float(g["eps"]), True)
+    same = (np.ascontiguousarray(out[0, 3:6].T).view(np.uint32) == np.ascontiguousarray(got1).view(np.uint32)).mean()
+    assert same >= 0.97, same
+    adv = ws.nb_attack(model, dev(images_np), dev(g["labels"].astype(np.int32)), float(g["eps"]), float(g["alpha"]), 4)
+    torch.cuda.synchronize()
+    out = adv.cpu().numpy()
+    assert np.abs(out[:, 3:6] - images_np[:, 3:6]).max() <= 4 * float(g["alpha"]) + 1e-6
+    assert np.array_equal(out[:, :3], images_np[:, :3]) and np.array_equal(out[:, 6:], images_np[:, 6:])
+    steps = np.round((out[:, 3:6] - images_np[:, 3:6]) / np.float32(g["alpha"]))
+    assert np.abs(steps).max() <= 4 and (steps != 0).mean() > 0.5   # whole sign steps (+-+- can cancel)

@@ -1,0 +1,56 @@
+"""CPU tests: the ResGCN oracle (oracle/resgcn.py) against fixtures generated from the reference
+(tests/golden/make_golden_gcn.py)."""
+import numpy as np
+import pytest
+
+from oracle import resgcn
+
+
+def test_pairwise_distance_bits(golden_gcn_room):
+    g = golden_gcn_room
+    d = resgcn.pairwise_distance(g["feat0"][:64])
+    assert np.array_equal(d.view(np.uint32), g["pd_bits"])      # torch_edge.py:41-43, fp32 order pinned
+
+
+def test_knn_graphs(golden_gcn_room):
+    g = golden_gcn_room
+    # exact-distance ties are the only allowed differences (torch.topk leaves their order unspecified)
+    assert (resgcn.knn_dilated(g["feat0"], 27) == g["nbr_d27"]).mean() >= 0.9998
+    assert (resgcn.knn_dilated(g["room"][:, :3], 1) == g["nbr0"]).mean() >= 0.9998
+    assert (resgcn.knn_dilated(g["feat0"], 1) == g["nbr1"]).mean() >= 0.9998
+
+
+def test_forward_backward_teacher_forced(golden_gcn_room, gcn_oracle):
+    g = golden_gcn_room
+    graphs = [g["nbr%d" % e].astype(np.int32) for e in range(5)]
+    logits, cache = gcn_oracle.forward(g["room"], graphs=graphs)
+    for e in range(5):
+        assert np.abs(cache["feats"][:, 64 * e:64 * e + 64] - g["feat%d" % e]).max() <= 1e-4
+    assert np.abs(logits - g["logits"]).max() <= 1e-4
+    dl, cost = resgcn.ce_mean_grad(logits, g["labels"].astype(np.int64))
+    assert abs(cost - float(g["cost"])) <= 1e-5
+    dx = gcn_oracle.backward(cache, dl)
+    ref = g["dx"]
+    assert (np.sign(dx) == np.sign(ref)).mean() >= 0.999
+    assert np.abs(dx - ref).max() <= 1e-3 * np.abs(ref).max()
+
+
+def test_forward_free_running_graph_overlap(golden_gcn_room, gcn_oracle):
+    g = golden_gcn_room
+    _, cache = gcn_oracle.forward(g["room"])
+    for e in range(5):
+        ov = np.mean([len(set(a) & set(b)) / 16.0 for a, b in zip(cache["nbr"][e], g["nbr%d" % e])])
+        assert ov >= 0.99, (e, ov)
+
+
+@pytest.mark.parametrize("t", [0, 3])
+def test_nb_attack_step(golden_gcn_nb, gcn_oracle, t):
+    g = golden_gcn_nb
+    iters = int(g["iters"])
+    xr = g["rooms"][0]
+    graphs = [g["graphs_it%d" % t][e].astype(np.int32) for e in range(5)]
+    nxt = g["adv_color_final"][0].T if t == iters - 1 else g["state_it%d" % (t + 1)][0].T
+    got, _, _, _ = resgcn.nb_step(gcn_oracle, xr, np.ascontiguousarray(g["state_it%d" % t][0].T), xr[:, 3:6].copy(),
+                                  g["labels"][0].astype(np.int64), float(g["alpha"]), float(g["eps"]), t == iters - 1,
+                                  graphs=graphs)
+    assert (np.ascontiguousarray(got).view(np.uint32) == np.ascontiguousarray(nxt).view(np.uint32)).mean() >= 0.999
