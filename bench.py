@@ -75,10 +75,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--workload", default="pointnet2", choices=["pointnet2", "resgcn"],
+                    help="pointnet2 = BASELINE configs[1] (headline metric); resgcn = configs[3] (secondary, ResGCN-28)")
     ap.add_argument("--concurrency", type=int, default=4,
                     help="independent attack steps in flight per GPU (one HIP stream + workspace each)")
     args = ap.parse_args()
 
+    if args.workload == "resgcn":
+        return main_resgcn(args)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -201,6 +205,65 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return result
+
+
+def main_resgcn(args):
+    """BASELINE configs[3]: ResGCN-28 dense sem_seg forward/backward + non-targeted NB PGD, kNN k=16, 4096 points,
+    one MI355X; the harness values eps=0.3, alpha=2/255, 50 iterations (ResGCN/sem_seg_dense/attacks.py:134),
+    batch = 1 room per call like the reference's loader.  Random-init weights of the 28-block architecture."""
+    import torch
+    from pointsecguard_amd import runtime
+    from pointsecguard_amd.synthetic import make_rooms, rule_labels
+    n_blocks, iters, batch = 28, 50, 1
+    rng = np.random.default_rng(7)
+    sd = {}
+
+    def conv(name, cout, cin):
+        sd[name + ".weight"] = (rng.standard_normal((cout, cin)) * np.sqrt(2.0 / cin)).astype(np.float32)
+        sd[name + ".bias"] = np.zeros(cout, np.float32)
+
+    def bn(name, c):
+        sd[name + ".weight"] = np.ones(c, np.float32); sd[name + ".bias"] = np.zeros(c, np.float32)
+        sd[name + ".running_mean"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
+        sd[name + ".running_var"] = (1.0 + 0.1 * rng.random(c)).astype(np.float32)
+
+    for e in range(n_blocks):
+        base = "head.gconv.nn" if e == 0 else "backbone.%d.body.gconv.nn" % (e - 1)
+        conv(base + ".0", 64, 18 if e == 0 else 128); bn(base + ".2", 64)
+    F = 64 * n_blocks
+    conv("fusion_block.0", 1024, F); bn("fusion_block.2", 1024)
+    conv("prediction.0.0", 512, F + 1024); bn("prediction.0.2", 512)
+    conv("prediction.1.0", 256, 512); bn("prediction.1.2", 256)
+    conv("prediction.3.0", 13, 256)
+    torch.cuda.set_device(0)
+    model = runtime.GCNModel(sd, n_blocks)
+    ws = runtime.GCNWorkspace(batch, NPOINT, n_blocks)
+    n_steps = args.steps + args.warmup
+    rooms = [make_rooms(batch, 5000 + s) for s in range(n_steps)]
+    d_images = [torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 1))).cuda() for r in rooms]
+    d_labels = [torch.from_numpy(rule_labels(r).astype(np.int32)).cuda() for r in rooms]
+    d_adv = [torch.empty_like(x) for x in d_images]
+    for i in range(args.warmup):
+        ws.nb_attack(model, d_images[i], d_labels[i], 0.3, 2 / 255, iters, out=d_adv[i])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_steps):
+        ws.nb_attack(model, d_images[i], d_labels[i], 0.3, 2 / 255, iters, out=d_adv[i])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # algorithmic FLOPs per PGD iteration per room (kNN distance GEMMs + split EdgeConv + fusion/prediction + transposes)
+    n = NPOINT
+    gmac = (27 * n * n * 64 + n * n * 3 + 28 * n * 64 * 128 * 2 + n * F * 1024 + n * F * 512 * 2 + n * 512 * 256 * 2 +
+            n * 256 * 13 * 2) / 1e9
+    result = {"metric": "attacked rooms/sec (ResGCN-28, 4096 pts, 50 PGD iters)", "value": batch * args.steps / elapsed,
+              "unit": "rooms/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "dtype": "f32", "data": "synthetic",
+              "config": {"workload": "ResGCN-28 dense sem_seg NB non-targeted PGD (eps=0.3, alpha=2/255, 50 iters), kNN k=16, "
+                                     "batch=1 room x 4096 pts (BASELINE configs[3]); random-init weights"},
+              "tflops_effective": 2 * gmac * iters * batch * args.steps / elapsed / 1e3}
+    print(json.dumps(result), flush=True)
     return result
 
 

@@ -1,0 +1,103 @@
+"""DenseDeepGCN behind the reference's constructor and forward contract
+(ResGCN/sem_seg_dense/architecture.py:6-68): `DenseDeepGCN(opt)` with opt.{n_filters,k,act,norm,bias,epsilon,
+stochastic,conv,n_blocks,block,in_channels,dropout,n_classes}; forward(inputs [B,9,N,1]) -> logits [B,13,N].
+Sub-module / parameter names equal the reference's, so its checkpoints load with load_state_dict.  The
+computation is one whole-network libpsg call (autograd sees a single Function; backward = HIP input gradient)."""
+import torch
+from torch.nn import Sequential as Seq
+
+from pointsecguard_amd import _lib, runtime
+from pointsecguard_amd.resgcn.gcn_lib.dense import BasicConv, DenseDilatedKnnGraph, GraphConv2d, ResDynBlock2d
+
+
+class _GCNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, module):
+        B, C, N, _ = inputs.shape
+        model, ws = module._packed(), module._workspace(B, N)
+        x = inputs.detach()[:, :, :, 0].contiguous().float()
+        x0 = torch.empty(B, N, C, device=x.device, dtype=torch.float32)
+        _lib.call("psg_to_point_major", runtime.ptr(x), B, C, N, runtime.ptr(x0), runtime.stream())
+        logits = ws.forward(model, x0)
+        out = torch.empty(B, 13, N, device=x.device, dtype=torch.float32)
+        _lib.call("psg_to_channel_major", runtime.ptr(logits), B, 13, N, runtime.ptr(out), runtime.stream())
+        module._generation += 1
+        ctx.module, ctx.model, ctx.ws, ctx.generation = module, model, ws, module._generation
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.generation != ctx.module._generation:
+            raise RuntimeError("only the most recent forward of this module can be back-propagated")
+        ws = ctx.ws
+        B, N = ws.batch, ws.n_point
+        dl = torch.empty(B, N, 13, device=dout.device, dtype=torch.float32)
+        _lib.call("psg_to_point_major", runtime.ptr(dout.contiguous().float()), B, 13, N, runtime.ptr(dl), runtime.stream())
+        dx0 = ws.backward(ctx.model, dl)
+        dx = torch.empty(B, 9, N, device=dout.device, dtype=torch.float32)
+        _lib.call("psg_to_channel_major", runtime.ptr(dx0), B, 9, N, runtime.ptr(dx), runtime.stream())
+        return dx.unsqueeze(-1), None
+
+
+class DenseDeepGCN(torch.nn.Module):
+    def __init__(self, opt):
+        super(DenseDeepGCN, self).__init__()
+        channels, k = opt.n_filters, opt.k
+        act, norm, bias = opt.act, opt.norm, opt.bias
+        epsilon, stochastic, conv = opt.epsilon, opt.stochastic, opt.conv
+        if (channels, k, conv, opt.block.lower(), opt.in_channels, opt.n_classes) != (64, 16, "edge", "res", 9, 13):
+            raise NotImplementedError("the gfx950 kernels implement the reference's default configuration "
+                                      "(n_filters=64, k=16, conv='edge', block='res', in_channels=9, n_classes=13)")
+        if epsilon != 0 or opt.dropout != 0:
+            raise NotImplementedError("epsilon / dropout must be 0 (attack path runs in eval mode)")
+        self.n_blocks = opt.n_blocks
+        self.knn = DenseDilatedKnnGraph(k, 1, stochastic, epsilon)
+        self.head = GraphConv2d(opt.in_channels, channels, conv, act, norm, bias)
+        self.backbone = Seq(*[ResDynBlock2d(channels, k, 1 + i, conv, act, norm, bias, stochastic, epsilon)
+                              for i in range(self.n_blocks - 1)])
+        fusion_dims = int(channels + channels * (self.n_blocks - 1))
+        self.fusion_block = BasicConv([fusion_dims, 1024], act, norm, bias)
+        self.prediction = Seq(*[BasicConv([fusion_dims + 1024, 512], act, norm, bias),
+                                BasicConv([512, 256], act, norm, bias),
+                                torch.nn.Dropout(p=opt.dropout),
+                                BasicConv([256, opt.n_classes], None, None, bias)])
+        self.stochastic = stochastic
+        self.model_init()
+        self._psg_model, self._psg_key, self._psg_ws, self._generation = None, None, {}, 0
+
+    def model_init(self):
+        for m in self.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.kaiming_normal_(m.weight)
+                m.weight.requires_grad = True
+                if m.bias is not None:
+                    m.bias.data.zero_()
+                    m.bias.requires_grad = True
+
+    def _packed(self):
+        tensors = list(self.parameters()) + list(self.buffers())
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if self._psg_model is None or key != self._psg_key:
+            sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
+            self._psg_model = runtime.GCNModel(sd, self.n_blocks)
+            self._psg_key = key
+        return self._psg_model
+
+    def _workspace(self, batch, n_point):
+        key = (batch, n_point)
+        if key not in self._psg_ws:
+            self._psg_ws[key] = runtime.GCNWorkspace(batch, n_point, self.n_blocks)
+        return self._psg_ws[key]
+
+    def forward(self, inputs):
+        if self.training:
+            raise NotImplementedError("pointsecguard_amd implements the eval-mode attack path only; call .eval()")
+        runtime.require_cuda(inputs, "inputs")
+        if inputs.dim() != 4 or inputs.shape[1] != 9 or inputs.shape[3] != 1:
+            raise ValueError("expected inputs [B, 9, N, 1], got %s" % (tuple(inputs.shape),))
+        if self.stochastic:
+            # the reference draws torch.rand(1) in every DenseDilated.forward even in eval (torch_edge.py:21):
+            # knn is called twice on xyz (architecture.py:59-60) + once per backbone block
+            for _ in range(2 + self.n_blocks - 1):
+                torch.rand(1)
+        return _GCNFunction.apply(inputs, self)

@@ -1,0 +1,36 @@
+"""Non-targeted colour attacks on DenseDeepGCN with the reference's signatures
+(ResGCN/sem_seg_dense/attacks/torchattacks/attacks/colper.py: NB_attack :9-39)."""
+import torch
+
+from ..attack import Attack
+
+
+def _gcn(model):
+    if not hasattr(model, "_packed") or not hasattr(model, "n_blocks"):
+        raise TypeError("pointsecguard_amd ResGCN attacks drive pointsecguard_amd.resgcn...DenseDeepGCN; got %s"
+                        % type(model).__name__)
+    return model
+
+
+class NB_attack(Attack):
+    """PGD on colour: CrossEntropyLoss() (mean) on the logits, sign ascent, L-inf projection; one fused libpsg
+    call.  Returns the un-projected last step like the reference (colper.py:35-39)."""
+
+    def __init__(self, model, eps=0.3, alpha=2 / 255, iters=40):
+        super(NB_attack, self).__init__("NB_attack", model)
+        self.model, self.eps, self.alpha, self.iters = model, eps, alpha, iters
+
+    def forward(self, images, labels, atype="Color"):
+        if atype != "Color":
+            raise NotImplementedError("only atype='Color' is defined by the reference")
+        net = _gcn(self.model)
+        images = images.detach().to(self.device).float()
+        B, C, N, _ = images.shape
+        x = images[:, :, :, 0].contiguous()
+        labels = labels.detach().to(self.device).to(torch.int32).contiguous()
+        if net.stochastic:
+            for _ in range(self.iters * (2 + net.n_blocks - 1)):
+                torch.rand(1)                        # RNG parity: one draw per DenseDilated.forward
+        net._generation += 1
+        adv = net._workspace(B, N).nb_attack(net._packed(), x, labels, self.eps, self.alpha, self.iters)
+        return adv.unsqueeze(-1)
