@@ -60,9 +60,14 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
             for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.0f;
 
     for (int k0 = 0; k0 < a.K; k0 += 32) {
-        // ---- stage in[row0.., k0..k0+31] and w[col0.., k0..k0+31] (zero filled outside the matrices)
-        for (int t = tid; t < BR * 8; t += 256) {
-            const int r = t >> 3, q = t & 7, k = k0 + 4 * q;
+        // ---- stage in[row0.., k0..k0+31] and w[col0.., k0..k0+31] (zero filled outside the matrices).  All global
+        // loads of the step are issued into registers first, then written to LDS: otherwise every 16-byte piece
+        // pays its own round trip (a 16-workgroup GEMM went from 34 us to a few us with this).
+        constexpr int NI = BR * 8 / 256, NWL = BN * 8 / 256;
+        float4 vi[NI], vw[NWL];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int t = tid + u * 256, r = t >> 3, q = t & 7, k = k0 + 4 * q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row0 + r < a.rows) {
                 const float *p = a.in + (size_t)(row0 + r) * a.ld_in + k;
@@ -74,19 +79,11 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
                     if (k + 3 < a.K) v.w = p[3];
                 }
             }
-            float *d = s_in + (q >> 1) * BLK_R + r * 8;
-            if (ASC_K) {  // element k%8 = 2t+h goes to slot 4h+t
-                const int e = (q & 1) * 4;
-                d[((e + 0) & 1) * 4 + ((e + 0) >> 1)] = v.x;
-                d[((e + 1) & 1) * 4 + ((e + 1) >> 1)] = v.y;
-                d[((e + 2) & 1) * 4 + ((e + 2) >> 1)] = v.z;
-                d[((e + 3) & 1) * 4 + ((e + 3) >> 1)] = v.w;
-            } else {
-                *(float4 *)(d + (q & 1) * 4) = v;
-            }
+            vi[u] = v;
         }
-        for (int t = tid; t < BN * 8; t += 256) {
-            const int r = t >> 3, q = t & 7, k = k0 + 4 * q;
+#pragma unroll
+        for (int u = 0; u < NWL; ++u) {
+            const int t = tid + u * 256, r = t >> 3, q = t & 7, k = k0 + 4 * q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (col0 + r < a.M) {
                 const float *p = a.w + (size_t)(col0 + r) * a.ld_w + k;
@@ -98,6 +95,27 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
                     if (k + 3 < a.K) v.w = p[3];
                 }
             }
+            vw[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int t = tid + u * 256, r = t >> 3, q = t & 7;
+            const float4 v = vi[u];
+            float *d = s_in + (q >> 1) * BLK_R + r * 8;
+            if (ASC_K) {  // element k%8 = 2t+h goes to slot 4h+t
+                const int e = (q & 1) * 4;
+                d[((e + 0) & 1) * 4 + ((e + 0) >> 1)] = v.x;
+                d[((e + 1) & 1) * 4 + ((e + 1) >> 1)] = v.y;
+                d[((e + 2) & 1) * 4 + ((e + 2) >> 1)] = v.z;
+                d[((e + 3) & 1) * 4 + ((e + 3) >> 1)] = v.w;
+            } else {
+                *(float4 *)(d + (q & 1) * 4) = v;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NWL; ++u) {
+            const int t = tid + u * 256, r = t >> 3, q = t & 7;
+            const float4 v = vw[u];
             float *d = s_w + (q >> 1) * BLK_N + r * 8;
             if (ASC_K) {
                 const int e = (q & 1) * 4;

@@ -88,38 +88,101 @@ __global__ void sumsq_rows_kernel(const float *__restrict__ x, int ld, int C, si
     out[r] = s;
 }
 
-// ---- dilated kNN selection: one workgroup per query row sorts (distance, index) keys of its distance-matrix
-// row in LDS (bitonic, 64-bit keys: order-preserving float bits << 32 | index => ascending distance, lowest
-// index on ties) and emits the neighbours at ranks 0, d, 2d, ... (torch.topk(-dist, k*d)[..., ::d]).
-__global__ __launch_bounds__(256) void knn_select_kernel(const float *__restrict__ dist, int N, int NP2, int k, int d,
-                                                         int32_t *__restrict__ out)
+// ---- dilated kNN selection: ONE WAVE per query row, no workgroup barriers and no atomics.  Only the KK = (k-1)*d+1
+// (<= 406) smallest of the N <= 4096 distances matter, so instead of sorting the row:
+//   1. every lane keeps 64 keys in registers; composite key = (order-preserving distance bits << 12) | index is
+//      unique: ascending distance, lowest index on ties (torch.topk leaves tie order unspecified);
+//   2. bisection on the key value (count = per-lane compares + one DPP-free shuffle reduction per round) finds ANY
+//      threshold with KK <= #(keys <= t) <= M, M = the power of two the final sort runs on;
+//   3. those keys are compacted into LDS with ballot prefix sums and bitonic-sorted by the wave;
+//   4. ranks 0, d, 2d, ... are emitted (torch.topk(-dist, k*d)[..., ::d], torch_edge.py:56,29).
+constexpr int KS_WAVES = 4;          // rows per workgroup (independent waves)
+constexpr int KS_PER_LANE = 64;      // N <= 4096
+constexpr int KS_MAX_SEL = 512;
+
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
 {
-    extern __shared__ unsigned long long keys[];  // [NP2]
-    const size_t row = blockIdx.x;                 // global row over all rooms
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(KS_WAVES * 64) void knn_select_kernel(const float *__restrict__ dist, int N, size_t rows,
+                                                                  int k, int d, int32_t *__restrict__ out)
+{
+    __shared__ unsigned long long cand_all[KS_WAVES][KS_MAX_SEL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t row = (size_t)blockIdx.x * KS_WAVES + wave;
+    if (row >= rows) return;
+    unsigned long long *cand = cand_all[wave];
     const float *drow = dist + row * (size_t)N;
-    for (int t = threadIdx.x; t < NP2; t += 256) {
-        unsigned long long key = ~0ull;
-        if (t < N) {
-            unsigned u = __float_as_uint(drow[t]);
-            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // total order of floats as unsigned
-            key = ((unsigned long long)u << 32) | (unsigned)t;
+    const unsigned KK = (unsigned)((k - 1) * d + 1);
+    unsigned M = 64;
+    while (M < KK) M <<= 1;          // sort size; any count in [KK, M] is acceptable
+
+    unsigned long long key[KS_PER_LANE];   // composite keys of elements q*64 + lane
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+#pragma unroll
+    for (int q = 0; q < KS_PER_LANE; ++q) {
+        const int i = q * 64 + lane;
+        unsigned long long kv = ~0ull;     // padding sorts last and is never selected
+        if (i < N) {
+            unsigned u = __float_as_uint(drow[i]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            kv = ((unsigned long long)u << 12) | (unsigned)i;
+            kmin = kv < kmin ? kv : kmin;
+            kmax = kv > kmax ? kv : kmax;
         }
-        keys[t] = key;
+        key[q] = kv;
     }
-    __syncthreads();
-    for (int size = 2; size <= NP2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = threadIdx.x; t < NP2 / 2; t += 256) {
-                const int lo = ((t / stride) * stride * 2) + (t % stride);
-                const int hi = lo + stride;
-                const bool up = ((lo & size) == 0);
-                const unsigned long long a = keys[lo], b = keys[hi];
-                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long a = ((unsigned long long)__shfl_xor((unsigned)(kmin >> 32), o) << 32) | __shfl_xor((unsigned)kmin, o);
+        const unsigned long long b = ((unsigned long long)__shfl_xor((unsigned)(kmax >> 32), o) << 32) | __shfl_xor((unsigned)kmax, o);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    // invariant: #(keys <= lo) < KK <= #(keys <= hi)
+    unsigned long long lo = kmin - 1, hi = kmax, thr = kmax;
+    unsigned cnt = (unsigned)N;
+    while (cnt > M) {
+        const unsigned long long mid = lo + ((hi - lo) >> 1);
+        unsigned c = 0;
+#pragma unroll
+        for (int q = 0; q < KS_PER_LANE; ++q) c += key[q] <= mid ? 1u : 0u;
+        c = wave_sum_u32(c);
+        if (c < KK) lo = mid;
+        else { hi = mid; thr = mid; cnt = c; }
+        if (hi - lo <= 1) break;       // cannot happen with unique keys unless cnt <= M already
+    }
+    // compact the keys <= thr (KK <= cnt <= M) into LDS; order is irrelevant, the sort follows
+    for (unsigned t = lane; t < M; t += 64) cand[t] = ~0ull;
+    wave_lds_fence();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned base = 0;
+#pragma unroll
+    for (int q = 0; q < KS_PER_LANE; ++q) {
+        const bool p = key[q] <= thr;
+        const unsigned long long m = __ballot(p);
+        if (p) cand[base + __popcll(m & lt_mask)] = key[q];
+        base += __popcll(m);
+    }
+    wave_lds_fence();
+    for (unsigned size = 2; size <= M; size <<= 1) {
+        for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+            for (unsigned t = lane; t < M / 2; t += 64) {
+                const unsigned lo_i = ((t / stride) * stride * 2) + (t % stride);
+                const unsigned hi_i = lo_i + stride;
+                const bool up = ((lo_i & size) == 0);
+                const unsigned long long a = cand[lo_i], bb = cand[hi_i];
+                if ((a > bb) == up) { cand[lo_i] = bb; cand[hi_i] = a; }
             }
-            __syncthreads();
+            wave_lds_fence();
         }
     }
-    for (int t = threadIdx.x; t < k; t += 256) out[row * k + t] = (int32_t)(keys[(size_t)t * d] & 0xFFFFFFFFull);
+    if (lane < k) out[row * k + lane] = (int32_t)(cand[(size_t)lane * d] & 0xFFFull);
 }
 
 // ---- EdgeConv edge pass (forward): y[i][c] = max_k ( s_c * relu(P[i][c] + Q[nbr(i,k)][c]) + t_c ) (+ residual)
@@ -178,56 +241,67 @@ __global__ void add_slice_kernel(float *__restrict__ g, const float *__restrict_
     if (t < rows * GC) g[t] += src[(t / GC) * ld_src + (t % GC)];
 }
 
-// ---- global max over the N points of a room, per channel (torch.max_pool2d over [N,1], architecture.py:64)
-__global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ x, int N, int C, float *__restrict__ mx,
-                                                     int32_t *__restrict__ arg)
+// ---- global max over the N points of a room, per channel (torch.max_pool2d over [N,1], architecture.py:64).
+// Row chunks reduce in parallel into one 64-bit atomicMax per (room, channel): key = ordered value bits << 32 |
+// ~row, so the maximum value wins and equal values resolve to the lowest row.  `keys` must be zeroed.
+__global__ __launch_bounds__(256) void colmax_partial_kernel(const float *__restrict__ x, int N, int C, int rows_per_chunk,
+                                                             unsigned long long *__restrict__ keys)
 {
-    // grid (C/64, rooms); thread (cc = tid&63, part = tid>>6) scans rows part, part+4, ...
-    __shared__ float s_v[4][64];
-    __shared__ int s_i[4][64];
     const int cc = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cc;
-    const size_t room = blockIdx.y;
-    float best = -INFINITY;
-    int bi = 0;
-    for (int i = part; i < N; i += 4) {
-        const float v = x[(room * N + i) * C + c];
-        if (v > best) { best = v; bi = i; }
+    const size_t room = blockIdx.z;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(N, r0 + rows_per_chunk);
+    unsigned long long best = 0ull;
+    for (int i = r0 + part; i < r1; i += 4) {
+        unsigned u = __float_as_uint(x[(room * N + i) * C + c]);
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        const unsigned long long key = ((unsigned long long)u << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+        best = key > best ? key : best;
     }
-    s_v[part][cc] = best; s_i[part][cc] = bi;
-    __syncthreads();
-    if (part == 0) {
-        for (int q = 1; q < 4; ++q)
-            if (s_v[q][cc] > best || (s_v[q][cc] == best && s_i[q][cc] < bi)) { best = s_v[q][cc]; bi = s_i[q][cc]; }
-        mx[room * C + c] = best;
-        arg[room * C + c] = bi;
-    }
+    atomicMax(keys + room * C + c, best);
 }
 
-// out[room][m] = sum_k w[m][k] * v[room][k]   (small mat-vec; w row-major with leading dimension ld_w)
-__global__ void matvec_kernel(const float *__restrict__ w, int ld_w, const float *__restrict__ v, int K, int M,
-                              float *__restrict__ out)
+__global__ void colmax_decode_kernel(const unsigned long long *__restrict__ keys, size_t n, float *__restrict__ mx,
+                                     int32_t *__restrict__ arg)
 {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const unsigned long long key = keys[t];
+    unsigned u = (unsigned)(key >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    mx[t] = __uint_as_float(u);
+    arg[t] = (int32_t)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+}
+
+// out[room][m] = sum_k w[m][k] * v[room][k]   (small mat-vec; one wave per output, lanes stride over k: coalesced)
+__global__ __launch_bounds__(256) void matvec_kernel(const float *__restrict__ w, int ld_w, const float *__restrict__ v, int K,
+                                                     int M, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     const size_t room = blockIdx.y;
     if (m >= M) return;
     float acc = 0.0f;
-    for (int k = 0; k < K; ++k) acc += w[(size_t)m * ld_w + k] * v[room * K + k];
-    out[room * M + m] = acc;
+    for (int k = lane; k < K; k += 64) acc += w[(size_t)m * ld_w + k] * v[room * K + k];
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) out[room * M + m] = acc;
 }
 
-// column sums over the N rows of each room: out[room][c] = sum_i x[room*N+i][c]
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, int N, int C, float *__restrict__ out)
+// column sums over the N rows of each room: out[room][c] = sum_i x[room*N+i][c]; row chunks in parallel,
+// one float atomicAdd per (chunk, channel).  `out` must be zeroed.
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, int N, int C, int rows_per_chunk,
+                                                     float *__restrict__ out)
 {
     __shared__ float s_v[4][64];
     const int cc = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cc;
-    const size_t room = blockIdx.y;
+    const size_t room = blockIdx.z;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(N, r0 + rows_per_chunk);
     float acc = 0.0f;
-    for (int i = part; i < N; i += 4) acc += x[(room * N + i) * C + c];
+    for (int i = r0 + part; i < r1; i += 4) acc += x[(room * N + i) * C + c];
     s_v[part][cc] = acc;
     __syncthreads();
-    if (part == 0) out[room * C + c] = ((s_v[0][cc] + s_v[1][cc]) + s_v[2][cc]) + s_v[3][cc];
+    if (part == 0) atomicAdd(out + room * C + c, ((s_v[0][cc] + s_v[1][cc]) + s_v[2][cc]) + s_v[3][cc]);
 }
 
 // fusion backward: dfeats[argmax point of channel c][:] += gvec[c] * s_c[active] * Wf[c][:]
@@ -294,6 +368,7 @@ struct psg_gcn_ws {
     float *fused;              // [B*N][1024]
     uint32_t *mask_f, *mask1, *mask2;
     float *fmax; int32_t *farg; // [B][1024]
+    unsigned long long *fkeys;  // [B][1024] packed (value, ~row) keys of the global max
     float *gb1;                // [B][512]
     float *h1, *h2;            // [B*N][512], [B*N][256]
     float *g2, *g1;            // backward buffers [B*N][256], [B*N][512]
@@ -352,8 +427,8 @@ int knn_graph(psg_gcn_ws *ws, const float *x, int ld, int C, int d, int32_t *out
         int rc = launch_gemm<2, 2, EPI_KNN_DIST, true>(a, st);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)rows), dim3(256), (size_t)ws->NP2 * 8, st, ws->dist, ws->N,
-                       ws->NP2, KNB, d, out);
+    hipLaunchKernelGGL(knn_select_kernel, dim3((unsigned)ceil_div((int)rows, KS_WAVES)), dim3(KS_WAVES * 64), 0, st, ws->dist,
+                       ws->N, rows, KNB, d, out);
     PSG_LAUNCH_CHECK();
     return PSG_OK;
 }
@@ -482,6 +557,7 @@ extern "C" int psg_gcn_ws_create(psg_ctx *ctx, int batch, int n_point, int n_blo
         ws->mask2 = (uint32_t *)take(R * 8 * 4);
         ws->fmax = (float *)take((size_t)batch * 1024 * 4);
         ws->farg = (int32_t *)take((size_t)batch * 1024 * 4);
+        ws->fkeys = (unsigned long long *)take((size_t)batch * 1024 * 8);
         ws->gb1 = (float *)take((size_t)batch * 512 * 4);
         ws->h1 = (float *)take(R * 512 * 4);
         ws->h2 = (float *)take(R * 256 * 4);
@@ -582,11 +658,16 @@ extern "C" int psg_gcn_forward(psg_gcn_model *m, psg_gcn_ws *ws, const float *x0
         GemmArgs a = gemm_args(ws->feats, F, m->wf, F, ws->fused, 1024, (int)R, F, 1024);
         a.bias = m->bf; a.scale = m->sf; a.shift = m->tf; a.mask_out = ws->mask_f;
         if ((rc = launch_gemm<2, 2, EPI_RELU_AFFINE, false>(a, st))) return rc;
-        hipLaunchKernelGGL(colmax_kernel, dim3(1024 / 64, B), dim3(256), 0, st, ws->fused, N, 1024, ws->fmax, ws->farg);
+        PSG_CHECK_HIP(hipMemsetAsync(ws->fkeys, 0, (size_t)B * 1024 * 8, st));
+        hipLaunchKernelGGL(colmax_partial_kernel, dim3(1024 / 64, ceil_div(N, 64), B), dim3(256), 0, st, ws->fused, N, 1024, 64,
+                           ws->fkeys);
+        PSG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(colmax_decode_kernel, dim3(ceil_div(B * 1024, 256)), dim3(256), 0, st, ws->fkeys, (size_t)B * 1024,
+                           ws->fmax, ws->farg);
         PSG_LAUNCH_CHECK();
     }
     // prediction.0 on cat(fusion broadcast, feats): the broadcast half is a per-room bias W1a . fmax
-    hipLaunchKernelGGL(matvec_kernel, dim3(ceil_div(512, 256), B), dim3(256), 0, st, m->wp1, 1024 + F, ws->fmax, 1024, 512,
+    hipLaunchKernelGGL(matvec_kernel, dim3(ceil_div(512, 4), B), dim3(256), 0, st, m->wp1, 1024 + F, ws->fmax, 1024, 512,
                        ws->gb1);
     PSG_LAUNCH_CHECK();
     {
@@ -638,9 +719,10 @@ extern "C" int psg_gcn_backward(psg_gcn_model *m, psg_gcn_ws *ws, const float *d
     }
     // fusion half: gradient of the broadcast vector = (s1 * W1a)^T . (column sum of g1), then back through the
     // global max (one point per channel), ReLU/BN of the fusion block and its 1x1 conv: 1024 scaled row adds
-    hipLaunchKernelGGL(colsum_kernel, dim3(512 / 64, B), dim3(256), 0, st, ws->g1, N, 512, ws->g1sum);
+    PSG_CHECK_HIP(hipMemsetAsync(ws->g1sum, 0, (size_t)B * 512 * 4, st));
+    hipLaunchKernelGGL(colsum_kernel, dim3(512 / 64, ceil_div(N, 64), B), dim3(256), 0, st, ws->g1, N, 512, 64, ws->g1sum);
     PSG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(matvec_kernel, dim3(ceil_div(1024, 256), B), dim3(256), 0, st, m->wp1a_st, 512, ws->g1sum, 512, 1024,
+    hipLaunchKernelGGL(matvec_kernel, dim3(ceil_div(1024, 4), B), dim3(256), 0, st, m->wp1a_st, 512, ws->g1sum, 512, 1024,
                        ws->gfvec);
     PSG_LAUNCH_CHECK();
     hipLaunchKernelGGL(fusion_bwd_kernel, dim3(1024, B), dim3(256), 0, st, ws->gfvec, ws->farg, ws->mask_f, m->sf, m->wf, F,
