@@ -187,10 +187,19 @@ int psg_nu_tanh_color(const float *w, const uint8_t *mask, int B, int N, float *
 int psg_nu_f_loss_grad(const float *logp, const int32_t *labels, int target, int rows, int n_cls, float kappa,
                        float tsign, float *dlogp_out, float *f_sum, int32_t *pred_out, psg_stream stream);
 
+/* f-loss of the ResGCN NU attacks on raw logits [rows][n_cls] (ResGCN/.../attacks/colper.py:108-113,
+ * tcolper.py:145-163); the reference's one-hot masking makes a 0 take part in each max.  mode 0 = NU_attack.f over
+ * all rows; mode 1 = tar_NU non_f, mode 2 = tar_NU tar_f (class `target`), both over batch row 0 under `mask` only.
+ * Writes scale * d(sum f)/d(logits), adds sum f to *f_sum (nullable), arg-max class to pred_out (nullable). */
+int psg_gcn_f_loss_grad(const float *logits, const int32_t *labels, int target, const uint8_t *mask, int mode, int rows,
+                        int n_point, int n_cls, float kappa, float tsign, float scale, float *dlogits_out, float *f_sum,
+                        int32_t *pred_out, psg_stream stream);
+
 /* Smooth loss (nontarget.py:131-135): for each of the N adversarial colours (rows of `adv_color`, stride
  * in floats) the nb smallest Euclidean distances to the N reference colours; adds their total to *dist_sum
  * and writes d(total)/d(adv colour) to grad_out [N][3].  Distances are evaluated directly (the reference's
- * cdist uses the matmul expansion; values agree to ~1e-4 absolute).  nb <= 16, N <= 8192. */
+ * cdist's matmul-expansion distance is reproduced).  Passing ref_color == adv_color selects the ResGCN
+ * variants' smooth(adv, adv) (colper.py:115-120): the gradient then flows through both arguments.  nb <= 16, N <= 8192. */
 int psg_smooth_knn(const float *adv_color, int adv_stride, const float *ref_color, int ref_stride, int N, int nb,
                    float *dist_sum, float *grad_out, psg_stream stream);
 

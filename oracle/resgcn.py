@@ -171,3 +171,79 @@ def nb_step(orc, x, state, ori, labels, alpha, eps, last, graphs=None):
     stepped = (state + F(alpha) * np.sign(g)).astype(F)
     proj = np.clip(ori + np.clip(stepped - ori, -F(eps), F(eps)), 0, 1).astype(F)
     return (stepped if last else proj), g, logits, cost
+
+
+# ------------------------------------------------------------------------------------------------
+# ResGCN NU attacks: colper.py:42-120 (NU_attack), tcolper.py:51-170 (tar_NU_attack)
+# ------------------------------------------------------------------------------------------------
+def f_loss_grad_logits(z, y, mode, kappa, tsign, mask=None, target=None):
+    """f-loss on raw logits with the reference's one-hot masking (a 0 takes part in every max).
+    mode 0: NU f over all points; 1: tar_NU non_f, 2: tar_NU tar_f (class `target`), both over `mask` only.
+    Returns (sum f, d sum f / d z)."""
+    n, ncls = z.shape
+    rows = np.arange(n)
+    yy = np.full(n, int(target), np.int64) if mode == 2 else np.asarray(y, np.int64)
+    others = z.copy()
+    others[rows, yy] = -np.inf
+    oi = others.argmax(axis=1)
+    oth = others[rows, oi]
+    oth_live = oth > 0
+    oth = np.where(oth_live, oth, F(0))
+    own = z[rows, yy]
+    own_live = np.ones(n, bool)
+    if mode == 0:
+        own_live = own > 0
+        own = np.where(own_live, own, F(0))
+    jv, iv = (oth, own) if mode == 2 else (own, oth)
+    val = F(tsign) * (jv - iv)
+    passed = val >= -F(kappa)
+    counted = np.ones(n, bool) if mode == 0 else np.asarray(mask, bool)
+    g = np.zeros_like(z)
+    gs = np.where(passed & counted, F(tsign), F(0))
+    if mode == 2:
+        g[rows, oi] += np.where(oth_live, gs, F(0))
+        g[rows, yy] -= gs
+    else:
+        g[rows, yy] += np.where(own_live, gs, F(0))
+        g[rows, oi] -= np.where(oth_live, gs, F(0))
+    fsum = float(np.where(passed, val, -F(kappa))[counted].sum(dtype=np.float64))
+    return fsum, g.astype(F)
+
+
+def smooth_self_loss_grad(a, nb):
+    """smooth(adv, adv) (colper.py:115-120): k smallest cdist(adv, adv) entries per row; gradient through BOTH
+    arguments of cdist."""
+    d, idx = pn2.smooth_knn(a, a, nb)
+    diff = a[:, None, :].astype(F) - a[idx].astype(F)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u = np.where(d[:, :, None] > 0, diff / d[:, :, None], F(0)).astype(np.float64)
+    g = u.sum(axis=1)
+    np.add.at(g, idx.reshape(-1), -u.reshape(-1, 3))
+    return float(d.sum(dtype=np.float64)), g.astype(F)
+
+
+def nu_step(orc, x_orig, x_base, w, m, v, t, labels, c, kappa, lr, nb, targeted_variant=False, mask=None, target=None,
+            tsign=1.0, graphs=None):
+    """One ResGCN NU / tar_NU optimisation step for a single room.  x_orig/x_base [N,9]; w,m,v [3,M] (reference
+    layout, M = N or mask count).  Returns dict(cost, f, smooth, l2, grad_w, w, m, v, adv)."""
+    from .attacks import adam_update, tanh_space
+    sel = slice(None) if mask is None else np.asarray(mask, bool)
+    adv = x_base.copy()
+    col = adv[:, 3:6].T.copy()            # [3,N]
+    col[:, sel] = tanh_space(w)
+    adv[:, 3:6] = col.T
+    logits, cache = orc.forward(adv, graphs=graphs)
+    mode = 0 if not targeted_variant else (2 if target is not None else 1)
+    fsum, dz = f_loss_grad_logits(logits, labels, mode, kappa, tsign, mask=mask, target=target)
+    c_f, c_l2 = (c, 1.0) if not targeted_variant else (1.0, c)
+    g_color = orc.backward(cache, (dz * F(c_f)).astype(F))[:, 3:6].T.copy()     # [3,N]
+    sm, sg = smooth_self_loss_grad(np.ascontiguousarray(adv[:, 3:6]), nb)
+    g_color += F(1e-4) * sg.T
+    diff = (adv - x_orig).astype(F)
+    l2 = float((diff.astype(np.float64) ** 2).sum())
+    g_color += F(c_l2) * F(2) * diff[:, 3:6].T
+    th = np.tanh(w.astype(F))
+    g_w = (g_color[:, sel] * F(0.5) * (F(1) - th * th)).astype(F)
+    w2, m2, v2 = adam_update(w, m, v, g_w, lr, t)
+    return dict(cost=c_f * fsum + 1e-4 * sm + c_l2 * l2, f=fsum, smooth=sm, l2=l2, grad_w=g_w, w=w2, m=m2, v=v2, adv=adv,
+                pred=logits.argmax(axis=1))

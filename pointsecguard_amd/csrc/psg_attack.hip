@@ -237,12 +237,67 @@ __global__ void nu_f_loss_grad_kernel(const float *__restrict__ logp, const int3
     if ((threadIdx.x & 63) == 0 && f_sum) atomicAdd(f_sum, fval);
 }
 
+// f-loss of the ResGCN NU attacks, on raw logits (ResGCN/.../attacks/colper.py:108-113, tcolper.py:145-163).
+// The reference multiplies the logits by one-hot masks before torch.max, so a masked-out slot contributes a 0:
+//   mode 0 (NU_attack.f):        j = max(z_y, 0),            i = max(max_{k!=y} z_k, 0),  f = clamp(t*(j - i), -kappa)
+//   mode 1 (tar_NU non_f):       j = z_y,                    i = max(max_{k!=y} z_k, 0),  f = clamp(t*(j - i), -kappa)
+//   mode 2 (tar_NU tar_f, y=T):  j = max(max_{k!=T} z_k, 0), i = z_T,                     f = clamp(t*(j - i), -kappa)
+// Modes 1/2 only count batch row 0 under `mask` ([0][self.mask] in the reference).  Writes scale * d(sum f)/dz.
+__global__ void gcn_f_loss_grad_kernel(const float *__restrict__ z, const int32_t *__restrict__ labels, int target,
+                                       const uint8_t *__restrict__ mask, int mode, int rows, int N, int n_cls, float kappa,
+                                       float tsign, float scale, float *__restrict__ dz, float *__restrict__ f_sum,
+                                       int32_t *__restrict__ pred)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    float fval = 0.0f;
+    if (r < rows) {
+        const float *zr = z + (size_t)r * n_cls;
+        float v[MAXC];
+        float m = -INFINITY;
+        int am = 0;
+        for (int c = 0; c < n_cls; ++c) {
+            v[c] = zr[c];
+            if (v[c] > m) { m = v[c]; am = c; }
+        }
+        if (pred) pred[r] = am;
+        float *g = dz + (size_t)r * n_cls;
+        for (int c = 0; c < n_cls; ++c) g[c] = 0.0f;
+        const bool counted = mode == 0 || (r < N && (!mask || mask[r]));
+        if (counted) {
+            const int y = (mode == 2 || !labels) ? target : labels[r];
+            float oth = 0.0f;       // the zeroed slot of the true class takes part in the max
+            int oi = -1;
+            for (int c = 0; c < n_cls; ++c)
+                if (c != y && v[c] > oth) { oth = v[c]; oi = c; }
+            float own = v[y];
+            bool own_live = true;
+            if (mode == 0 && !(own > 0.0f)) { own = 0.0f; own_live = false; }
+            const float jv = mode == 2 ? oth : own, iv = mode == 2 ? own : oth;
+            const float val = tsign * (jv - iv);
+            const bool pass = val >= -kappa;
+            fval = pass ? val : -kappa;
+            if (pass) {
+                const float gs = tsign * scale;
+                if (mode == 2) {
+                    if (oi >= 0) g[oi] += gs;
+                    g[y] -= gs;
+                } else {
+                    if (own_live) g[y] += gs;
+                    if (oi >= 0) g[oi] -= gs;
+                }
+            }
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1) fval += __shfl_xor(fval, o);
+    if ((threadIdx.x & 63) == 0 && f_sum) atomicAdd(f_sum, fval);
+}
+
 // Smooth loss (nontarget.py:131-135): for every adversarial colour of room 0 the `nb` smallest
 // Euclidean distances to the reference colours; returns their sum and d(sum)/d(adv colour).
 constexpr int SM_MAX_NB = 16;
 __global__ __launch_bounds__(256) void smooth_knn_kernel(const float *__restrict__ adv, int adv_stride,
                                                          const float *__restrict__ ref, int ref_stride, int N, int nb,
-                                                         float *__restrict__ dist_sum, float *__restrict__ grad)
+                                                         float *__restrict__ dist_sum, float *__restrict__ grad, int symmetric)
 {
     extern __shared__ float4 s_ref[];
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
@@ -291,11 +346,21 @@ __global__ __launch_bounds__(256) void smooth_knn_kernel(const float *__restrict
                 local += d;
                 if (d > 0.0f) {
                     const float4 q = s_ref[bi[t]];
-                    gx += (ax - q.x) / d; gy += (ay - q.y) / d; gz += (az - q.z) / d;
+                    const float ux = (ax - q.x) / d, uy = (ay - q.y) / d, uz = (az - q.z) / d;
+                    gx += ux; gy += uy; gz += uz;
+                    if (symmetric) {  // the neighbour is an adversarial colour too: it receives the opposite pull
+                        atomicAdd(grad + (size_t)bi[t] * 3, -ux);
+                        atomicAdd(grad + (size_t)bi[t] * 3 + 1, -uy);
+                        atomicAdd(grad + (size_t)bi[t] * 3 + 2, -uz);
+                    }
                 }
             }
         }
-        grad[(size_t)i * 3] = gx; grad[(size_t)i * 3 + 1] = gy; grad[(size_t)i * 3 + 2] = gz;
+        if (symmetric) {
+            atomicAdd(grad + (size_t)i * 3, gx); atomicAdd(grad + (size_t)i * 3 + 1, gy); atomicAdd(grad + (size_t)i * 3 + 2, gz);
+        } else {
+            grad[(size_t)i * 3] = gx; grad[(size_t)i * 3 + 1] = gy; grad[(size_t)i * 3 + 2] = gz;
+        }
     }
     for (int o = 32; o >= 1; o >>= 1) local += __shfl_xor(local, o);
     if ((threadIdx.x & 63) == 0 && dist_sum) atomicAdd(dist_sum, local);
@@ -365,6 +430,20 @@ extern "C" int psg_nu_f_loss_grad(const float *logp, const int32_t *labels, int 
     return PSG_OK;
 }
 
+extern "C" int psg_gcn_f_loss_grad(const float *logits, const int32_t *labels, int target, const uint8_t *mask, int mode,
+                                   int rows, int n_point, int n_cls, float kappa, float tsign, float scale,
+                                   float *dlogits_out, float *f_sum, int32_t *pred_out, psg_stream stream)
+{
+    PSG_REQUIRE(logits && dlogits_out && rows > 0 && n_point > 0, "psg_gcn_f_loss_grad: bad argument");
+    PSG_REQUIRE(mode >= 0 && mode <= 2, "psg_gcn_f_loss_grad: mode %d out of range", mode);
+    PSG_REQUIRE(n_cls > 1 && n_cls <= MAXC, "psg_gcn_f_loss_grad: n_cls=%d out of range", n_cls);
+    PSG_REQUIRE((mode != 2 && labels) || (target >= 0 && target < n_cls), "psg_gcn_f_loss_grad: labels / target missing");
+    hipLaunchKernelGGL(gcn_f_loss_grad_kernel, dim3(psg::ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream, logits,
+                       labels, target, mask, mode, rows, n_point, n_cls, kappa, tsign, scale, dlogits_out, f_sum, pred_out);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
 extern "C" int psg_smooth_knn(const float *adv_color, int adv_stride, const float *ref_color, int ref_stride, int N,
                               int nb, float *dist_sum, float *grad_out, psg_stream stream)
 {
@@ -375,8 +454,11 @@ extern "C" int psg_smooth_knn(const float *adv_color, int adv_stride, const floa
     if (lds > 48 * 1024)
         PSG_CHECK_HIP(hipFuncSetAttribute((const void *)smooth_knn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds));
+    // ref_color == adv_color selects the ResGCN variants' smooth(adv, adv): gradient through both arguments
+    const int symmetric = ref_color == adv_color && ref_stride == adv_stride;
+    if (symmetric) PSG_CHECK_HIP(hipMemsetAsync(grad_out, 0, (size_t)N * 3 * sizeof(float), (hipStream_t)stream));
     hipLaunchKernelGGL(smooth_knn_kernel, dim3(psg::ceil_div(N, 256)), dim3(256), lds, (hipStream_t)stream, adv_color,
-                       adv_stride, ref_color, ref_stride, N, nb, dist_sum, grad_out);
+                       adv_stride, ref_color, ref_stride, N, nb, dist_sum, grad_out, symmetric);
     PSG_LAUNCH_CHECK();
     return PSG_OK;
 }

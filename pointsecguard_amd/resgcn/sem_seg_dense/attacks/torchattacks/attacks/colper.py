@@ -34,3 +34,15 @@ class NB_attack(Attack):
         net._generation += 1
         adv = net._workspace(B, N).nb_attack(net._packed(), x, labels, self.eps, self.alpha, self.iters)
         return adv.unsqueeze(-1)
+
+
+class NU_attack(Attack):
+    """Norm-unbounded attack (colper.py:42-120): Adam on w (tanh space), cost = c*f + 1e-4*Smooth + L2."""
+
+    def __init__(self, model, c=1e-4, kappa=0, steps=1000, lr=0.01, target=None, ori=None):
+        super(NU_attack, self).__init__("NU_attack", model)
+        self.c, self.kappa, self.steps, self.lr, self.target, self.ori = c, kappa, steps, lr, target, ori
+
+    def forward(self, images, labels):
+        from .nu import gcn_nu_attack
+        return gcn_nu_attack(self, images, labels, neighbour=10)

@@ -51,3 +51,16 @@ class tar_NB_attack(Attack):
             _lib.call("psg_pgd_step", runtime.ptr(x0), runtime.ptr(dx0), runtime.ptr(ori), runtime.ptr(mask_d), B, N,
                       float(self.alpha), float(self.eps), -1.0, 0, st())
         return snapshot()
+
+
+class tar_NU_attack(Attack):
+    """Targeted norm-unbounded attack (tcolper.py:51-170): masked colours, cost = f + 1e-4*Smooth + c*L2, learning
+    rate halved with a fresh optimiser every 50 steps, restart check every 10 steps."""
+
+    def __init__(self, model, c=1e-4, kappa=0, steps=1000, lr=0.01, target=None, mask=None):
+        super(tar_NU_attack, self).__init__("tar_NU_attack", model)
+        self.c, self.kappa, self.steps, self.lr, self.target, self.mask = c, kappa, steps, lr, target, mask
+
+    def forward(self, images, labels):
+        from .nu import gcn_nu_attack
+        return gcn_nu_attack(self, images, labels, mask=self.mask, target=self.target, neighbour=5, targeted_variant=True)

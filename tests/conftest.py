@@ -77,3 +77,13 @@ def golden_gcn_nb():
 def gcn_oracle(gcn_weights_sd):
     from oracle import resgcn
     return resgcn.GCNOracle(gcn_weights_sd, n_blocks=5)
+
+
+@pytest.fixture(scope="session")
+def golden_gcn_nu():
+    return dict(np.load(os.path.join(GOLDEN, "gcn_nu.npz")))
+
+
+@pytest.fixture(scope="session")
+def golden_gcn_tarnu():
+    return dict(np.load(os.path.join(GOLDEN, "gcn_tarnu.npz")))

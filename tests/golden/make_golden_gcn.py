@@ -163,6 +163,93 @@ def gen_nb():
     print("gcn nb done")
 
 
+class Instrument:
+    """Records what the UNMODIFIED reference NU attacks compute internally by patching torch only: every Adam
+    step (w before, grad, w/m/v after, lr, step count) and the scalar each .backward() is called on (the cost)."""
+
+    def __init__(self):
+        self.adam, self.costs = [], []
+
+    def __enter__(self):
+        self._step, self._backward = torch.optim.Adam.step, torch.Tensor.backward
+        inst = self
+
+        def step(opt, *a, **k):
+            p = opt.param_groups[0]["params"][0]
+            rec = {"w_before": p.detach().numpy().copy(), "grad": p.grad.detach().numpy().copy(),
+                   "lr": opt.param_groups[0]["lr"]}
+            r = inst._step(opt, *a, **k)
+            st = opt.state[p]
+            rec.update(w_after=p.detach().numpy().copy(), m=st["exp_avg"].numpy().copy(),
+                       v=st["exp_avg_sq"].numpy().copy(), t=int(st["step"]))
+            inst.adam.append(rec)
+            return r
+
+        def backward(t, *a, **k):
+            if t.dim() == 0:
+                inst.costs.append(float(t.item()))
+            return inst._backward(t, *a, **k)
+
+        torch.optim.Adam.step, torch.Tensor.backward = step, backward
+        return self
+
+    def __exit__(self, *exc):
+        torch.optim.Adam.step, torch.Tensor.backward = self._step, self._backward
+
+
+def _run_nu(make_attack, x, y, keep, extra):
+    m = load_model()
+    rec = Recorder(m).eval()
+    graphs = []
+    mods = [m.knn] + [blk.body.dilated_knn_graph for blk in m.backbone]
+    hooks = [mod.register_forward_hook(lambda mod_, i, res, e=e: graphs.append((e, res[0, 0].numpy().astype(np.int16))))
+             for e, mod in enumerate(mods)]
+    with Instrument() as inst:
+        adv = make_attack(rec)(x, torch.from_numpy(y)).detach()
+    for h in hooks:
+        h.remove()
+    per_fwd = len(mods) + 1
+    out = dict(extra)
+    out.update(adv_final=adv[:, :, :, 0].numpy(), n_steps_run=len(inst.adam), costs=np.array(inst.costs, np.float64),
+               keep=np.array([t for t in keep if t < len(inst.adam)]))
+    for t in out["keep"]:
+        r = inst.adam[t]
+        for k_ in ("w_before", "grad", "w_after", "m", "v"):
+            out["s%d_%s" % (t, k_)] = r[k_][..., 0] if r[k_].ndim == 4 else r[k_]
+        out["s%d_lr" % t], out["s%d_t" % t] = r["lr"], r["t"]
+        first = {}
+        for e, tab in graphs[t * per_fwd:(t + 1) * per_fwd]:
+            first.setdefault(e, tab)
+        out["graphs_s%d" % t] = np.stack([first[e] for e in range(len(mods))])
+    return out, inst
+
+
+def gen_nu():
+    torch.set_num_threads(1)
+    torch.manual_seed(11)
+    r, y = rooms(1, 79)
+    c, kappa, lr, steps = 0.1, 0, 0.1, 10
+    out, inst = _run_nu(lambda mdl: torchattacks.NU_attack(mdl, c=c, kappa=kappa, steps=steps, lr=lr), to_input(r), y,
+                        (0, 1, 2, 5, 9), {"rooms": r, "labels": y.astype(np.int16), "c": c, "kappa": kappa, "lr": lr,
+                                          "steps": steps})
+    np.savez_compressed(os.path.join(HERE, "gcn_nu.npz"), **out)
+    print("gcn nu: steps", len(inst.adam), "costs", np.round(inst.costs, 3).tolist())
+
+
+def gen_tarnu():
+    torch.set_num_threads(1)
+    torch.manual_seed(12)
+    r, y = rooms(1, 80)
+    c, kappa, lr, steps, target, origin = 1.0, 0, 0.1, 23, 6, 11
+    mask = y[0] == origin
+    out, inst = _run_nu(lambda mdl: torchattacks.tar_NU_attack(mdl, c=c, kappa=kappa, steps=steps, lr=lr, target=target,
+                                                              mask=torch.from_numpy(mask)), to_input(r), y,
+                        (0, 1, 2, 19, 20, 21, 22), {"rooms": r, "labels": y.astype(np.int16), "mask": mask, "c": c,
+                                                    "kappa": kappa, "lr": lr, "steps": steps, "target": target})
+    np.savez_compressed(os.path.join(HERE, "gcn_tarnu.npz"), **out)
+    print("gcn tarnu: steps", len(inst.adam), "mask", int(mask.sum()), "costs", np.round(inst.costs, 3).tolist())
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("weights", "all"):
@@ -171,3 +258,7 @@ if __name__ == "__main__":
         gen_room()
     if what in ("nb", "all"):
         gen_nb()
+    if what in ("nu", "all"):
+        gen_nu()
+    if what in ("tarnu", "all"):
+        gen_tarnu()

@@ -176,3 +176,95 @@ def test_resgcn_python_api(gcn_weights_sd, golden_gcn_room, golden_gcn_nb):
     moved = (tadv[:, 3:6, :, 0] != x[:, 3:6, :, 0]).any(dim=1)[0].cpu().numpy()
     assert not moved[~mask].any() and moved[mask].mean() > 0.5
     assert float(tadv[:, 3:6].min()) >= 0.0 and float(tadv[:, 3:6].max()) <= 1.0   # projected colours written back
+
+
+def _expand(a, mask, n):
+    out = np.zeros((1, 3, n), np.float32)
+    if mask is None:
+        out[0] = a
+    else:
+        out[0][:, mask] = a
+    return np.ascontiguousarray(out.transpose(0, 2, 1))
+
+
+def _gcn_nu_step_gpu(model, ws, g, t, nb, tv):
+    from pointsecguard_amd import _lib, runtime
+    from pointsecguard_amd.attacks.torchattacks.attacks.nu import ADAM_EPS, BETA1, BETA2, ctypes_off
+    N = 1024
+    mask = g["mask"] if tv else None
+    mask_d = dev(mask.astype(np.uint8)) if tv else None
+    x0 = dev(g["rooms"])
+    ori = x0[:, :, 3:6].contiguous()
+    labels = dev(g["labels"].astype(np.int32))
+    w = dev(_expand(g["s%d_w_before" % t][0], mask, N))
+    m = dev(_expand(g["s%d_m" % (t - 1)][0], mask, N)) if t else torch.zeros_like(w)
+    v = dev(_expand(g["s%d_v" % (t - 1)][0], mask, N)) if t else torch.zeros_like(w)
+    ws.set_graphs(dev(g["graphs_s%d" % t].astype(np.int32)[:, None]))
+    st = runtime.stream
+    _lib.call("psg_nu_tanh_color", runtime.ptr(w), runtime.ptr(mask_d), 1, N, runtime.ptr(x0), st())
+    logits = ws.forward(model, x0)
+    scal = torch.zeros(3, device="cuda")
+    dl = torch.empty_like(logits)
+    c = float(g["c"])
+    c_f, c_l2 = (c, 1.0) if not tv else (1.0, c)
+    _lib.call("psg_gcn_f_loss_grad", runtime.ptr(logits), runtime.ptr(labels), int(g["target"]) if tv else 0,
+              runtime.ptr(mask_d), 2 if tv else 0, N, N, 13, float(g["kappa"]), 1.0, c_f, runtime.ptr(dl),
+              runtime.ptr(scal[0:1]), None, st())
+    dx0 = ws.backward(model, dl)
+    sgrad = torch.empty(N, 3, device="cuda")
+    _lib.call("psg_smooth_knn", ctypes_off(x0, 3), 9, ctypes_off(x0, 3), 9, N, nb, runtime.ptr(scal[1:2]), runtime.ptr(sgrad), st())
+    m0 = m.clone()
+    _lib.call("psg_nu_adam_step", runtime.ptr(w), runtime.ptr(m), runtime.ptr(v), runtime.ptr(mask_d), runtime.ptr(dx0),
+              runtime.ptr(x0), runtime.ptr(ori), runtime.ptr(sgrad), 1e-4, c_l2, float(g["s%d_lr" % t]), BETA1, BETA2, ADAM_EPS,
+              int(g["s%d_t" % t]), 1, N, runtime.ptr(scal[2:3]), st())
+    torch.cuda.synchronize()
+    ws.set_graphs(None)
+    f, sm, l2 = (float(z) for z in scal.cpu())
+    sel = slice(None) if mask is None else mask
+    grad = ((m - m0) / (1.0 - BETA1) + m0).cpu().numpy().transpose(0, 2, 1)[0][:, sel]
+    return c_f * f + 1e-4 * sm + c_l2 * l2, grad, w.cpu().numpy().transpose(0, 2, 1)[0][:, sel]
+
+
+@pytest.mark.parametrize("name,nb,tv,steps", [("nu", 10, False, (0, 1, 2)), ("tarnu", 5, True, (0, 20, 22))])
+def test_gcn_nu_steps_with_reference_graphs(gcn, golden_gcn_nu, golden_gcn_tarnu, name, nb, tv, steps):
+    model, ws = gcn
+    g = golden_gcn_tarnu if tv else golden_gcn_nu
+    for t in steps:
+        cost, grad, w_after = _gcn_nu_step_gpu(model, ws, g, t, nb, tv)
+        ref = g["s%d_grad" % t][0]
+        assert abs(cost - g["costs"][t]) <= 1e-4 * abs(g["costs"][t]) + 1e-2, (t, cost, g["costs"][t])
+        assert (np.abs(grad - ref) <= 1e-2 * np.abs(ref).max()).mean() >= 0.99, t
+        assert (np.abs(w_after - g["s%d_w_after" % t][0]) <= 1e-4).mean() >= 0.99, t
+
+
+def test_gcn_nu_attack_api(gcn_weights_sd, golden_gcn_nu, golden_gcn_tarnu):
+    from types import SimpleNamespace
+    from pointsecguard_amd.resgcn.sem_seg_dense.architecture import DenseDeepGCN
+    from pointsecguard_amd.resgcn.sem_seg_dense.attacks import torchattacks
+    from pointsecguard_amd.resgcn.sem_seg_dense.attacks.torchattacks.attacks.nu import gcn_nu_attack
+    opt = SimpleNamespace(n_filters=64, k=16, act="relu", norm="batch", bias=True, epsilon=0.0, stochastic=True,
+                          conv="edge", n_blocks=NB, block="res", in_channels=9, dropout=0.0, n_classes=13)
+    net = DenseDeepGCN(opt)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in gcn_weights_sd.items()})
+    net = net.cuda().eval()
+    g = golden_gcn_nu
+    x = dev(g["rooms"].transpose(0, 2, 1)[:, :, :, None])
+    y = dev(g["labels"].astype(np.int64))
+    atk = torchattacks.NU_attack(net, c=float(g["c"]), kappa=0, steps=int(g["steps"]), lr=float(g["lr"]))
+    costs = []
+    adv = gcn_nu_attack(atk, x, y, neighbour=10, trace=lambda **kw: costs.append(kw["cost"]))
+    assert adv.shape == x.shape and len(costs) == int(g["n_steps_run"])
+    # dynamic graphs + Adam: trajectories agree closely at the start and keep decreasing alike
+    assert np.allclose(costs[:3], g["costs"][:3], rtol=2e-2), (costs[:3], g["costs"][:3])
+    assert abs(costs[-1] - g["costs"][-1]) <= 0.1 * g["costs"][-1]
+    assert torch.equal(adv[:, :3], x[:, :3]) and torch.equal(adv[:, 6:], x[:, 6:])
+    gt = golden_gcn_tarnu
+    xt = dev(gt["rooms"].transpose(0, 2, 1)[:, :, :, None])
+    yt = dev(gt["labels"].astype(np.int64))
+    tatk = torchattacks.tar_NU_attack(net, c=1.0, kappa=0, steps=5, lr=0.1, target=int(gt["target"]), mask=gt["mask"])
+    tcosts = []
+    tadv = gcn_nu_attack(tatk, xt, yt, mask=gt["mask"], target=int(gt["target"]), neighbour=5, targeted_variant=True,
+                         trace=lambda **kw: tcosts.append(kw["cost"]))
+    assert np.allclose(tcosts[:3], gt["costs"][:3], rtol=2e-2), (tcosts[:3], gt["costs"][:3])
+    moved = (tadv[:, 3:6, :, 0] != xt[:, 3:6, :, 0]).any(dim=1)[0].cpu().numpy()
+    assert not moved[~gt["mask"]].any()

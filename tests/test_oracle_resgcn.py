@@ -54,3 +54,32 @@ def test_nb_attack_step(golden_gcn_nb, gcn_oracle, t):
                                   g["labels"][0].astype(np.int64), float(g["alpha"]), float(g["eps"]), t == iters - 1,
                                   graphs=graphs)
     assert (np.ascontiguousarray(got).view(np.uint32) == np.ascontiguousarray(nxt).view(np.uint32)).mean() >= 0.999
+
+
+def _gcn_nu_check(orc, g, t, nb, tv):
+    x = g["rooms"][0]
+    w = g["s%d_w_before" % t][0]
+    if t == 0:
+        m, v = np.zeros_like(w), np.zeros_like(w)
+    else:
+        m, v = g["s%d_m" % (t - 1)][0], g["s%d_v" % (t - 1)][0]
+    graphs = [g["graphs_s%d" % t][e].astype(np.int32) for e in range(5)]
+    r = resgcn.nu_step(orc, x, x, w, m, v, int(g["s%d_t" % t]), g["labels"][0].astype(np.int64), float(g["c"]),
+                       float(g["kappa"]), float(g["s%d_lr" % t]), nb, targeted_variant=tv,
+                       mask=g["mask"] if tv else None, target=int(g["target"]) if tv else None, graphs=graphs)
+    ref = g["s%d_grad" % t][0]
+    assert abs(r["cost"] - g["costs"][t]) <= 1e-5 * abs(g["costs"][t]) + 1e-3
+    assert (np.abs(r["grad_w"] - ref) <= 1e-2 * np.abs(ref).max()).mean() >= 0.995
+    assert (np.abs(r["w"] - g["s%d_w_after" % t][0]) <= 1e-4).mean() >= 0.995
+
+
+@pytest.mark.parametrize("t", [0, 1, 2])
+def test_gcn_nu_attack_step(golden_gcn_nu, gcn_oracle, t):
+    """colper.NU_attack: c*f(logits) + 1e-4*Smooth(adv, adv) + L2, torch Adam; teacher-forced graphs."""
+    _gcn_nu_check(gcn_oracle, golden_gcn_nu, t, 10, False)
+
+
+@pytest.mark.parametrize("t", [0, 20, 22])
+def test_gcn_tar_nu_attack_step(golden_gcn_tarnu, gcn_oracle, t):
+    """tcolper.tar_NU_attack: masked tar_f on row 0 + 1e-4*Smooth + c*L2."""
+    _gcn_nu_check(gcn_oracle, golden_gcn_tarnu, t, 5, True)
