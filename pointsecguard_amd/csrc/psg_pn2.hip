@@ -308,6 +308,7 @@ int run_fp_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *logp, hipStream
     a.n_layers = nl;
     static const int diag = getenv("PSG_DIAG") ? atoi(getenv("PSG_DIAG")) : 0;
     a.diag = diag;
+    if ((diag & 512) && ((diag >> 16) & 7) != LVL + 1) a.diag &= ~512;   // phase stamps for one module only
     a.dbg = ws->dbg;
     if (diag & 2) for (int i = 0; i < nl; ++i) a.layer[i].mask = nullptr;
     if (diag & 64) for (int i = 0; i < nl; ++i) a.layer[i].k8 = 4;    // timing only: 1/4 .. 1/24 of the MFMAs
@@ -425,7 +426,7 @@ size_t ws_layout(psg_pn2_ws *ws, char *base)
     ws->gzero_bytes = bp.off - g0;
     ws->x0 = bp.take<float>((size_t)B * ws->N * 9);
     ws->ori = bp.take<float>((size_t)B * ws->N * 3);
-    ws->dbg = bp.take<unsigned long long>(16 * 8192);
+    ws->dbg = bp.take<unsigned long long>(16 * 8 * 1024);
     return (bp.off + 255) & ~(size_t)255;
 }
 
@@ -514,7 +515,7 @@ extern "C" size_t psg_pn2_ws_bytes(const psg_pn2_ws *ws) { return ws ? ws->bytes
 
 extern "C" int psg_pn2_debug_read(psg_pn2_ws *ws, unsigned long long *host_out, int n_words)
 {
-    PSG_REQUIRE(ws && host_out && n_words > 0 && n_words <= 16 * 8192, "psg_pn2_debug_read: bad argument");
+    PSG_REQUIRE(ws && host_out && n_words > 0 && n_words <= 16 * 8 * 1024, "psg_pn2_debug_read: bad argument");
     PSG_CHECK_HIP(hipMemcpy(host_out, ws->dbg, (size_t)n_words * 8, hipMemcpyDeviceToHost));
     return PSG_OK;
 }

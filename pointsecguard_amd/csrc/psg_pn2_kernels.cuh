@@ -216,6 +216,7 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
     const int tid = threadIdx.x;
     const int b = blockIdx.y, n0 = blockIdx.x * P;
     const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 15] = __builtin_amdgcn_s_memtime();
     if ((a.diag & 256) && tid == 0) {
         a.dbg[wg * 4 + 0] = __builtin_amdgcn_s_memtime();
         a.dbg[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime();
@@ -244,12 +245,12 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
     }
     __syncthreads();
     float *in = buf0, *out = buf1;
-    if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 4 + (tid >> 6)) * 16 + 0] = __builtin_amdgcn_s_memtime();
+    if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 0] = __builtin_amdgcn_s_memtime();
     for (int l = 0; l < a.n_layers; ++l) {
         if (!(a.diag & 8)) layer_fwd<P, NW>(a.layer[l], in, out, wg);
-        if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 4 + (tid >> 6)) * 16 + 1 + 2 * l] = __builtin_amdgcn_s_memtime();
+        if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 1 + 2 * l] = __builtin_amdgcn_s_memtime();
         if (!(a.diag & 16)) __syncthreads();
-        if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 4 + (tid >> 6)) * 16 + 2 + 2 * l] = __builtin_amdgcn_s_memtime();
+        if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 2 + 2 * l] = __builtin_amdgcn_s_memtime();
         float *t = in; in = out; out = t;
     }
     // `in` now holds the last layer's output
