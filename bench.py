@@ -77,8 +77,11 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=6)
     ap.add_argument("--workload", default="pointnet2", choices=["pointnet2", "resgcn"],
                     help="pointnet2 = BASELINE configs[1] (headline metric); resgcn = configs[3] (secondary, ResGCN-28)")
-    ap.add_argument("--concurrency", type=int, default=4,
-                    help="independent attack steps in flight per GPU (one HIP stream + workspace each)")
+    ap.add_argument("--coalesce", type=int, default=4,
+                    help="consecutive steps (batches of 8 rooms) fused into one device batch per launch; rooms are "
+                         "independent, so results are identical and small kernels get more workgroups")
+    ap.add_argument("--concurrency", type=int, default=2,
+                    help="device batches in flight per GPU (one HIP stream + workspace each)")
     args = ap.parse_args()
 
     if args.workload == "resgcn":
@@ -102,30 +105,36 @@ def main():
 
     sd = dict(np.load(os.path.join(ROOT, "tests", "golden", "pn2_weights.npz")))
     model = runtime.PN2Model(runtime.fold_state_dict(sd))
-    conc = max(1, min(args.concurrency, args.steps))
-    wss = [runtime.PN2Workspace(BATCH, NPOINT, ITERS) for _ in range(conc)]
+    import math
+    G = max(1, math.gcd(args.coalesce, args.steps)) if args.coalesce > 1 else 1   # steps per device batch
+    DB = BATCH * G                                                                # rooms per launch
+    n_groups = args.steps // G
+    n_warm = max(1, -(-args.warmup // G)) if args.warmup > 0 else 0
+    conc = max(1, min(args.concurrency, n_groups))
+    wss = [runtime.PN2Workspace(DB, NPOINT, ITERS) for _ in range(conc)]
     streams = [torch.cuda.Stream() for _ in range(conc)]
     ws = wss[0]
 
-    n_steps = args.steps + args.warmup
-    # each rank attacks its own shard of rooms (weak scaling: BATCH rooms per GPU per step)
-    rooms = [make_rooms(BATCH, 1000 + rank * 100003 + s) for s in range(n_steps)]
+    n_all = n_groups + n_warm
+    # each rank attacks its own shard of rooms (weak scaling: BATCH rooms per GPU per step); group j holds the
+    # rooms of steps j*G .. j*G+G-1
+    rooms = [make_rooms(DB, 1000 + rank * 100003 + s) for s in range(n_all)]
     labels = [rule_labels(r) for r in rooms]
     rng = np.random.default_rng(1234 + rank)
-    starts = [np.stack([rng.integers(0, n, (ITERS, BATCH)) for n in (NPOINT, 1024, 256, 64)], axis=1).astype(np.int32)
-              for _ in range(n_steps)]
+    starts = [np.stack([rng.integers(0, n, (ITERS, DB)) for n in (NPOINT, 1024, 256, 64)], axis=1).astype(np.int32)
+              for _ in range(n_all)]
     d_images = [torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 1))).cuda() for r in rooms]
     d_labels = [torch.from_numpy(l.astype(np.int32)).cuda() for l in labels]
     d_starts = [torch.from_numpy(s).cuda() for s in starts]
     d_adv = [torch.empty_like(x) for x in d_images]
 
     def step(i):
-        # steps are independent batches: step i runs on stream i % conc with its own workspace, so
-        # small kernels of one attack overlap with kernels of the others (no cross-step dependency)
+        # device batch i (= G steps) runs on stream i % conc with its own workspace: batches are independent, so
+        # kernels of one overlap with kernels of the others (no cross-step dependency, no collective)
         with torch.cuda.stream(streams[i % conc]):
             wss[i % conc].nb_attack(model, d_images[i], d_labels[i], d_starts[i], EPS, ALPHA, ITERS, out=d_adv[i])
 
-    for i in range(args.warmup):
+    for i in range(n_warm):
         step(i)
 
     def fence():
@@ -136,7 +145,7 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    for i in range(args.warmup, n_steps):
+    for i in range(n_warm, n_all):
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
@@ -148,8 +157,8 @@ def main():
     # ---- attack statistics over the timed steps: clean vs adversarial accuracy / mIoU (RCCL all-reduce of counters)
     clean = torch.zeros(3, 13, dtype=torch.int64, device="cuda")
     adv = torch.zeros(3, 13, dtype=torch.int64, device="cuda")
-    ev = runtime.PN2Workspace(BATCH, NPOINT, 1)
-    for i in range(args.warmup, min(n_steps, args.warmup + 4)):
+    ev = runtime.PN2Workspace(DB, NPOINT, 1)
+    for i in range(n_warm, min(n_all, n_warm + 2)):
         ev_starts = d_starts[i][:1].contiguous()
         for src, ctr in ((d_images[i], clean), (d_adv[i], adv)):
             x0 = src.transpose(1, 2).contiguous()
@@ -169,12 +178,11 @@ def main():
         value = total_rooms / elapsed
         # ---- roofline of the dominant kernel: one extra attack with HIP-event timing of every launch
         ws.prof_enable(True)
-        ws.nb_attack(model, d_images[args.warmup], d_labels[args.warmup], d_starts[args.warmup], EPS, ALPHA, ITERS,
-                     out=d_adv[args.warmup])
+        ws.nb_attack(model, d_images[n_warm], d_labels[n_warm], d_starts[n_warm], EPS, ALPHA, ITERS, out=d_adv[n_warm])
         torch.cuda.synchronize()
         prof = ws.prof_read()
         ws.prof_enable(False)
-        flops = kernel_flops(BATCH)
+        flops = kernel_flops(DB)
         mlp = {k: v for k, v in prof.items() if k in flops}
         dom = max(mlp, key=lambda k: mlp[k][0])
         avg_ms = mlp[dom][0] / mlp[dom][1]
@@ -187,7 +195,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "NB non-targeted PGD (eps=0.05, alpha=2/255, 40 iters) on PointNet++ SSG sem_seg, "
                                    "batch=8 rooms x 4096 pts x 9 ch per GPU (BASELINE configs[1])",
-                       "rooms_per_step_per_gpu": BATCH, "concurrent_steps_per_gpu": conc, "weights": "tests/golden/pn2_weights.npz (fitted fixture)",
+                       "rooms_per_step_per_gpu": BATCH, "steps_coalesced_per_launch": G, "device_batch_rooms": DB,
+                       "launches_in_flight_per_gpu": conc, "weights": "tests/golden/pn2_weights.npz (fitted fixture)",
                        "sharding": "rooms sharded by rank, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
@@ -199,8 +208,8 @@ def main():
                        "adv_miou": adv_miou, "rooms_evaluated": int(clean[0].sum() // NPOINT)},
         }
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(sd, rooms[args.warmup], labels[args.warmup], starts[args.warmup],
-                                                  args.cpu_iters)
+            result["cpu_baseline"] = cpu_baseline(sd, rooms[n_warm][:BATCH], labels[n_warm][:BATCH],
+                                                  starts[n_warm][:, :, :BATCH], args.cpu_iters)
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
