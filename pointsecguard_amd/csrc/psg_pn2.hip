@@ -68,6 +68,9 @@ struct psg_pn2_ws {
     int32_t *gidx[4];     // [F*B][S_l][32]
     int32_t *nn_idx[4];   // [F*B][N_l][3]
     float *nn_w[4];
+    int32_t *inv_off[4];  // inverse 3-NN lists (CSR by coarse point): [F*B][S_l + 1]
+    int2 *inv_ent[4];     // [F*B][3*N_l] {fine point, weight bits}, ascending fine point inside a list
+    float *dint[4];       // [B][N_l][C2_l] interpolated-part gradient rows of fp_bwd level l
     int planned = 0;
     // activations of one forward
     float *act[7];        // l1..l4, fp4 out (64 pts), fp3 out (256), fp2 out (1024)
@@ -254,6 +257,14 @@ int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *dx0, int c_lo, 
     const size_t prob = (size_t)fwd * B;
     SaBwdArgs a;
     a.dout = ws->dact[LVL];
+    a.nninv_off = nullptr; a.nninv_ent = nullptr; a.dint = nullptr; a.n_fine = 0;
+    if (LVL == 3) {   // l4_points feed only fp4: its gradient is gathered from fp4's interpolated-part rows
+        a.dout = nullptr;
+        a.nninv_off = ws->inv_off[3] + prob * (kS[3] + 1);
+        a.nninv_ent = ws->inv_ent[3] + prob * ws->Nl[3] * 3;
+        a.dint = ws->dint[3];
+        a.n_fine = ws->Nl[3];
+    }
     a.arg = ws->arg[LVL];
     a.gidx = ws->gidx[LVL] + prob * S * K;
     a.dfeat = LVL == 0 ? dx0 : ws->dact[LVL - 1];
@@ -337,7 +348,9 @@ int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, con
     a.C1 = LVL == 0 ? 0 : kSaC[LVL];
     a.C2 = m->L[kFpFirst[LVL]].cin - a.C1;
     a.dfeat1 = LVL == 0 ? nullptr : ws->dact[LVL - 1];
-    a.dfeat2 = ws->dact[fp_in2_slot(LVL)];
+    a.dfeat2 = nullptr;
+    a.dint_out = ws->dint[LVL];
+    a.nninv_off = nullptr; a.nninv_ent = nullptr; a.dint = nullptr; a.n_fine = 0;
     const int first = kFpFirst[LVL], cnt = kFpCount[LVL];
     int nl = 0;
     a.dout = nullptr; a.mask_last = nullptr; a.logp = nullptr; a.dlogp = nullptr;
@@ -347,7 +360,11 @@ int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, con
         a.layer[nl++] = bwd_layer(m->L[22], ws->mask[21]);            // conv2^T, then bn1/conv1 ReLU mask
         a.layer[nl++] = bwd_layer(m->L[21], ws->mask[first + cnt - 1]); // conv1^T, then fp1 last ReLU mask
     } else {
-        a.dout = ws->dact[fp_out_slot(LVL)];
+        // gradient of this module's output = transpose of the finer module's interpolation, gathered
+        a.nninv_off = ws->inv_off[LVL - 1] + prob * (N + 1);
+        a.nninv_ent = ws->inv_ent[LVL - 1] + prob * ws->Nl[LVL - 1] * 3;
+        a.dint = ws->dint[LVL - 1];
+        a.n_fine = ws->Nl[LVL - 1];
         a.mask_last = ws->mask[first + cnt - 1];
         a.Cout = m->L[first + cnt - 1].cout;
         a.mb_last = m->L[first + cnt - 1].mbf();
@@ -386,6 +403,47 @@ __global__ void gather_starts_kernel(const int32_t *__restrict__ starts, int32_t
     if (p < P) out[p] = starts[((size_t)(p / B) * 4 + level) * B + (p % B)];
 }
 
+// Inverse of the 3-NN tables: for every coarse point the (fine point, weight) pairs that interpolate from it,
+// as CSR sorted by fine point, so the backward pass can GATHER (fixed summation order, no atomics) what the
+// reference's autograd scatter-adds (index_points backward, pointnet_util.py:308).
+__global__ __launch_bounds__(256) void build_inv_nn_kernel(const int32_t *__restrict__ nn_idx, const float *__restrict__ nn_w,
+                                                           int N, int S, int32_t *__restrict__ inv_off,
+                                                           int2 *__restrict__ inv_ent)
+{
+    extern __shared__ int s_cnt[];   // [S + 1]
+    const size_t p = blockIdx.x;
+    const int32_t *idx = nn_idx + p * N * 3;
+    const float *w = nn_w + p * N * 3;
+    int32_t *off = inv_off + p * (S + 1);
+    int2 *ent = inv_ent + p * N * 3;
+    for (int i = threadIdx.x; i <= S; i += 256) s_cnt[i] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 3 * N; e += 256) atomicAdd(&s_cnt[idx[e]], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < S; ++i) { const int c = s_cnt[i]; s_cnt[i] = run; off[i] = run; run += c; }
+        off[S] = run;
+        s_cnt[S] = run;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 3 * N; e += 256) {
+        const int pos = atomicAdd(&s_cnt[idx[e]], 1);
+        ent[pos] = make_int2(e / 3, __float_as_int(w[e]));
+    }
+    __syncthreads();
+    // after the fill s_cnt[i] == end of list i; start = end of list i-1 (0 for i == 0)
+    for (int i = threadIdx.x; i < S; i += 256) {
+        const int lo = i ? s_cnt[i - 1] : 0, hi = s_cnt[i];
+        for (int a = lo + 1; a < hi; ++a) {   // insertion sort by fine point (lists are short)
+            const int2 key = ent[a];
+            int q = a - 1;
+            while (q >= lo && ent[q].x > key.x) { ent[q + 1] = ent[q]; --q; }
+            ent[q + 1] = key;
+        }
+    }
+}
+
 size_t ws_layout(psg_pn2_ws *ws, char *base)
 {
     Bump bp;
@@ -400,6 +458,12 @@ size_t ws_layout(psg_pn2_ws *ws, char *base)
         ws->gidx[l] = bp.take<int32_t>(PR * kS[l] * K);
         ws->nn_idx[l] = bp.take<int32_t>(PR * ws->Nl[l] * 3);
         ws->nn_w[l] = bp.take<float>(PR * ws->Nl[l] * 3);
+        ws->inv_off[l] = bp.take<int32_t>(PR * (kS[l] + 1));
+        ws->inv_ent[l] = bp.take<int2>(PR * ws->Nl[l] * 3);
+    }
+    {
+        const int c2[4] = {128, 256, 256, 512};
+        for (int l = 0; l < 4; ++l) ws->dint[l] = bp.take<float>((size_t)B * ws->Nl[l] * c2[l]);
     }
     const int actN[7] = {1024, 256, 64, 16, 64, 256, 1024};
     const int actC[7] = {64, 128, 256, 512, 256, 256, 128};
@@ -583,6 +647,9 @@ extern "C" int psg_pn2_plan_build(psg_pn2_ws *ws, const float *x0, const int32_t
             if ((rc = psg_three_nn(ws->ctx, ws->xyz[l], n_clouds, ws->xyz[l + 1], P, Np, S, ws->nn_idx[l], ws->nn_w[l],
                                    st)))
                 return rc;
+            hipLaunchKernelGGL(build_inv_nn_kernel, dim3(P), dim3(256), (size_t)(S + 1) * 4, st, ws->nn_idx[l], ws->nn_w[l],
+                               Np, S, ws->inv_off[l], ws->inv_ent[l]);
+            PSG_LAUNCH_CHECK();
         }
     }
     ws->planned = n_forward;

@@ -30,7 +30,12 @@ struct SaFwdArgs {
 };
 
 struct SaBwdArgs {
-    const float *dout;    // [B][S][C3]
+    const float *dout;    // [B][S][C3] (direct), or null when the gradient is gathered through nninv_*
+    // gather form: dout[s][c] = sum over the fine points p whose 3-NN lists contain s of w * dint[p][c]
+    const int32_t *nninv_off;   // [B][S+1]
+    const int2 *nninv_ent;      // [B][3*n_fine] {fine point, weight bits}, sorted by fine point per list
+    const float *dint;          // [B][n_fine][C3]
+    int n_fine;
     const uint8_t *arg;   // [B][S][C3]
     const int32_t *gidx;  // [B][S][32]
     float *dfeat;         // [B][Np][D]  (atomicAdd)
@@ -57,6 +62,12 @@ struct FpFwdArgs {
 
 struct FpBwdArgs {
     const float *dout;          // [B][N][Cout] gradient of the last layer's (post-ReLU) output, or null
+    // gather form of dout (deterministic transpose of the finer module's 3-NN interpolation):
+    const int32_t *nninv_off;   // [B][N+1] or null
+    const int2 *nninv_ent;      // [B][3*n_fine]
+    const float *dint;          // [B][n_fine][Cout] interpolated-part gradient rows written by the finer module
+    int n_fine;
+    float *dint_out;            // [B][N][C2]: this module's interpolated-part gradient rows (plain stores)
     const uint16_t *mask_last;  // ReLU mask of that layer
     const float *logp;          // head mode: [B][N][n_cls]
     const float *dlogp;         // head mode: [B][N][n_cls]
@@ -163,6 +174,23 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     const int b = blockIdx.y, s0 = blockIdx.x * G;
     const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
 
+    // gradient of the pooled output: read directly, or gathered (no atomics, fixed summation order) from the
+    // interpolated-part rows of the feature-propagation module that upsampled this level
+    const float *dsrc = a.dout ? a.dout + ((size_t)b * a.S + s0) * a.C3 : buf1;   // buf1 is free until l3t writes it
+    if (!a.dout) {
+        for (int t = tid; t < G * a.C3; t += NT) {
+            const int g = t / a.C3, c = t - g * a.C3;
+            const int32_t *off = a.nninv_off + (size_t)b * (a.S + 1) + s0 + g;
+            const int2 *ent = a.nninv_ent + (size_t)b * 3 * a.n_fine;
+            float acc = 0.0f;
+            for (int e = off[0]; e < off[1]; ++e) {
+                const int2 pe = ent[e];
+                acc += __int_as_float(pe.y) * a.dint[((size_t)b * a.n_fine + pe.x) * a.C3 + c];
+            }
+            buf1[t] = acc;
+        }
+        __syncthreads();
+    }
     // max-pool backward: dZ3[c][g*32+k] = dout[g][c] if k == arg[g][c] else 0.
     // One (point, 8-channel block) per thread; arg/dout reads are broadcasts across the 32 samples.
     const int nblk = a.C3 >> 3;
@@ -171,7 +199,8 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
         const int g = pnt >> 5, k = pnt & 31;
         const size_t o = ((size_t)b * a.S + s0 + g) * a.C3 + blk * 8;
         const uint2 am = *(const uint2 *)(a.arg + o);
-        const float4 d0 = *(const float4 *)(a.dout + o), d1 = *(const float4 *)(a.dout + o + 4);
+        const float *dp = dsrc + (size_t)g * a.C3 + blk * 8;
+        const float4 d0 = *(const float4 *)dp, d1 = *(const float4 *)(dp + 4);
         float4 v0, v1;
         v0.x = (int)(am.x & 0xFF) == k ? d0.x : 0.f;
         v0.y = (int)((am.x >> 8) & 0xFF) == k ? d0.y : 0.f;
@@ -298,18 +327,39 @@ __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
     const int b = blockIdx.y, n0 = blockIdx.x * P;
     const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
 
-    if (a.dout) {
+    if (a.dout || a.nninv_off) {
         // dZ_last = dout * mask_last, loaded tile-wise so the mask bits line up with the forward epilogue
         const int j = lane & 31, h = lane >> 5;
         const int ntask = a.mb_last * PB;
         for (int task = wave; task < ntask; task += NW) {
             const int mb = task / PB, pb = task - mb * PB;
             const unsigned m = a.mask_last[(wg * ntask + task) * 64 + lane];
-            const float *row = a.dout + ((size_t)b * a.N + n0 + pb * 32 + j) * a.Cout + mb * 32 + 4 * h;
+            float4 dq[4];
+            if (a.nninv_off) {
+                // deterministic transpose of the finer module's interpolation: sum_w * (its gradient rows)
+                const int32_t *off = a.nninv_off + (size_t)b * (a.N + 1) + n0 + pb * 32 + j;
+                const int2 *ent = a.nninv_ent + (size_t)b * 3 * a.n_fine;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) dq[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int e = off[0]; e < off[1]; ++e) {
+                    const int2 pe = ent[e];
+                    const float w = __int_as_float(pe.y);
+                    const float *src = a.dint + ((size_t)b * a.n_fine + pe.x) * a.Cout + mb * 32 + 4 * h;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 d = *(const float4 *)(src + 8 * g);
+                        dq[g].x += w * d.x; dq[g].y += w * d.y; dq[g].z += w * d.z; dq[g].w += w * d.w;
+                    }
+                }
+            } else {
+                const float *row = a.dout + ((size_t)b * a.N + n0 + pb * 32 + j) * a.Cout + mb * 32 + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) dq[g] = *(const float4 *)(row + 8 * g);
+            }
             f32x16 v;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 d = *(const float4 *)(row + 8 * g);
+                const float4 d = dq[g];
                 v[4 * g] = ((m >> (4 * g)) & 1u) ? d.x : 0.0f;
                 v[4 * g + 1] = ((m >> (4 * g + 1)) & 1u) ? d.y : 0.0f;
                 v[4 * g + 2] = ((m >> (4 * g + 2)) & 1u) ? d.z : 0.0f;
@@ -350,6 +400,14 @@ __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
             const float v = in[L::off(c, j)];
             if (v != 0.0f) atomicAdd(a.dfeat1 + ((size_t)b * a.N + n0 + j) * a.C1 + c, v);
         }
+    }
+    if (a.dint_out) {
+        // interpolated-part gradient as plain rows; the coarser module gathers them through the inverse 3-NN lists
+        for (int t = tid; t < P * a.C2; t += NT) {
+            const int j = t / a.C2, c = t - j * a.C2;
+            a.dint_out[((size_t)b * a.N + n0 + j) * a.C2 + c] = in[L::off(a.C1 + c, j)];
+        }
+        return;
     }
     for (int t = tid; t < P * a.C2; t += NT) {
         const int j = t / a.C2, c = t - j * a.C2;
