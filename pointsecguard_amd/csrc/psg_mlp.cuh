@@ -262,7 +262,11 @@ __device__ __forceinline__ void layer_fwd(const FwdLayer &L, const float *__rest
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int ntask = L.mb * PB;
-    for (int task = wave; task < ntask; task += NW) {
+    // tiles are dealt to waves starting at a wave that rotates with the workgroup: a layer with fewer tiles than
+    // waves (the 13-class head: one tile) or a ragged count (10 tiles on 8 waves) would otherwise always load the
+    // same SIMDs of the CU, and the co-resident workgroups could not even it out
+    static_assert((NW & (NW - 1)) == 0, "NW must be a power of two");
+    for (int task = (wave + (int)(wg_linear & (NW - 1))) & (NW - 1); task < ntask; task += NW) {
         const int mb = task / PB, pb = task - mb * PB;
         // bias: 4 x float4 issued before the k-loop, consumed after it (latency hidden behind the MFMAs)
         const float4 *bp = (const float4 *)(L.bias + mb * 32 + 4 * h);
@@ -298,7 +302,11 @@ __device__ __forceinline__ void layer_bwd(const BwdLayer &L, const float *__rest
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int ntask = L.mb * PB;
-    for (int task = wave; task < ntask; task += NW) {
+    // tiles are dealt to waves starting at a wave that rotates with the workgroup: a layer with fewer tiles than
+    // waves (the 13-class head: one tile) or a ragged count (10 tiles on 8 waves) would otherwise always load the
+    // same SIMDs of the CU, and the co-resident workgroups could not even it out
+    static_assert((NW & (NW - 1)) == 0, "NW must be a power of two");
+    for (int task = (wave + (int)(wg_linear & (NW - 1))) & (NW - 1); task < ntask; task += NW) {
         const int mb = task / PB, pb = task - mb * PB;
         unsigned m = 0xFFFFu;
         if (L.mask) m = L.mask[(wg_linear * ntask + task) * 64 + lane];

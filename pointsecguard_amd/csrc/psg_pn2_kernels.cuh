@@ -14,6 +14,19 @@
 
 namespace psg {
 
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (dispatch id % 8), each with a private
+// 4 MiB L2; taking logical tile (id % 8) * T/8 + id / 8 gives every XCD a contiguous run of tiles, i.e. whole
+// rooms, so the rows a room's tiles gather (grouped / interpolated features) stay in ONE L2 instead of being
+// fetched into all eight (measured with FETCH_SIZE: fp1 forward 124 MB -> see DESIGN.md).
+__device__ __forceinline__ void xcd_tile(int &x, int &b)
+{
+    const unsigned gx = gridDim.x, T = gx * gridDim.y, id = blockIdx.y * gx + blockIdx.x;
+    unsigned L = id;
+    if ((T & 7u) == 0) L = (id & 7u) * (T >> 3) + (id >> 3);
+    b = (int)(L / gx);
+    x = (int)(L - (unsigned)b * gx);
+}
+
 struct SaFwdArgs {
     const float *xyz;      // [B][Np][xyz_stride], first 3 floats of a row = xyz
     const float *feat;     // [B][Np][D]
@@ -93,8 +106,10 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
     extern __shared__ float lds[];
     float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * L::BLK;   // rows0/rows1 are counted in 8-channel blocks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y, s0 = blockIdx.x * G;
-    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    int bx, b;
+    xcd_tile(bx, b);
+    const int s0 = bx * G;
+    const size_t wg = (size_t)b * gridDim.x + bx;
 
     {   // gather the P grouped points
         const int j = tid % P, part = tid / P;
@@ -171,8 +186,10 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     extern __shared__ float lds[];
     float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * L::BLK;
     const int tid = threadIdx.x;
-    const int b = blockIdx.y, s0 = blockIdx.x * G;
-    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    int bx, b;
+    xcd_tile(bx, b);
+    const int s0 = bx * G;
+    const size_t wg = (size_t)b * gridDim.x + bx;
 
     // gradient of the pooled output: read directly, or gathered (no atomics, fixed summation order) from the
     // interpolated-part rows of the feature-propagation module that upsampled this level
@@ -243,8 +260,10 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
     extern __shared__ float lds[];
     float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * L::BLK;
     const int tid = threadIdx.x;
-    const int b = blockIdx.y, n0 = blockIdx.x * P;
-    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    int bx, b;
+    xcd_tile(bx, b);
+    const int n0 = bx * P;
+    const size_t wg = (size_t)b * gridDim.x + bx;
     if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 15] = __builtin_amdgcn_s_memtime();
     if ((a.diag & 256) && tid == 0) {
         a.dbg[wg * 4 + 0] = __builtin_amdgcn_s_memtime();
@@ -289,25 +308,27 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
             a.out[((size_t)b * a.N + n0 + j) * a.Cout + c] = in[L::off(c, j)];
         }
     }
-    if (a.logp && tid < P && !(a.diag & 4)) {
-        const int j = tid;
-        float z[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v = *(const float4 *)(in + L::off(4 * q, j));
-            z[4 * q] = v.x; z[4 * q + 1] = v.y; z[4 * q + 2] = v.z; z[4 * q + 3] = v.w;
+    if (a.logp && !(a.diag & 4)) {
+        // log_softmax over the n_cls (<= 16) head rows: 8 lanes per point, classes q and q + 8 per lane
+        for (int t = tid; t < P * 8; t += NT) {
+            const int j = t >> 3, q = t & 7;
+            const bool has0 = q < a.n_cls;
+            const float z0 = has0 ? in[L::off(q, j)] : -INFINITY;
+            const bool has1 = q + 8 < a.n_cls;
+            const float z1 = has1 ? in[L::off(q + 8, j)] : -INFINITY;
+            float m = fmaxf(z0, z1);
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fmaxf(m, __shfl_xor(m, 2));
+            m = fmaxf(m, __shfl_xor(m, 4));
+            float s = (has0 ? expf(z0 - m) : 0.0f) + (has1 ? expf(z1 - m) : 0.0f);
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            const float lse = logf(s);
+            float *o = a.logp + ((size_t)b * a.N + n0 + j) * a.n_cls;
+            if (has0) o[q] = (z0 - m) - lse;
+            if (has1) o[q + 8] = (z1 - m) - lse;
         }
-        float m = -INFINITY;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) m = c < a.n_cls ? fmaxf(m, z[c]) : m;
-        float s = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) s += c < a.n_cls ? expf(z[c] - m) : 0.0f;
-        const float lse = logf(s);
-        float *o = a.logp + ((size_t)b * a.N + n0 + j) * a.n_cls;
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (c < a.n_cls) o[c] = (z[c] - m) - lse;
     }
     if ((a.diag & 256) && tid == 0) {
         a.dbg[wg * 4 + 2] = __builtin_amdgcn_s_memtime();
@@ -324,8 +345,10 @@ __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
     extern __shared__ float lds[];
     float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * L::BLK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y, n0 = blockIdx.x * P;
-    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    int bx, b;
+    xcd_tile(bx, b);
+    const int n0 = bx * P;
+    const size_t wg = (size_t)b * gridDim.x + bx;
 
     if (a.dout || a.nninv_off) {
         // dZ_last = dout * mask_last, loaded tile-wise so the mask bits line up with the forward epilogue
