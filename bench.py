@@ -188,6 +188,7 @@ def main():
         avg_ms = mlp[dom][0] / mlp[dom][1]
         achieved = flops[dom] / (avg_ms * 1e-3) / 1e12
         total_ms = sum(v[0] for v in prof.values())
+        traffic, traffic_src = pmc_traffic(dom, DB)
         result = {
             "metric": "attacked rooms/sec (4096 pts, 40 PGD iters)", "value": value, "unit": "rooms/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -199,8 +200,8 @@ def main():
                        "launches_in_flight_per_gpu": conc, "weights": "tests/golden/pn2_weights.npz (fitted fixture)",
                        "sharding": "rooms sharded by rank, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
-                         "avg_launch_us": avg_ms * 1e3, "launches": mlp[dom][1],
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
+                         "traffic_source": traffic_src, "avg_launch_us": avg_ms * 1e3, "launches": mlp[dom][1],
                          "flop_per_launch": flops[dom]},
             "kernel_ms_per_attack": {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
             "kernel_ms_total_per_attack": round(total_ms, 3),
@@ -215,6 +216,31 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+# HIP symbols of the modules whose kernel instantiation is unique (PMC rows are keyed by symbol, not by module)
+PMC_SYMBOL = {"fp1_head_fwd": "void psg::fp_fwd_kernel<32, 4>(psg::FpFwdArgs)",
+              "fp1_head_bwd": "void psg::fp_bwd_kernel<32, 4>(psg::FpBwdArgs)",
+              "sa1_fwd": "void psg::sa_fwd_kernel<128, 4>(psg::SaFwdArgs)",
+              "sa1_bwd": "void psg::sa_bwd_kernel<128, 4>(psg::SaBwdArgs)",
+              "sa2_fwd": "void psg::sa_fwd_kernel<64, 4>(psg::SaFwdArgs)",
+              "sa2_bwd": "void psg::sa_bwd_kernel<64, 4>(psg::SaBwdArgs)"}
+
+
+def pmc_traffic(tag, device_batch):
+    """HBM bytes per launch of kernel `tag` from the newest committed PMC summary (profiles/*_pmc_traffic.json,
+    written by tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes of this bench at a 32-room device
+    batch, gfx950 read-doubling correction applied).  PMC cannot be sampled from inside the process, so the
+    figure is the committed one, and only reported when the device batch matches."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    if not files or tag not in PMC_SYMBOL or device_batch != 32:
+        return None, None
+    with open(files[-1]) as fh:
+        row = json.load(fh).get(PMC_SYMBOL[tag])
+    if not row:
+        return None, None
+    return row["hbm_bytes_per_launch"], "profiles/" + os.path.basename(files[-1])
 
 
 def main_resgcn(args):
