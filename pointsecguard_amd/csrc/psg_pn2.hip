@@ -231,6 +231,8 @@ int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *x0, hipSt
     const PackedLayer *L = &m->L[3 * LVL];
     const size_t prob = (size_t)fwd * B;
     SaFwdArgs a;
+    static const int sa_diag = getenv("PSG_DIAG") ? atoi(getenv("PSG_DIAG")) : 0;
+    a.diag = sa_diag;
     a.xyz = LVL == 0 ? x0 : ws->xyz[LVL] + prob * Np * 3;
     a.xyz_stride = LVL == 0 ? 9 : 3;
     a.feat = LVL == 0 ? x0 : ws->act[LVL - 1];
@@ -256,6 +258,8 @@ int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *dx0, int c_lo, 
     const PackedLayer *L = &m->L[3 * LVL];
     const size_t prob = (size_t)fwd * B;
     SaBwdArgs a;
+    static const int sa_diag = getenv("PSG_DIAG") ? atoi(getenv("PSG_DIAG")) : 0;
+    a.diag = sa_diag;
     a.dout = ws->dact[LVL];
     a.nninv_off = nullptr; a.nninv_ent = nullptr; a.dint = nullptr; a.n_fine = 0;
     if (LVL == 3) {   // l4_points feed only fp4: its gradient is gathered from fp4's interpolated-part rows

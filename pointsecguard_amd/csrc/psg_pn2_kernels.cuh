@@ -40,6 +40,7 @@ struct SaFwdArgs {
     int k8_3, nb3;
     int xyz_stride, D, Np, S, C3;
     int rows0, rows1;      // LDS buffer sizes in 8-channel blocks
+    int diag;              // timing diagnostics only (PSG_DIAG env): skip sections, results are then wrong
 };
 
 struct SaBwdArgs {
@@ -56,6 +57,7 @@ struct SaBwdArgs {
     int D, Np, S, C3;
     int c_lo, c_hi;       // feature channels [c_lo, c_hi) of the grouped-input gradient are scattered
     int rows0, rows1;
+    int diag;             // timing diagnostics only (PSG_DIAG env)
 };
 
 struct FpFwdArgs {
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
     const int s0 = bx * G;
     const size_t wg = (size_t)b * gridDim.x + bx;
 
-    {   // gather the P grouped points
+    if (!(a.diag & 1)) {   // gather the P grouped points
         const int j = tid % P, part = tid / P;
         const int s = s0 + (j >> 5);
         const int src = a.gidx[((size_t)b * a.S + s) * 32 + (j & 31)];
@@ -143,10 +145,11 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
         }
     }
     __syncthreads();
-    layer_fwd<P, NW>(a.l1, buf0, buf1, wg);
-    __syncthreads();
-    layer_fwd<P, NW>(a.l2, buf1, buf0, wg);
-    __syncthreads();
+    if (!(a.diag & 8)) layer_fwd<P, NW>(a.l1, buf0, buf1, wg);
+    if (!(a.diag & 16)) __syncthreads();
+    if (!(a.diag & 8)) layer_fwd<P, NW>(a.l2, buf1, buf0, wg);
+    if (!(a.diag & 16)) __syncthreads();
+    if (a.diag & 32) return;
 
     // last layer with the tile flipped (D[point][channel]) so the max over the 32 samples of a
     // group is an in-lane max over 16 accumulators + one exchange between lane halves.
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     // max-pool backward: dZ3[c][g*32+k] = dout[g][c] if k == arg[g][c] else 0.
     // One (point, 8-channel block) per thread; arg/dout reads are broadcasts across the 32 samples.
     const int nblk = a.C3 >> 3;
-    for (int t = tid; t < P * nblk; t += NT) {
+    for (int t = tid; t < ((a.diag & 1) ? 0 : P * nblk); t += NT) {
         const int pnt = t % P, blk = t / P;
         const int g = pnt >> 5, k = pnt & 31;
         const size_t o = ((size_t)b * a.S + s0 + g) * a.C3 + blk * 8;
@@ -232,12 +235,13 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
         *(float4 *)(dst + 4) = v1;
     }
     __syncthreads();
-    layer_bwd<P, NW>(a.l3t, buf0, buf1, wg);
+    if (!(a.diag & 8)) layer_bwd<P, NW>(a.l3t, buf0, buf1, wg);
+    if (!(a.diag & 16)) __syncthreads();
+    if (!(a.diag & 8)) layer_bwd<P, NW>(a.l2t, buf1, buf0, wg);
+    if (!(a.diag & 16)) __syncthreads();
+    if (!(a.diag & 8)) layer_bwd<P, NW>(a.l1t, buf0, buf1, wg);
     __syncthreads();
-    layer_bwd<P, NW>(a.l2t, buf1, buf0, wg);
-    __syncthreads();
-    layer_bwd<P, NW>(a.l1t, buf0, buf1, wg);
-    __syncthreads();
+    if (a.diag & 32) return;
     // index_points backward: scatter-add the feature rows [c_lo, c_hi) of the grouped-input gradient
     // (LDS channel order is [feats, rel_xyz]: LDS channel c is feature channel c)
     const int nc = a.c_hi - a.c_lo;
@@ -256,7 +260,7 @@ template <int P, int NW>
 __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
 {
     using L = Lds<P>;
-    constexpr int NT = NW * 64, NPART = NT / P;
+    constexpr int NT = NW * 64;
     extern __shared__ float lds[];
     float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * L::BLK;
     const int tid = threadIdx.x;
@@ -270,25 +274,42 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
         a.dbg[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     }
     if (!(a.diag & 1)) {
-        const int j = tid % P, part = tid / P;
-        const size_t n = (size_t)b * a.N + n0 + j;
-        if (a.feat1) {
-            const float4 *f4 = (const float4 *)(a.feat1 + n * a.C1);
-            for (int q = part; q < (a.C1 >> 2); q += NPART) *(float4 *)(buf0 + L::off(4 * q, j)) = f4[q];
+        // 32 consecutive lanes read consecutive float4 of ONE source row (512 contiguous bytes per row group), so a
+        // wave-wide load touches 8 cache lines instead of 64; neighbour indices / weights are broadcast loads.
+        constexpr int RG = NT / 32, JI = P / RG;
+        static_assert(P % RG == 0, "row groups must tile the points");
+        const int ql = tid & 31, rg = tid >> 5;
+        int i0[JI], i1[JI], i2[JI];
+        float w0[JI], w1[JI], w2[JI];
+#pragma unroll
+        for (int u = 0; u < JI; ++u) {
+            const size_t n = (size_t)b * a.N + n0 + rg + u * RG;
+            i0[u] = a.nn_idx[n * 3]; i1[u] = a.nn_idx[n * 3 + 1]; i2[u] = a.nn_idx[n * 3 + 2];
+            w0[u] = a.nn_w[n * 3]; w1[u] = a.nn_w[n * 3 + 1]; w2[u] = a.nn_w[n * 3 + 2];
         }
-        const int i0 = a.nn_idx[n * 3], i1 = a.nn_idx[n * 3 + 1], i2 = a.nn_idx[n * 3 + 2];
-        const float w0 = a.nn_w[n * 3], w1 = a.nn_w[n * 3 + 1], w2 = a.nn_w[n * 3 + 2];
-        const float4 *g0 = (const float4 *)(a.feat2 + ((size_t)b * a.S + i0) * a.C2);
-        const float4 *g1 = (const float4 *)(a.feat2 + ((size_t)b * a.S + i1) * a.C2);
-        const float4 *g2 = (const float4 *)(a.feat2 + ((size_t)b * a.S + i2) * a.C2);
-        for (int q = part; q < (a.C2 >> 2); q += NPART) {
-            const float4 u0 = g0[q], u1 = g1[q], u2 = g2[q];
-            float4 r;
-            r.x = u0.x * w0 + u1.x * w1 + u2.x * w2;
-            r.y = u0.y * w0 + u1.y * w1 + u2.y * w2;
-            r.z = u0.z * w0 + u1.z * w1 + u2.z * w2;
-            r.w = u0.w * w0 + u1.w * w1 + u2.w * w2;
-            *(float4 *)(buf0 + L::off(a.C1 + 4 * q, j)) = r;
+        if (a.feat1) {
+#pragma unroll
+            for (int u = 0; u < JI; ++u) {
+                const int j = rg + u * RG;
+                const float4 *f4 = (const float4 *)(a.feat1 + ((size_t)b * a.N + n0 + j) * a.C1);
+                for (int q = ql; q < (a.C1 >> 2); q += 32) *(float4 *)(buf0 + L::off(4 * q, j)) = f4[q];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < JI; ++u) {
+            const int j = rg + u * RG;
+            const float4 *g0 = (const float4 *)(a.feat2 + ((size_t)b * a.S + i0[u]) * a.C2);
+            const float4 *g1 = (const float4 *)(a.feat2 + ((size_t)b * a.S + i1[u]) * a.C2);
+            const float4 *g2 = (const float4 *)(a.feat2 + ((size_t)b * a.S + i2[u]) * a.C2);
+            for (int q = ql; q < (a.C2 >> 2); q += 32) {
+                const float4 u0 = g0[q], u1 = g1[q], u2 = g2[q];
+                float4 r;
+                r.x = u0.x * w0[u] + u1.x * w1[u] + u2.x * w2[u];
+                r.y = u0.y * w0[u] + u1.y * w1[u] + u2.y * w2[u];
+                r.z = u0.z * w0[u] + u1.z * w1[u] + u2.z * w2[u];
+                r.w = u0.w * w0[u] + u1.w * w1[u] + u2.w * w2[u];
+                *(float4 *)(buf0 + L::off(a.C1 + 4 * q, j)) = r;
+            }
         }
     }
     __syncthreads();
