@@ -105,34 +105,45 @@ def main():
 
     sd = dict(np.load(os.path.join(ROOT, "tests", "golden", "pn2_weights.npz")))
     model = runtime.PN2Model(runtime.fold_state_dict(sd))
-    import math
-    G = max(1, math.gcd(args.coalesce, args.steps)) if args.coalesce > 1 else 1   # steps per device batch
-    DB = BATCH * G                                                                # rooms per launch
-    n_groups = args.steps // G
-    n_warm = max(1, -(-args.warmup // G)) if args.warmup > 0 else 0
+    # K steps of BATCH rooms are coalesced G at a time into device batches (launches); when G does not divide K the
+    # last device batch is simply smaller.  Warm-up runs whole device batches (>= W steps, untimed).
+    G = max(1, min(args.coalesce, args.steps))                                    # steps per device batch
+    DB = BATCH * G                                                                # rooms per full launch
+    sizes = [G] * (args.steps // G) + ([args.steps % G] if args.steps % G else [])
+    n_warm = -(-args.warmup // G) if args.warmup > 0 else 0
+    sizes = [G] * n_warm + sizes                                                  # steps in device batch i
+    n_all, n_groups = len(sizes), len(sizes) - n_warm
     conc = max(1, min(args.concurrency, n_groups))
-    wss = [runtime.PN2Workspace(DB, NPOINT, ITERS) for _ in range(conc)]
     streams = [torch.cuda.Stream() for _ in range(conc)]
-    ws = wss[0]
+    ws_cache = {}
 
-    n_all = n_groups + n_warm
-    # each rank attacks its own shard of rooms (weak scaling: BATCH rooms per GPU per step); group j holds the
-    # rooms of steps j*G .. j*G+G-1
-    rooms = [make_rooms(DB, 1000 + rank * 100003 + s) for s in range(n_all)]
+    def workspace(slot, rooms_in_batch):
+        key = (slot, rooms_in_batch)
+        if key not in ws_cache:
+            ws_cache[key] = runtime.PN2Workspace(rooms_in_batch, NPOINT, ITERS)
+        return ws_cache[key]
+
+    ws = workspace(0, DB)
+
+    # each rank attacks its own shard of rooms (weak scaling: BATCH rooms per GPU per step)
+    rooms = [make_rooms(BATCH * sizes[s], 1000 + rank * 100003 + s) for s in range(n_all)]
     labels = [rule_labels(r) for r in rooms]
     rng = np.random.default_rng(1234 + rank)
-    starts = [np.stack([rng.integers(0, n, (ITERS, DB)) for n in (NPOINT, 1024, 256, 64)], axis=1).astype(np.int32)
-              for _ in range(n_all)]
+    starts = [np.stack([rng.integers(0, n, (ITERS, BATCH * sizes[s])) for n in (NPOINT, 1024, 256, 64)],
+                       axis=1).astype(np.int32) for s in range(n_all)]
     d_images = [torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 1))).cuda() for r in rooms]
     d_labels = [torch.from_numpy(l.astype(np.int32)).cuda() for l in labels]
     d_starts = [torch.from_numpy(s).cuda() for s in starts]
     d_adv = [torch.empty_like(x) for x in d_images]
+    for i in range(n_all):
+        workspace(i % conc, BATCH * sizes[i])                                     # allocate outside the timed region
 
     def step(i):
-        # device batch i (= G steps) runs on stream i % conc with its own workspace: batches are independent, so
-        # kernels of one overlap with kernels of the others (no cross-step dependency, no collective)
+        # device batch i runs on stream i % conc with its own workspace: batches are independent, so kernels of
+        # one overlap with kernels of the others (no cross-step dependency, no collective)
         with torch.cuda.stream(streams[i % conc]):
-            wss[i % conc].nb_attack(model, d_images[i], d_labels[i], d_starts[i], EPS, ALPHA, ITERS, out=d_adv[i])
+            workspace(i % conc, BATCH * sizes[i]).nb_attack(model, d_images[i], d_labels[i], d_starts[i], EPS, ALPHA,
+                                                            ITERS, out=d_adv[i])
 
     for i in range(n_warm):
         step(i)
@@ -159,6 +170,8 @@ def main():
     adv = torch.zeros(3, 13, dtype=torch.int64, device="cuda")
     ev = runtime.PN2Workspace(DB, NPOINT, 1)
     for i in range(n_warm, min(n_all, n_warm + 2)):
+        if sizes[i] != G:
+            continue
         ev_starts = d_starts[i][:1].contiguous()
         for src, ctr in ((d_images[i], clean), (d_adv[i], adv)):
             x0 = src.transpose(1, 2).contiguous()
@@ -197,6 +210,7 @@ def main():
             "config": {"workload": "NB non-targeted PGD (eps=0.05, alpha=2/255, 40 iters) on PointNet++ SSG sem_seg, "
                                    "batch=8 rooms x 4096 pts x 9 ch per GPU (BASELINE configs[1])",
                        "rooms_per_step_per_gpu": BATCH, "steps_coalesced_per_launch": G, "device_batch_rooms": DB,
+                       "launch_sizes_in_steps": sizes[n_warm:],
                        "launches_in_flight_per_gpu": conc, "weights": "tests/golden/pn2_weights.npz (fitted fixture)",
                        "sharding": "rooms sharded by rank, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,

@@ -15,6 +15,7 @@
 
 #include "psg_common.h"
 #include "psg_pn2_kernels.cuh"
+#include "psg_chain.cuh"
 
 using namespace psg;
 
@@ -38,6 +39,8 @@ struct PackedLayer {
     float4 *wf = nullptr;  // forward packing  [mb(cout)][k8(cin)][64]
     float4 *wb = nullptr;  // transposed packing [mb(cin)][k8(cout)][64]
     float *bias = nullptr; // [mb(cout)*32]
+    float4 *wf4 = nullptr; // forward packing, k8-major [k8][mb = 4][64] (wave-private chain kernels, psg_chain.cuh)
+    float4 *wb4 = nullptr; // transposed packing, k8-major
     int cin = 0, cout = 0;
     // K is padded to a multiple of 32 (k8 multiple of 4: the MFMA loop is unrolled by 4 chunks)
     int k8f() const { return round_up(ceil_div(cin, 8), 4); }
@@ -131,6 +134,17 @@ std::vector<float> pack_bwd(const float *w, int cin, int cout, const std::vector
                     if (o < cout && c < cin)
                         out[(((size_t)m * k8 + k) * 64 + lane) * 4 + t] = w[(size_t)o * cin + (perm ? (*perm)[c] : c)];
                 }
+    return out;
+}
+
+// [mb][k8][64] float4 -> [k8][mb][64] float4 (one k8-step of all four 32-row blocks contiguous)
+std::vector<float> k8_major(const std::vector<float> &packed, int mb, int k8)
+{
+    std::vector<float> out((size_t)mb * k8 * 256, 0.0f);
+    for (int m = 0; m < mb; ++m)
+        for (int k = 0; k < k8; ++k)
+            std::copy(packed.begin() + ((size_t)m * k8 + k) * 256, packed.begin() + ((size_t)m * k8 + k + 1) * 256,
+                      out.begin() + ((size_t)k * mb + m) * 256);
     return out;
 }
 
@@ -293,12 +307,40 @@ const int kFpCount[4] = {3, 2, 2, 2};
 inline int fp_out_slot(int lvl) { return 7 - lvl; }          // lvl 3 -> 4, 2 -> 5, 1 -> 6
 inline int fp_in2_slot(int lvl) { return lvl == 3 ? 3 : fp_out_slot(lvl + 1); }
 
+// PSG_FP1_WAVE=1 selects the wave-private fp1 + head kernels (psg_chain.cuh) instead of the workgroup-cooperative
+// ones.  Measured on MI355X at a 32-room device batch: forward 193 vs 193 us, backward 211 vs 189 us, so the
+// cooperative kernels stay the default (DESIGN.md section 4 has the analysis).
+inline bool fp1_wave()
+{
+    static const bool v = getenv("PSG_FP1_WAVE") && atoi(getenv("PSG_FP1_WAVE")) != 0;
+    return v;
+}
+
 template <int LVL>
 int run_fp_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *logp, hipStream_t st)
 {
     constexpr int P = FpCfg<LVL>::P, NW = FpCfg<LVL>::NW;
     const int B = ws->B, N = ws->Nl[LVL], S = ws->Nl[LVL + 1];
     const size_t prob = (size_t)fwd * B;
+    if (LVL == 0 && fp1_wave()) {
+        // fp1 + classifier head as a wave-private chain (psg_chain.cuh): one wave per 32 points, no barriers
+        Fp1FwdArgs w;
+        w.feat2 = ws->act[fp_in2_slot(0)];
+        w.nn_idx = ws->nn_idx[0] + prob * N * 3;
+        w.nn_w = ws->nn_w[0] + prob * N * 3;
+        w.logp = logp;
+        for (int i = 0; i < 4; ++i) {
+            const PackedLayer &L = m->L[18 + i];
+            w.mask[i] = (unsigned long long *)ws->mask[18 + i];
+            w.layer[i].w4 = L.wf4; w.layer[i].bias = L.bias; w.layer[i].k8 = L.k8f();
+        }
+        w.head = fwd_layer(m->L[22], false, nullptr);
+        w.N = N; w.S = S; w.n_cls = NCLS;
+        ProfScope prof(ws, TAG_FP_FWD + 0, st);
+        hipLaunchKernelGGL(fp1_fwd_wave_kernel, dim3(N / 32, B), dim3(64), (size_t)16 * WBLK * sizeof(float), st, w);
+        PSG_LAUNCH_CHECK();
+        return PSG_OK;
+    }
     FpFwdArgs a;
     a.feat1 = LVL == 0 ? nullptr : ws->act[LVL - 1];
     a.C1 = LVL == 0 ? 0 : kSaC[LVL];
@@ -345,6 +387,21 @@ int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, con
     constexpr int P = FpCfg<LVL>::P, NW = FpCfg<LVL>::NW;
     const int B = ws->B, N = ws->Nl[LVL], S = ws->Nl[LVL + 1];
     const size_t prob = (size_t)fwd * B;
+    if (LVL == 0 && fp1_wave()) {
+        Fp1BwdArgs w;
+        w.logp = logp; w.dlogp = dlogp;
+        for (int i = 0; i < 4; ++i) w.mask[i] = (const unsigned long long *)ws->mask[18 + i];
+        for (int i = 0; i < 5; ++i) {   // conv2^T, conv1^T, mlp2^T, mlp1^T, mlp0^T
+            const PackedLayer &L = m->L[22 - i];
+            w.layer[i].w4 = L.wb4; w.layer[i].bias = nullptr; w.layer[i].k8 = L.k8b();
+        }
+        w.dint_out = ws->dint[0];
+        w.N = N; w.n_cls = NCLS;
+        ProfScope prof(ws, TAG_FP_BWD + 0, st);
+        hipLaunchKernelGGL(fp1_bwd_wave_kernel, dim3(N / 32, B), dim3(64), (size_t)16 * WBLK * sizeof(float), st, w);
+        PSG_LAUNCH_CHECK();
+        return PSG_OK;
+    }
     FpBwdArgs a;
     a.nn_idx = ws->nn_idx[LVL] + prob * N * 3;
     a.nn_w = ws->nn_w[LVL] + prob * N * 3;
@@ -508,7 +565,7 @@ extern "C" int psg_pn2_model_create(psg_ctx *ctx, const float *const *weights, c
     PSG_CHECK_HIP(hipSetDevice(ctx->device));
     auto *m = new psg_pn2_model();
     m->ctx = ctx;
-    std::vector<std::vector<float>> wf(kNumReal), wb(kNumReal), bs(kNumReal);
+    std::vector<std::vector<float>> wf(kNumReal), wb(kNumReal), bs(kNumReal), wf4(kNumReal), wb4(kNumReal);
     size_t total = 0;
     for (int i = 0; i < kNumReal; ++i) {
         if (!weights[i] || !biases[i]) { delete m; set_error("psg_pn2_model_create: layer %d is null", i); return PSG_ERR_ARG; }
@@ -519,7 +576,11 @@ extern "C" int psg_pn2_model_create(psg_ctx *ctx, const float *const *weights, c
         wb[i] = pack_bwd(weights[i], kCin[i], kCout[i], sa_first ? &perm : nullptr);
         bs[i].assign((size_t)ceil_div(kCout[i], 32) * 32, 0.0f);
         std::copy(biases[i], biases[i] + kCout[i], bs[i].begin());
-        total += ((wf[i].size() + wb[i].size() + bs[i].size()) * 4 + 3 * 256);
+        if (i >= 18) {   // fp1 + head run as wave-private chains: k8-major packings of the 128-wide sides
+            if (kCout[i] == 128) wf4[i] = k8_major(wf[i], 4, round_up(ceil_div(kCin[i], 8), 4));
+            wb4[i] = k8_major(wb[i], 4, round_up(ceil_div(kCout[i], 8), 4));
+        }
+        total += ((wf[i].size() + wb[i].size() + bs[i].size() + wf4[i].size() + wb4[i].size()) * 4 + 5 * 256);
     }
     PSG_CHECK_HIP(hipMalloc(&m->arena, total));
     Bump bp;
@@ -533,6 +594,14 @@ extern "C" int psg_pn2_model_create(psg_ctx *ctx, const float *const *weights, c
         PSG_CHECK_HIP(hipMemcpy(L.wf, wf[i].data(), wf[i].size() * 4, hipMemcpyHostToDevice));
         PSG_CHECK_HIP(hipMemcpy(L.wb, wb[i].data(), wb[i].size() * 4, hipMemcpyHostToDevice));
         PSG_CHECK_HIP(hipMemcpy(L.bias, bs[i].data(), bs[i].size() * 4, hipMemcpyHostToDevice));
+        if (!wf4[i].empty()) {
+            L.wf4 = bp.take<float4>(wf4[i].size() / 4);
+            PSG_CHECK_HIP(hipMemcpy(L.wf4, wf4[i].data(), wf4[i].size() * 4, hipMemcpyHostToDevice));
+        }
+        if (!wb4[i].empty()) {
+            L.wb4 = bp.take<float4>(wb4[i].size() / 4);
+            PSG_CHECK_HIP(hipMemcpy(L.wb4, wb4[i].data(), wb4[i].size() * 4, hipMemcpyHostToDevice));
+        }
     }
     *out = m;
     return PSG_OK;

@@ -14,19 +14,6 @@
 
 namespace psg {
 
-// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (dispatch id % 8), each with a private
-// 4 MiB L2; taking logical tile (id % 8) * T/8 + id / 8 gives every XCD a contiguous run of tiles, i.e. whole
-// rooms, so the rows a room's tiles gather (grouped / interpolated features) stay in ONE L2 instead of being
-// fetched into all eight (measured with FETCH_SIZE: fp1 forward 124 MB -> see DESIGN.md).
-__device__ __forceinline__ void xcd_tile(int &x, int &b)
-{
-    const unsigned gx = gridDim.x, T = gx * gridDim.y, id = blockIdx.y * gx + blockIdx.x;
-    unsigned L = id;
-    if ((T & 7u) == 0) L = (id & 7u) * (T >> 3) + (id >> 3);
-    b = (int)(L / gx);
-    x = (int)(L - (unsigned)b * gx);
-}
-
 struct SaFwdArgs {
     const float *xyz;      // [B][Np][xyz_stride], first 3 floats of a row = xyz
     const float *feat;     // [B][Np][D]

@@ -1,5 +1,6 @@
 """In-kernel shader clock under load: PSG_DIAG=256 makes the fp1+head forward kernel stamp
-{s_memtime, s_memrealtime} per workgroup; clock = d(memtime)/d(memrealtime) x 100 MHz."""
+{s_memtime, s_memrealtime} per workgroup; clock = d(memtime)/d(memrealtime) x 100 MHz.
+usage: clock_probe.py [device batch rooms]  (runs whole 40-iteration attacks so the clock is the sustained one)"""
 import ctypes, os, sys
 import numpy as np
 os.environ["PSG_DIAG"] = "256"
@@ -10,15 +11,18 @@ from pointsecguard_amd.synthetic import make_rooms
 
 sd = dict(np.load("tests/golden/pn2_weights.npz"))
 model = runtime.PN2Model(runtime.fold_state_dict(sd))
-B = 8
-ws = runtime.PN2Workspace(B, 4096, 1)
-x0 = torch.from_numpy(make_rooms(B, 1)).cuda()
-starts = torch.zeros(1, 4, B, dtype=torch.int32, device="cuda")
-ws.plan_build(x0, starts, 1)
-for _ in range(200):
-    ws.forward(model, 0, x0)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+ITERS = 40
+ws = runtime.PN2Workspace(B, 4096, ITERS)
+rooms = make_rooms(B, 1)
+images = torch.from_numpy(np.ascontiguousarray(rooms.transpose(0, 2, 1))).cuda()
+labels = torch.zeros(B, 4096, dtype=torch.int32, device="cuda")
+starts = torch.zeros(ITERS, 4, B, dtype=torch.int32, device="cuda")
+adv = torch.empty_like(images)
+for _ in range(6):          # sustained load: six full 40-iteration attacks back to back, stamps of the last launch
+    ws.nb_attack(model, images, labels, starts, 0.05, 2 / 255, ITERS, out=adv)
 torch.cuda.synchronize()
-n = 1024 * 4
+n = 128 * B * 4
 buf = (ctypes.c_ulonglong * n)()
 _lib.call("psg_pn2_debug_read", ws.handle, buf, n)
 a = np.array(buf[:], dtype=np.uint64).reshape(-1, 4).astype(np.float64)
