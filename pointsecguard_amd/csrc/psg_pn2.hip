@@ -33,6 +33,7 @@ const int kS[4] = {1024, 256, 64, 16};
 // float32(radius**2) with radius**2 evaluated in double, as Python does (pointnet_util.py:102)
 const float kRadius2[4] = {(float)(0.1 * 0.1), (float)(0.2 * 0.2), (float)(0.4 * 0.4), (float)(0.8 * 0.8)};
 const int kSaC[5] = {9, 64, 128, 256, 512};  // feature channels of level 0..4
+const int kGsaC[4] = {12, 64, 128, 256};     // row stride of the grouped-input gradient rows of sa_bwd level 0..3
 constexpr int K = 32;                        // nsample
 
 struct PackedLayer {
@@ -74,6 +75,9 @@ struct psg_pn2_ws {
     int32_t *inv_off[4];  // inverse 3-NN lists (CSR by coarse point): [F*B][S_l + 1]
     int2 *inv_ent[4];     // [F*B][3*N_l] {fine point, weight bits}, ascending fine point inside a list
     float *dint[4];       // [B][N_l][C2_l] interpolated-part gradient rows of fp_bwd level l
+    int32_t *ginv_off[4]; // inverse group lists (CSR by source point, lists sorted by grouped row): [F*B][N_l + 1]
+    int32_t *ginv_pos[4]; // [F*B][S_l*32] inverse permutation: slot of a grouped row in the concatenated lists
+    float *gsa[4];        // [B][S_l*32][CG_l] grouped-input gradient rows of sa_bwd level l (CG = 12, 64, 128, 256)
     int planned = 0;
     // activations of one forward
     float *act[7];        // l1..l4, fp4 out (64 pts), fp3 out (256), fp2 out (1024)
@@ -249,7 +253,7 @@ int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *x0, hipSt
     a.diag = sa_diag;
     a.xyz = LVL == 0 ? x0 : ws->xyz[LVL] + prob * Np * 3;
     a.xyz_stride = LVL == 0 ? 9 : 3;
-    a.feat = LVL == 0 ? x0 : ws->act[LVL - 1];
+    a.feat = LVL == 0 ? x0 : ws->act[LVL > 0 ? LVL - 1 : 0];
     a.new_xyz = ws->xyz[LVL + 1] + prob * S * 3;
     a.gidx = ws->gidx[LVL] + prob * S * K;
     a.out = ws->act[LVL];
@@ -274,8 +278,17 @@ int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *dx0, int c_lo, 
     SaBwdArgs a;
     static const int sa_diag = getenv("PSG_DIAG") ? atoi(getenv("PSG_DIAG")) : 0;
     a.diag = sa_diag;
-    a.dout = ws->dact[LVL];
+    a.dout = ws->dact[LVL];   // skip-link gradient rows written by fp_bwd level LVL + 1
     a.nninv_off = nullptr; a.nninv_ent = nullptr; a.dint = nullptr; a.n_fine = 0;
+    a.ginv_off = nullptr; a.gsa = nullptr; a.g_rows = 0;
+    if (LVL < 3) {   // plus the transposed grouping of SA level LVL + 1, gathered through its inverse lists
+        a.g_rows = kS[LVL + 1] * K;
+        a.ginv_off = ws->ginv_off[LVL + 1] + prob * (S + 1);
+        a.gsa = ws->gsa[LVL + 1];
+    }
+    a.gsa_out = ws->gsa[LVL];
+    a.gpos_out = ws->ginv_pos[LVL] + prob * S * K;
+    a.cg_out = (LVL == 0 && c_hi - c_lo == 3) ? 4 : kGsaC[LVL];   // colour-only: compact float4 rows
     if (LVL == 3) {   // l4_points feed only fp4: its gradient is gathered from fp4's interpolated-part rows
         a.dout = nullptr;
         a.nninv_off = ws->inv_off[3] + prob * (kS[3] + 1);
@@ -285,7 +298,6 @@ int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *dx0, int c_lo, 
     }
     a.arg = ws->arg[LVL];
     a.gidx = ws->gidx[LVL] + prob * S * K;
-    a.dfeat = LVL == 0 ? dx0 : ws->dact[LVL - 1];
     a.l3t = bwd_layer(L[2], ws->mask[3 * LVL + 1]);
     a.l2t = bwd_layer(L[1], ws->mask[3 * LVL]);
     a.l1t = bwd_layer(L[0], nullptr);
@@ -342,7 +354,7 @@ int run_fp_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *logp, hipStream
         return PSG_OK;
     }
     FpFwdArgs a;
-    a.feat1 = LVL == 0 ? nullptr : ws->act[LVL - 1];
+    a.feat1 = LVL == 0 ? nullptr : ws->act[LVL > 0 ? LVL - 1 : 0];
     a.C1 = LVL == 0 ? 0 : kSaC[LVL];
     a.feat2 = ws->act[fp_in2_slot(LVL)];
     a.C2 = m->L[kFpFirst[LVL]].cin - a.C1;
@@ -408,8 +420,7 @@ int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, con
     a.N = N; a.S = S;
     a.C1 = LVL == 0 ? 0 : kSaC[LVL];
     a.C2 = m->L[kFpFirst[LVL]].cin - a.C1;
-    a.dfeat1 = LVL == 0 ? nullptr : ws->dact[LVL - 1];
-    a.dfeat2 = nullptr;
+    a.dfeat1 = LVL == 0 ? nullptr : ws->dact[LVL > 0 ? LVL - 1 : 0];
     a.dint_out = ws->dint[LVL];
     a.nninv_off = nullptr; a.nninv_ent = nullptr; a.dint = nullptr; a.n_fine = 0;
     const int first = kFpFirst[LVL], cnt = kFpCount[LVL];
@@ -422,10 +433,11 @@ int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, con
         a.layer[nl++] = bwd_layer(m->L[21], ws->mask[first + cnt - 1]); // conv1^T, then fp1 last ReLU mask
     } else {
         // gradient of this module's output = transpose of the finer module's interpolation, gathered
-        a.nninv_off = ws->inv_off[LVL - 1] + prob * (N + 1);
-        a.nninv_ent = ws->inv_ent[LVL - 1] + prob * ws->Nl[LVL - 1] * 3;
-        a.dint = ws->dint[LVL - 1];
-        a.n_fine = ws->Nl[LVL - 1];
+        constexpr int LF = LVL > 0 ? LVL - 1 : 0;   // the finer FP level
+        a.nninv_off = ws->inv_off[LF] + prob * (N + 1);
+        a.nninv_ent = ws->inv_ent[LF] + prob * ws->Nl[LF] * 3;
+        a.dint = ws->dint[LF];
+        a.n_fine = ws->Nl[LF];
         a.mask_last = ws->mask[first + cnt - 1];
         a.Cout = m->L[first + cnt - 1].cout;
         a.mb_last = m->L[first + cnt - 1].mbf();
@@ -505,6 +517,108 @@ __global__ __launch_bounds__(256) void build_inv_nn_kernel(const int32_t *__rest
     }
 }
 
+// Inverse of the group tables: for every source point the grouped rows (group*32 + sample) that gathered it, as
+// offsets of a CSR whose lists are sorted by grouped row, plus the inverse permutation `pos` (slot of a grouped row
+// in the concatenated lists): sa_bwd stores row r at slot pos[r], so a consumer reads the rows of one point
+// contiguously and in a fixed order.  (query_ball_point pads a group by repeating its first member, so a point
+// can occur several times in one group: every occurrence is listed, as autograd's index backward sums every
+// occurrence.)  One workgroup per problem, the whole list array staged in LDS (<= 32768 16-bit row ids + 8193 counters).
+constexpr int INV_NT = 1024;
+__global__ __launch_bounds__(INV_NT) void build_inv_group_kernel(const int32_t *__restrict__ gidx, int n_rows, int n_src,
+                                                                 int32_t *__restrict__ inv_off, int32_t *__restrict__ inv_pos)
+{
+    extern __shared__ int s_inv[];
+    int *s_cnt = s_inv;               // [n_src + 1]
+    unsigned short *s_ent = (unsigned short *)(s_inv + n_src + 1);   // [n_rows] row ids (< 32768: 16 bits)
+    const size_t p = blockIdx.x;
+    const int32_t *idx = gidx + p * n_rows;
+    int32_t *off = inv_off + p * (n_src + 1);
+    int32_t *pos = inv_pos + p * n_rows;
+    for (int i = threadIdx.x; i <= n_src; i += INV_NT) s_cnt[i] = 0;
+    __syncthreads();
+    // Padding rows (sample k > 0 repeating the group's first member) are left out: they duplicate sample 0, the
+    // max-pool's lowest-index tie rule never routes gradient to them, so their rows are exactly zero.  pos = -1
+    // tells sa_bwd not to store them.  That also bounds a list by the number of GROUPS containing the point.
+    for (int e = threadIdx.x; e < n_rows; e += INV_NT) {
+        const bool pad = (e & 31) != 0 && idx[e] == idx[e & ~31];
+        if (!pad) atomicAdd(&s_cnt[idx[e]], 1);
+        else pos[e] = -1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {   // exclusive scan by one wave: 64 contiguous chunks, then a scan of the chunk sums
+        const int lane = threadIdx.x, chunk = (n_src + 63) / 64, lo = min(n_src, lane * chunk), hi = min(n_src, lo + chunk);
+        int sum = 0;
+        for (int i = lo; i < hi; ++i) sum += s_cnt[i];
+        int incl = sum;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        int run = incl - sum;
+        for (int i = lo; i < hi; ++i) { const int c = s_cnt[i]; s_cnt[i] = run; off[i] = run; run += c; }
+        if (lane == 63) { off[n_src] = incl; s_cnt[n_src] = incl; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_rows; e += INV_NT) {
+        const bool pad = (e & 31) != 0 && idx[e] == idx[e & ~31];
+        if (!pad) s_ent[atomicAdd(&s_cnt[idx[e]], 1)] = (unsigned short)e;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_src; i += INV_NT) {   // s_cnt[i] is now the END of list i
+        const int lo = i ? s_cnt[i - 1] : 0, hi = s_cnt[i];
+        for (int a = lo + 1; a < hi; ++a) {   // insertion sort by row id (the fill order above is not deterministic)
+            const unsigned short key = s_ent[a];
+            int q = a - 1;
+            while (q >= lo && s_ent[q] > key) { s_ent[q + 1] = s_ent[q]; --q; }
+            s_ent[q + 1] = key;
+        }
+    }
+    __syncthreads();
+    const int n_listed = s_cnt[n_src - 1];   // end of the last list
+    for (int a = threadIdx.x; a < n_listed; a += INV_NT) pos[s_ent[a]] = a;
+}
+
+// dx0[q][c] = sum over the grouped rows of sa1 that gathered point q (c in [c_lo, c_hi)); sa1_bwd stored its rows in
+// list order, so the rows of point q are the contiguous slots [off[q], off[q+1]), summed in ascending order.
+// COMPACT: rows are {c_lo, c_lo+1, c_lo+2, 0} float4 (attack loop), one thread per point; else rows of `cg` floats
+// indexed by channel, one thread per (point, channel).
+template <bool COMPACT>
+__global__ void dx0_gather_kernel(const int32_t *__restrict__ inv_off, const float *__restrict__ gsa, int B, int N,
+                                  int g_rows, int cg, int c_lo, int c_hi, float *__restrict__ dx0)
+{
+    const int nc = COMPACT ? 1 : c_hi - c_lo;
+    const size_t total = (size_t)B * N * nc;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int c = c_lo + (int)(t % nc);
+        const size_t pq = t / nc;
+        const int b = (int)(pq / N), q = (int)(pq - (size_t)b * N);
+        const int32_t *off = inv_off + (size_t)b * (N + 1) + q;
+        const int e1 = off[1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = off[0]; e < e1; e += 8) {
+            if (COMPACT) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = e + u < e1 ? *(const float4 *)(gsa + ((size_t)b * g_rows + e + u) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; }
+            } else {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = e + u < e1 ? gsa[((size_t)b * g_rows + e + u) * cg + c] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc.x += v[u];
+            }
+        }
+        if (COMPACT) {
+            dx0[pq * 9 + c_lo] = acc.x; dx0[pq * 9 + c_lo + 1] = acc.y; dx0[pq * 9 + c_lo + 2] = acc.z;
+        } else {
+            dx0[pq * 9 + c] = acc.x;
+        }
+    }
+}
+
 size_t ws_layout(psg_pn2_ws *ws, char *base)
 {
     Bump bp;
@@ -521,7 +635,10 @@ size_t ws_layout(psg_pn2_ws *ws, char *base)
         ws->nn_w[l] = bp.take<float>(PR * ws->Nl[l] * 3);
         ws->inv_off[l] = bp.take<int32_t>(PR * (kS[l] + 1));
         ws->inv_ent[l] = bp.take<int2>(PR * ws->Nl[l] * 3);
+        ws->ginv_off[l] = bp.take<int32_t>(PR * (ws->Nl[l] + 1));
+        ws->ginv_pos[l] = bp.take<int32_t>(PR * kS[l] * K);
     }
+    for (int l = 0; l < 4; ++l) ws->gsa[l] = bp.take<float>((size_t)B * kS[l] * K * kGsaC[l]);
     {
         const int c2[4] = {128, 256, 256, 512};
         for (int l = 0; l < 4; ++l) ws->dint[l] = bp.take<float>((size_t)B * ws->Nl[l] * c2[l]);
@@ -714,6 +831,11 @@ extern "C" int psg_pn2_plan_build(psg_pn2_ws *ws, const float *x0, const int32_t
             if ((rc = psg_ball_query(ws->ctx, ws->xyz[l], n_clouds, ws->xyz[l + 1], P, Np, S, kRadius2[l], K,
                                      ws->gidx[l], st)))
                 return rc;
+            const size_t inv_lds = (size_t)(Np + 1) * 4 + (size_t)S * K * 2;
+            if (inv_lds > 48 * 1024) PSG_CHECK_HIP(allow_big_lds((const void *)build_inv_group_kernel));
+            hipLaunchKernelGGL(build_inv_group_kernel, dim3(P), dim3(INV_NT), inv_lds, st, ws->gidx[l], S * K, Np,
+                               ws->ginv_off[l], ws->ginv_pos[l]);
+            PSG_LAUNCH_CHECK();
         }
         {
             ProfScope prof(ws, TAG_NN, st);
@@ -777,12 +899,7 @@ static int backward_impl(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float 
                          float *dx0, int c_lo, int c_hi, hipStream_t st)
 {
     int rc;
-    // all gradient buffers are accumulated with atomics: zero them (dx0 too when it is workspace-owned)
-    {
-        ProfScope prof(ws, TAG_ZERO, st);
-        PSG_CHECK_HIP(hipMemsetAsync(ws->gzero, 0, ws->gzero_bytes, st));
-        if (dx0 != ws->dx0) PSG_CHECK_HIP(hipMemsetAsync(dx0, 0, (size_t)ws->B * ws->N * 9 * 4, st));
-    }
+    // no gradient buffer is accumulated into: every row has exactly one writer, consumers gather (fixed order)
     if ((rc = run_fp_bwd<0>(m, ws, fwd, logp, dlogp, st))) return rc;
     if ((rc = run_fp_bwd<1>(m, ws, fwd, nullptr, nullptr, st))) return rc;
     if ((rc = run_fp_bwd<2>(m, ws, fwd, nullptr, nullptr, st))) return rc;
@@ -791,6 +908,20 @@ static int backward_impl(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float 
     if ((rc = run_sa_bwd<2>(m, ws, fwd, dx0, 0, kSaC[2], st))) return rc;
     if ((rc = run_sa_bwd<1>(m, ws, fwd, dx0, 0, kSaC[1], st))) return rc;
     if ((rc = run_sa_bwd<0>(m, ws, fwd, dx0, c_lo, c_hi, st))) return rc;
+    {
+        ProfScope prof(ws, TAG_ZERO, st);   // (tag kept: the slot that used to be the gradient memset)
+        const bool compact = c_hi - c_lo == 3;
+        const size_t total = (size_t)ws->B * ws->N * (compact ? 1 : c_hi - c_lo);
+        const dim3 grid((unsigned)std::min<size_t>(8192, (total + 255) / 256));
+        const int32_t *off = ws->ginv_off[0] + (size_t)fwd * ws->B * (ws->N + 1);
+        if (compact)
+            hipLaunchKernelGGL(dx0_gather_kernel<true>, grid, dim3(256), 0, st, off, ws->gsa[0], ws->B, ws->N, kS[0] * K, 4,
+                               c_lo, c_hi, dx0);
+        else
+            hipLaunchKernelGGL(dx0_gather_kernel<false>, grid, dim3(256), 0, st, off, ws->gsa[0], ws->B, ws->N, kS[0] * K,
+                               kGsaC[0], c_lo, c_hi, dx0);
+        PSG_LAUNCH_CHECK();
+    }
     return PSG_OK;
 }
 

@@ -37,9 +37,15 @@ struct SaBwdArgs {
     const int2 *nninv_ent;      // [B][3*n_fine] {fine point, weight bits}, sorted by fine point per list
     const float *dint;          // [B][n_fine][C3]
     int n_fine;
+    // grouping-transpose form: dout[s][c] += sum over the grouped rows e of the next SA level that gathered point s
+    const int32_t *ginv_off;    // [B][S+1] or null: list of point s = rows [off[s], off[s+1]) of gsa
+    const float *gsa;           // [B][g_rows][C3] gradient rows written by the next level's sa_bwd IN LIST ORDER
+    int g_rows;
+    float *gsa_out;             // [B][S*32][cg_out]: this module's grouped-input gradient rows (plain stores), row
+    const int32_t *gpos_out;    // (group*32 + sample) stored at position gpos_out[row] = its slot in the consumer's lists
+    int cg_out;
     const uint8_t *arg;   // [B][S][C3]
     const int32_t *gidx;  // [B][S][32]
-    float *dfeat;         // [B][Np][D]  (atomicAdd)
     BwdLayer l3t, l2t, l1t;
     int D, Np, S, C3;
     int c_lo, c_hi;       // feature channels [c_lo, c_hi) of the grouped-input gradient are scattered
@@ -75,8 +81,7 @@ struct FpBwdArgs {
     const float *dlogp;         // head mode: [B][N][n_cls]
     const int32_t *nn_idx;
     const float *nn_w;
-    float *dfeat1;              // [B][N][C1] (atomicAdd) or null
-    float *dfeat2;              // [B][S][C2] (atomicAdd)
+    float *dfeat1;              // [B][N][C1] skip-link gradient rows (plain stores) or null
     BwdLayer layer[MAX_LAYERS];
     int n_layers;
     int C1, C2, N, S, Cout, n_cls, mb_last;
@@ -183,21 +188,36 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
 
     // gradient of the pooled output: read directly, or gathered (no atomics, fixed summation order) from the
     // interpolated-part rows of the feature-propagation module that upsampled this level
-    const float *dsrc = a.dout ? a.dout + ((size_t)b * a.S + s0) * a.C3 : buf1;   // buf1 is free until l3t writes it
-    if (!a.dout) {
-        for (int t = tid; t < G * a.C3; t += NT) {
-            const int g = t / a.C3, c = t - g * a.C3;
+    // dout[s][c] = skip-link gradient (plain rows) + transposed 3-NN interpolation + transposed grouping of the
+    // next level, every sum in a fixed order (ascending fine point / grouped row)
+    const float *dsrc = buf1;   // buf1 is free until l3t writes it
+    for (int t = tid; t < G * a.C3; t += NT) {
+        const int g = t / a.C3, c = t - g * a.C3;
+        float acc = a.dout ? a.dout[((size_t)b * a.S + s0 + g) * a.C3 + c] : 0.0f;
+        if (a.nninv_off) {
             const int32_t *off = a.nninv_off + (size_t)b * (a.S + 1) + s0 + g;
             const int2 *ent = a.nninv_ent + (size_t)b * 3 * a.n_fine;
-            float acc = 0.0f;
             for (int e = off[0]; e < off[1]; ++e) {
                 const int2 pe = ent[e];
                 acc += __int_as_float(pe.y) * a.dint[((size_t)b * a.n_fine + pe.x) * a.C3 + c];
             }
-            buf1[t] = acc;
         }
-        __syncthreads();
+        if (a.ginv_off) {
+            // the producer stored its rows in list order: the rows of point s are contiguous, ascending grouped row
+            const int32_t *off = a.ginv_off + (size_t)b * (a.S + 1) + s0 + g;
+            const float *rows = a.gsa + (size_t)b * a.g_rows * a.C3 + c;
+            const int e1 = off[1];
+            for (int e = off[0]; e < e1; e += 8) {   // absent entries add +0.0f: still the ascending chain
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = e + u < e1 ? rows[(size_t)(e + u) * a.C3] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+        }
+        buf1[t] = acc;
     }
+    __syncthreads();
     // max-pool backward: dZ3[c][g*32+k] = dout[g][c] if k == arg[g][c] else 0.
     // One (point, 8-channel block) per thread; arg/dout reads are broadcasts across the 32 samples.
     const int nblk = a.C3 >> 3;
@@ -229,16 +249,22 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     if (!(a.diag & 8)) layer_bwd<P, NW>(a.l1t, buf0, buf1, wg);
     __syncthreads();
     if (a.diag & 32) return;
-    // index_points backward: scatter-add the feature rows [c_lo, c_hi) of the grouped-input gradient
-    // (LDS channel order is [feats, rel_xyz]: LDS channel c is feature channel c)
+    // index_points backward (pointnet_util.py:119,131): the feature rows [c_lo, c_hi) of the grouped-input gradient
+    // are stored as plain rows; the consumer (previous level's sa_bwd, or dx0_gather_kernel) sums them through the
+    // inverse group lists.  (LDS channel order is [feats, rel_xyz]: LDS channel c is feature channel c.)
     const int nc = a.c_hi - a.c_lo;
+    const int32_t *pos = a.gpos_out + (size_t)b * a.S * 32 + (size_t)s0 * 32;
+    float *orow = a.gsa_out + (size_t)b * a.S * 32 * a.cg_out;
+    if (a.cg_out == 4) {   // colour-only request of the attack loop: one 16-byte row {c_lo, c_lo+1, c_lo+2, 0} per lane
+        for (int j = tid; j < P; j += NT) {
+            const float4 v = make_float4(buf1[L::off(a.c_lo, j)], buf1[L::off(a.c_lo + 1, j)], buf1[L::off(a.c_lo + 2, j)], 0.0f);
+            if (pos[j] >= 0) *(float4 *)(orow + (size_t)pos[j] * 4) = v;   // padding rows (always zero) are not listed
+        }
+        return;
+    }
     for (int t = tid; t < P * nc; t += NT) {
         const int j = t / nc, c = a.c_lo + (t - j * nc);
-        const float v = buf1[L::off(c, j)];
-        if (v != 0.0f) {
-            const int src = a.gidx[((size_t)b * a.S + s0 + (j >> 5)) * 32 + (j & 31)];
-            atomicAdd(a.dfeat + ((size_t)b * a.Np + src) * a.D + c, v);
-        }
+        if (pos[j] >= 0) orow[(size_t)pos[j] * a.cg_out + c] = buf1[L::off(c, j)];   // padding rows are not listed
     }
 }
 
@@ -429,26 +455,14 @@ __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
         for (int t = tid; t < P * a.C1; t += NT) {
             const int j = t / a.C1, c = t - j * a.C1;
             const float v = in[L::off(c, j)];
-            if (v != 0.0f) atomicAdd(a.dfeat1 + ((size_t)b * a.N + n0 + j) * a.C1 + c, v);
+            a.dfeat1[((size_t)b * a.N + n0 + j) * a.C1 + c] = v;   // sole writer of the skip-link gradient: plain store
         }
     }
-    if (a.dint_out) {
-        // interpolated-part gradient as plain rows; the coarser module gathers them through the inverse 3-NN lists
-        for (int t = tid; t < P * a.C2; t += NT) {
-            const int j = t / a.C2, c = t - j * a.C2;
-            a.dint_out[((size_t)b * a.N + n0 + j) * a.C2 + c] = in[L::off(a.C1 + c, j)];
-        }
-        return;
-    }
+    // interpolated-part gradient as plain rows; the coarser module gathers them through the inverse 3-NN lists
+    // (pointnet_util.py:308: the transpose of index_points + weighted sum, without atomics)
     for (int t = tid; t < P * a.C2; t += NT) {
         const int j = t / a.C2, c = t - j * a.C2;
-        const float v = in[L::off(a.C1 + c, j)];
-        if (v != 0.0f) {
-            const size_t n = (size_t)b * a.N + n0 + j;
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                atomicAdd(a.dfeat2 + ((size_t)b * a.S + a.nn_idx[n * 3 + k]) * a.C2 + c, a.nn_w[n * 3 + k] * v);
-        }
+        a.dint_out[((size_t)b * a.N + n0 + j) * a.C2 + c] = in[L::off(a.C1 + c, j)];
     }
 }
 
