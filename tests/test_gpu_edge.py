@@ -193,3 +193,19 @@ def test_degenerate_geometry():
     assert np.array_equal(idx, np.broadcast_to(np.arange(64)[None, :, None], (1, 64, 32)))
     fps = runtime.fps(lonely, 64, torch.tensor([7], dtype=torch.int32).cuda()).cpu().numpy()
     assert sorted(fps[0].tolist()) == list(range(64)) and fps[0, 0] == 7
+
+
+def test_fps_many_problems_path():
+    """More than 512 problems take the 256-thread x 16-point FPS kernel: same indices as the oracle."""
+    from oracle import pn2
+    from pointsecguard_amd import runtime
+    from pointsecguard_amd.synthetic import make_rooms
+    P, N, S = 520, 4096, 1024
+    xyz = np.ascontiguousarray(make_rooms(4, 5)[:, :, :3])
+    rng = np.random.default_rng(0)
+    start = rng.integers(0, N, P).astype(np.int32)
+    clouds = torch.from_numpy(xyz[np.arange(P) % 4]).cuda().contiguous()
+    idx = runtime.fps(clouds, S, torch.from_numpy(start).cuda()).cpu().numpy()
+    for p in (0, 257, 519):
+        assert np.array_equal(idx[p], pn2.fps(xyz[p % 4], S, int(start[p])).astype(np.int32)), p
+    assert all(len(set(row.tolist())) == S for row in idx[::37])
