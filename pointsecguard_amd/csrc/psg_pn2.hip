@@ -286,6 +286,10 @@ int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *dx0, int c_lo, 
         a.ginv_off = ws->ginv_off[LVL + 1] + prob * (S + 1);
         a.gsa = ws->gsa[LVL + 1];
     }
+    if (P * (kSaC[LVL + 1] / 8) > 4 * NW * 64) {   // sa_bwd_kernel pre-loads exactly 4 arg-max tasks per thread
+        set_error("run_sa_bwd<%d>: %d max-pool tasks exceed 4 per thread", LVL, P * (kSaC[LVL + 1] / 8));
+        return PSG_ERR_STATE;
+    }
     a.gsa_out = ws->gsa[LVL];
     a.gpos_out = ws->ginv_pos[LVL] + prob * S * K;
     a.cg_out = (LVL == 0 && c_hi - c_lo == 3) ? 4 : kGsaC[LVL];   // colour-only: compact float4 rows

@@ -188,6 +188,19 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
 
     // gradient of the pooled output: read directly, or gathered (no atomics, fixed summation order) from the
     // interpolated-part rows of the feature-propagation module that upsampled this level
+    // arg-max bytes of this workgroup's groups: issued first, so their latency overlaps the gradient gather below
+    const int nblk = a.C3 >> 3;
+    constexpr int NTASK = 4;   // (point, 8-channel block) tasks per thread: P * C3 / 8 / NT = 4 for every SA level
+    uint2 am_pre[NTASK];
+#pragma unroll
+    for (int i = 0; i < NTASK; ++i) {
+        const int t = tid + i * NT;
+        am_pre[i] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (t < P * nblk && !(a.diag & 1)) {
+            const int pnt = t % P, blk = t / P;
+            am_pre[i] = *(const uint2 *)(a.arg + ((size_t)b * a.S + s0 + (pnt >> 5)) * a.C3 + blk * 8);
+        }
+    }
     // dout[s][c] = skip-link gradient (plain rows) + transposed 3-NN interpolation + transposed grouping of the
     // next level, every sum in a fixed order (ascending fine point / grouped row)
     const float *dsrc = buf1;   // buf1 is free until l3t writes it
@@ -220,12 +233,13 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     __syncthreads();
     // max-pool backward: dZ3[c][g*32+k] = dout[g][c] if k == arg[g][c] else 0.
     // One (point, 8-channel block) per thread; arg/dout reads are broadcasts across the 32 samples.
-    const int nblk = a.C3 >> 3;
-    for (int t = tid; t < ((a.diag & 1) ? 0 : P * nblk); t += NT) {
+#pragma unroll
+    for (int i = 0; i < NTASK; ++i) {
+        const int t = tid + i * NT;
+        if (t >= P * nblk || (a.diag & 1)) break;
         const int pnt = t % P, blk = t / P;
         const int g = pnt >> 5, k = pnt & 31;
-        const size_t o = ((size_t)b * a.S + s0 + g) * a.C3 + blk * 8;
-        const uint2 am = *(const uint2 *)(a.arg + o);
+        const uint2 am = am_pre[i];
         const float *dp = dsrc + (size_t)g * a.C3 + blk * 8;
         const float4 d0 = *(const float4 *)dp, d1 = *(const float4 *)(dp + 4);
         float4 v0, v1;
