@@ -412,14 +412,27 @@ __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
                 const int2 *ent = a.nninv_ent + (size_t)b * 3 * a.n_fine;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) dq[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int e = off[0]; e < off[1]; ++e) {
-                    const int2 pe = ent[e];
-                    const float w = __int_as_float(pe.y);
-                    const float *src = a.dint + ((size_t)b * a.n_fine + pe.x) * a.Cout + mb * 32 + 4 * h;
+                const int e1 = off[1];
+                // two list entries per pass (both entry records first, then their 8 row pieces): half the dependent
+                // memory round trips; an absent second entry contributes w = 0 times row 0
+                for (int e = off[0]; e < e1; e += 2) {
+                    const int2 pa = ent[e];
+                    const int2 pb = e + 1 < e1 ? ent[e + 1] : make_int2(0, 0);
+                    const float wa = __int_as_float(pa.y), wb = __int_as_float(pb.y);
+                    const float *sa = a.dint + ((size_t)b * a.n_fine + pa.x) * a.Cout + mb * 32 + 4 * h;
+                    const float *sb = a.dint + ((size_t)b * a.n_fine + pb.x) * a.Cout + mb * 32 + 4 * h;
+                    float4 da[4], db[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) { da[g] = *(const float4 *)(sa + 8 * g); db[g] = *(const float4 *)(sb + 8 * g); }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const float4 d = *(const float4 *)(src + 8 * g);
-                        dq[g].x += w * d.x; dq[g].y += w * d.y; dq[g].z += w * d.z; dq[g].w += w * d.w;
+                        dq[g].x += wa * da[g].x; dq[g].y += wa * da[g].y; dq[g].z += wa * da[g].z; dq[g].w += wa * da[g].w;
+                    }
+                    if (e + 1 < e1) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            dq[g].x += wb * db[g].x; dq[g].y += wb * db[g].y; dq[g].z += wb * db[g].z; dq[g].w += wb * db[g].w;
+                        }
                     }
                 }
             } else {
