@@ -162,7 +162,7 @@ __device__ __forceinline__ f32x16 tile_mac(const float4 *__restrict__ w, int k8n
             "v_mfma_f32_32x32x2_f32 %[acc], v87, v79, %[acc]\n\t"
             "s_nop 15\n\t"
             "s_nop 3\n\t"
-            : [acc] "+a"(acc), [wp] "+v"(wp), [lds] "+v"(lds), [n] "+s"(n)
+            : [acc] "+v"(acc), [wp] "+v"(wp), [lds] "+v"(lds), [n] "+s"(n)
             : [step] "s"(step), [s1] "n"(S1), [s2] "n"(S2), [s3] "n"(S3), [s4] "n"(S4)
             : "memory", "scc", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
               "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87");
@@ -235,7 +235,7 @@ __device__ __forceinline__ f32x16 tile_mac(const float4 *__restrict__ w, int k8n
             "v_mfma_f32_32x32x2_f32 %[acc], v79, v87, %[acc]\n\t"
             "s_nop 15\n\t"
             "s_nop 3\n\t"
-            : [acc] "+a"(acc), [wp] "+v"(wp), [lds] "+v"(lds), [n] "+s"(n)
+            : [acc] "+v"(acc), [wp] "+v"(wp), [lds] "+v"(lds), [n] "+s"(n)
             : [step] "s"(step), [s1] "n"(S1), [s2] "n"(S2), [s3] "n"(S3), [s4] "n"(S4)
             : "memory", "scc", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
               "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87");
@@ -268,17 +268,16 @@ __device__ __forceinline__ void layer_fwd(const FwdLayer &L, const float *__rest
     static_assert((NW & (NW - 1)) == 0, "NW must be a power of two");
     for (int task = (wave + (int)(wg_linear & (NW - 1))) & (NW - 1); task < ntask; task += NW) {
         const int mb = task / PB, pb = task - mb * PB;
-        // bias: 4 x float4 issued before the k-loop, consumed after it (latency hidden behind the MFMAs)
         const float4 *bp = (const float4 *)(L.bias + mb * 32 + 4 * h);
         const float4 bq0 = bp[0], bq1 = bp[2], bq2 = bp[4], bq3 = bp[6];
+        // the accumulators (plain VGPRs: the matrix cores of gfx950 read and write them directly, so there are no
+        // accvgpr moves around the tile) start from the bias: the loads land in the accumulator registers
         f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        acc[0] = bq0.x; acc[1] = bq0.y; acc[2] = bq0.z; acc[3] = bq0.w;
+        acc[4] = bq1.x; acc[5] = bq1.y; acc[6] = bq1.z; acc[7] = bq1.w;
+        acc[8] = bq2.x; acc[9] = bq2.y; acc[10] = bq2.z; acc[11] = bq2.w;
+        acc[12] = bq3.x; acc[13] = bq3.y; acc[14] = bq3.z; acc[15] = bq3.w;
         acc = tile_mac<BLK, false>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, in + (pb * 32 + j) * 8 + 4 * h, acc);
-        acc[0] += bq0.x; acc[1] += bq0.y; acc[2] += bq0.z; acc[3] += bq0.w;
-        acc[4] += bq1.x; acc[5] += bq1.y; acc[6] += bq1.z; acc[7] += bq1.w;
-        acc[8] += bq2.x; acc[9] += bq2.y; acc[10] += bq2.z; acc[11] += bq2.w;
-        acc[12] += bq3.x; acc[13] += bq3.y; acc[14] += bq3.z; acc[15] += bq3.w;
         if (L.relu) {
             unsigned m = 0;
 #pragma unroll
