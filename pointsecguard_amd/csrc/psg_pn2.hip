@@ -262,10 +262,16 @@ int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *x0, hipSt
     a.l2 = fwd_layer(L[1], true, ws->mask[3 * LVL + 1]);
     a.w3 = L[2].wf; a.b3 = L[2].bias; a.k8_3 = L[2].k8f(); a.nb3 = L[2].mbf();
     a.D = D; a.Np = Np; a.S = S; a.C3 = L[2].cout;
-    a.rows0 = std::max(a.l1.k8, a.l2.mb * 4) + 1;   // + 1 spare block: the operand prefetch runs one chunk ahead
-    a.rows1 = std::max(a.l1.mb * 4, a.l2.k8) + 1;
-    return launch_lds(ws, TAG_SA_FWD + LVL, sa_fwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, a.rows0 + a.rows1,
-                      Lds<P>::BLK, a, st);
+    a.rows0 = std::max(a.l1.k8, a.l2.mb * 4) + PSG_LDS_SPARE;
+    a.rows1 = std::max(a.l1.mb * 4, a.l2.k8) + PSG_LDS_SPARE;
+    int blocks = a.rows0 + a.rows1;
+    if (a.l1.mb == 1 && a.l2.mb == 1 && P / 32 == NW) {
+        // every layer is ONE 32-row tile per group and every wave keeps its own group through l1 and l2: a tile's
+        // reads are complete before its write-back, so the layers run in place (buf1 == buf0) and LDS halves
+        blocks = std::max(a.rows0, a.rows1);
+        a.rows0 = 0;
+    }
+    return launch_lds(ws, TAG_SA_FWD + LVL, sa_fwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, blocks, Lds<P>::BLK, a, st);
 }
 
 template <int LVL>
@@ -307,10 +313,18 @@ int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *dx0, int c_lo, 
     a.l1t = bwd_layer(L[0], nullptr);
     a.D = D; a.Np = Np; a.S = S; a.C3 = L[2].cout;
     a.c_lo = c_lo; a.c_hi = c_hi;
-    a.rows0 = std::max(std::max(a.l3t.k8, a.l2t.mb * 4), a.l1t.k8) + 1;
-    a.rows1 = std::max(std::max(a.l3t.mb * 4, a.l1t.mb * 4), a.l2t.k8) + 1;
-    return launch_lds(ws, TAG_SA_BWD + LVL, sa_bwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, a.rows0 + a.rows1,
-                      Lds<P>::BLK, a, st);
+    a.rows0 = std::max(std::max(a.l3t.k8, a.l2t.mb * 4), a.l1t.k8) + PSG_LDS_SPARE;
+    a.rows1 = std::max(std::max(a.l3t.mb * 4, a.l1t.mb * 4), a.l2t.k8) + PSG_LDS_SPARE;
+    int blocks = a.rows0 + a.rows1;
+    a.dsrc_blk = a.rows0;   // the pooled-output gradient is staged in buf1
+    if (a.l3t.mb == 1 && a.l2t.mb == 1 && a.l1t.mb == 1 && P / 32 == NW) {
+        // in place (see run_sa_fwd); the staged gradient then needs a block of its own
+        const int main_blocks = std::max(a.rows0, a.rows1);
+        a.dsrc_blk = main_blocks;
+        blocks = main_blocks + ceil_div((P / 32) * a.C3, Lds<P>::BLK);
+        a.rows0 = 0;
+    }
+    return launch_lds(ws, TAG_SA_BWD + LVL, sa_bwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, blocks, Lds<P>::BLK, a, st);
 }
 
 // FP module `LVL` (0 = fp1 ... 3 = fp4) upsamples level LVL+1 -> level LVL.
@@ -392,7 +406,7 @@ int run_fp_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *logp, hipStream
         if (i + 1 < nl) rows = std::max(rows, a.layer[i + 1].k8);
         if (i & 1) a.rows0 = std::max(a.rows0, rows); else a.rows1 = std::max(a.rows1, rows);
     }
-    a.rows0 += 1; a.rows1 += 1;
+    a.rows0 += PSG_LDS_SPARE; a.rows1 += PSG_LDS_SPARE;
     return launch_lds(ws, TAG_FP_FWD + LVL, fp_fwd_kernel<P, NW>, dim3(N / P, B), NW * 64, a.rows0 + a.rows1,
                       Lds<P>::BLK, a, st);
 }
@@ -456,7 +470,7 @@ int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, con
         if (i + 1 < nl) rows = std::max(rows, a.layer[i + 1].k8);
         if (i & 1) a.rows0 = std::max(a.rows0, rows); else a.rows1 = std::max(a.rows1, rows);
     }
-    a.rows0 += 1; a.rows1 += 1;
+    a.rows0 += PSG_LDS_SPARE; a.rows1 += PSG_LDS_SPARE;
     return launch_lds(ws, TAG_FP_BWD + LVL, fp_bwd_kernel<P, NW>, dim3(N / P, B), NW * 64, a.rows0 + a.rows1,
                       Lds<P>::BLK, a, st);
 }

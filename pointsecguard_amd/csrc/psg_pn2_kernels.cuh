@@ -50,6 +50,7 @@ struct SaBwdArgs {
     int D, Np, S, C3;
     int c_lo, c_hi;       // feature channels [c_lo, c_hi) of the grouped-input gradient are scattered
     int rows0, rows1;
+    int dsrc_blk;         // LDS block where the gathered pooled-output gradient is staged
     int diag;             // timing diagnostics only (PSG_DIAG env)
 };
 
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     }
     // dout[s][c] = skip-link gradient (plain rows) + transposed 3-NN interpolation + transposed grouping of the
     // next level, every sum in a fixed order (ascending fine point / grouped row)
-    const float *dsrc = buf1;   // buf1 is free until l3t writes it
+    float *dsrc = lds + (size_t)a.dsrc_blk * L::BLK;   // = buf1 (free until l3t writes it), or a block of its own
     for (int t = tid; t < G * a.C3; t += NT) {
         const int g = t / a.C3, c = t - g * a.C3;
         float acc = a.dout ? a.dout[((size_t)b * a.S + s0 + g) * a.C3 + c] : 0.0f;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
                 for (int u = 0; u < 8; ++u) acc += v[u];
             }
         }
-        buf1[t] = acc;
+        dsrc[t] = acc;
     }
     __syncthreads();
     // max-pool backward: dZ3[c][g*32+k] = dout[g][c] if k == arg[g][c] else 0.
