@@ -262,69 +262,102 @@ __device__ __forceinline__ void store_tile(float *__restrict__ out, int mb, int 
         *(float4 *)(o + (size_t)g * Lds<P>::BLK) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 }
 
-// Forward layer: out[m][p] = act(W in[:, p] + b).  Tiles (mb x P/32) are dealt round-robin to waves.
-template <int P, int NW>
-__device__ __forceinline__ void layer_fwd(const FwdLayer &L, const float *__restrict__ in, float *__restrict__ out,
-                                          size_t wg_linear)
+// Layers run IN PLACE on one LDS buffer: every wave first computes its tiles into registers (up to MAXT tiles of
+// a ragged layer), the workgroup meets at a barrier (all reads of the input are complete), then the tiles are
+// written back over the input.  One buffer of max(K, M) channels instead of an input and an output buffer: the
+// LDS footprint, not registers, is what bounds the number of co-resident workgroups of these kernels, and more of
+// them is what hides a workgroup's gather / epilogue / barrier phases (sa2 backward: 2 -> 4 workgroups per CU).
+// The caller places a barrier after the layer, as before.
+//
+// Tiles (mb x P/32) are dealt round-robin to waves, starting at a wave that rotates with the workgroup: a layer
+// with fewer tiles than waves (the 13-class head: one tile) or a ragged count (10 tiles on 8 waves) would otherwise
+// always load the same SIMDs of the CU.
+
+// Forward layer: buf[m][p] <- act(W buf[:, p] + b).
+template <int P, int NW, int MAXT>
+__device__ __forceinline__ void layer_fwd(const FwdLayer &L, float *__restrict__ buf, size_t wg_linear)
 {
     constexpr int PB = P / 32, BLK = Lds<P>::BLK;
+    static_assert((NW & (NW - 1)) == 0, "NW must be a power of two");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int ntask = L.mb * PB;
-    // tiles are dealt to waves starting at a wave that rotates with the workgroup: a layer with fewer tiles than
-    // waves (the 13-class head: one tile) or a ragged count (10 tiles on 8 waves) would otherwise always load the
-    // same SIMDs of the CU, and the co-resident workgroups could not even it out
-    static_assert((NW & (NW - 1)) == 0, "NW must be a power of two");
-    for (int task = (wave + (int)(wg_linear & (NW - 1))) & (NW - 1); task < ntask; task += NW) {
-        const int mb = task / PB, pb = task - mb * PB;
-        const float4 *bp = (const float4 *)(L.bias + mb * 32 + 4 * h);
-        const float4 bq0 = bp[0], bq1 = bp[2], bq2 = bp[4], bq3 = bp[6];
-        // the accumulators (plain VGPRs: the matrix cores of gfx950 read and write them directly, so there are no
-        // accvgpr moves around the tile) start from the bias: the loads land in the accumulator registers
-        f32x16 acc;
-        acc[0] = bq0.x; acc[1] = bq0.y; acc[2] = bq0.z; acc[3] = bq0.w;
-        acc[4] = bq1.x; acc[5] = bq1.y; acc[6] = bq1.z; acc[7] = bq1.w;
-        acc[8] = bq2.x; acc[9] = bq2.y; acc[10] = bq2.z; acc[11] = bq2.w;
-        acc[12] = bq3.x; acc[13] = bq3.y; acc[14] = bq3.z; acc[15] = bq3.w;
-        acc = tile_mac<BLK, false>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, in + (pb * 32 + j) * 8 + 4 * h, acc);
-        if (L.relu) {
-            unsigned m = 0;
+    const int first = (wave + (int)(wg_linear & (NW - 1))) & (NW - 1);
+    f32x16 acc[MAXT];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool pos = acc[r] > 0.0f;
-                acc[r] = pos ? acc[r] : 0.0f;
-                m |= (unsigned)pos << r;
+    for (int i = 0; i < MAXT; ++i) {
+        const int task = first + i * NW;
+        if (task < ntask) {
+            const int mb = task / PB, pb = task - mb * PB;
+            // the accumulators (plain VGPRs: the matrix cores of gfx950 read and write them directly, no accvgpr
+            // moves around the tile) start from the bias: the loads land in the accumulator registers
+            const float4 *bp = (const float4 *)(L.bias + mb * 32 + 4 * h);
+            const float4 bq0 = bp[0], bq1 = bp[2], bq2 = bp[4], bq3 = bp[6];
+            f32x16 c;
+            c[0] = bq0.x; c[1] = bq0.y; c[2] = bq0.z; c[3] = bq0.w;
+            c[4] = bq1.x; c[5] = bq1.y; c[6] = bq1.z; c[7] = bq1.w;
+            c[8] = bq2.x; c[9] = bq2.y; c[10] = bq2.z; c[11] = bq2.w;
+            c[12] = bq3.x; c[13] = bq3.y; c[14] = bq3.z; c[15] = bq3.w;
+            c = tile_mac<BLK, false>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, buf + (pb * 32 + j) * 8 + 4 * h, c);
+            if (L.relu) {
+                unsigned m = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool pos = c[r] > 0.0f;
+                    c[r] = pos ? c[r] : 0.0f;
+                    m |= (unsigned)pos << r;
+                }
+                if (L.mask) L.mask[(wg_linear * ntask + task) * 64 + lane] = (uint16_t)m;
             }
-            if (L.mask) L.mask[(wg_linear * ntask + task) * 64 + lane] = (uint16_t)m;
+            acc[i] = c;
         }
-        store_tile<P>(out, mb, pb * 32 + j, h, acc);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int task = first + i * NW;
+        if (task < ntask) {
+            const int mb = task / PB, pb = task - mb * PB;
+            store_tile<P>(buf, mb, pb * 32 + j, h, acc[i]);
+        }
     }
 }
 
-// Backward (input-gradient) layer: out[m][p] = mask * (W^T in[:, p]).
-template <int P, int NW>
-__device__ __forceinline__ void layer_bwd(const BwdLayer &L, const float *__restrict__ in, float *__restrict__ out,
-                                          size_t wg_linear)
+// Backward (input-gradient) layer: buf[m][p] <- mask * (W^T buf[:, p]).
+template <int P, int NW, int MAXT>
+__device__ __forceinline__ void layer_bwd(const BwdLayer &L, float *__restrict__ buf, size_t wg_linear)
 {
     constexpr int PB = P / 32, BLK = Lds<P>::BLK;
+    static_assert((NW & (NW - 1)) == 0, "NW must be a power of two");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int ntask = L.mb * PB;
-    // tiles are dealt to waves starting at a wave that rotates with the workgroup: a layer with fewer tiles than
-    // waves (the 13-class head: one tile) or a ragged count (10 tiles on 8 waves) would otherwise always load the
-    // same SIMDs of the CU, and the co-resident workgroups could not even it out
-    static_assert((NW & (NW - 1)) == 0, "NW must be a power of two");
-    for (int task = (wave + (int)(wg_linear & (NW - 1))) & (NW - 1); task < ntask; task += NW) {
-        const int mb = task / PB, pb = task - mb * PB;
-        unsigned m = 0xFFFFu;
-        if (L.mask) m = L.mask[(wg_linear * ntask + task) * 64 + lane];
-        f32x16 acc;
+    const int first = (wave + (int)(wg_linear & (NW - 1))) & (NW - 1);
+    f32x16 acc[MAXT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        acc = tile_mac<BLK, false>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, in + (pb * 32 + j) * 8 + 4 * h, acc);
+    for (int i = 0; i < MAXT; ++i) {
+        const int task = first + i * NW;
+        if (task < ntask) {
+            const int mb = task / PB, pb = task - mb * PB;
+            unsigned m = 0xFFFFu;
+            if (L.mask) m = L.mask[(wg_linear * ntask + task) * 64 + lane];
+            f32x16 c;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = ((m >> r) & 1u) ? acc[r] : 0.0f;
-        store_tile<P>(out, mb, pb * 32 + j, h, acc);
+            for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+            c = tile_mac<BLK, false>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, buf + (pb * 32 + j) * 8 + 4 * h, c);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = ((m >> r) & 1u) ? c[r] : 0.0f;
+            acc[i] = c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int task = first + i * NW;
+        if (task < ntask) {
+            const int mb = task / PB, pb = task - mb * PB;
+            store_tile<P>(buf, mb, pb * 32 + j, h, acc[i]);
+        }
     }
 }
 

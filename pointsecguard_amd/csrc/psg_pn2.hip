@@ -240,6 +240,13 @@ template <> struct SaCfg<2> { static constexpr int P = 32, NW = 4; };
 template <> struct SaCfg<3> { static constexpr int P = 32, NW = 8; };
 template <int LVL> struct FpCfg { static constexpr int P = 32, NW = 8; };
 template <> struct FpCfg<0> { static constexpr int P = 32, NW = 4; };
+// tiles a wave may hold across the in-place barrier of a backward layer: ceil(widest layer's tiles / waves)
+// (sa2 67->96: 6 tiles on 4 waves; sa3 131->160: 5 on 4; sa4 259->288: 9 on 8; fp2 320: 10 on 8; fp3 384: 12 on 8;
+// fp4 768: 24 on 8); every forward layer has at most one tile per wave
+constexpr int kSaBwdMaxT[4] = {1, 2, 2, 2};
+constexpr int kFpBwdMaxT[4] = {1, 2, 2, 3};
+
+inline int layer_blocks(int k8, int mb) { return std::max(k8, mb * 4); }
 
 template <int LVL>
 int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *x0, hipStream_t st)
@@ -262,14 +269,11 @@ int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *x0, hipSt
     a.l2 = fwd_layer(L[1], true, ws->mask[3 * LVL + 1]);
     a.w3 = L[2].wf; a.b3 = L[2].bias; a.k8_3 = L[2].k8f(); a.nb3 = L[2].mbf();
     a.D = D; a.Np = Np; a.S = S; a.C3 = L[2].cout;
-    a.rows0 = std::max(a.l1.k8, a.l2.mb * 4) + PSG_LDS_SPARE;
-    a.rows1 = std::max(a.l1.mb * 4, a.l2.k8) + PSG_LDS_SPARE;
-    int blocks = a.rows0 + a.rows1;
-    if (a.l1.mb == 1 && a.l2.mb == 1 && P / 32 == NW) {
-        // every layer is ONE 32-row tile per group and every wave keeps its own group through l1 and l2: a tile's
-        // reads are complete before its write-back, so the layers run in place (buf1 == buf0) and LDS halves
-        blocks = std::max(a.rows0, a.rows1);
-        a.rows0 = 0;
+    // one in-place activation buffer: the widest of the layers' K / M extents (psg_mlp.cuh)
+    const int blocks = std::max(std::max(layer_blocks(a.l1.k8, a.l1.mb), layer_blocks(a.l2.k8, a.l2.mb)), a.k8_3) + PSG_LDS_SPARE;
+    if (a.l1.mb * (P / 32) > NW || a.l2.mb * (P / 32) > NW) {
+        set_error("run_sa_fwd<%d>: more tiles than waves in a layer", LVL);
+        return PSG_ERR_STATE;
     }
     return launch_lds(ws, TAG_SA_FWD + LVL, sa_fwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, blocks, Lds<P>::BLK, a, st);
 }
@@ -313,18 +317,16 @@ int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *dx0, int c_lo, 
     a.l1t = bwd_layer(L[0], nullptr);
     a.D = D; a.Np = Np; a.S = S; a.C3 = L[2].cout;
     a.c_lo = c_lo; a.c_hi = c_hi;
-    a.rows0 = std::max(std::max(a.l3t.k8, a.l2t.mb * 4), a.l1t.k8) + PSG_LDS_SPARE;
-    a.rows1 = std::max(std::max(a.l3t.mb * 4, a.l1t.mb * 4), a.l2t.k8) + PSG_LDS_SPARE;
-    int blocks = a.rows0 + a.rows1;
-    a.dsrc_blk = a.rows0;   // the pooled-output gradient is staged in buf1
-    if (a.l3t.mb == 1 && a.l2t.mb == 1 && a.l1t.mb == 1 && P / 32 == NW) {
-        // in place (see run_sa_fwd); the staged gradient then needs a block of its own
-        const int main_blocks = std::max(a.rows0, a.rows1);
-        a.dsrc_blk = main_blocks;
-        blocks = main_blocks + ceil_div((P / 32) * a.C3, Lds<P>::BLK);
-        a.rows0 = 0;
+    constexpr int MAXT = kSaBwdMaxT[LVL];
+    const int main_blocks = std::max(std::max(layer_blocks(a.l3t.k8, a.l3t.mb), layer_blocks(a.l2t.k8, a.l2t.mb)),
+                                     layer_blocks(a.l1t.k8, a.l1t.mb)) + PSG_LDS_SPARE;
+    a.dsrc_blk = main_blocks;   // the gathered pooled-output gradient is staged behind the activation buffer
+    const int blocks = main_blocks + ceil_div((P / 32) * a.C3, Lds<P>::BLK);
+    if (std::max(std::max(a.l3t.mb, a.l2t.mb), a.l1t.mb) * (P / 32) > MAXT * NW) {
+        set_error("run_sa_bwd<%d>: more than %d tiles per wave in a layer", LVL, MAXT);
+        return PSG_ERR_STATE;
     }
-    return launch_lds(ws, TAG_SA_BWD + LVL, sa_bwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, blocks, Lds<P>::BLK, a, st);
+    return launch_lds(ws, TAG_SA_BWD + LVL, (sa_bwd_kernel<P, NW, MAXT>), dim3(S / (P / 32), B), NW * 64, blocks, Lds<P>::BLK, a, st);
 }
 
 // FP module `LVL` (0 = fp1 ... 3 = fp4) upsamples level LVL+1 -> level LVL.
@@ -400,15 +402,16 @@ int run_fp_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *logp, hipStream
     if (diag & 2) for (int i = 0; i < nl; ++i) a.layer[i].mask = nullptr;
     if (diag & 64) for (int i = 0; i < nl; ++i) a.layer[i].k8 = 4;    // timing only: 1/4 .. 1/24 of the MFMAs
     if (diag & 128) for (int i = 0; i < nl; ++i) a.layer[i].relu = 0; // timing only: no ReLU/mask epilogue
-    a.rows0 = a.layer[0].k8; a.rows1 = 0;
+    int blocks = 0;
     for (int i = 0; i < nl; ++i) {
-        int rows = a.layer[i].mb * 4;
-        if (i + 1 < nl) rows = std::max(rows, a.layer[i + 1].k8);
-        if (i & 1) a.rows0 = std::max(a.rows0, rows); else a.rows1 = std::max(a.rows1, rows);
+        blocks = std::max(blocks, layer_blocks(a.layer[i].k8, a.layer[i].mb));
+        if (a.layer[i].mb * (P / 32) > NW) {
+            set_error("run_fp_fwd<%d>: more tiles than waves in layer %d", LVL, i);
+            return PSG_ERR_STATE;
+        }
     }
-    a.rows0 += PSG_LDS_SPARE; a.rows1 += PSG_LDS_SPARE;
-    return launch_lds(ws, TAG_FP_FWD + LVL, fp_fwd_kernel<P, NW>, dim3(N / P, B), NW * 64, a.rows0 + a.rows1,
-                      Lds<P>::BLK, a, st);
+    blocks += PSG_LDS_SPARE;
+    return launch_lds(ws, TAG_FP_FWD + LVL, fp_fwd_kernel<P, NW>, dim3(N / P, B), NW * 64, blocks, Lds<P>::BLK, a, st);
 }
 
 template <int LVL>
@@ -463,16 +466,17 @@ int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, con
     for (int i = cnt - 1; i >= 0; --i)
         a.layer[nl++] = bwd_layer(m->L[first + i], i > 0 ? ws->mask[first + i - 1] : nullptr);
     a.n_layers = nl;
-    a.rows0 = std::max(a.layer[0].k8, a.mb_last * 4);
-    a.rows1 = 0;
+    constexpr int MAXT = kFpBwdMaxT[LVL];
+    int blocks = a.mb_last * 4;
     for (int i = 0; i < nl; ++i) {
-        int rows = a.layer[i].mb * 4;
-        if (i + 1 < nl) rows = std::max(rows, a.layer[i + 1].k8);
-        if (i & 1) a.rows0 = std::max(a.rows0, rows); else a.rows1 = std::max(a.rows1, rows);
+        blocks = std::max(blocks, layer_blocks(a.layer[i].k8, a.layer[i].mb));
+        if (a.layer[i].mb * (P / 32) > MAXT * NW) {
+            set_error("run_fp_bwd<%d>: more than %d tiles per wave in layer %d", LVL, MAXT, i);
+            return PSG_ERR_STATE;
+        }
     }
-    a.rows0 += PSG_LDS_SPARE; a.rows1 += PSG_LDS_SPARE;
-    return launch_lds(ws, TAG_FP_BWD + LVL, fp_bwd_kernel<P, NW>, dim3(N / P, B), NW * 64, a.rows0 + a.rows1,
-                      Lds<P>::BLK, a, st);
+    blocks += PSG_LDS_SPARE;
+    return launch_lds(ws, TAG_FP_BWD + LVL, (fp_bwd_kernel<P, NW, MAXT>), dim3(N / P, B), NW * 64, blocks, Lds<P>::BLK, a, st);
 }
 
 __global__ void extract_xyz_kernel(const float *__restrict__ x0, float *__restrict__ xyz, size_t rows)

@@ -26,7 +26,6 @@ struct SaFwdArgs {
     const float *b3;
     int k8_3, nb3;
     int xyz_stride, D, Np, S, C3;
-    int rows0, rows1;      // LDS buffer sizes in 8-channel blocks
     int diag;              // timing diagnostics only (PSG_DIAG env): skip sections, results are then wrong
 };
 
@@ -49,7 +48,6 @@ struct SaBwdArgs {
     BwdLayer l3t, l2t, l1t;
     int D, Np, S, C3;
     int c_lo, c_hi;       // feature channels [c_lo, c_hi) of the grouped-input gradient are scattered
-    int rows0, rows1;
     int dsrc_blk;         // LDS block where the gathered pooled-output gradient is staged
     int diag;             // timing diagnostics only (PSG_DIAG env)
 };
@@ -64,7 +62,6 @@ struct FpFwdArgs {
     FwdLayer layer[MAX_LAYERS];
     int n_layers;
     int C1, C2, N, S, Cout, n_cls;
-    int rows0, rows1;
     int diag;               // timing diagnostics only (PSG_DIAG env): skip sections, results are then wrong
     unsigned long long *dbg; // diag & 256: per-workgroup {memtime, memrealtime} at entry and exit
 };
@@ -86,7 +83,6 @@ struct FpBwdArgs {
     BwdLayer layer[MAX_LAYERS];
     int n_layers;
     int C1, C2, N, S, Cout, n_cls, mb_last;
-    int rows0, rows1;
 };
 
 // ------------------------------------------------------------------------------------------ SA fwd
@@ -99,7 +95,7 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
     using L = Lds<P>;
     constexpr int G = P / 32, NT = NW * 64, NPART = NT / P;
     extern __shared__ float lds[];
-    float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * L::BLK;   // rows0/rows1 are counted in 8-channel blocks
+    float *buf0 = lds;   // the one activation buffer (layers run in place)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx, b;
     xcd_tile(bx, b);
@@ -138,9 +134,9 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
         }
     }
     __syncthreads();
-    if (!(a.diag & 8)) layer_fwd<P, NW>(a.l1, buf0, buf1, wg);
+    if (!(a.diag & 8)) layer_fwd<P, NW, 1>(a.l1, buf0, wg);
     if (!(a.diag & 16)) __syncthreads();
-    if (!(a.diag & 8)) layer_fwd<P, NW>(a.l2, buf1, buf0, wg);
+    if (!(a.diag & 8)) layer_fwd<P, NW, 1>(a.l2, buf0, wg);
     if (!(a.diag & 16)) __syncthreads();
     if (a.diag & 32) return;
 
@@ -174,13 +170,13 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
 }
 
 // ------------------------------------------------------------------------------------------ SA bwd
-template <int P, int NW>
+template <int P, int NW, int MAXT>
 __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
 {
     using L = Lds<P>;
     constexpr int G = P / 32, NT = NW * 64;
     extern __shared__ float lds[];
-    float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * L::BLK;
+    float *buf0 = lds;   // the one activation buffer (layers run in place)
     const int tid = threadIdx.x;
     int bx, b;
     xcd_tile(bx, b);
@@ -204,7 +200,7 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     }
     // dout[s][c] = skip-link gradient (plain rows) + transposed 3-NN interpolation + transposed grouping of the
     // next level, every sum in a fixed order (ascending fine point / grouped row)
-    float *dsrc = lds + (size_t)a.dsrc_blk * L::BLK;   // = buf1 (free until l3t writes it), or a block of its own
+    float *dsrc = lds + (size_t)a.dsrc_blk * L::BLK;   // staging block(s) behind the activation buffer
     for (int t = tid; t < G * a.C3; t += NT) {
         const int g = t / a.C3, c = t - g * a.C3;
         float acc = a.dout ? a.dout[((size_t)b * a.S + s0 + g) * a.C3 + c] : 0.0f;
@@ -257,11 +253,11 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
         *(float4 *)(dst + 4) = v1;
     }
     __syncthreads();
-    if (!(a.diag & 8)) layer_bwd<P, NW>(a.l3t, buf0, buf1, wg);
+    if (!(a.diag & 8)) layer_bwd<P, NW, MAXT>(a.l3t, buf0, wg);
     if (!(a.diag & 16)) __syncthreads();
-    if (!(a.diag & 8)) layer_bwd<P, NW>(a.l2t, buf1, buf0, wg);
+    if (!(a.diag & 8)) layer_bwd<P, NW, MAXT>(a.l2t, buf0, wg);
     if (!(a.diag & 16)) __syncthreads();
-    if (!(a.diag & 8)) layer_bwd<P, NW>(a.l1t, buf0, buf1, wg);
+    if (!(a.diag & 8)) layer_bwd<P, NW, MAXT>(a.l1t, buf0, wg);
     __syncthreads();
     if (a.diag & 32) return;
     // index_points backward (pointnet_util.py:119,131): the feature rows [c_lo, c_hi) of the grouped-input gradient
@@ -272,14 +268,14 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     float *orow = a.gsa_out + (size_t)b * a.S * 32 * a.cg_out;
     if (a.cg_out == 4) {   // colour-only request of the attack loop: one 16-byte row {c_lo, c_lo+1, c_lo+2, 0} per lane
         for (int j = tid; j < P; j += NT) {
-            const float4 v = make_float4(buf1[L::off(a.c_lo, j)], buf1[L::off(a.c_lo + 1, j)], buf1[L::off(a.c_lo + 2, j)], 0.0f);
+            const float4 v = make_float4(buf0[L::off(a.c_lo, j)], buf0[L::off(a.c_lo + 1, j)], buf0[L::off(a.c_lo + 2, j)], 0.0f);
             if (pos[j] >= 0) *(float4 *)(orow + (size_t)pos[j] * 4) = v;   // padding rows (always zero) are not listed
         }
         return;
     }
     for (int t = tid; t < P * nc; t += NT) {
         const int j = t / nc, c = a.c_lo + (t - j * nc);
-        if (pos[j] >= 0) orow[(size_t)pos[j] * a.cg_out + c] = buf1[L::off(c, j)];   // padding rows are not listed
+        if (pos[j] >= 0) orow[(size_t)pos[j] * a.cg_out + c] = buf0[L::off(c, j)];   // padding rows are not listed
     }
 }
 
@@ -290,7 +286,7 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
     using L = Lds<P>;
     constexpr int NT = NW * 64;
     extern __shared__ float lds[];
-    float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * L::BLK;
+    float *buf0 = lds;   // the one activation buffer (layers run in place)
     const int tid = threadIdx.x;
     int bx, b;
     xcd_tile(bx, b);
@@ -341,14 +337,13 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
         }
     }
     __syncthreads();
-    float *in = buf0, *out = buf1;
+    float *in = buf0;
     if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 0] = __builtin_amdgcn_s_memtime();
     for (int l = 0; l < a.n_layers; ++l) {
-        if (!(a.diag & 8)) layer_fwd<P, NW>(a.layer[l], in, out, wg);
+        if (!(a.diag & 8)) layer_fwd<P, NW, 1>(a.layer[l], in, wg);
         if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 1 + 2 * l] = __builtin_amdgcn_s_memtime();
         if (!(a.diag & 16)) __syncthreads();
         if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 2 + 2 * l] = __builtin_amdgcn_s_memtime();
-        float *t = in; in = out; out = t;
     }
     // `in` now holds the last layer's output
     if (a.out) {
@@ -386,13 +381,13 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
 }
 
 // ------------------------------------------------------------------------------------------ FP bwd
-template <int P, int NW>
+template <int P, int NW, int MAXT>
 __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
 {
     using L = Lds<P>;
     constexpr int PB = P / 32, NT = NW * 64;
     extern __shared__ float lds[];
-    float *buf0 = lds, *buf1 = lds + (size_t)a.rows0 * L::BLK;
+    float *buf0 = lds;   // the one activation buffer (layers run in place)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bx, b;
     xcd_tile(bx, b);
@@ -472,11 +467,10 @@ __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
         }
     }
     __syncthreads();
-    float *in = buf0, *out = buf1;
+    float *in = buf0;
     for (int l = 0; l < a.n_layers; ++l) {
-        layer_bwd<P, NW>(a.layer[l], in, out, wg);
+        layer_bwd<P, NW, MAXT>(a.layer[l], in, wg);
         __syncthreads();
-        float *t = in; in = out; out = t;
     }
     // `in` = gradient of the concat input [C1 skip rows | C2 interpolated rows][point]
     if (a.dfeat1) {
