@@ -6,7 +6,7 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 O=gpurun_out/prof_$TAG
 mkdir -p $O
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pn2 -o pn2 -- python3 bench.py --steps 8 --warmup 4 --no-cpu-baseline > $O/pn2.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pn2 -o pn2 -- python3 bench.py --steps 8 --warmup 4 --concurrency 1 --no-cpu-baseline > $O/pn2.log 2>&1 || exit 1
 grep '^{' $O/pn2.log > $O/pn2_bench.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gcn -o gcn -- python3 bench.py --workload resgcn --steps 2 --warmup 1 --no-cpu-baseline > $O/gcn.log 2>&1 || exit 1
 grep '^{' $O/gcn.log > $O/gcn_bench.json
