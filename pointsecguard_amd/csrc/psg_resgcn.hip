@@ -90,11 +90,15 @@ __global__ void sumsq_rows_kernel(const float *__restrict__ x, int ld, int C, si
 
 // ---- dilated kNN selection: ONE WAVE per query row, no workgroup barriers and no atomics.  Only the KK = (k-1)*d+1
 // (<= 406) smallest of the N <= 4096 distances matter, so instead of sorting the row:
-//   1. every lane keeps 64 keys in registers; composite key = (order-preserving distance bits << 12) | index is
-//      unique: ascending distance, lowest index on ties (torch.topk leaves tie order unspecified);
-//   2. bisection on the key value (count = per-lane compares + one DPP-free shuffle reduction per round) finds ANY
-//      threshold with KK <= #(keys <= t) <= M, M = the power of two the final sort runs on;
-//   3. those keys are compacted into LDS with ballot prefix sums and bitonic-sorted by the wave;
+//   1. every lane keeps 64 order-preserving 32-bit distance keys in registers (element q*64 + lane);
+//   2. a threshold t with KK <= #(keys <= t) <= M (M = the power of two the final sort runs on) is found by
+//      bisection on the DISTANCE value (arithmetic mean of the two bounds: the bit patterns between a ~0 self
+//      distance and the populated binades would cost ~10 extra halvings), started from a bracket read off a
+//      64-key sample (sample[i] has about (i+1)*N/64 keys below it).  Counts are per-lane compares + a DPP wave
+//      sum: no LDS round trips in the loop;
+//   3. the selected keys are compacted in index order into LDS as composite keys (distance << 12 | index: ascending
+//      distance, lowest index on ties; torch.topk leaves tie order unspecified) and bitonic-sorted by the wave.  If
+//      more than M keys tie at the threshold, the lowest-index ones are taken, which is exactly that order;
 //   4. ranks 0, d, 2d, ... are emitted (torch.topk(-dist, k*d)[..., ::d], torch_edge.py:56,29).
 constexpr int KS_WAVES = 4;          // rows per workgroup (independent waves)
 constexpr int KS_PER_LANE = 64;      // N <= 4096
@@ -102,12 +106,39 @@ constexpr int KS_MAX_SEL = 512;
 
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_get(unsigned v)   // lanes of rows outside ROW_MASK read 0
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+// sum over the 64 lanes, wave-uniform result (row butterflies, then row_bcast15 / row_bcast31 into lane 63)
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_get<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v += dpp_get<0x141, 0xF>(v);   // row_half_mirror
+    v += dpp_get<0x140, 0xF>(v);   // row_mirror: every lane holds its row's sum
+    v += dpp_get<0x142, 0xA>(v);   // row_bcast15 -> rows 1, 3
+    v += dpp_get<0x143, 0xC>(v);   // row_bcast31 -> rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+    unsigned o;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false); v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false); v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false); v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false); v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false); v = o > v ? o : v;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false); v = o > v ? o : v;
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned key_of(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dist_of(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
 
 __global__ __launch_bounds__(KS_WAVES * 64) void knn_select_kernel(const float *__restrict__ dist, int N, size_t rows,
                                                                   int k, int d, int32_t *__restrict__ out)
@@ -122,52 +153,82 @@ __global__ __launch_bounds__(KS_WAVES * 64) void knn_select_kernel(const float *
     unsigned M = 64;
     while (M < KK) M <<= 1;          // sort size; any count in [KK, M] is acceptable
 
-    unsigned long long key[KS_PER_LANE];   // composite keys of elements q*64 + lane
-    unsigned long long kmin = ~0ull, kmax = 0ull;
+    unsigned key[KS_PER_LANE];       // keys of elements q*64 + lane; padding = 0xFFFFFFFF sorts last
 #pragma unroll
     for (int q = 0; q < KS_PER_LANE; ++q) {
         const int i = q * 64 + lane;
-        unsigned long long kv = ~0ull;     // padding sorts last and is never selected
-        if (i < N) {
-            unsigned u = __float_as_uint(drow[i]);
-            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-            kv = ((unsigned long long)u << 12) | (unsigned)i;
-            kmin = kv < kmin ? kv : kmin;
-            kmax = kv > kmax ? kv : kmax;
-        }
-        key[q] = kv;
+        key[q] = i < N ? key_of(drow[i]) : 0xFFFFFFFFu;
     }
+    // invariant of the search: #(keys <= lo) = c_lo < KK <= #(keys <= hi); lo starts just below the row minimum
+    unsigned kmin = key[0], kmax = 0u;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const unsigned long long a = ((unsigned long long)__shfl_xor((unsigned)(kmin >> 32), o) << 32) | __shfl_xor((unsigned)kmin, o);
-        const unsigned long long b = ((unsigned long long)__shfl_xor((unsigned)(kmax >> 32), o) << 32) | __shfl_xor((unsigned)kmax, o);
-        kmin = a < kmin ? a : kmin;
-        kmax = b > kmax ? b : kmax;
+    for (int q = 0; q < KS_PER_LANE; ++q) {
+        kmin = key[q] < kmin ? key[q] : kmin;
+        kmax = (key[q] != 0xFFFFFFFFu && key[q] > kmax) ? key[q] : kmax;   // padding excluded
     }
-    // invariant: #(keys <= lo) < KK <= #(keys <= hi)
-    unsigned long long lo = kmin - 1, hi = kmax, thr = kmax;
-    unsigned cnt = (unsigned)N;
-    while (cnt > M) {
-        const unsigned long long mid = lo + ((hi - lo) >> 1);
+    kmin = ~wave_max_u32(~kmin);
+    kmax = wave_max_u32(kmax);
+    unsigned lo = kmin ? kmin - 1u : 0u, hi = kmax;
+    unsigned c_lo = 0, cnt = (unsigned)N;
+    {   // bracket from the 64-key sample of elements 0..63: rank of every sample key among the samples
+        const unsigned sv = key[0];
+        unsigned rank = 0;
+        for (int l = 0; l < 64; ++l) {
+            const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)sv, l);
+            rank += (o < sv || (o == sv && l < lane)) ? 1u : 0u;
+        }
+        const int i0 = (int)((KK * 64u) / (unsigned)N);
+        const int ilo = i0 - 2 - (i0 >> 3), ihi = i0 + 2 + (i0 >> 3);
+        unsigned blo = lo, bhi = hi;
+        if (ilo >= 0 && ilo < 64) blo = (unsigned)__builtin_amdgcn_readlane((int)sv, __builtin_ctzll(__ballot(rank == (unsigned)ilo)));
+        if (ihi < 64) bhi = (unsigned)__builtin_amdgcn_readlane((int)sv, __builtin_ctzll(__ballot(rank == (unsigned)ihi)));
+        unsigned a = 0, b = 0;
+#pragma unroll
+        for (int q = 0; q < KS_PER_LANE; ++q) {
+            a += key[q] <= blo ? 1u : 0u;
+            b += key[q] <= bhi ? 1u : 0u;
+        }
+        a = wave_sum_u32(a);
+        b = wave_sum_u32(b);
+        if (b >= KK) {
+            hi = bhi; cnt = b;
+            if (a < KK && blo > lo) { lo = blo; c_lo = a; }
+        } else {
+            lo = bhi; c_lo = b;
+        }
+    }
+    while (cnt > M && hi - lo > 1u) {
+        unsigned mid = key_of(0.5f * dist_of(lo) + 0.5f * dist_of(hi));
+        if (!(mid > lo && mid < hi)) mid = lo + ((hi - lo) >> 1);
         unsigned c = 0;
 #pragma unroll
         for (int q = 0; q < KS_PER_LANE; ++q) c += key[q] <= mid ? 1u : 0u;
         c = wave_sum_u32(c);
-        if (c < KK) lo = mid;
-        else { hi = mid; thr = mid; cnt = c; }
-        if (hi - lo <= 1) break;       // cannot happen with unique keys unless cnt <= M already
+        if (c < KK) { lo = mid; c_lo = c; }
+        else { hi = mid; cnt = c; }
     }
-    // compact the keys <= thr (KK <= cnt <= M) into LDS; order is irrelevant, the sort follows
+    // compact into LDS in index order: every key below hi, and keys equal to hi while there is room (only when more
+    // than M keys tie at hi does that cut anything: then hi = lo + 1, c_lo < KK of them are below, and the first
+    // M - c_lo of the tied ones in index order are exactly the lowest-index ones)
     for (unsigned t = lane; t < M; t += 64) cand[t] = ~0ull;
     wave_lds_fence();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    unsigned base = 0;
+    const unsigned thr = hi;
+    const bool cut = cnt > M;          // more than M keys <= thr: thr = lo + 1 and the keys equal to thr are rationed
+    unsigned base_a = 0, base_b = 0;   // class a: always taken (slots from 0); class b: tied keys (slots from c_lo)
 #pragma unroll
     for (int q = 0; q < KS_PER_LANE; ++q) {
-        const bool p = key[q] <= thr;
-        const unsigned long long m = __ballot(p);
-        if (p) cand[base + __popcll(m & lt_mask)] = key[q];
-        base += __popcll(m);
+        const bool pa = cut ? key[q] < thr : key[q] <= thr;
+        const bool pb = cut && key[q] == thr;
+        const unsigned long long ma = __ballot(pa), mb = __ballot(pb);
+        const unsigned long long ck = ((unsigned long long)key[q] << 12) | (unsigned)(q * 64 + lane);
+        if (pa) cand[base_a + __popcll(ma & lt_mask)] = ck;
+        if (pb) {
+            const unsigned slot = c_lo + base_b + __popcll(mb & lt_mask);
+            if (slot < M) cand[slot] = ck;
+        }
+        base_a += __popcll(ma);
+        base_b += __popcll(mb);
     }
     wave_lds_fence();
     for (unsigned size = 2; size <= M; size <<= 1) {
