@@ -218,6 +218,26 @@ int psg_seg_stats(const float *logp, const int32_t *labels, int rows, int n_cls,
                   int32_t *pred_out, psg_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Whole-scene evaluation harness.
+ * ------------------------------------------------------------------------------------------ */
+
+/* add_vote (PointNet/NB_nontarget_test_semseg.py:55-62): for every block point r with weight[r] != 0 (weight
+ * nullable = all), pool[point_idx[r]][pred[r]] += 1, pred = the given labels (int32 [rows]) or, when `pred` is
+ * null, argmax(logp[r]) with the first index on ties (`seg_pred.max(2)[1]`).  pool: int32 [n_points][n_cls],
+ * accumulated in place.  *bad_flag (int32, device) is OR-ed with 1 if an index is out of range. */
+int psg_vote_add(const float *logp, const int32_t *pred, const int32_t *point_idx, const float *weight, int rows,
+                 int n_cls, int n_points, int32_t *pool, int32_t *bad_flag, psg_stream stream);
+
+/* Per-scene statistics of NB_nontarget_test_semseg.py:219-229: pred = np.argmax(pool, 1) (first index on ties),
+ * counters int64 [3][n_cls] += seen, correct, union against `labels` (int32 [n_points]).  pred_out nullable. */
+int psg_vote_stats(const int32_t *pool, const int32_t *labels, int n_points, int n_cls, long long *counters,
+                   int32_t *pred_out, psg_stream stream);
+
+/* torch.dist(a, b) (p = 2) of NB_nontarget_test_semseg.py:184: out[0] = sqrt(sum (a-b)^2), accumulated in double
+ * in a fixed order.  scratch256: 256 doubles of device scratch. */
+int psg_l2_dist(const float *a, const float *b, size_t n, double *scratch256, float *out, psg_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * ResGCN-28 dense DeepGCN sem-seg network (ResGCN/sem_seg_dense/architecture.py:6-68), eval mode:
  * head EdgeConv(9->64) on the xyz kNN graph, n_blocks-1 residual dynamic EdgeConv blocks (feature-space
  * kNN, k = 16, dilation 1..n_blocks-1), fusion 1x1 conv + global max, prediction MLP.  BasicConv order is

@@ -65,6 +65,9 @@ SIGNATURES = {
     "psg_gcn_edge_ptr": (vp, [vp, ci]),
     "psg_gcn_feats_ptr": (vp, [vp]),
     "psg_seg_stats": (ci, [vp, vp, ci, ci, vp, vp, vp]),
+    "psg_vote_add": (ci, [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]),
+    "psg_vote_stats": (ci, [vp, vp, ci, ci, vp, vp, vp]),
+    "psg_l2_dist": (ci, [vp, vp, ctypes.c_size_t, vp, vp, vp]),
 }
 
 _lib = None

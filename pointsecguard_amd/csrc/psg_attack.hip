@@ -167,6 +167,127 @@ extern "C" int psg_seg_stats(const float *logp, const int32_t *labels, int rows,
 }
 
 // =============================================================================================
+// Whole-scene evaluation harness: vote pool, vote arg-max statistics, L2 distance.
+// Reference: PointNet/NB_nontarget_test_semseg.py:55-62 (add_vote), :184 (torch.dist), :219-241 (per-scene IoU).
+// =============================================================================================
+namespace {
+
+// pool[point_idx[r]][argmax logp[r]] += 1 where weight[r] != 0 (integer votes: the adds commute, result exact)
+__global__ void vote_add_kernel(const float *__restrict__ logp, const int32_t *__restrict__ pred_in,
+                                const int32_t *__restrict__ point_idx, const float *__restrict__ weight, int rows,
+                                int n_cls, int n_points, int32_t *__restrict__ pool, int *__restrict__ bad)
+{
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+        if (weight && weight[r] == 0.0f) continue;
+        int bi;
+        if (pred_in) bi = pred_in[r];
+        else {
+            const float *lp = logp + (size_t)r * n_cls;
+            float best = lp[0];
+            bi = 0;
+            for (int c = 1; c < n_cls; ++c)
+                if (lp[c] > best) { best = lp[c]; bi = c; }
+        }
+        const int p = point_idx[r];
+        if (p < 0 || p >= n_points || bi < 0 || bi >= n_cls) { atomicOr(bad, 1); continue; }
+        atomicAdd(&pool[(size_t)p * n_cls + bi], 1);
+    }
+}
+
+// per scene: pred = argmax over the votes (first index on ties, np.argmax), then the seen / correct / union counters
+__global__ void vote_stats_kernel(const int32_t *__restrict__ pool, const int32_t *__restrict__ labels, int n_points,
+                                  int n_cls, unsigned long long *__restrict__ counters, int32_t *__restrict__ pred_out)
+{
+    __shared__ unsigned int h[3 * MAXC];
+    for (int i = threadIdx.x; i < 3 * MAXC; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n_points; p += gridDim.x * blockDim.x) {
+        const int32_t *v = pool + (size_t)p * n_cls;
+        int best = v[0], bi = 0;
+        for (int c = 1; c < n_cls; ++c)
+            if (v[c] > best) { best = v[c]; bi = c; }
+        const int y = labels[p];
+        if (pred_out) pred_out[p] = bi;
+        atomicAdd(&h[y], 1u);
+        if (bi == y) {
+            atomicAdd(&h[MAXC + y], 1u);
+            atomicAdd(&h[2 * MAXC + y], 1u);
+        } else {
+            atomicAdd(&h[2 * MAXC + y], 1u);
+            atomicAdd(&h[2 * MAXC + bi], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * n_cls; i += blockDim.x) {
+        int k = i / n_cls, c = i % n_cls;
+        unsigned v = h[k * MAXC + c];
+        if (v) atomicAdd(&counters[k * n_cls + c], (unsigned long long)v);
+    }
+}
+
+// sum of squared differences in double (one partial per workgroup, fixed tree inside the workgroup; the final sum
+// over <= 256 partials runs on one thread in index order): deterministic
+__global__ void sqdiff_partial_kernel(const float *__restrict__ a, const float *__restrict__ b, size_t n,
+                                      double *__restrict__ part)
+{
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double d = (double)a[i] - (double)b[i];
+        acc += d * d;
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+__global__ void sqdiff_final_kernel(const double *__restrict__ part, int n_part, float *__restrict__ out)
+{
+    double acc = 0.0;
+    for (int i = 0; i < n_part; ++i) acc += part[i];
+    out[0] = (float)sqrt(acc);
+}
+
+}  // namespace
+
+extern "C" int psg_vote_add(const float *logp, const int32_t *pred, const int32_t *point_idx, const float *weight,
+                            int rows, int n_cls, int n_points, int32_t *pool, int32_t *bad_flag, psg_stream stream)
+{
+    PSG_REQUIRE((logp || pred) && point_idx && pool && bad_flag && rows > 0 && n_points > 0, "psg_vote_add: bad argument");
+    PSG_REQUIRE(n_cls > 0 && n_cls <= MAXC, "psg_vote_add: n_cls=%d out of range (1..%d)", n_cls, MAXC);
+    hipLaunchKernelGGL(vote_add_kernel, dim3(grid_for((size_t)rows)), dim3(256), 0, (hipStream_t)stream, logp, pred,
+                       point_idx, weight, rows, n_cls, n_points, pool, bad_flag);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+extern "C" int psg_vote_stats(const int32_t *pool, const int32_t *labels, int n_points, int n_cls, long long *counters,
+                              int32_t *pred_out, psg_stream stream)
+{
+    PSG_REQUIRE(pool && labels && counters && n_points > 0, "psg_vote_stats: bad argument");
+    PSG_REQUIRE(n_cls > 0 && n_cls <= MAXC, "psg_vote_stats: n_cls=%d out of range (1..%d)", n_cls, MAXC);
+    hipLaunchKernelGGL(vote_stats_kernel, dim3(std::min(256, psg::ceil_div(n_points, 256))), dim3(256), 0,
+                       (hipStream_t)stream, pool, labels, n_points, n_cls, (unsigned long long *)counters, pred_out);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+extern "C" int psg_l2_dist(const float *a, const float *b, size_t n, double *scratch256, float *out, psg_stream stream)
+{
+    PSG_REQUIRE(a && b && scratch256 && out && n > 0, "psg_l2_dist: bad argument");
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 256);
+    hipLaunchKernelGGL(sqdiff_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, n, scratch256);
+    PSG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sqdiff_final_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, scratch256, blocks, out);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+// =============================================================================================
 // NU (norm-unbounded, Adam in tanh space) attack arithmetic.
 // Reference: PointNet/attacks/torchattacks/attacks/nontarget.py:52-135 (NU_attack),
 //            PointNet/attacks/torchattacks/attacks/target.py:62-175 (tar_NU_attack).

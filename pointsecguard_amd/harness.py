@@ -1,0 +1,247 @@
+"""Whole-scene evaluation harness on the device.
+
+Mirrors, relative to /root/reference/PointNet:
+  data_utils/S3DISDataLoader.py:81-178      ScannetDatasetWholeScene  (host-side block slicing: numpy, like the reference)
+  NB_nontarget_test_semseg.py:55-62         add_vote                  (device: psg_vote_add)
+  NB_nontarget_test_semseg.py:126-291       the per-scene loop: clean / adversarial predictions of every block batch,
+                                            vote pools, per-batch TSV log rows, per-scene and total IoU / accuracy
+What moves to the GPU is everything the reference does per point on the host: the add_vote double loop
+(4096 x B Python iterations per batch), the arg-max / per-class counters and the L2 distance; only 13-entry
+counter vectors and one scalar per batch come back.  Scenes are the sharding unit across GPUs (the vote pool
+of a scene never leaves its rank); the counters are all-reduced once at the end.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, runtime
+from .sharding import reduce_counters, shard_scenes
+
+NUM_CLASSES = runtime.NUM_CLASSES
+CLASSES = ['ceiling', 'floor', 'wall', 'beam', 'column', 'window', 'door', 'table', 'chair', 'sofa', 'bookcase',
+           'board', 'clutter']   # NB_nontarget_test_semseg.py:35
+LOG_HEADER = "index\tL2_dis\tadv_acc\tacc\tadv_miou\tmiou\n"            # :110
+LOG_ROW = "%d\t%.3f\t%.5f\t%.5f\t%.5f\t\t%.5f\n"                         # :213-215
+
+
+class ScannetDatasetWholeScene:
+    """Whole rooms cut into overlapping block_size x block_size columns of `block_points` points each
+    (S3DISDataLoader.py:81-178).  `root` is a directory of S3DIS-format `Area_<k>_<room>.npy` arrays [n, 7]
+    (xyz in metres, rgb 0..255, label); `scenes` (dict name -> array) supplies them directly instead.
+    Random padding / shuffling draws come from numpy's global generator in the reference's order, so
+    np.random.seed(s) reproduces the reference's blocks."""
+
+    def __init__(self, root, block_points=4096, split='test', test_area=5, stride=0.5, block_size=1.0, padding=0.001,
+                 scenes=None):
+        assert split in ('train', 'test')
+        self.block_points, self.block_size, self.padding = block_points, block_size, padding
+        self.root, self.split, self.stride = root, split, stride
+        names = list(scenes.keys()) if scenes is not None else os.listdir(root)
+        tag = 'Area_%d' % test_area
+        self.file_list = [d for d in names if (tag in d) == (split == 'test')]
+        self.scene_points_list, self.semantic_labels_list = [], []
+        self.room_coord_min, self.room_coord_max, self.scene_points_num = [], [], []
+        counts = np.zeros(13)
+        for name in self.file_list:
+            data = scenes[name] if scenes is not None else np.load(os.path.join(root, name))
+            self.scene_points_list.append(data[:, :6])
+            self.semantic_labels_list.append(data[:, 6])
+            self.room_coord_min.append(np.amin(data[:, :3], axis=0))
+            self.room_coord_max.append(np.amax(data[:, :3], axis=0))
+            self.scene_points_num.append(data.shape[0])
+            counts += np.histogram(data[:, 6], range(14))[0]
+        freq = counts.astype(np.float32)
+        freq = freq / np.sum(freq)
+        self.labelweights = np.power(np.amax(freq) / freq, 1 / 3.0)
+
+    def __len__(self):
+        return len(self.scene_points_list)
+
+    def __getitem__(self, index):
+        points = self.scene_points_list[index][:, :6]
+        labels = self.semantic_labels_list[index]
+        cmin, cmax = np.amin(points, axis=0)[:3], np.amax(points, axis=0)[:3]
+        bs, st, pad, bp = self.block_size, self.stride, self.padding, self.block_points
+        grid_x = int(np.ceil(float(cmax[0] - cmin[0] - bs) / st) + 1)
+        grid_y = int(np.ceil(float(cmax[1] - cmin[1] - bs) / st) + 1)
+        data_parts, label_parts, weight_parts, index_parts = [], [], [], []
+        for iy in range(grid_y):
+            for ix in range(grid_x):
+                e_x = min(cmin[0] + ix * st + bs, cmax[0])
+                s_x = e_x - bs
+                e_y = min(cmin[1] + iy * st + bs, cmax[1])
+                s_y = e_y - bs
+                inside = np.where((points[:, 0] >= s_x - pad) & (points[:, 0] <= e_x + pad) &
+                                  (points[:, 1] >= s_y - pad) & (points[:, 1] <= e_y + pad))[0]
+                if inside.size == 0:
+                    continue
+                total = int(np.ceil(inside.size / bp)) * bp
+                extra = total - inside.size
+                fill = np.random.choice(inside, extra, replace=extra > inside.size)
+                idx = np.concatenate((inside, fill))
+                np.random.shuffle(idx)
+                block = points[idx, :]                      # a copy: the scene itself is never modified
+                norm_xyz = block[:, :3] / cmax              # "normalised" location in the room: divided by the max corner
+                block[:, 0] = block[:, 0] - (s_x + bs / 2.0)
+                block[:, 1] = block[:, 1] - (s_y + bs / 2.0)
+                block[:, 3:6] /= 255.0
+                lab = labels[idx].astype(int)
+                data_parts.append(np.concatenate((block, norm_xyz), axis=1))
+                label_parts.append(lab)
+                weight_parts.append(self.labelweights[lab])
+                index_parts.append(idx)
+        data_room = np.vstack(data_parts).reshape((-1, bp, 9))
+        label_room = np.hstack(label_parts).reshape((-1, bp))
+        # the reference's hstack starts from an empty float64 array, which promotes the float32 class weights
+        sample_weight = np.hstack(weight_parts).astype(np.float64).reshape((-1, bp))
+        index_room = np.hstack(index_parts).reshape((-1, bp))
+        return data_room, label_room, sample_weight, index_room
+
+
+def _cuda(t, name, dtype):
+    return runtime.require_cuda(t, name, dtype)
+
+
+def add_vote(vote_label_pool, point_idx, pred_label, weight):
+    """vote_label_pool[point_idx[b, n], pred_label[b, n]] += 1 where weight[b, n] != 0
+    (NB_nontarget_test_semseg.py:55-62), on the device.  vote_label_pool int32 [n_points, 13]; point_idx int32
+    [B, N]; weight float32 [B, N] or None; pred_label int32 [B, N], or the [B, N, 13] log-probs themselves (the
+    arg-max, first index on ties, is then taken in the same kernel).  Returns vote_label_pool."""
+    _cuda(vote_label_pool, "vote_label_pool", torch.int32)
+    _cuda(point_idx, "point_idx", torch.int32)
+    if weight is not None:
+        _cuda(weight, "weight", torch.float32)
+    logp = pred = None
+    if pred_label.dtype == torch.float32:
+        logp = _cuda(pred_label, "pred_label", torch.float32)
+        assert logp.shape[-1] == vote_label_pool.shape[1]
+    else:
+        pred = _cuda(pred_label, "pred_label", torch.int32)
+    rows = point_idx.numel()
+    bad = torch.zeros(1, dtype=torch.int32, device=vote_label_pool.device)
+    _lib.call("psg_vote_add", runtime.ptr(logp), runtime.ptr(pred), runtime.ptr(point_idx), runtime.ptr(weight), rows,
+              vote_label_pool.shape[1], vote_label_pool.shape[0], runtime.ptr(vote_label_pool), runtime.ptr(bad),
+              runtime.stream())
+    if int(bad.item()):
+        raise IndexError("add_vote: a point index or a label is out of range")
+    return vote_label_pool
+
+
+def vote_stats(vote_label_pool, labels, counters=None, want_pred=False):
+    """Scene counters of :219-229: pred = argmax of the votes; returns int64 [3, 13] = seen, correct, union
+    (accumulated into `counters` when given) and, optionally, the predicted labels."""
+    _cuda(vote_label_pool, "vote_label_pool", torch.int32)
+    _cuda(labels, "labels", torch.int32)
+    if counters is None:
+        counters = torch.zeros(3, vote_label_pool.shape[1], dtype=torch.int64, device=labels.device)
+    pred = torch.empty(labels.numel(), dtype=torch.int32, device=labels.device) if want_pred else None
+    _lib.call("psg_vote_stats", runtime.ptr(vote_label_pool), runtime.ptr(labels), labels.numel(),
+              vote_label_pool.shape[1], runtime.ptr(counters), runtime.ptr(pred), runtime.stream())
+    return (counters, pred) if want_pred else counters
+
+
+def l2_distance(a, b):
+    """torch.dist(a, b) of :184 as a device scalar (float32 tensor of one element)."""
+    _cuda(a, "a", torch.float32)
+    _cuda(b, "b", torch.float32)
+    assert a.numel() == b.numel()
+    scratch = torch.empty(256, dtype=torch.float64, device=a.device)
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    _lib.call("psg_l2_dist", runtime.ptr(a.contiguous()), runtime.ptr(b.contiguous()), a.numel(), runtime.ptr(scratch),
+              runtime.ptr(out), runtime.stream())
+    return out
+
+
+def _miou(counters):
+    c = counters.to(torch.float64).cpu().numpy()
+    iou = c[1] / (c[2] + 1e-6)
+    present = c[0] != 0
+    return float(np.mean(iou[present])) if present.any() else 0.0
+
+
+def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_votes=1, log_path=None, rank=0, world=1,
+                         log=print):
+    """The reference's evaluation loop (NB_nontarget_test_semseg.py:126-291) with the per-point work on the GPU.
+
+    classifier: an eval-mode `get_model` on the GPU; make_attack(classifier) -> a torchattacks attack object (e.g.
+    lambda m: torchattacks.NB_attack(m, eps=0.1, alpha=0.05, iters=10), :169); dataset: ScannetDatasetWholeScene.
+    Scenes are dealt round-robin to ranks; the int64 counters are summed over ranks at the end.  Returns a dict with
+    the totals the reference prints (:272-291) and per-scene mIoUs; TSV rows go to `log_path` (rank-suffixed when
+    world > 1) in the reference's format."""
+    dev = next(classifier.parameters()).device
+    attack = make_attack(classifier)
+    n_pt = dataset.block_points
+    total = torch.zeros(2, 3, NUM_CLASSES, dtype=torch.int64, device=dev)   # [clean | adversarial][seen, correct, union]
+    scene_rows = []
+    fh = None
+    if log_path is not None:
+        path = log_path if world == 1 else "%s.rank%d" % (log_path, rank)
+        fh = open(path, "w")
+        fh.write(LOG_HEADER)
+    my_scenes = shard_scenes(list(range(len(dataset))), rank, world)
+    for si in my_scenes:
+        labels_np = dataset.semantic_labels_list[si]
+        n_scene = labels_np.shape[0]
+        scene_labels = torch.from_numpy(labels_np.astype(np.int32)).to(dev)
+        pool = torch.zeros(n_scene, NUM_CLASSES, dtype=torch.int32, device=dev)
+        adv_pool = torch.zeros_like(pool)
+        for _ in range(num_votes):
+            scene_data, scene_label, scene_smpw, scene_point_index = dataset[si]
+            num_blocks = scene_data.shape[0]
+            for sbatch in range((num_blocks + batch_size - 1) // batch_size):
+                lo, hi = sbatch * batch_size, min((sbatch + 1) * batch_size, num_blocks)
+                torch_data = torch.from_numpy(scene_data[lo:hi]).float().to(dev).transpose(2, 1).contiguous()
+                gt_np = scene_label[lo:hi]
+                gt = torch.from_numpy(gt_np.astype(np.int32)).to(dev)
+                idx = torch.from_numpy(scene_point_index[lo:hi].astype(np.int32)).to(dev)
+                smpw = torch.from_numpy(scene_smpw[lo:hi].astype(np.float32)).to(dev)
+                seg_pred, _ = classifier(torch_data)
+                seg_pred = seg_pred.detach().contiguous()
+                adv_images = attack(torch_data, gt_np)
+                adv_seg_pred, _ = classifier(adv_images)
+                adv_seg_pred = adv_seg_pred.detach().contiguous()
+                add_vote(pool, idx, seg_pred, smpw)
+                add_vote(adv_pool, idx, adv_seg_pred, smpw)
+                c_clean, _ = runtime.seg_stats(seg_pred, gt)
+                c_adv, _ = runtime.seg_stats(adv_seg_pred, gt)
+                dis = l2_distance(adv_images, torch_data)
+                rows = float((hi - lo) * n_pt)
+                acc = float(c_clean[1].sum().item()) / rows
+                adv_acc = float(c_adv[1].sum().item()) / rows
+                line = LOG_ROW % (sbatch, float(dis.item()), adv_acc, acc, _miou(c_adv), _miou(c_clean))
+                if fh is not None:
+                    fh.write(line)
+        c_scene = vote_stats(pool, scene_labels)
+        c_scene_adv = vote_stats(adv_pool, scene_labels)
+        total[0] += c_scene
+        total[1] += c_scene_adv
+        name = dataset.file_list[si][:-4]
+        scene_rows.append((name, _miou(c_scene), _miou(c_scene_adv)))
+        log('Mean IoU of %s: %.4f' % (name, scene_rows[-1][1]))
+        log('Mean IoU of %s: %.4f' % (name, scene_rows[-1][2]))
+    if fh is not None:
+        fh.close()
+    reduce_counters(total)
+    t = total.to(torch.float64).cpu().numpy()
+    out = {"scenes": scene_rows, "counters": total.cpu().numpy()}
+    for tag, c in (("", t[0]), ("adv_", t[1])):
+        seen = t[0][0]                                   # the reference divides the adversarial counters by the clean `seen`
+        out[tag + "iou_per_class"] = (c[1] / (c[2] + 1e-6)).tolist()
+        out[tag + "miou"] = float(np.mean(c[1] / (c[2] + 1e-6)))                          # :272-273, :282
+        out[tag + "avg_class_acc"] = float(np.mean(c[1] / (seen + 1e-6)))                 # :283-284, :288-289
+        out[tag + "accuracy"] = float(np.sum(c[1]) / float(np.sum(seen) + 1e-6))          # :285-286, :290-291
+    if rank == 0:
+        log('------- IoU --------')
+        for l in range(NUM_CLASSES):
+            denom = t[0][2][l]
+            log('class %s, IoU: %.3f ' % (CLASSES[l] + ' ' * (14 - len(CLASSES[l])), t[0][1][l] / denom if denom else math.nan))
+        log('eval point avg class IoU: %f' % out["miou"])
+        log('eval whole scene point avg class acc: %f' % out["avg_class_acc"])
+        log('eval whole scene point accuracy: %f' % out["accuracy"])
+        log("-------attack--------")
+        log('eval point avg class IoU: %f' % out["adv_miou"])
+        log('eval whole scene point avg class acc: %f' % out["adv_avg_class_acc"])
+        log('eval whole scene point accuracy: %f' % out["adv_accuracy"])
+    return out
