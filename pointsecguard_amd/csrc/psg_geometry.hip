@@ -30,6 +30,8 @@ __device__ __forceinline__ float sqdist(float sx, float sy, float sz, float ssq,
     return __fadd_rn(__fadd_rn(__fmul_rn(-2.0f, dot), ssq), dsq);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));   // operand of the packed-fp32 pipe (v_pk_*_f32)
+
 // ---- wave-level max with DPP (no LDS round trips) --------------------------------------------
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned dpp_max_u32(unsigned v)
@@ -147,12 +149,17 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float *__r
                                                                 const float *__restrict__ new_xyz, int N, int S,
                                                                 float r2, int K, int32_t *__restrict__ out)
 {
-    extern __shared__ float4 s_pts[];  // [N]
+    // structure-of-arrays staging: a lane's points j and j + 64 of one plane come back from ONE ds_read2_b32 in
+    // adjacent registers, i.e. directly as an operand of the packed-fp32 pipe (two distances per instruction)
+    extern __shared__ float s_soa[];   // x[NP] y[NP] z[NP] |p|^2[NP], NP = N rounded up to 256
+    const int NP = (N + 255) & ~255;
+    float *s_x = s_soa, *s_y = s_soa + NP, *s_z = s_soa + 2 * NP, *s_q = s_soa + 3 * NP;
     const int p = blockIdx.y;
     const float *src = xyz + (size_t)(p % n_clouds) * N * 3;
-    for (int i = threadIdx.x; i < N; i += BQ_THREADS) {
-        float x = src[3 * i], y = src[3 * i + 1], z = src[3 * i + 2];
-        s_pts[i] = make_float4(x, y, z, sumsq3(x, y, z));
+    for (int i = threadIdx.x; i < NP; i += BQ_THREADS) {
+        float x = 0.f, y = 0.f, z = 0.f, q = INFINITY;       // padding points are infinitely far away
+        if (i < N) { x = src[3 * i]; y = src[3 * i + 1]; z = src[3 * i + 2]; q = sumsq3(x, y, z); }
+        s_x[i] = x; s_y[i] = y; s_z[i] = z; s_q[i] = q;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -162,19 +169,23 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float *__r
         const float *cp = new_xyz + ((size_t)p * S + c) * 3;
         const float cx = cp[0], cy = cp[1], cz = cp[2];
         const float csq = sumsq3(cx, cy, cz);
+        const v2f cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz}, cs2 = {csq, csq}, m2 = {-2.0f, -2.0f};
         int32_t *o = out + ((size_t)p * S + c) * K;
         int cnt = 0, first = N;
         for (int base = 0; base < N && cnt < K; base += 64 * BQ_UNROLL) {
             bool in[BQ_UNROLL];
 #pragma unroll
-            for (int u = 0; u < BQ_UNROLL; ++u) {
-                const int j = base + u * 64 + lane;
-                in[u] = false;
-                if (j < N) {
-                    float4 q = s_pts[j];
-                    float d = sqdist(cx, cy, cz, csq, q.x, q.y, q.z, q.w);
-                    in[u] = !(d > r2);
-                }
+            for (int u = 0; u < BQ_UNROLL; u += 2) {
+                const int j = base + u * 64 + lane;             // and j + 64
+                const v2f qx = {s_x[j], s_x[j + 64]}, qy = {s_y[j], s_y[j + 64]}, qz = {s_z[j], s_z[j + 64]},
+                          qs = {s_q[j], s_q[j + 64]};
+                // square_distance order: ((-2 * fma chain) + |centroid|^2) + |point|^2, as sqdist()
+                v2f dot = cx2 * qx;
+                dot = __builtin_elementwise_fma(cy2, qy, dot);
+                dot = __builtin_elementwise_fma(cz2, qz, dot);
+                const v2f dd = ((m2 * dot) + cs2) + qs;
+                in[u] = !(dd[0] > r2);                          // padding: +inf > r2
+                in[u + 1] = !(dd[1] > r2);
             }
 #pragma unroll
             for (int u = 0; u < BQ_UNROLL; ++u) {
@@ -198,16 +209,24 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float *__r
 // ---------------------------------------------------------------------------------------------
 constexpr int NN_THREADS = 256;
 
+// Two coarse points per step on the packed-fp32 pipe (v_pk_mul/fma/add_f32: two IEEE fp32 results per lane per
+// instruction, each bit-identical to the scalar op): the coarse cloud is staged in LDS as pairs
+// {x0,x1,y0,y1} {z0,z1,|p0|^2,|p1|^2}; an odd tail is padded with a point at infinite distance.
 __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__restrict__ xyz1, int n_clouds1,
                                                               const float *__restrict__ xyz2, int N, int S,
                                                               int32_t *__restrict__ idx, float *__restrict__ w)
 {
-    extern __shared__ float4 s_pts[];  // [S] coarse points
+    extern __shared__ float4 s_pair[];  // [2 * ceil(S/2)]
     const int p = blockIdx.y;
     const float *c2 = xyz2 + (size_t)p * S * 3;
-    for (int i = threadIdx.x; i < S; i += NN_THREADS) {
-        float x = c2[3 * i], y = c2[3 * i + 1], z = c2[3 * i + 2];
-        s_pts[i] = make_float4(x, y, z, sumsq3(x, y, z));
+    const int S2 = (S + 1) >> 1;
+    for (int i = threadIdx.x; i < S2; i += NN_THREADS) {
+        const int a = 2 * i, b = 2 * i + 1;
+        const float xa = c2[3 * a], ya = c2[3 * a + 1], za = c2[3 * a + 2];
+        float xb = 0.f, yb = 0.f, zb = 0.f, sb = INFINITY;
+        if (b < S) { xb = c2[3 * b]; yb = c2[3 * b + 1]; zb = c2[3 * b + 2]; sb = sumsq3(xb, yb, zb); }
+        s_pair[2 * i] = make_float4(xa, xb, ya, yb);
+        s_pair[2 * i + 1] = make_float4(za, zb, sumsq3(xa, ya, za), sb);
     }
     __syncthreads();
     const int i = blockIdx.x * NN_THREADS + threadIdx.x;
@@ -215,17 +234,28 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__res
     const float *fp = xyz1 + ((size_t)(p % n_clouds1) * N + i) * 3;
     const float fx = fp[0], fy = fp[1], fz = fp[2];
     const float fsq = sumsq3(fx, fy, fz);
+    const v2f fx2 = {fx, fx}, fy2 = {fy, fy}, fz2 = {fz, fz}, fs2 = {fsq, fsq}, m2 = {-2.0f, -2.0f};
     float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
     int i0 = 0, i1 = 0, i2 = 0;
-    for (int j = 0; j < S; ++j) {
-        float4 q = s_pts[j];
-        float d = sqdist(fx, fy, fz, fsq, q.x, q.y, q.z, q.w);
-        if (d < d2) {
-            if (d < d1) {
-                d2 = d1; i2 = i1;
-                if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = j; }
-                else { d1 = d; i1 = j; }
-            } else { d2 = d; i2 = j; }
+    for (int jj = 0; jj < S2; ++jj) {
+        const float4 q0 = s_pair[2 * jj], q1 = s_pair[2 * jj + 1];
+        const v2f qx = {q0.x, q0.y}, qy = {q0.z, q0.w}, qz = {q1.x, q1.y}, qs = {q1.z, q1.w};
+        // square_distance order: ((-2 * (fma chain over x, y, z)) + |fine|^2) + |coarse|^2
+        v2f dot = fx2 * qx;
+        dot = __builtin_elementwise_fma(fy2, qy, dot);
+        dot = __builtin_elementwise_fma(fz2, qz, dot);
+        const v2f dd = ((m2 * dot) + fs2) + qs;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float d = dd[u];
+            const int j = 2 * jj + u;
+            if (d < d2) {
+                if (d < d1) {
+                    d2 = d1; i2 = i1;
+                    if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = j; }
+                    else { d1 = d; i1 = j; }
+                } else { d2 = d; i2 = j; }
+            }
         }
     }
     float r0 = __fdiv_rn(1.0f, __fadd_rn(d0, 1e-8f));
@@ -315,7 +345,7 @@ extern "C" int psg_ball_query(psg_ctx *ctx, const float *xyz, int n_clouds, cons
     PSG_REQUIRE(ctx && xyz && new_xyz && out_idx, "psg_ball_query: null argument");
     PSG_REQUIRE(P > 0 && n_clouds > 0 && N > 0 && S > 0 && K > 0, "psg_ball_query: bad sizes");
     PSG_REQUIRE(N <= 8192, "psg_ball_query: N=%d exceeds the LDS-resident limit 8192", N);
-    size_t lds = (size_t)N * sizeof(float4);
+    size_t lds = (size_t)((N + 255) & ~255) * 4 * sizeof(float);
     if (lds > 48 * 1024)
         PSG_CHECK_HIP(hipFuncSetAttribute((const void *)ball_query_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds));
@@ -331,7 +361,7 @@ extern "C" int psg_three_nn(psg_ctx *ctx, const float *xyz1, int n_clouds1, cons
     PSG_REQUIRE(ctx && xyz1 && xyz2 && out_idx && out_w, "psg_three_nn: null argument");
     PSG_REQUIRE(P > 0 && n_clouds1 > 0 && N > 0 && S >= 3, "psg_three_nn: bad sizes (need S >= 3)");
     PSG_REQUIRE(S <= 8192, "psg_three_nn: S=%d exceeds the LDS-resident limit 8192", S);
-    size_t lds = (size_t)S * sizeof(float4);
+    size_t lds = (size_t)2 * ((S + 1) / 2) * sizeof(float4);
     if (lds > 48 * 1024)
         PSG_CHECK_HIP(hipFuncSetAttribute((const void *)three_nn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)lds));
