@@ -82,28 +82,38 @@ __global__ __launch_bounds__(NT) void fps_kernel(const float *__restrict__ xyz, 
     for (int i = tid; i < NT * PPT * 3; i += NT) s_xyz[i] = i < N * 3 ? src[i] : 0.0f;
     __syncthreads();
 
-    float px[PPT], py[PPT], pz[PPT], dist[PPT];
+    // points in registers as pairs: the distance update runs on the packed-fp32 pipe (two points per instruction,
+    // every lane result bit-identical to the scalar sub / mul / add sequence of sumsq3)
+    constexpr int PP = (PPT + 1) / 2;
+    v2f px[PP], py[PP], pz[PP], dist[PP];
 #pragma unroll
-    for (int q = 0; q < PPT; ++q) {
-        const int i = tid * PPT + q;
-        px[q] = s_xyz[3 * i]; py[q] = s_xyz[3 * i + 1]; pz[q] = s_xyz[3 * i + 2];
-        dist[q] = 1e10f;
+    for (int q = 0; q < PP; ++q) {
+        const int i = tid * PPT + 2 * q, i1 = (2 * q + 1 < PPT) ? i + 1 : i;
+        px[q] = v2f{s_xyz[3 * i], s_xyz[3 * i1]};
+        py[q] = v2f{s_xyz[3 * i + 1], s_xyz[3 * i1 + 1]};
+        pz[q] = v2f{s_xyz[3 * i + 2], s_xyz[3 * i1 + 2]};
+        dist[q] = v2f{1e10f, 1e10f};
     }
     int far = start[p];
     int32_t *o = out + (size_t)p * S;
     for (int s = 0; s < S; ++s) {
         if (tid == 0) o[s] = far;
         const float cx = s_xyz[3 * far], cy = s_xyz[3 * far + 1], cz = s_xyz[3 * far + 2];
+        const v2f cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
         unsigned best = 0u;
         int bq = 0;
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            float dx = __fsub_rn(px[q], cx), dy = __fsub_rn(py[q], cy), dz = __fsub_rn(pz[q], cz);
-            float d = sumsq3(dx, dy, dz);
-            dist[q] = d < dist[q] ? d : dist[q];
-            // points past N never win: their key is 0 and the real maximum is >= 0 at a lower index
-            unsigned key = (tid * PPT + q) < N ? __float_as_uint(dist[q]) : 0u;
-            if (key > best) { best = key; bq = q; }
+        for (int q = 0; q < PP; ++q) {
+            const v2f dx = px[q] - cx2, dy = py[q] - cy2, dz = pz[q] - cz2;
+            const v2f d = ((dx * dx) + (dy * dy)) + (dz * dz);
+            dist[q] = v2f{d[0] < dist[q][0] ? d[0] : dist[q][0], d[1] < dist[q][1] ? d[1] : dist[q][1]};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (2 * q + u >= PPT) break;
+                // points past N never win: their key is 0 and the real maximum is >= 0 at a lower index
+                unsigned key = (tid * PPT + 2 * q + u) < N ? __float_as_uint(dist[q][u]) : 0u;
+                if (key > best) { best = key; bq = 2 * q + u; }
+            }
         }
         const unsigned wmax = wave_max_u32(best);
         const unsigned long long hit = __ballot(best == wmax);
