@@ -94,12 +94,19 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (
             args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; PSG_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the multi-rank path on a
+    # single-GPU box (RCCL refuses two ranks on one device)
+    backend = os.environ.get("PSG_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     from pointsecguard_amd import runtime
     from pointsecguard_amd.synthetic import make_rooms, rule_labels
