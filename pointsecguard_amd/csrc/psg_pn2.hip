@@ -271,7 +271,7 @@ int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *x0, hipSt
     a.D = D; a.Np = Np; a.S = S; a.C3 = L[2].cout;
     // one in-place activation buffer: the widest of the layers' K / M extents (psg_mlp.cuh)
     const int blocks = std::max(std::max(layer_blocks(a.l1.k8, a.l1.mb), layer_blocks(a.l2.k8, a.l2.mb)), a.k8_3) + PSG_LDS_SPARE;
-    if (a.l1.mb * (P / 32) > NW || a.l2.mb * (P / 32) > NW) {
+    if (a.l1.mb * (P / 32) > NW || a.l2.mb * (P / 32) > NW || a.nb3 * (P / 32) > 2 * NW) {
         set_error("run_sa_fwd<%d>: more tiles than waves in a layer", LVL);
         return PSG_ERR_STATE;
     }

@@ -134,6 +134,16 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
         }
     }
     __syncthreads();
+    // biases of this wave's last-layer tiles: fetched now, so their latency is spent under the first two layers
+    // (every SA level has nb3 * G = 2 * NW last-layer tiles, i.e. two per wave)
+    const int jj = lane & 31, h = lane >> 5;
+    constexpr int T3 = 2;
+    float bias3[T3];
+#pragma unroll
+    for (int i = 0; i < T3; ++i) {
+        const int task = wave + i * NW;
+        bias3[i] = task < a.nb3 * G ? a.b3[(task / G) * 32 + jj] : 0.0f;
+    }
     if (!(a.diag & 8)) layer_fwd<P, NW, 1>(a.l1, buf0, wg);
     if (!(a.diag & 16)) __syncthreads();
     if (!(a.diag & 8)) layer_fwd<P, NW, 1>(a.l2, buf0, wg);
@@ -142,13 +152,14 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
 
     // last layer with the tile flipped (D[point][channel]) so the max over the 32 samples of a
     // group is an in-lane max over 16 accumulators + one exchange between lane halves.
-    const int jj = lane & 31, h = lane >> 5;
-    for (int task = wave; task < a.nb3 * G; task += NW) {
+#pragma unroll
+    for (int i = 0; i < T3; ++i) {
+        const int task = wave + i * NW;
+        if (task >= a.nb3 * G) break;
         const int nb = task / G, g = task - nb * G;
         f32x16 acc;
-        const float bias = a.b3[nb * 32 + jj];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = bias;
+        for (int r = 0; r < 16; ++r) acc[r] = bias3[i];
         acc = tile_mac<L::BLK, true>(a.w3 + (size_t)nb * a.k8_3 * 64 + lane, a.k8_3, buf0 + (g * 32 + jj) * 8 + 4 * h,
                                      acc);
         float best = -1.0f;
