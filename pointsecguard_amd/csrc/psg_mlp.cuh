@@ -289,16 +289,18 @@ __device__ __forceinline__ void layer_fwd(const FwdLayer &L, float *__restrict__
         const int task = first + i * NW;
         if (task < ntask) {
             const int mb = task / PB, pb = task - mb * PB;
-            // the accumulators (plain VGPRs: the matrix cores of gfx950 read and write them directly, no accvgpr
-            // moves around the tile) start from the bias: the loads land in the accumulator registers
+            // bias: 4 x float4 issued before the k-loop and consumed after it, so the load latency hides behind the
+            // MFMAs (initialising the accumulators from it would put that latency in front of the first MFMA)
             const float4 *bp = (const float4 *)(L.bias + mb * 32 + 4 * h);
             const float4 bq0 = bp[0], bq1 = bp[2], bq2 = bp[4], bq3 = bp[6];
             f32x16 c;
-            c[0] = bq0.x; c[1] = bq0.y; c[2] = bq0.z; c[3] = bq0.w;
-            c[4] = bq1.x; c[5] = bq1.y; c[6] = bq1.z; c[7] = bq1.w;
-            c[8] = bq2.x; c[9] = bq2.y; c[10] = bq2.z; c[11] = bq2.w;
-            c[12] = bq3.x; c[13] = bq3.y; c[14] = bq3.z; c[15] = bq3.w;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = 0.0f;
             c = tile_mac<BLK, false>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, buf + (pb * 32 + j) * 8 + 4 * h, c);
+            c[0] += bq0.x; c[1] += bq0.y; c[2] += bq0.z; c[3] += bq0.w;
+            c[4] += bq1.x; c[5] += bq1.y; c[6] += bq1.z; c[7] += bq1.w;
+            c[8] += bq2.x; c[9] += bq2.y; c[10] += bq2.z; c[11] += bq2.w;
+            c[12] += bq3.x; c[13] += bq3.y; c[14] += bq3.z; c[15] += bq3.w;
             if (L.relu) {
                 unsigned m = 0;
 #pragma unroll
