@@ -58,6 +58,7 @@ def nu_attack(atk, images, labels, mask, target, neighbour, targeted_variant=Fal
     tsign = float(atk._targeted)
     use_target = targeted_variant and target is not None
     planned_until = 0
+    n_mask = int(mask_b.sum().item()) if mask_b is not None else 0   # once: the loop reads back ONE tensor per step
     out = torch.empty_like(images)
 
     def snapshot():
@@ -89,7 +90,8 @@ def nu_attack(atk, images, labels, mask, target, neighbour, targeted_variant=Fal
         # ---- control flow of the reference (one read-back per step, like its .item() calls)
         correct = pred.eq(labels_d)
         if targeted_variant:
-            tgt_hits = (pred.eq(int(target)) if use_target else correct)[:, mask_b].sum()
+            # masked count as a logical AND (boolean-mask indexing would synchronise and launch a nonzero every step)
+            tgt_hits = ((pred.eq(int(target)) if use_target else correct) & mask_b.unsqueeze(0)).sum()
             stats = torch.stack([correct.sum().float(), tgt_hits.float(), scal[0], scal[1], scal[2]]).cpu()
         else:
             stats = torch.stack([correct.sum().float(), scal[0], scal[0], scal[1], scal[2]]).cpu()
@@ -103,7 +105,7 @@ def nu_attack(atk, images, labels, mask, target, neighbour, targeted_variant=Fal
             if n_correct / 4096 < 1 / 13:          # nontarget.py:87,95-96
                 return snapshot()
             continue
-        target_acc = n_tgt / float(mask_b.sum().item())
+        target_acc = n_tgt / float(n_mask)
         if (not use_target and target_acc < 1 / 13) or (use_target and target_acc > 0.9):   # target.py:116-121
             return snapshot()
         if step > 0 and step % 50 == 0:             # target.py:123-125: halve lr, NEW optimiser (moments reset)
@@ -112,7 +114,7 @@ def nu_attack(atk, images, labels, mask, target, neighbour, targeted_variant=Fal
             m.zero_()
             v.zero_()
         if step > 10 and step % 10 == 0 and cost >= prev_cost[step - 10]:   # target.py:127-132
-            noise = torch.empty(B, 3, int(mask_b.sum().item()), device=dev, dtype=torch.float32).uniform_(0, 1)
+            noise = torch.empty(B, 3, n_mask, device=dev, dtype=torch.float32).uniform_(0, 1)
             col = x0[:, :, 3:6].transpose(1, 2)      # view [B,3,N]
             col[:, :, mask_b] = col[:, :, mask_b] + noise
             x0.clamp_(min=0, max=1)                 # ALL channels, like the reference
