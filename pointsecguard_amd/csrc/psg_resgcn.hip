@@ -18,6 +18,7 @@
 //     the broadcast fusion term of the first prediction layer becomes a per-room bias (forward) and a
 //     column sum + mat-vec (backward).
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "psg_common.h"
@@ -440,6 +441,13 @@ struct psg_gcn_ws {
     float *xyz;                // [B*N][3]
     bool have_fwd = false;
     bool fixed_graphs = false;  // psg_gcn_set_graphs: forward uses the supplied neighbour tables
+    // hipGraph of one interior PGD iteration (forward, CE, backward, step): ~300 short launches replayed as one
+    // graph launch; valid for (model, eps, alpha) below, rebuilt when they change
+    int32_t *nb_labels;        // [B*N] the attack's labels, copied so that the captured kernels' arguments never change
+    hipGraphExec_t nb_exec = nullptr;
+    const void *nb_model = nullptr;
+    float nb_eps = 0.f, nb_alpha = 0.f;
+    bool nb_fixed = false;
 };
 
 namespace {
@@ -633,6 +641,7 @@ extern "C" int psg_gcn_ws_create(psg_ctx *ctx, int batch, int n_point, int n_blo
         ws->ori = (float *)take(R * 3 * 4);
         ws->dx0 = (float *)take(R * 9 * 4);
         ws->xyz = (float *)take(R * 3 * 4);
+        ws->nb_labels = (int32_t *)take(R * 4);
         if (!pass) {
             ws->bytes = (off + 255) & ~(size_t)255;
             hipError_t e = hipMalloc(&ws->arena, ws->bytes);
@@ -650,6 +659,7 @@ extern "C" int psg_gcn_ws_create(psg_ctx *ctx, int batch, int n_point, int n_blo
 extern "C" int psg_gcn_ws_destroy(psg_gcn_ws *ws)
 {
     if (!ws) return PSG_OK;
+    if (ws->nb_exec) (void)hipGraphExecDestroy(ws->nb_exec);
     if (ws->arena) (void)hipFree(ws->arena);
     delete ws;
     return PSG_OK;
@@ -829,12 +839,50 @@ extern "C" int psg_gcn_nb_attack(psg_gcn_model *m, psg_gcn_ws *ws, const float *
     if ((rc = psg_to_point_major(images, B, 9, N, ws->x0, st))) return rc;
     hipLaunchKernelGGL(extract_color3_kernel, dim3(ceil_div((int)(R * 3), 256)), dim3(256), 0, st, ws->x0, ws->ori, R);
     PSG_LAUNCH_CHECK();
-    for (int it = 0; it < iters; ++it) {
-        if ((rc = psg_gcn_forward(m, ws, ws->x0, ws->logits, st))) return rc;
-        if ((rc = psg_ce_logp_grad(ws->logits, labels, 0, (int)R, (int)R, NCLS, 1.0f / (float)R, ws->dlogits, nullptr, st)))
-            return rc;
-        if ((rc = psg_gcn_backward(m, ws, ws->dlogits, ws->dx0, st))) return rc;
-        if ((rc = psg_pgd_step(ws->x0, ws->dx0, ws->ori, nullptr, B, N, alpha, eps, 1.0f, it == iters - 1, st))) return rc;
+    PSG_CHECK_HIP(hipMemcpyAsync(ws->nb_labels, labels, R * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    auto iteration = [&](bool last) -> int {
+        int r;
+        if ((r = psg_gcn_forward(m, ws, ws->x0, ws->logits, st))) return r;
+        if ((r = psg_ce_logp_grad(ws->logits, ws->nb_labels, 0, (int)R, (int)R, NCLS, 1.0f / (float)R, ws->dlogits, nullptr, st)))
+            return r;
+        if ((r = psg_gcn_backward(m, ws, ws->dlogits, ws->dx0, st))) return r;
+        return psg_pgd_step(ws->x0, ws->dx0, ws->ori, nullptr, B, N, alpha, eps, 1.0f, last ? 1 : 0, st);
+    };
+    int it = 0;
+    // The first iteration runs eagerly (it also sets kernel attributes outside any capture).  The interior
+    // iterations 1 .. iters-2 enqueue exactly the same ~300 short launches with the same arguments: they are captured
+    // once into a hipGraph (kept in the workspace) and replayed, which removes most of the per-launch cost that
+    // bounds a single-room ResGCN iteration.  Capture is not possible on the legacy default stream; the loop then
+    // simply stays eager.  The last iteration differs (it returns the un-projected step) and is eager again.
+    if ((rc = iteration(iters == 1))) return rc;
+    it = 1;
+    static const bool use_graph = !(getenv("PSG_GCN_NO_GRAPH") && atoi(getenv("PSG_GCN_NO_GRAPH")));
+    if (use_graph && iters - 1 - it >= 2) {
+        if (ws->nb_exec && (ws->nb_model != (const void *)m || ws->nb_eps != eps || ws->nb_alpha != alpha ||
+                            ws->nb_fixed != ws->fixed_graphs)) {
+            PSG_CHECK_HIP(hipStreamSynchronize(st));
+            (void)hipGraphExecDestroy(ws->nb_exec);
+            ws->nb_exec = nullptr;
+        }
+        if (!ws->nb_exec) {
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int crc = iteration(false);
+                hipGraph_t graph = nullptr;
+                const hipError_t e = hipStreamEndCapture(st, &graph);
+                if (crc == PSG_OK && e == hipSuccess && graph) {
+                    if (hipGraphInstantiate(&ws->nb_exec, graph, nullptr, nullptr, 0) != hipSuccess) ws->nb_exec = nullptr;
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+                if (crc != PSG_OK) return crc;
+                ws->nb_model = m; ws->nb_eps = eps; ws->nb_alpha = alpha; ws->nb_fixed = ws->fixed_graphs;
+            }
+            (void)hipGetLastError();   // a refused capture (legacy stream) is not an error of this call
+        }
+        if (ws->nb_exec) {
+            for (; it < iters - 1; ++it) PSG_CHECK_HIP(hipGraphLaunch(ws->nb_exec, st));
+        }
     }
+    for (; it < iters; ++it)
+        if ((rc = iteration(it == iters - 1))) return rc;
     return psg_to_channel_major(ws->x0, B, 9, N, adv_out, st);
 }

@@ -137,6 +137,35 @@ def test_fused_nb_attack_vs_oracle(gcn, gcn_oracle, golden_gcn_nb):
     assert np.abs(steps).max() <= 4 and (steps != 0).mean() > 0.5   # whole sign steps (+-+- can cancel)
 
 
+def test_graph_replayed_attack_matches_eager(gcn, golden_gcn_nb):
+    """On a non-default stream the interior PGD iterations are replayed from a captured hipGraph; on the default
+    stream (where capture is refused) every iteration is launched eagerly.  Same kernels, same arguments: the two
+    must agree up to the last-bit noise of the backward's fp32 atomics (a few flipped signs of ~0 gradients)."""
+    model, ws = gcn
+    g = golden_gcn_nb
+    images = dev(np.ascontiguousarray(g["rooms"].transpose(0, 2, 1)))
+    labels = dev(g["labels"].astype(np.int32))
+    eps, alpha, iters = float(g["eps"]), float(g["alpha"]), 6
+    eager = ws.nb_attack(model, images, labels, eps, alpha, iters).clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    outs = []
+    for _ in range(2):                       # second call re-uses the cached graph
+        with torch.cuda.stream(side):
+            outs.append(ws.nb_attack(model, images, labels, eps, alpha, iters).clone())
+        side.synchronize()
+    for o in outs:
+        assert torch.equal(o[:, :3], images[:, :3]) and torch.equal(o[:, 6:], images[:, 6:])
+        assert float((o[:, 3:6] - images[:, 3:6]).abs().max()) <= iters * alpha + 1e-6
+        same = (o[:, 3:6] == eager[:, 3:6]).float().mean().item()
+        assert same >= 0.98, same
+    # different attack parameters invalidate the cached graph
+    with torch.cuda.stream(side):
+        o2 = ws.nb_attack(model, images, labels, eps, alpha * 0.5, iters).clone()
+    side.synchronize()
+    assert float((o2[:, 3:6] - images[:, 3:6]).abs().max()) <= iters * alpha * 0.5 + 1e-6
+
+
 def test_resgcn_python_api(gcn_weights_sd, golden_gcn_room, golden_gcn_nb):
     """Drop-in surface: DenseDeepGCN(opt) loads the reference state_dict, forward/backward through autograd,
     torchattacks.NB_attack / tar_NB_attack with the reference's call signatures."""
