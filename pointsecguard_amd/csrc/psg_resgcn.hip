@@ -208,28 +208,59 @@ __global__ __launch_bounds__(KS_WAVES * 64) void knn_select_kernel(const float *
         if (c < KK) { lo = mid; c_lo = c; }
         else { hi = mid; cnt = c; }
     }
-    // compact into LDS in index order: every key below hi, and keys equal to hi while there is room (only when more
-    // than M keys tie at hi does that cut anything: then hi = lo + 1, c_lo < KK of them are below, and the first
-    // M - c_lo of the tied ones in index order are exactly the lowest-index ones)
+    // compact the selected keys into LDS as composite keys (distance << 12 | index)
     for (unsigned t = lane; t < M; t += 64) cand[t] = ~0ull;
     wave_lds_fence();
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const unsigned thr = hi;
     const bool cut = cnt > M;          // more than M keys <= thr: thr = lo + 1 and the keys equal to thr are rationed
-    unsigned base_a = 0, base_b = 0;   // class a: always taken (slots from 0); class b: tied keys (slots from c_lo)
+    if (!cut) {
+        // usual case: everything <= thr is taken and the order in LDS is irrelevant (the sort follows).  Every lane
+        // counts its own hits, one DPP scan gives it a private range of slots, and it fills that range by itself.
+        unsigned mine = 0;
 #pragma unroll
-    for (int q = 0; q < KS_PER_LANE; ++q) {
-        const bool pa = cut ? key[q] < thr : key[q] <= thr;
-        const bool pb = cut && key[q] == thr;
-        const unsigned long long ma = __ballot(pa), mb = __ballot(pb);
-        const unsigned long long ck = ((unsigned long long)key[q] << 12) | (unsigned)(q * 64 + lane);
-        if (pa) cand[base_a + __popcll(ma & lt_mask)] = ck;
-        if (pb) {
-            const unsigned slot = c_lo + base_b + __popcll(mb & lt_mask);
-            if (slot < M) cand[slot] = ck;
+        for (int q = 0; q < KS_PER_LANE; ++q) mine += key[q] <= thr ? 1u : 0u;
+        unsigned incl = mine;
+        incl += dpp_get<0x111, 0xF>(incl);   // row_shr:1 (lanes shifted in from outside the row read 0)
+        incl += dpp_get<0x112, 0xF>(incl);   // row_shr:2
+        incl += dpp_get<0x114, 0xF>(incl);   // row_shr:4
+        incl += dpp_get<0x118, 0xF>(incl);   // row_shr:8: inclusive scan inside each row of 16 lanes
+        incl += dpp_get<0x142, 0xA>(incl);   // row_bcast15: rows 1, 3 += total of the row before
+        incl += dpp_get<0x143, 0xC>(incl);   // row_bcast31: rows 2, 3 += total of rows 0..1
+        unsigned slot = incl - mine;
+        uint2 *cand2 = (uint2 *)cand;
+#pragma unroll
+        for (int q = 0; q < KS_PER_LANE; ++q) {
+            if (key[q] <= thr) {
+                // composite key built right here (volatile asm: left to itself the compiler pre-computes all 64
+                // composite keys up front, which costs 128 VGPRs and half the occupancy)
+                unsigned lo32, hi32;
+                asm volatile("v_lshl_or_b32 %0, %2, 12, %3\n\tv_or_b32 %0, %4, %0\n\tv_lshrrev_b32 %1, 20, %2"
+                             : "=&v"(lo32), "=&v"(hi32) : "v"(key[q]), "v"(lane), "n"(q * 64));
+                cand2[slot] = make_uint2(lo32, hi32);
+                ++slot;
+            }
         }
-        base_a += __popcll(ma);
-        base_b += __popcll(mb);
+    } else {
+        // tie cut (rare: more than M - KK equal distances): index order matters, so this path walks the row in index
+        // order with ballots; it re-reads the distances instead of indexing the register copy (a rolled loop over
+        // key[] would force the whole array into scratch, an unrolled one doubles the kernel's registers)
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        unsigned base_a = 0, base_b = 0;   // class a: keys below thr (slots from 0); class b: tied keys (slots from c_lo)
+#pragma unroll 1
+        for (int q = 0; q < KS_PER_LANE; ++q) {
+            const int i = q * 64 + lane;
+            const unsigned kq = i < N ? key_of(drow[i]) : 0xFFFFFFFFu;
+            const bool pa = kq < thr, pb = kq == thr;
+            const unsigned long long ma = __ballot(pa), mb = __ballot(pb);
+            const unsigned long long ck = ((unsigned long long)kq << 12) | (unsigned)i;
+            if (pa) cand[base_a + __popcll(ma & lt_mask)] = ck;
+            if (pb) {
+                const unsigned s2 = c_lo + base_b + __popcll(mb & lt_mask);
+                if (s2 < M) cand[s2] = ck;
+            }
+            base_a += __popcll(ma);
+            base_b += __popcll(mb);
+        }
     }
     wave_lds_fence();
     for (unsigned size = 2; size <= M; size <<= 1) {
