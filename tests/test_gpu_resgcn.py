@@ -40,6 +40,20 @@ def test_knn_graphs_on_fixture_features(gcn, golden_gcn_room):
     assert (got == g["nbr0"]).mean() >= 0.9998
 
 
+def test_knn_with_massive_ties(gcn):
+    """More equal distances than the selection's sort window: 700 of 1024 points share one feature vector, so for
+    those queries > 512 candidates tie at distance 0 and the lowest indices must win (oracle: stable order)."""
+    from oracle import resgcn
+    _, ws = gcn
+    rng = np.random.default_rng(3)
+    f = rng.standard_normal((1024, 64)).astype(np.float32)
+    dup = rng.permutation(1024)[:700]
+    f[dup] = f[dup[0]]
+    for d in (1, 4, 27):
+        got = ws.knn(dev(f[None]), d)[0].cpu().numpy()
+        assert np.array_equal(got, resgcn.knn_dilated(f, d)), d
+
+
 def test_forward_dynamic_graphs(gcn, golden_gcn_room):
     """Free-running forward: every dynamic graph must be EXACTLY the oracle's kNN of the features the GPU itself
     produced for the previous block (kernel correctness in situ, dilation 1..4), and stay close to the
