@@ -38,11 +38,13 @@ struct GemmArgs {
     int accumulate;       // out += result
 };
 
-template <int WM, int WN, int EPI, bool ASC_K>
+// TQ x TI = 32-row x 32-channel MFMA tiles per wave (2 x 2 by default; 1 x 1 gives 64 x 64 workgroup tiles, i.e. four
+// times as many workgroups, for the per-vertex GEMMs of a single 4096-point room that would otherwise occupy 16-32 CUs)
+template <int WM, int WN, int EPI, bool ASC_K, int TQ = 2, int TI = 2>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
 {
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    constexpr int BR = 64 * WM, BN = 64 * WN;
+    constexpr int BR = 32 * TQ * WM, BN = 32 * TI * WN;
     constexpr int BLK_R = BR * 8 + 8, BLK_N = BN * 8 + 8;  // floats per 8-k block (+8: bank de-phasing)
     __shared__ float s_in[4 * BLK_R];
     __shared__ float s_w[4 * BLK_N];
@@ -51,11 +53,11 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
     const int wr = wave / WN, wc = wave % WN;
     const int row0 = blockIdx.x * BR, col0 = blockIdx.y * BN;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][TQ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < TQ; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.0f;
 
@@ -130,26 +132,26 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
         __syncthreads();
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) {
-            float4 wa[2], xb[2];
+            float4 wa[TI], xb[TQ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) wa[i] = *(const float4 *)(s_w + k8 * BLK_N + (wc * 64 + i * 32 + j) * 8 + 4 * h);
+            for (int i = 0; i < TI; ++i) wa[i] = *(const float4 *)(s_w + k8 * BLK_N + (wc * 32 * TI + i * 32 + j) * 8 + 4 * h);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) xb[q] = *(const float4 *)(s_in + k8 * BLK_R + (wr * 64 + q * 32 + j) * 8 + 4 * h);
+            for (int q = 0; q < TQ; ++q) xb[q] = *(const float4 *)(s_in + k8 * BLK_R + (wr * 32 * TQ + q * 32 + j) * 8 + 4 * h);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) acc[i][q] = mfma4<false>(wa[i], xb[q], acc[i][q]);
+                for (int q = 0; q < TQ; ++q) acc[i][q] = mfma4<false>(wa[i], xb[q], acc[i][q]);
         }
         __syncthreads();
     }
 
     // ---- epilogue: lane (j,h) of tile (i,q) holds channels cbase + 8g + 4h + (0..3) of row rbase + j
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int row = row0 + wr * 64 + q * 32 + j;
+    for (int q = 0; q < TQ; ++q) {
+        const int row = row0 + wr * 32 * TQ + q * 32 + j;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int cbase = col0 + wc * 64 + i * 32;
+        for (int i = 0; i < TI; ++i) {
+            const int cbase = col0 + wc * 32 * TI + i * 32;
             unsigned mbits = 0;
             unsigned min_bits = 0xFFFFFFFFu;
             if (a.mask_in && row < a.rows && cbase < a.M) min_bits = a.mask_in[(size_t)row * ((a.M + 31) >> 5) + (cbase >> 5)];

@@ -37,6 +37,13 @@ int launch_gemm(const GemmArgs &a, hipStream_t st)
 {
     constexpr int BR = 64 * WM, BN = 64 * WN;
     dim3 grid(ceil_div(a.rows, BR), ceil_div(a.M, BN));
+    if (!ASC && (size_t)grid.x * grid.y < 128) {
+        // too few 128-wide tiles to fill the GPU (per-vertex GEMMs of one room): 64 x 64 tiles, one MFMA tile per wave
+        dim3 small(ceil_div(a.rows, 64), ceil_div(a.M, 64));
+        hipLaunchKernelGGL((gemm_rows_kernel<2, 2, EPI, ASC, 1, 1>), small, dim3(256), 0, st, a);
+        PSG_LAUNCH_CHECK();
+        return PSG_OK;
+    }
     hipLaunchKernelGGL((gemm_rows_kernel<WM, WN, EPI, ASC>), grid, dim3(256), 0, st, a);
     PSG_LAUNCH_CHECK();
     return PSG_OK;
