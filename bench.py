@@ -82,7 +82,7 @@ def main():
                     help="consecutive steps (batches of 8 rooms) fused into one device batch per launch; rooms are "
                          "independent, so results are identical and small kernels get more workgroups")
     ap.add_argument("--nu-steps", type=int, default=100, help="tarnu workload: optimiser step cap per attack")
-    ap.add_argument("--gcn-concurrency", type=int, default=2, help="resgcn workload: attacks in flight (streams)")
+    ap.add_argument("--gcn-concurrency", type=int, default=3, help="resgcn workload: attacks in flight (streams)")
     ap.add_argument("--concurrency", type=int, default=2,
                     help="device batches in flight per GPU (one HIP stream + workspace each)")
     args = ap.parse_args()
