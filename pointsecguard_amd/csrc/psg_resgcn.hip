@@ -148,6 +148,57 @@ __device__ __forceinline__ unsigned key_of(float f)
 }
 __device__ __forceinline__ float dist_of(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
 
+// Bitonic sort of M = 64 * SL composite keys held SL per lane (element e = lane * SL + slot): strides below SL
+// are compare-exchanges between a lane's own registers, strides of SL and more exchange whole registers with the
+// partner lane (two 32-bit cross-lane permutes per key); nothing goes through LDS memory and there is no fence per
+// step (the LDS version spent 23 us of the 60 us selection here).
+template <int SL, int STRIDE>
+__device__ __forceinline__ void sort_intra(unsigned long long (&v)[SL], int lane, unsigned size)
+{
+    if constexpr (STRIDE >= 1 && STRIDE < SL) {
+#pragma unroll
+        for (int s0 = 0; s0 < SL; ++s0) {
+            if ((s0 & STRIDE) == 0) {
+                const unsigned e = (unsigned)lane * SL + s0;
+                const bool up = (e & size) == 0;
+                const unsigned long long a = v[s0], b = v[s0 | STRIDE];
+                const bool sw = (a > b) == up;
+                v[s0] = sw ? b : a;
+                v[s0 | STRIDE] = sw ? a : b;
+            }
+        }
+    }
+}
+
+template <int SL>
+__device__ __forceinline__ void wave_sort_keys(unsigned long long *cand, int lane)
+{
+    unsigned long long v[SL];
+#pragma unroll
+    for (int s0 = 0; s0 < SL; ++s0) v[s0] = cand[lane * SL + s0];
+    constexpr unsigned M = 64u * SL;
+    for (unsigned size = 2; size <= M; size <<= 1) {
+        for (unsigned stride = size >> 1; stride >= (unsigned)SL; stride >>= 1) {   // partner lane = lane ^ (stride / SL)
+            const int ls = (int)(stride / SL);
+            const bool lower = (lane & ls) == 0;
+#pragma unroll
+            for (int s0 = 0; s0 < SL; ++s0) {
+                const unsigned e = (unsigned)lane * SL + s0;
+                const bool up = (e & size) == 0;
+                const unsigned long long o =
+                    ((unsigned long long)__shfl_xor((unsigned)(v[s0] >> 32), ls) << 32) | __shfl_xor((unsigned)v[s0], ls);
+                const bool keep_min = lower == up;
+                v[s0] = keep_min ? (o < v[s0] ? o : v[s0]) : (o > v[s0] ? o : v[s0]);
+            }
+        }
+        if (size > 4) sort_intra<SL, 4>(v, lane, size);
+        if (size > 2) sort_intra<SL, 2>(v, lane, size);
+        sort_intra<SL, 1>(v, lane, size);
+    }
+#pragma unroll
+    for (int s0 = 0; s0 < SL; ++s0) cand[lane * SL + s0] = v[s0];
+}
+
 __global__ __launch_bounds__(KS_WAVES * 64) void knn_select_kernel(const float *__restrict__ dist, int N, size_t rows,
                                                                   int k, int d, int32_t *__restrict__ out)
 {
@@ -270,18 +321,13 @@ __global__ __launch_bounds__(KS_WAVES * 64) void knn_select_kernel(const float *
         }
     }
     wave_lds_fence();
-    for (unsigned size = 2; size <= M; size <<= 1) {
-        for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
-            for (unsigned t = lane; t < M / 2; t += 64) {
-                const unsigned lo_i = ((t / stride) * stride * 2) + (t % stride);
-                const unsigned hi_i = lo_i + stride;
-                const bool up = ((lo_i & size) == 0);
-                const unsigned long long a = cand[lo_i], bb = cand[hi_i];
-                if ((a > bb) == up) { cand[lo_i] = bb; cand[hi_i] = a; }
-            }
-            wave_lds_fence();
-        }
+    switch (M) {
+    case 64: wave_sort_keys<1>(cand, lane); break;
+    case 128: wave_sort_keys<2>(cand, lane); break;
+    case 256: wave_sort_keys<4>(cand, lane); break;
+    default: wave_sort_keys<8>(cand, lane); break;
     }
+    wave_lds_fence();
     if (lane < k) out[row * k + lane] = (int32_t)(cand[(size_t)lane * d] & 0xFFFull);
 }
 
