@@ -166,12 +166,13 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
     """The reference's evaluation loop (NB_nontarget_test_semseg.py:126-291) with the per-point work on the GPU.
 
     classifier: an eval-mode `get_model` on the GPU; make_attack(classifier) -> a torchattacks attack object (e.g.
-    lambda m: torchattacks.NB_attack(m, eps=0.1, alpha=0.05, iters=10), :169); dataset: ScannetDatasetWholeScene.
+    lambda m: torchattacks.NB_attack(m, eps=0.1, alpha=0.05, iters=10), :169), or None for the clean evaluation of
+    PointNet/test_semseg.py (the "adversarial" columns then repeat the clean ones); dataset: ScannetDatasetWholeScene.
     Scenes are dealt round-robin to ranks; the int64 counters are summed over ranks at the end.  Returns a dict with
     the totals the reference prints (:272-291) and per-scene mIoUs; TSV rows go to `log_path` (rank-suffixed when
     world > 1) in the reference's format."""
     dev = next(classifier.parameters()).device
-    attack = make_attack(classifier)
+    attack = make_attack(classifier) if make_attack is not None else None
     n_pt = dataset.block_points
     total = torch.zeros(2, 3, NUM_CLASSES, dtype=torch.int64, device=dev)   # [clean | adversarial][seen, correct, union]
     scene_rows = []
@@ -199,9 +200,12 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
                 smpw = torch.from_numpy(scene_smpw[lo:hi].astype(np.float32)).to(dev)
                 seg_pred, _ = classifier(torch_data)
                 seg_pred = seg_pred.detach().contiguous()
-                adv_images = attack(torch_data, gt_np)
-                adv_seg_pred, _ = classifier(adv_images)
-                adv_seg_pred = adv_seg_pred.detach().contiguous()
+                if attack is not None:
+                    adv_images = attack(torch_data, gt_np)
+                    adv_seg_pred, _ = classifier(adv_images)
+                    adv_seg_pred = adv_seg_pred.detach().contiguous()
+                else:
+                    adv_images, adv_seg_pred = torch_data, seg_pred
                 add_vote(pool, idx, seg_pred, smpw)
                 add_vote(adv_pool, idx, adv_seg_pred, smpw)
                 c_clean, _ = runtime.seg_stats(seg_pred, gt)

@@ -109,3 +109,9 @@ def test_whole_scene_loop_end_to_end(tmp_path, weights_sd):
     assert (c[0][1] <= c[0][0]).all() and (c[0][2] >= c[0][0]).all()
     assert len(results[0]["scenes"]) == 2 and 0.0 <= results[0]["miou"] <= 1.0
     assert any(l.startswith("eval whole scene point accuracy") for l in lines)
+    # clean evaluation (test_semseg.py): no attack object, adversarial columns repeat the clean ones
+    np.random.seed(3)
+    torch.manual_seed(3)
+    clean = harness.evaluate_whole_scene(net, ds, None, batch_size=4, log=lambda *_: None)
+    assert np.array_equal(clean["counters"][0], clean["counters"][1])
+    assert np.array_equal(clean["counters"][0][0], c[0][0])
