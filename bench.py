@@ -71,14 +71,14 @@ def cpu_baseline(sd, rooms, labels, starts, iters_sample):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=6)
     ap.add_argument("--workload", default="pointnet2", choices=["pointnet2", "resgcn", "tarnu"],
                     help="pointnet2 = BASELINE configs[1] (headline metric); resgcn = configs[3] (secondary, ResGCN-28); "
                          "tarnu = configs[2] (secondary, targeted NU attack, batch 32)")
-    ap.add_argument("--coalesce", type=int, default=4,
+    ap.add_argument("--coalesce", type=int, default=8,
                     help="consecutive steps (batches of 8 rooms) fused into one device batch per launch; rooms are "
                          "independent, so results are identical and small kernels get more workgroups")
     ap.add_argument("--nu-steps", type=int, default=100, help="tarnu workload: optimiser step cap per attack")
@@ -255,16 +255,17 @@ PMC_SYMBOL = {"fp1_head_fwd": "void psg::fp_fwd_kernel<32, 4>(psg::FpFwdArgs)",
 
 def pmc_traffic(tag, device_batch):
     """HBM bytes per launch of kernel `tag` from the newest committed PMC summary (profiles/*_pmc_traffic.json,
-    written by tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes of this bench at a 32-room device
+    written by tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes of this bench at the default device
     batch, gfx950 read-doubling correction applied).  PMC cannot be sampled from inside the process, so the
     figure is the committed one, and only reported when the device batch matches."""
     import glob
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
-    if not files or tag not in PMC_SYMBOL or device_batch != 32:
+    if not files or tag not in PMC_SYMBOL:
         return None, None
     with open(files[-1]) as fh:
-        row = json.load(fh).get(PMC_SYMBOL[tag])
-    if not row:
+        table = json.load(fh)
+    row = table.get(PMC_SYMBOL[tag])
+    if not row or table.get("_meta", {}).get("device_batch_rooms", 32) != device_batch:
         return None, None
     return row["hbm_bytes_per_launch"], "profiles/" + os.path.basename(files[-1])
 

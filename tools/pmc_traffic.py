@@ -1,6 +1,6 @@
 """Summarise rocprofv3 PMC passes into per-kernel HBM traffic per launch.
 
-usage: pmc_traffic.py FETCH_DIR WRITE_DIR OUT.json
+usage: pmc_traffic.py FETCH_DIR WRITE_DIR OUT.json [DEVICE_BATCH_ROOMS]
 FETCH_DIR / WRITE_DIR hold the counter_collection.csv of `rocprofv3 --pmc FETCH_SIZE` and
 `rocprofv3 --pmc WRITE_SIZE` runs of the same bench.py command (separate passes: the two counters do not
 fit the TCC slots together).  Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
@@ -40,9 +40,11 @@ def main():
             "write_bytes": wk * 1024.0,
             "hbm_bytes_per_launch": 2.0 * fk * 1024.0 + wk * 1024.0,
         }
+    out["_meta"] = {"device_batch_rooms": int(sys.argv[4]) if len(sys.argv) > 4 else 32}
     with open(sys.argv[3], "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
-    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:25]:
+    rows = {k: v for k, v in out.items() if k != "_meta"}
+    for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:25]:
         print("%10.2f MB/launch  (n=%d)  %s" % (v["hbm_bytes_per_launch"] / 1e6, v["launches_fetch_pass"], k[:110]))
 
 
