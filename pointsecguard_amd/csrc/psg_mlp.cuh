@@ -325,7 +325,25 @@ __device__ __forceinline__ void layer_fwd(const FwdLayer &L, float *__restrict__
     }
 }
 
+// accumulate a tile into LDS: buf[tile] += v  (same addressing as store_tile)
+template <int P>
+__device__ __forceinline__ void add_tile(float *__restrict__ out, int mb, int pcol, int h, const f32x16 &v)
+{
+    float *o = out + (size_t)(mb * 4) * Lds<P>::BLK + pcol * 8 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float4 c = *(float4 *)(o + (size_t)g * Lds<P>::BLK);
+        c.x += v[4 * g]; c.y += v[4 * g + 1]; c.z += v[4 * g + 2]; c.w += v[4 * g + 3];
+        *(float4 *)(o + (size_t)g * Lds<P>::BLK) = c;
+    }
+}
+
 // Backward (input-gradient) layer: buf[m][p] <- mask * (W^T buf[:, p]).
+//
+// Ragged layers (10 tiles on 8 waves, 5 on 4, 9 on 8 ...) would leave most waves idle in their last round: the
+// `rem` left-over tiles are instead split along K over groups of gsz = min(NW / rem, 4) waves (every wave gets a
+// K / gsz slice of one left-over tile), and the partial tiles are summed in LDS in slice order, one barrier per
+// slice (a fixed order: the result stays bit-reproducible; LDS float atomics would not be).
 template <int P, int NW, int MAXT>
 __device__ __forceinline__ void layer_bwd(const BwdLayer &L, float *__restrict__ buf, size_t wg_linear)
 {
@@ -335,30 +353,66 @@ __device__ __forceinline__ void layer_bwd(const BwdLayer &L, float *__restrict__
     const int j = lane & 31, h = lane >> 5;
     const int ntask = L.mb * PB;
     const int first = (wave + (int)(wg_linear & (NW - 1))) & (NW - 1);
+    // split of the last, partial round
+    const int full = ntask / NW, rem = ntask - full * NW;
+    int per = 1, gsz = 1;                       // waves per left-over tile, K slices actually used
+    bool split = false;
+    if (MAXT > 1 && rem > 0 && (NW % rem) == 0) {
+        per = NW / rem;
+        gsz = per < 4 ? per : 4;
+        split = gsz > 1 && (L.k8 % (4 * gsz)) == 0;
+    }
     f32x16 acc[MAXT];
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
-        const int task = first + i * NW;
-        if (task < ntask) {
+        int task = first + i * NW, k8_lo = 0, k8_n = L.k8;
+        bool active = task < ntask;
+        if (split && i == full) {               // this wave's share of the left-over tiles
+            const int slice = first % per;
+            task = full * NW + first / per;
+            active = slice < gsz;
+            k8_n = L.k8 / gsz;
+            k8_lo = slice * k8_n;
+        }
+        if (active) {
             const int mb = task / PB, pb = task - mb * PB;
             unsigned m = 0xFFFFu;
             if (L.mask) m = L.mask[(wg_linear * ntask + task) * 64 + lane];
             f32x16 c;
 #pragma unroll
             for (int r = 0; r < 16; ++r) c[r] = 0.0f;
-            c = tile_mac<BLK, false>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, buf + (pb * 32 + j) * 8 + 4 * h, c);
+            c = tile_mac<BLK, false>(L.w + ((size_t)mb * L.k8 + k8_lo) * 64 + lane, k8_n,
+                                     buf + (size_t)k8_lo * BLK + (pb * 32 + j) * 8 + 4 * h, c);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c[r] = ((m >> r) & 1u) ? c[r] : 0.0f;
+            for (int r = 0; r < 16; ++r) c[r] = ((m >> r) & 1u) ? c[r] : 0.0f;   // mask . (a + b) = mask . a + mask . b
             acc[i] = c;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
-        const int task = first + i * NW;
-        if (task < ntask) {
+        int task = first + i * NW;
+        bool active = task < ntask;
+        if (split && i == full) {
+            task = full * NW + first / per;
+            active = (first % per) == 0;        // slice 0 stores, the other slices add below
+        }
+        if (active) {
             const int mb = task / PB, pb = task - mb * PB;
             store_tile<P>(buf, mb, pb * 32 + j, h, acc[i]);
+        }
+    }
+    if (split) {
+        for (int sl = 1; sl < gsz; ++sl) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MAXT; ++i) {
+                if (i == full && (first % per) == sl) {
+                    const int task = full * NW + first / per;
+                    const int mb = task / PB, pb = task - mb * PB;
+                    add_tile<P>(buf, mb, pb * 32 + j, h, acc[i]);
+                }
+            }
         }
     }
 }
