@@ -209,3 +209,29 @@ def test_fps_many_problems_path():
     for p in (0, 257, 519):
         assert np.array_equal(idx[p], pn2.fps(xyz[p % 4], S, int(start[p])).astype(np.int32)), p
     assert all(len(set(row.tolist())) == S for row in idx[::37])
+
+
+def test_concurrent_attacks_on_two_streams_match_serial(gpu_model, full_batch):
+    """bench.py keeps two attacks in flight on separate HIP streams with separate workspaces: the overlapped runs must
+    return exactly what the same attacks return one after the other (the kernels share the model's weights only)."""
+    from pointsecguard_amd import runtime
+    rooms, labels, starts = full_batch
+    iters = 6
+    imgs = [dev(rooms[:4].transpose(0, 2, 1)), dev(rooms[4:].transpose(0, 2, 1))]
+    labs = [dev(labels[:4].astype(np.int32)), dev(labels[4:].astype(np.int32))]
+    sts = [dev(np.ascontiguousarray(starts[:iters, :, :4])), dev(np.ascontiguousarray(starts[:iters, :, 4:]))]
+    wss = [runtime.PN2Workspace(4, 4096, iters) for _ in range(2)]
+    serial = []
+    for i in range(2):
+        serial.append(wss[i].nb_attack(gpu_model, imgs[i], labs[i], sts[i], EPS, ALPHA, iters).clone())
+        torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    outs = [torch.empty_like(imgs[0]), torch.empty_like(imgs[1])]
+    for rep in range(3):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                wss[i].nb_attack(gpu_model, imgs[i], labs[i], sts[i], EPS, ALPHA, iters, out=outs[i])
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert np.array_equal(bits(outs[i]), bits(serial[i])), i
