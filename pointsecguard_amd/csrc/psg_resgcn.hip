@@ -525,6 +525,7 @@ struct psg_gcn_ws {
     float *xyz;                // [B*N][3]
     bool have_fwd = false;
     bool fixed_graphs = false;  // psg_gcn_set_graphs: forward uses the supplied neighbour tables
+    bool head_graph_frozen = false;  // inside an attack loop: xyz never changes, the head's xyz kNN graph is kept
     // hipGraph of one interior PGD iteration (forward, CE, backward, step): ~300 short launches replayed as one
     // graph launch; valid for (model, eps, alpha) below, rebuilt when they change
     int32_t *nb_labels;        // [B*N] the attack's labels, copied so that the captured kernels' arguments never change
@@ -796,7 +797,7 @@ extern "C" int psg_gcn_forward(psg_gcn_model *m, psg_gcn_ws *ws, const float *x0
         const float *xin = e == 0 ? x0 : ws->feats + (size_t)(e - 1) * GC;
         const int ld = e == 0 ? 9 : F;
         // graph: xyz kNN for the head (architecture.py:59), feature-space kNN with dilation e for block e (:61-62)
-        if (!ws->fixed_graphs &&
+        if (!ws->fixed_graphs && !(e == 0 && ws->head_graph_frozen) &&
             (rc = knn_graph(ws, e == 0 ? ws->xyz : xin, e == 0 ? 3 : ld, e == 0 ? 3 : GC, e == 0 ? 1 : e, nbr, st)))
             return rc;
         // [P | Q] = x . [W1 - W2 ; W2]^T + [b, 0]
@@ -938,8 +939,12 @@ extern "C" int psg_gcn_nb_attack(psg_gcn_model *m, psg_gcn_ws *ws, const float *
     // once into a hipGraph (kept in the workspace) and replayed, which removes most of the per-launch cost that
     // bounds a single-room ResGCN iteration.  Capture is not possible on the legacy default stream; the loop then
     // simply stays eager.  The last iteration differs (it returns the un-projected step) and is eager again.
+    ws->head_graph_frozen = false;
     if ((rc = iteration(iters == 1))) return rc;
     it = 1;
+    // the attack moves colours only: the head's kNN graph on xyz (architecture.py:59) is the same in every iteration
+    struct Unfreeze { psg_gcn_ws *w; ~Unfreeze() { w->head_graph_frozen = false; } } unfreeze{ws};
+    ws->head_graph_frozen = true;
     static const bool use_graph = !(getenv("PSG_GCN_NO_GRAPH") && atoi(getenv("PSG_GCN_NO_GRAPH")));
     if (use_graph && iters - 1 - it >= 2) {
         if (ws->nb_exec && (ws->nb_model != (const void *)m || ws->nb_eps != eps || ws->nb_alpha != alpha ||
