@@ -66,6 +66,58 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
         // loads of the step are issued into registers first, then written to LDS: otherwise every 16-byte piece
         // pays its own round trip (a 16-workgroup GEMM went from 34 us to a few us with this).
         constexpr int NI = BR * 8 / 256, NWL = BN * 8 / 256;
+        if constexpr (ASC_K) {
+            // ascending-k layout: one thread moves a whole 8-chunk (two 16-byte loads) and writes it as two
+            // ds_write_b128 {k0,k2,k4,k6} {k1,k3,k5,k7} (the first version scattered it with eight ds_write_b32)
+            constexpr int CI = BR * 4 / 256, CW = BN * 4 / 256;
+            float4 ia[CI][2], wa2[CW][2];
+#pragma unroll
+            for (int u = 0; u < CI; ++u) {
+                const int t = tid + u * 256, r = t >> 2, c8 = t & 3, k = k0 + 8 * c8;
+                float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                if (row0 + r < a.rows) {
+                    const float *p = a.in + (size_t)(row0 + r) * a.ld_in + k;
+                    if (k + 7 < a.K && ((a.ld_in & 3) == 0)) { v0 = *(const float4 *)p; v1 = *(const float4 *)(p + 4); }
+                    else {
+                        float e[8];
+#pragma unroll
+                        for (int z = 0; z < 8; ++z) e[z] = k + z < a.K ? p[z] : 0.f;
+                        v0 = make_float4(e[0], e[1], e[2], e[3]); v1 = make_float4(e[4], e[5], e[6], e[7]);
+                    }
+                }
+                ia[u][0] = v0; ia[u][1] = v1;
+            }
+#pragma unroll
+            for (int u = 0; u < CW; ++u) {
+                const int t = tid + u * 256, r = t >> 2, c8 = t & 3, k = k0 + 8 * c8;
+                float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                if (col0 + r < a.M) {
+                    const float *p = a.w + (size_t)(col0 + r) * a.ld_w + k;
+                    if (k + 7 < a.K && ((a.ld_w & 3) == 0)) { v0 = *(const float4 *)p; v1 = *(const float4 *)(p + 4); }
+                    else {
+                        float e[8];
+#pragma unroll
+                        for (int z = 0; z < 8; ++z) e[z] = k + z < a.K ? p[z] : 0.f;
+                        v0 = make_float4(e[0], e[1], e[2], e[3]); v1 = make_float4(e[4], e[5], e[6], e[7]);
+                    }
+                }
+                wa2[u][0] = v0; wa2[u][1] = v1;
+            }
+#pragma unroll
+            for (int u = 0; u < CI; ++u) {
+                const int t = tid + u * 256, r = t >> 2, c8 = t & 3;
+                float *d = s_in + c8 * BLK_R + r * 8;     // element k%8 = 2t+h goes to slot 4h+t
+                *(float4 *)d = make_float4(ia[u][0].x, ia[u][0].z, ia[u][1].x, ia[u][1].z);
+                *(float4 *)(d + 4) = make_float4(ia[u][0].y, ia[u][0].w, ia[u][1].y, ia[u][1].w);
+            }
+#pragma unroll
+            for (int u = 0; u < CW; ++u) {
+                const int t = tid + u * 256, r = t >> 2, c8 = t & 3;
+                float *d = s_w + c8 * BLK_N + r * 8;
+                *(float4 *)d = make_float4(wa2[u][0].x, wa2[u][0].z, wa2[u][1].x, wa2[u][1].z);
+                *(float4 *)(d + 4) = make_float4(wa2[u][0].y, wa2[u][0].w, wa2[u][1].y, wa2[u][1].w);
+            }
+        } else {
         float4 vi[NI], vw[NWL];
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
@@ -128,6 +180,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
             } else {
                 *(float4 *)(d + (q & 1) * 4) = v;
             }
+        }
         }
         __syncthreads();
 #pragma unroll
