@@ -73,8 +73,8 @@ __device__ __forceinline__ f32x16 mfma4(const float4 a, const float4 b, f32x16 a
     return acc;
 }
 
-// One 32x32 output tile: acc += sum_k A[.,k] B[k,.].  k8n is a multiple of 4 (K padded to 32 on the host,
-// pad rows of the activation block are zero).
+// One 32x32 output tile: acc += sum_k A[.,k] B[k,.] over k8n chunks, k8n a positive multiple of 4 (see tile_mac
+// below for the general case).
 //
 // The k-loop is hand-scheduled in inline assembly.  hipcc cannot express this pipeline: left to itself it
 // sinks every weight re-load to just before its use, and with the order pinned by sched_barrier it still
@@ -93,8 +93,8 @@ __device__ __forceinline__ f32x16 mfma4(const float4 a, const float4 b, f32x16 a
 #define PSG_RELOAD(x) x
 #endif
 template <int BLK, bool FLIP>
-__device__ __forceinline__ f32x16 tile_mac(const float4 *__restrict__ w, int k8n, const float *__restrict__ bptr,
-                                           f32x16 acc)
+__device__ __forceinline__ f32x16 tile_mac4(const float4 *__restrict__ w, int k8n, const float *__restrict__ bptr,
+                                            f32x16 acc)
 {
     // w already offset to [mb][0][lane]; bptr = act + (pb*32 + (lane&31))*8 + 4*(lane>>5)
     unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)bptr;
@@ -248,6 +248,23 @@ __device__ __forceinline__ f32x16 tile_mac(const float4 *__restrict__ w, int k8n
             : [step] "s"(step), [s1] "n"(S1), [s2] "n"(S2), [s3] "n"(S3), [s4] "n"(S4)
             : "memory", "scc", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
               "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87");
+    }
+    return acc;
+}
+
+// One 32x32 output tile over k8n chunks of 8 input channels: the multiple-of-4 part runs in the pipelined assembly
+// loop above, a tail of 1..3 chunks (first layers whose K is not a multiple of 32: 12+4, 67+5, 131+5, 259+5 channels,
+// and the 13-class head's transpose) as plain MFMAs, instead of padding K to 32 with zero work.
+template <int BLK, bool FLIP>
+__device__ __forceinline__ f32x16 tile_mac(const float4 *__restrict__ w, int k8n, const float *__restrict__ bptr,
+                                           f32x16 acc)
+{
+    const int k4 = k8n & ~3;
+    if (k4) acc = tile_mac4<BLK, FLIP>(w, k4, bptr, acc);
+    for (int k8 = k4; k8 < k8n; ++k8) {
+        const float4 a = w[(size_t)k8 * 64];
+        const float4 b = *(const float4 *)(bptr + (size_t)k8 * BLK);
+        acc = mfma4<FLIP>(a, b, acc);
     }
     return acc;
 }

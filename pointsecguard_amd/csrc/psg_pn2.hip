@@ -43,10 +43,10 @@ struct PackedLayer {
     float4 *wf4 = nullptr; // forward packing, k8-major [k8][mb = 4][64] (wave-private chain kernels, psg_chain.cuh)
     float4 *wb4 = nullptr; // transposed packing, k8-major
     int cin = 0, cout = 0;
-    // K is padded to a multiple of 32 (k8 multiple of 4: the MFMA loop is unrolled by 4 chunks)
-    int k8f() const { return round_up(ceil_div(cin, 8), 4); }
+    // K is padded to a multiple of 8 only (tile_mac runs a tail of 1..3 chunks behind its 4-chunk pipeline)
+    int k8f() const { return ceil_div(cin, 8); }
     int mbf() const { return ceil_div(cout, 32); }
-    int k8b() const { return round_up(ceil_div(cout, 8), 4); }
+    int k8b() const { return ceil_div(cout, 8); }
     int mbb() const { return ceil_div(cin, 32); }
 };
 
@@ -113,7 +113,7 @@ std::vector<int> sa_input_perm(int cin)
 
 std::vector<float> pack_fwd(const float *w, int cin, int cout, const std::vector<int> *perm)
 {
-    const int k8 = round_up(ceil_div(cin, 8), 4), mb = ceil_div(cout, 32);
+    const int k8 = ceil_div(cin, 8), mb = ceil_div(cout, 32);
     std::vector<float> out(((size_t)mb * k8 + 4) * 64 * 4, 0.0f);  // + 4 chunks: prefetch over-read slack
     for (int m = 0; m < mb; ++m)
         for (int k = 0; k < k8; ++k)
@@ -128,7 +128,7 @@ std::vector<float> pack_fwd(const float *w, int cin, int cout, const std::vector
 
 std::vector<float> pack_bwd(const float *w, int cin, int cout, const std::vector<int> *perm)
 {
-    const int k8 = round_up(ceil_div(cout, 8), 4), mb = ceil_div(cin, 32);
+    const int k8 = ceil_div(cout, 8), mb = ceil_div(cin, 32);
     std::vector<float> out(((size_t)mb * k8 + 4) * 64 * 4, 0.0f);  // + 4 chunks: prefetch over-read slack
     for (int m = 0; m < mb; ++m)
         for (int k = 0; k < k8; ++k)
@@ -145,6 +145,17 @@ std::vector<float> pack_bwd(const float *w, int cin, int cout, const std::vector
 std::vector<float> k8_major(const std::vector<float> &packed, int mb, int k8)
 {
     std::vector<float> out((size_t)mb * k8 * 256, 0.0f);
+    for (int m = 0; m < mb; ++m)
+        for (int k = 0; k < k8; ++k)
+            std::copy(packed.begin() + ((size_t)m * k8 + k) * 256, packed.begin() + ((size_t)m * k8 + k + 1) * 256,
+                      out.begin() + ((size_t)k * mb + m) * 256);
+    return out;
+}
+
+// same, zero-padding k8 up to k8_pad chunks (the wave-private chain kernels want multiples of 4)
+std::vector<float> k8_major_padded(const std::vector<float> &packed, int mb, int k8, int k8_pad)
+{
+    std::vector<float> out((size_t)mb * k8_pad * 256, 0.0f);
     for (int m = 0; m < mb; ++m)
         for (int k = 0; k < k8; ++k)
             std::copy(packed.begin() + ((size_t)m * k8 + k) * 256, packed.begin() + ((size_t)m * k8 + k + 1) * 256,
@@ -426,7 +437,7 @@ int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, con
         for (int i = 0; i < 4; ++i) w.mask[i] = (const unsigned long long *)ws->mask[18 + i];
         for (int i = 0; i < 5; ++i) {   // conv2^T, conv1^T, mlp2^T, mlp1^T, mlp0^T
             const PackedLayer &L = m->L[22 - i];
-            w.layer[i].w4 = L.wb4; w.layer[i].bias = nullptr; w.layer[i].k8 = L.k8b();
+            w.layer[i].w4 = L.wb4; w.layer[i].bias = nullptr; w.layer[i].k8 = round_up(L.k8b(), 4);
         }
         w.dint_out = ws->dint[0];
         w.N = N; w.n_cls = NCLS;
@@ -716,8 +727,8 @@ extern "C" int psg_pn2_model_create(psg_ctx *ctx, const float *const *weights, c
         bs[i].assign((size_t)ceil_div(kCout[i], 32) * 32, 0.0f);
         std::copy(biases[i], biases[i] + kCout[i], bs[i].begin());
         if (i >= 18) {   // fp1 + head run as wave-private chains: k8-major packings of the 128-wide sides
-            if (kCout[i] == 128) wf4[i] = k8_major(wf[i], 4, round_up(ceil_div(kCin[i], 8), 4));
-            wb4[i] = k8_major(wb[i], 4, round_up(ceil_div(kCout[i], 8), 4));
+            if (kCout[i] == 128) wf4[i] = k8_major(wf[i], 4, ceil_div(kCin[i], 8));
+            wb4[i] = k8_major_padded(wb[i], 4, ceil_div(kCout[i], 8), round_up(ceil_div(kCout[i], 8), 4));
         }
         total += ((wf[i].size() + wb[i].size() + bs[i].size() + wf4[i].size() + wb4[i].size()) * 4 + 5 * 256);
     }
