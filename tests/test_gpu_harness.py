@@ -115,3 +115,21 @@ def test_whole_scene_loop_end_to_end(tmp_path, weights_sd):
     clean = harness.evaluate_whole_scene(net, ds, None, batch_size=4, log=lambda *_: None)
     assert np.array_equal(clean["counters"][0], clean["counters"][1])
     assert np.array_equal(clean["counters"][0][0], c[0][0])
+
+
+def test_whole_scene_sharded_over_ranks(tmp_path):
+    """Scenes dealt round-robin to two ranks (gloo group, both on this GPU) + one all-reduce of the counters give the
+    totals of the single-process run (the vote pool of a scene never leaves its rank)."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    one, two = tmp_path / "one.json", tmp_path / "two.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    subprocess.run([sys.executable, os.path.join(here, "_harness_rank.py"), str(one)], check=True, env=env, timeout=300)
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                    "127.0.0.1", "--master-port", "29533", os.path.join(here, "_harness_rank.py"), str(two)], check=True,
+                   env=env, timeout=300)
+    a, b = json.load(open(one)), json.load(open(two))
+    assert a["counters"] == b["counters"]
+    assert a["miou"] == b["miou"] and a["adv_miou"] == b["adv_miou"]
