@@ -227,7 +227,9 @@ def main():
                        "sharding": "rooms sharded by rank, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
-                         "traffic_source": traffic_src, "avg_launch_us": avg_ms * 1e3, "launches": mlp[dom][1],
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes": FP1_FWD_BYTES_PER_ROOM * DB if dom == "fp1_head_fwd" else None,
+                         "avg_launch_us": avg_ms * 1e3, "launches": mlp[dom][1],
                          "flop_per_launch": flops[dom]},
             "kernel_ms_per_attack": {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
             "kernel_ms_total_per_attack": round(total_ms, 3),
@@ -243,6 +245,10 @@ def main():
         dist.destroy_process_group()
     return result
 
+
+# compulsory HBM bytes of the fp1 + head forward per room: coarse features [1024][128] fp32 + 3-NN indices and weights
+# [4096][3] x 8 B in; log-probs [4096][13] fp32 + four layers of ReLU bits (16 bits per lane and 32x32 tile) out
+FP1_FWD_BYTES_PER_ROOM = 1024 * 128 * 4 + 4096 * 3 * 8 + 4096 * 13 * 4 + 4 * (4096 // 32) * 4 * 64 * 2
 
 # HIP symbols of the modules whose kernel instantiation is unique (PMC rows are keyed by symbol, not by module)
 PMC_SYMBOL = {"fp1_head_fwd": "void psg::fp_fwd_kernel<32, 4>(psg::FpFwdArgs)",
