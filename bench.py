@@ -201,6 +201,27 @@ def main():
     if rank == 0:
         total_rooms = BATCH * world * args.steps
         value = total_rooms / elapsed
+        # ---- for reference: the same attack launched one 8-room step at a time (no coalescing), 2 in flight
+        ref8 = None
+        if G > 1:
+            ws8 = [runtime.PN2Workspace(BATCH, NPOINT, ITERS) for _ in range(2)]
+            x8 = [d_images[n_warm][i * BATCH:(i + 1) * BATCH].contiguous() for i in range(min(4, G))]
+            l8 = [d_labels[n_warm][i * BATCH:(i + 1) * BATCH].contiguous() for i in range(min(4, G))]
+            s8 = [d_starts[n_warm][:, :, i * BATCH:(i + 1) * BATCH].contiguous() for i in range(min(4, G))]
+            o8 = [torch.empty_like(x) for x in x8]
+
+            def run8():
+                for i in range(len(x8)):
+                    with torch.cuda.stream(streams[i % len(streams)]):
+                        ws8[i % 2].nb_attack(model, x8[i], l8[i], s8[i], EPS, ALPHA, ITERS, out=o8[i])
+                torch.cuda.synchronize()
+
+            run8()
+            t8 = time.perf_counter()
+            run8()
+            ref8 = {"value": BATCH * len(x8) / (time.perf_counter() - t8), "unit": "rooms/s",
+                    "note": "one launch per 8-room step, no coalescing, up to 2 in flight (this GPU only)"}
+            del ws8
         # ---- roofline of the dominant kernel: one extra attack with HIP-event timing of every launch
         ws.prof_enable(True)
         ws.nb_attack(model, d_images[n_warm], d_labels[n_warm], d_starts[n_warm], EPS, ALPHA, ITERS, out=d_adv[n_warm])
@@ -233,6 +254,7 @@ def main():
                          "flop_per_launch": flops[dom]},
             "kernel_ms_per_attack": {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
             "kernel_ms_total_per_attack": round(total_ms, 3),
+            "uncoalesced_reference": ref8,
             "parity": {"clean_acc": acc, "adv_acc": adv_acc, "asr": 1.0 - adv_acc, "clean_miou": miou,
                        "adv_miou": adv_miou, "rooms_evaluated": int(clean[0].sum() // NPOINT)},
         }
