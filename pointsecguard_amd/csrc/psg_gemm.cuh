@@ -36,6 +36,8 @@ struct GemmArgs {
     const uint32_t *mask_in;  // multiply the result by these bits (backward through the producer's ReLU), or null
     int rows, K, M, ld_in, ld_w, ld_out, group_rows;
     int accumulate;       // out += result
+    const float *addend;  // with accumulate: out = (out + addend[row][c]) + result  (rows of ld_add floats), or null
+    int ld_add;
 };
 
 // TQ x TI = 32-row x 32-channel MFMA tiles per wave (2 x 2 by default; 1 x 1 gives 64 x 64 workgroup tiles, i.e. four
@@ -243,14 +245,23 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
                     if (c + 3 < a.M && ((a.ld_out & 3) == 0)) {
                         float4 v = make_float4(vals[4 * g], vals[4 * g + 1], vals[4 * g + 2], vals[4 * g + 3]);
                         float4 *dst = (float4 *)(o + 8 * g);
-                        if (a.accumulate) { float4 old = *dst; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+                        if (a.accumulate) {
+                            float4 old = *dst;
+                            if (a.addend) {
+                                const float4 ad = *(const float4 *)(a.addend + (size_t)row * a.ld_add + c);
+                                old.x += ad.x; old.y += ad.y; old.z += ad.z; old.w += ad.w;
+                            }
+                            v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                        }
                         *dst = v;
                     } else {
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
                             if (c + u < a.M) {
                                 float *dst = o + 8 * g + u;
-                                *dst = a.accumulate ? *dst + vals[4 * g + u] : vals[4 * g + u];
+                                float base = a.accumulate ? *dst : 0.0f;
+                                if (a.accumulate && a.addend) base += a.addend[(size_t)row * a.ld_add + c + u];
+                                *dst = a.accumulate ? vals[4 * g + u] + base : vals[4 * g + u];
                             }
                     }
                 }

@@ -54,7 +54,7 @@ GemmArgs gemm_args(const float *in, int ld_in, const float *w, int ld_w, float *
     GemmArgs a;
     a.in = in; a.w = w; a.bias = nullptr; a.gbias = nullptr; a.scale = nullptr; a.shift = nullptr; a.sq = nullptr;
     a.out = out; a.mask_out = nullptr; a.mask_in = nullptr;
-    a.rows = rows; a.K = K; a.M = M; a.ld_in = ld_in; a.ld_w = ld_w; a.ld_out = ld_out; a.group_rows = 1; a.accumulate = 0;
+    a.rows = rows; a.K = K; a.M = M; a.ld_in = ld_in; a.ld_w = ld_w; a.ld_out = ld_out; a.group_rows = 1; a.accumulate = 0; a.addend = nullptr; a.ld_add = 0;
     return a;
 }
 
@@ -895,10 +895,11 @@ extern "C" int psg_gcn_backward(psg_gcn_model *m, psg_gcn_ws *ws, const float *d
         PSG_LAUNCH_CHECK();
         if (e > 0) {
             // x_e = EdgeConv_e(x_{e-1}) + x_{e-1}:  G_{e-1} = dfeats[e-1] + G_e + [dP | dQ] . [W1-W2 ; W2]
-            hipLaunchKernelGGL(add_slice_kernel, dim3(g256), dim3(256), 0, st, ws->gcur, ws->dfeats + (size_t)(e - 1) * GC, F, R);
-            PSG_LAUNCH_CHECK();
+            // (the residual's gradient slice dfeats[e-1] is added inside the GEMM's accumulate epilogue)
             GemmArgs a = gemm_args(ws->dpq, 2 * GC, L.wcat_t, 2 * GC, ws->gcur, GC, (int)R, 2 * GC, GC);
             a.accumulate = 1;
+            a.addend = ws->dfeats + (size_t)(e - 1) * GC;
+            a.ld_add = F;
             if ((rc = launch_gemm<4, 1, EPI_LINEAR, false>(a, st))) return rc;
         } else {
             GemmArgs a = gemm_args(ws->dpq, 2 * GC, L.wcat_t, 2 * GC, dx0_out, 9, (int)R, 2 * GC, 9);
