@@ -66,7 +66,6 @@ struct psg_pn2_ws {
     size_t bytes = 0;
     // plan
     float *xyz0;          // [B][N][3]
-    int32_t *starts_dev;  // unused unless the caller has none
     int32_t *fps[4];      // [F*B][S_l]
     float *xyz[5];        // xyz[l+1]: [F*B][S_l][3]; xyz[0] = xyz0
     int32_t *gidx[4];     // [F*B][S_l][32]
@@ -84,8 +83,7 @@ struct psg_pn2_ws {
     uint8_t *arg[4];
     uint16_t *mask[kNumReal];
     float *logp, *dlogp;
-    // gradients (one contiguous zeroed arena)
-    float *gzero; size_t gzero_bytes;
+    // gradients (every buffer has exactly one writer: nothing is zeroed or accumulated into)
     float *dact[7];
     float *dx0;           // [B][N][9]
     // attack state
@@ -693,12 +691,9 @@ size_t ws_layout(psg_pn2_ws *ws, char *base)
     ws->logp = bp.take<float>((size_t)B * ws->N * NCLS);
     ws->dlogp = bp.take<float>((size_t)B * ws->N * NCLS);
     bp.off = (bp.off + 255) & ~(size_t)255;
-    size_t g0 = bp.off;
     for (int i = 0; i < 7; ++i) ws->dact[i] = bp.take<float>((size_t)B * actN[i] * actC[i]);
     ws->dx0 = bp.take<float>((size_t)B * ws->N * 9);
     bp.off = (bp.off + 255) & ~(size_t)255;
-    ws->gzero = base ? (float *)(base + g0) : nullptr;
-    ws->gzero_bytes = bp.off - g0;
     ws->x0 = bp.take<float>((size_t)B * ws->N * 9);
     ws->ori = bp.take<float>((size_t)B * ws->N * 3);
     ws->dbg = bp.take<unsigned long long>(16 * 8 * 1024);
