@@ -71,7 +71,7 @@ def cpu_baseline(sd, rooms, labels, starts, iters_sample):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=6)
@@ -83,7 +83,7 @@ def main():
                          "independent, so results are identical and small kernels get more workgroups")
     ap.add_argument("--nu-steps", type=int, default=100, help="tarnu workload: optimiser step cap per attack")
     ap.add_argument("--gcn-concurrency", type=int, default=3, help="resgcn workload: attacks in flight (streams)")
-    ap.add_argument("--concurrency", type=int, default=2,
+    ap.add_argument("--concurrency", type=int, default=3,
                     help="device batches in flight per GPU (one HIP stream + workspace each)")
     args = ap.parse_args()
 
