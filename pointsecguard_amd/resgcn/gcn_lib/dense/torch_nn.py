@@ -22,29 +22,39 @@ def norm_layer(norm, nc):
     return nn.BatchNorm2d(nc, affine=True)
 
 
+def _conv_stack(widths, act, norm, bias, drop):
+    """Sub-modules of one BasicConv in state_dict order: per layer a 1x1 Conv2d, then the optional activation,
+    BatchNorm2d (sized by the LAST width, like the reference) and Dropout2d."""
+    stack = []
+    for c_in, c_out in zip(widths[:-1], widths[1:]):
+        stack.append(Conv2d(c_in, c_out, 1, bias=bias))
+        stack.extend(layer for layer, wanted in ((act_layer(act) if act else None, act),
+                                                 (norm_layer(norm, widths[-1]) if norm else None, norm),
+                                                 (nn.Dropout2d(drop) if drop > 0 else None, drop > 0)) if wanted)
+    return stack
+
+
+def _default_init(module):
+    """Kaiming-normal conv weights, zero biases, unit BatchNorm scale (what the reference applies on construction)."""
+    for sub in module.modules():
+        if isinstance(sub, nn.Conv2d):
+            nn.init.kaiming_normal_(sub.weight)
+            if sub.bias is not None:
+                nn.init.zeros_(sub.bias)
+        elif isinstance(sub, nn.BatchNorm2d):
+            nn.init.ones_(sub.weight)
+            nn.init.zeros_(sub.bias)
+
+
 class BasicConv(Seq):
+    """Sequential(Conv2d 1x1 [, ReLU] [, BatchNorm2d] [, Dropout2d]) per consecutive pair of `channels`."""
+
     def __init__(self, channels, act="relu", norm=None, bias=True, drop=0.0):
-        m = []
-        for i in range(1, len(channels)):
-            m.append(Conv2d(channels[i - 1], channels[i], 1, bias=bias))
-            if act:
-                m.append(act_layer(act))
-            if norm:
-                m.append(norm_layer(norm, channels[-1]))
-            if drop > 0:
-                m.append(nn.Dropout2d(drop))
-        super(BasicConv, self).__init__(*m)
+        super().__init__(*_conv_stack(list(channels), act, norm, bias, drop))
         self.reset_parameters()
 
     def reset_parameters(self):
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d):
-                nn.init.kaiming_normal_(m.weight)
-                if m.bias is not None:
-                    nn.init.zeros_(m.bias)
-            elif isinstance(m, nn.BatchNorm2d):
-                m.weight.data.fill_(1)
-                m.bias.data.zero_()
+        _default_init(self)
 
 
 def batched_index_select(inputs, index):

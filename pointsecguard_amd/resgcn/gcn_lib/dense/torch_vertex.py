@@ -6,7 +6,7 @@ from torch import nn
 from .torch_edge import DenseDilatedKnnGraph
 from .torch_nn import BasicConv
 
-__all__ = ["EdgeConv2d", "GraphConv2d", "DynConv2d", "ResDynBlock2d"]
+__all__ = ["EdgeConv2d", "GraphConv2d", "DynConv2d", "ResDynBlock2d", "MRConv2d", "PlainDynBlock2d", "DenseDynBlock2d"]
 
 _MSG = "executed by the fused whole-network kernels of DenseDeepGCN; call the parent model"
 
@@ -56,3 +56,21 @@ class ResDynBlock2d(nn.Module):
 
     def forward(self, x):
         raise NotImplementedError("ResDynBlock2d.forward is " + _MSG)
+
+
+def _unsupported(name, where):
+    class _Unsupported(nn.Module):
+        """Importable so that `from gcn_lib.dense import ...` lines of the reference keep working; constructing it says
+        which configuration is missing (alternative blocks are not implemented)."""
+
+        def __init__(self, *args, **kwargs):
+            raise NotImplementedError("%s (%s) is not implemented: the gfx950 kernels cover the reference's attack "
+                                      "configuration (EdgeConv2d inside ResDynBlock2d)" % (name, where))
+
+    _Unsupported.__name__ = _Unsupported.__qualname__ = name
+    return _Unsupported
+
+
+MRConv2d = _unsupported("MRConv2d", "torch_vertex.py:8-20")
+PlainDynBlock2d = _unsupported("PlainDynBlock2d", "torch_vertex.py:74-85")
+DenseDynBlock2d = _unsupported("DenseDynBlock2d", "torch_vertex.py:103-115")
