@@ -258,7 +258,7 @@ def main():
             "parity": {"clean_acc": acc, "adv_acc": adv_acc, "asr": 1.0 - adv_acc, "clean_miou": miou,
                        "adv_miou": adv_miou, "rooms_evaluated": int(clean[0].sum() // NPOINT)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline(sd, rooms[n_warm][:BATCH], labels[n_warm][:BATCH],
                                                   starts[n_warm][:, :, :BATCH], args.cpu_iters)
         print(json.dumps(result), flush=True)
