@@ -336,7 +336,7 @@ __global__ __launch_bounds__(KS_WAVES * 64) void knn_select_kernel(const float *
 __global__ void edge_max_fwd_kernel(const float *__restrict__ pq, const int32_t *__restrict__ nbr,
                                     const float *__restrict__ scale, const float *__restrict__ shift,
                                     const float *__restrict__ resid, int ld_res, float *__restrict__ out, int ld_out,
-                                    uint8_t *__restrict__ arg, int N, size_t total)
+                                    uint8_t *__restrict__ arg, int N, size_t total, float *__restrict__ sq_out)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -359,6 +359,21 @@ __global__ void edge_max_fwd_kernel(const float *__restrict__ pq, const int32_t 
     if (resid) best += resid[v * ld_res + c];
     out[v * ld_out + c] = best;
     arg[t] = (uint8_t)(bk | (bact ? 0x80 : 0));
+    if (sq_out) {
+        // squared norm of the vertex's 64 new features for the next block's kNN, in torch.sum's order for 64
+        // contiguous floats (sumsq_rows_kernel): u_c = x_c^2 + x_{c+32}^2, t_l = ((u_l + u_{8+l}) + u_{16+l}) + u_{24+l},
+        // s = t_0 + t_1 + ... + t_7 left to right.  One wave holds exactly one vertex (lane = channel).
+        const int lane = threadIdx.x & 63;
+        const float q2 = __fmul_rn(best, best);
+        const float u = __fadd_rn(q2, __shfl(q2, (lane + 32) & 63));
+        float tl = __fadd_rn(u, __shfl(u, (lane + 8) & 63));
+        tl = __fadd_rn(tl, __shfl(u, (lane + 16) & 63));
+        tl = __fadd_rn(tl, __shfl(u, (lane + 24) & 63));      // valid in lanes 0..7
+        float sacc = __shfl(tl, 0);
+#pragma unroll
+        for (int l = 1; l < 8; ++l) sacc = __fadd_rn(sacc, __shfl(tl, l));
+        if (lane == 0) sq_out[v] = sacc;
+    }
 }
 
 // ---- EdgeConv edge pass (backward): g = dY * s_c where the winning edge was active;  dP[i][c] = g,
@@ -569,11 +584,13 @@ __global__ void extract_color3_kernel(const float *__restrict__ x0, float *__res
     if (t < rows * 3) ori[t] = x0[(t / 3) * 9 + 3 + (t % 3)];
 }
 
-int knn_graph(psg_gcn_ws *ws, const float *x, int ld, int C, int d, int32_t *out, hipStream_t st)
+int knn_graph(psg_gcn_ws *ws, const float *x, int ld, int C, int d, int32_t *out, hipStream_t st, bool have_sq = false)
 {
     const size_t rows = (size_t)ws->B * ws->N;
-    hipLaunchKernelGGL(sumsq_rows_kernel, dim3(ceil_div((int)rows, 256)), dim3(256), 0, st, x, ld, C, rows, ws->sq);
-    PSG_LAUNCH_CHECK();
+    if (!have_sq) {   // (the forward pass gets the norms of a block's output from its edge_max_fwd kernel)
+        hipLaunchKernelGGL(sumsq_rows_kernel, dim3(ceil_div((int)rows, 256)), dim3(256), 0, st, x, ld, C, rows, ws->sq);
+        PSG_LAUNCH_CHECK();
+    }
     for (int b = 0; b < ws->B; ++b) {  // distances never cross rooms
         GemmArgs a = gemm_args(x + (size_t)b * ws->N * ld, ld, x + (size_t)b * ws->N * ld, ld,
                                ws->dist + (size_t)b * ws->N * ws->N, ws->N, ws->N, C, ws->N);
@@ -798,7 +815,7 @@ extern "C" int psg_gcn_forward(psg_gcn_model *m, psg_gcn_ws *ws, const float *x0
         const int ld = e == 0 ? 9 : F;
         // graph: xyz kNN for the head (architecture.py:59), feature-space kNN with dilation e for block e (:61-62)
         if (!ws->fixed_graphs && !(e == 0 && ws->head_graph_frozen) &&
-            (rc = knn_graph(ws, e == 0 ? ws->xyz : xin, e == 0 ? 3 : ld, e == 0 ? 3 : GC, e == 0 ? 1 : e, nbr, st)))
+            (rc = knn_graph(ws, e == 0 ? ws->xyz : xin, e == 0 ? 3 : ld, e == 0 ? 3 : GC, e == 0 ? 1 : e, nbr, st, e > 0)))
             return rc;
         // [P | Q] = x . [W1 - W2 ; W2]^T + [b, 0]
         GemmArgs a = gemm_args(xin, ld, L.wcat, L.C, ws->pq, 2 * GC, (int)R, L.C, 2 * GC);
@@ -806,7 +823,7 @@ extern "C" int psg_gcn_forward(psg_gcn_model *m, psg_gcn_ws *ws, const float *x0
         if ((rc = launch_gemm<2, 2, EPI_LINEAR, false>(a, st))) return rc;
         hipLaunchKernelGGL(edge_max_fwd_kernel, dim3(g256), dim3(256), 0, st, ws->pq, nbr, L.scale, L.shift,
                            e == 0 ? nullptr : xin, F, ws->feats + (size_t)e * GC, F, ws->arg + (size_t)e * R * GC, N,
-                           R * GC);
+                           R * GC, ws->fixed_graphs ? nullptr : ws->sq);
         PSG_LAUNCH_CHECK();
     }
     // fusion: Conv(F -> 1024) + ReLU + BN, global max over the room
