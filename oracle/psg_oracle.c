@@ -182,7 +182,7 @@ void orc_linear_bwd(const float *dy, const float *y, const float *w, int m, int 
         const float *dyr = dy + (size_t)r * cout;
         const float *yr = y + (size_t)r * cout;
         float *dxr = dx + (size_t)r * cin;
-        acc_t acc[1024];
+        acc_t acc[2048];   /* widest layer input: MSG fp4, 1536 channels */
         for (int i = 0; i < cin; ++i) acc[i] = 0;
         for (int o = 0; o < cout; ++o) {
             float g = dyr[o];

@@ -64,3 +64,48 @@ def rule_labels(rooms):
     lab = 3 * band + np.argmax(rooms[..., 3:6], axis=-1)
     lab = np.where(x * y > np.float32(0.15), 12, lab)
     return lab.astype(np.int64)
+
+
+# (in_channel, mlp_list) of sa1..sa4 and (in_channel, mlp) of fp4..fp1 of the MSG network
+# (PointNet/models/pointnet2_sem_seg_msg.py:10-17 of the reference)
+MSG_SA = ((9, ((16, 16, 32), (32, 32, 64))), (96, ((64, 64, 128), (64, 96, 128))),
+          (256, ((128, 196, 256), (128, 196, 256))), (512, ((256, 256, 512), (256, 384, 512))))
+MSG_FP = (("fp4", 1536, (256, 256)), ("fp3", 512, (256, 256)), ("fp2", 352, (256, 128)), ("fp1", 128, (128, 128, 128)))
+
+
+def msg_state_dict(seed):
+    """Seeded random weights for pointnet2_sem_seg_msg.get_model(13) with the reference's state_dict keys and
+    shapes: He-scaled conv weights and non-trivial eval BatchNorm statistics, so that activations, ReLU patterns
+    and gradients are non-degenerate (no checkpoint of this variant ships with the reference)."""
+    rng = np.random.RandomState(int(seed))
+    sd = {}
+
+    def conv(name, cin, cout, dims):
+        shape = (cout, cin) + (1,) * dims
+        sd[name + ".weight"] = (rng.standard_normal(shape) * np.sqrt(2.0 / cin)).astype(np.float32)
+        sd[name + ".bias"] = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+
+    def bn(name, c):
+        sd[name + ".weight"] = rng.uniform(0.8, 1.2, c).astype(np.float32)
+        sd[name + ".bias"] = rng.uniform(-0.1, 0.1, c).astype(np.float32)
+        sd[name + ".running_mean"] = rng.uniform(-0.1, 0.1, c).astype(np.float32)
+        sd[name + ".running_var"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+        sd[name + ".num_batches_tracked"] = np.array(1, np.int64)
+
+    for l, (cin, mlps) in enumerate(MSG_SA, start=1):
+        for i, mlp in enumerate(mlps):
+            last = cin + 3
+            for j, c in enumerate(mlp):
+                conv("sa%d.conv_blocks.%d.%d" % (l, i, j), last, c, 2)
+                bn("sa%d.bn_blocks.%d.%d" % (l, i, j), c)
+                last = c
+    for name, cin, mlp in MSG_FP:
+        last = cin
+        for j, c in enumerate(mlp):
+            conv("%s.mlp_convs.%d" % (name, j), last, c, 1)
+            bn("%s.mlp_bns.%d" % (name, j), c)
+            last = c
+    conv("conv1", 128, 128, 1)
+    bn("bn1", 128)
+    conv("conv2", 128, NUM_CLASSES, 1)
+    return sd
