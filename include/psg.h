@@ -79,6 +79,10 @@ int psg_three_nn(psg_ctx *ctx, const float *xyz1, int n_clouds1, const float *xy
 #define PSG_PN2_NUM_LAYERS 23 /* sa1..sa4 (3 each), fp4, fp3, fp2 (2 each), fp1 (3), conv1, conv2 */
 #define PSG_PN2_NUM_CLASSES 13
 #define PSG_PN2_IN_CHANNELS 9
+/* the two PointNet++ sem-seg architectures of the reference */
+#define PSG_PN2_ARCH_SSG 0        /* PointNet/models/pointnet2_sem_seg.py: single-scale grouping, 23 conv layers */
+#define PSG_PN2_ARCH_MSG 1        /* PointNet/models/pointnet2_sem_seg_msg.py: two radii per SA level, 35 conv layers */
+#define PSG_PN2_MSG_NUM_LAYERS 35
 
 /* Build the device-resident, MFMA-packed weights.  `weights[i]` / `biases[i]` are HOST pointers to the
  * row-major [cout][cin] weight and [cout] bias of layer i with the eval-mode BatchNorm already
@@ -87,11 +91,18 @@ int psg_three_nn(psg_ctx *ctx, const float *xyz1, int n_clouds1, const float *xy
  * Blocking (uploads synchronously); not for use inside a timed loop. */
 int psg_pn2_model_create(psg_ctx *ctx, const float *const *weights, const float *const *biases,
                          psg_pn2_model **out);
+/* Same for either architecture.  PSG_PN2_ARCH_MSG (replaces pointnet2_sem_seg_msg.py:7-21 + pointnet_util.py:210-227)
+ * takes its n_layers = 35 layers in state_dict order: sa1 scale 0 layers 0-2, sa1 scale 1 layers 0-2, sa2 ..., sa4
+ * (conv_blocks.i.j + bn_blocks.i.j), fp4.0-1, fp3.0-1, fp2.0-1, fp1.0-2, conv1(+bn1), conv2. */
+int psg_pn2_model_create_arch(psg_ctx *ctx, int arch, const float *const *weights, const float *const *biases,
+                              int n_layers, psg_pn2_model **out);
 int psg_pn2_model_destroy(psg_pn2_model *model);
 
 /* Workspace: geometry plan for up to `max_forwards` forwards of a batch of `batch` rooms of
  * `n_point` points, plus activations / ReLU masks / gradient buffers for ONE forward in flight. */
 int psg_pn2_ws_create(psg_ctx *ctx, int batch, int n_point, int max_forwards, psg_pn2_ws **out);
+/* Workspace for a model of architecture `arch`; forward / backward / nb_attack refuse a mismatched pair. */
+int psg_pn2_ws_create_arch(psg_ctx *ctx, int arch, int batch, int n_point, int max_forwards, psg_pn2_ws **out);
 int psg_pn2_ws_destroy(psg_pn2_ws *ws);
 size_t psg_pn2_ws_bytes(const psg_pn2_ws *ws);
 
@@ -117,12 +128,14 @@ int psg_pn2_debug_read(psg_pn2_ws *ws, unsigned long long *host_out, int n_words
 int psg_pn2_plan_build(psg_pn2_ws *ws, const float *x0, const int32_t *starts, int n_forward, psg_stream stream);
 
 /* Read-back of plan slices for parity tests (device pointers into the workspace).
- * what: 0 fps idx [S_l], 1 group idx [S_l][32], 2 nn idx [N_l][3], 3 nn weights [N_l][3], 4 xyz of level+1 */
+ * what: 0 fps idx [S_l], 1 group idx [S_l][K] (MSG: scale 0, K = 16), 2 nn idx [N_l][3], 3 nn weights [N_l][3],
+ * 4 xyz of level+1, 5 group idx of MSG scale 1 [S_l][32] (null for SSG) */
 const void *psg_pn2_plan_ptr(const psg_pn2_ws *ws, int what, int level, int forward, int room);
 
 /* get_model.forward (pointnet2_sem_seg.py:22-40) with the geometry of plan slot `forward`.
  * x0 [batch][n_point][9]; logp_out [batch][n_point][13] = log_softmax; l4_out (nullable)
- * [batch][16][512] = l4_points point-major.  Leaves the ReLU / arg-max masks in the workspace. */
+ * [batch][16][512] (MSG: [batch][16][1024]) = l4_points point-major.  Leaves the ReLU / arg-max masks in the
+ * workspace.  For PSG_PN2_ARCH_MSG this is pointnet2_sem_seg_msg.py:23-42. */
 int psg_pn2_forward(psg_pn2_model *model, psg_pn2_ws *ws, int forward, const float *x0, float *logp_out,
                     float *l4_out, psg_stream stream);
 
@@ -137,6 +150,7 @@ int psg_pn2_backward(psg_pn2_model *model, psg_pn2_ws *ws, int forward, const fl
 /* Per-layer activations of the last forward, for parity tests: which 0..3 = l1..l4 points (sa1..sa4
  * outputs), 4..6 = fp4, fp3, fp2 outputs.  Returns a device pointer [batch][points][channels]. */
 const float *psg_pn2_activation_ptr(const psg_pn2_ws *ws, int which);
+int psg_pn2_activation_channels(const psg_pn2_ws *ws, int which);   /* channels of that tensor (architecture dependent) */
 
 /* ------------------------------------------------------------------------------------------
  * Attack-loop arithmetic (PointNet/attacks/torchattacks/attacks/nontarget.py, target.py).

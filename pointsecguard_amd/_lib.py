@@ -29,8 +29,10 @@ SIGNATURES = {
     "psg_ball_query": (ci, [vp, vp, ci, vp, ci, ci, ci, cf, ci, vp, vp]),
     "psg_three_nn": (ci, [vp, vp, ci, vp, ci, ci, ci, vp, vp, vp]),
     "psg_pn2_model_create": (ci, [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]),
+    "psg_pn2_model_create_arch": (ci, [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(vp), ci, ctypes.POINTER(vp)]),
     "psg_pn2_model_destroy": (ci, [vp]),
     "psg_pn2_ws_create": (ci, [vp, ci, ci, ci, ctypes.POINTER(vp)]),
+    "psg_pn2_ws_create_arch": (ci, [vp, ci, ci, ci, ci, ctypes.POINTER(vp)]),
     "psg_pn2_ws_destroy": (ci, [vp]),
     "psg_pn2_ws_bytes": (ctypes.c_size_t, [vp]),
     "psg_pn2_debug_read": (ci, [vp, ctypes.POINTER(ctypes.c_ulonglong), ci]),
@@ -41,6 +43,7 @@ SIGNATURES = {
     "psg_pn2_forward": (ci, [vp, vp, ci, vp, vp, vp, vp]),
     "psg_pn2_backward": (ci, [vp, vp, ci, vp, vp, vp]),
     "psg_pn2_activation_ptr": (vp, [vp, ci]),
+    "psg_pn2_activation_channels": (ci, [vp, ci]),
     "psg_to_point_major": (ci, [vp, ci, ci, ci, vp, vp]),
     "psg_to_channel_major": (ci, [vp, ci, ci, ci, vp, vp]),
     "psg_ce_logp_grad": (ci, [vp, vp, ci, ci, ci, ci, cf, vp, vp, vp]),

@@ -1,12 +1,17 @@
-// Host side of the PointNet++ SSG sem-seg network on gfx950: weight packing, workspace layout,
-// geometry plan, forward, input-gradient backward and the fused NB attack loop.  Everything is
-// stream-ordered; nothing here synchronises the device except psg_pn2_model_create (upload).
+// Host side of the PointNet++ sem-seg networks on gfx950: weight packing, workspace layout, geometry plan, forward,
+// input-gradient backward and the fused NB attack loop, driven by an architecture descriptor (SSG or MSG).
+// Everything is stream-ordered; nothing here synchronises the device except psg_pn2_model_create* (upload).
 //
-// Architecture (PointNet/models/pointnet2_sem_seg.py:9-19 of the reference):
+// SSG (PointNet/models/pointnet2_sem_seg.py:9-19 of the reference):
 //   sa1 (1024, r .1, 32, 12 ->32,32,64)    sa2 (256, .2, 32, 67 ->64,64,128)
 //   sa3 (64, .4, 32, 131->128,128,256)     sa4 (16, .8, 32, 259->256,256,512)
 //   fp4 768->256,256   fp3 384->256,256    fp2 320->256,128    fp1 128->128,128,128
 //   conv1 128->128 (+bn1, ReLU, eval dropout = id), conv2 128->13, log_softmax
+// MSG (PointNet/models/pointnet2_sem_seg_msg.py:10-21): every SA level runs two radii on one FPS sample and
+// concatenates their pooled outputs (pointnet_util.py:210-267):
+//   sa1 (1024, r .05/.1, K 16/32, 12 ->16,16,32 | 32,32,64)      sa2 (256, .1/.2, 99 ->64,64,128 | 64,96,128)
+//   sa3 (64, .2/.4, 259->128,196,256 | 128,196,256)             sa4 (16, .4/.8, 515->256,256,512 | 256,384,512)
+//   fp4 1536->256,256   fp3 512->256,256   fp2 352->256,128    fp1 128->128,128,128, same head
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
@@ -21,20 +26,102 @@ using namespace psg;
 
 namespace {
 
-constexpr int NL = PSG_PN2_NUM_LAYERS;
+constexpr int MAXL = PSG_PN2_MSG_NUM_LAYERS;   // the larger of the two layer counts
 constexpr int NCLS = PSG_PN2_NUM_CLASSES;
-// cin / cout of the 23 conv layers (index = position in the weights array)
-const int kCin[NL] = {12, 32, 32, 67, 64, 64, 131, 128, 128, 259, 256, 256, 768, 256, 384, 256, 320, 256,
-                      128, 128, 128, 128, 128};
-const int kCout[NL] = {32, 32, 64, 64, 64, 128, 128, 128, 256, 256, 256, 512, 256, 256, 256, 256, 256, 128,
-                       128, 128, 128, 128, 13};
-constexpr int kNumReal = NL;
 const int kS[4] = {1024, 256, 64, 16};
-// float32(radius**2) with radius**2 evaluated in double, as Python does (pointnet_util.py:102)
-const float kRadius2[4] = {(float)(0.1 * 0.1), (float)(0.2 * 0.2), (float)(0.4 * 0.4), (float)(0.8 * 0.8)};
-const int kSaC[5] = {9, 64, 128, 256, 512};  // feature channels of level 0..4
-const int kGsaC[4] = {12, 64, 128, 256};     // row stride of the grouped-input gradient rows of sa_bwd level 0..3
-constexpr int K = 32;                        // nsample
+
+// One ball-query scale of an SA level: its three conv layers, the column of its pooled output inside the level's
+// rows, and the kernel configuration (points / waves per workgroup, tiles a wave may hold across a layer's barrier).
+struct ScaleDesc {
+    int K;          // nsample: 32, or 16 (two groups per 32-point MFMA tile)
+    float r2;       // float32(radius**2) with radius**2 evaluated in double, as Python does (pointnet_util.py:102)
+    int l0;         // index of the first of its 3 layers
+    int c_off;      // first column of its C3 channels in the level's output rows
+    int P, NW, maxt_f, maxt_b;
+};
+
+struct ArchDesc {
+    int id;                 // PSG_PN2_ARCH_*
+    int ns;                 // scales per SA level
+    ScaleDesc sc[4][2];
+    int C[5];               // feature channels of level 0..4
+    int n_layers;
+    int cin[MAXL], cout[MAXL];
+    int fp_first[4], fp_count[4];   // FP module LVL (0 = fp1 .. 3 = fp4): first layer index, layer count
+    int fp_maxt_b[4];
+    int head;               // conv1; conv2 = head + 1
+    bool sa_perm;           // reference concat order is [rel_xyz, feats] (SSG) rather than [feats, rel_xyz] (MSG)
+    bool fp4_big;           // fp4's concatenated input exceeds LDS: streamed first / last layer
+    int c3(int lvl, int s) const { return cout[sc[lvl][s].l0 + 2]; }
+};
+
+ArchDesc make_ssg()
+{
+    ArchDesc a{};
+    a.id = PSG_PN2_ARCH_SSG; a.ns = 1; a.n_layers = PSG_PN2_NUM_LAYERS; a.sa_perm = true; a.fp4_big = false;
+    const int cin[PSG_PN2_NUM_LAYERS] = {12, 32, 32, 67, 64, 64, 131, 128, 128, 259, 256, 256, 768, 256, 384, 256, 320, 256,
+                                         128, 128, 128, 128, 128};
+    const int cout[PSG_PN2_NUM_LAYERS] = {32, 32, 64, 64, 64, 128, 128, 128, 256, 256, 256, 512, 256, 256, 256, 256, 256, 128,
+                                          128, 128, 128, 128, 13};
+    for (int i = 0; i < a.n_layers; ++i) { a.cin[i] = cin[i]; a.cout[i] = cout[i]; }
+    const int C[5] = {9, 64, 128, 256, 512};
+    for (int i = 0; i < 5; ++i) a.C[i] = C[i];
+    const double r[4] = {0.1, 0.2, 0.4, 0.8};
+    // points / waves per workgroup of each module (forward and backward share P); backward tiles per wave:
+    // ceil(widest layer's tiles / waves) (sa2 67->96: 6 tiles on 4 waves; sa3 131->160: 5 on 4; sa4 259->288: 9 on 8)
+    const int P[4] = {128, 64, 32, 32}, NW[4] = {4, 4, 4, 8}, mb[4] = {1, 2, 2, 2};
+    for (int l = 0; l < 4; ++l) a.sc[l][0] = ScaleDesc{32, (float)(r[l] * r[l]), 3 * l, 0, P[l], NW[l], 1, mb[l]};
+    // layer indices: fp4 12,13  fp3 14,15  fp2 16,17  fp1 18,19,20 (+ head 21,22 fused into fp1)
+    const int ff[4] = {18, 16, 14, 12}, fc[4] = {3, 2, 2, 2}, fm[4] = {1, 2, 2, 3};   // fp2 320: 10 tiles on 8 waves; fp3 384: 12; fp4 768: 24
+    for (int l = 0; l < 4; ++l) { a.fp_first[l] = ff[l]; a.fp_count[l] = fc[l]; a.fp_maxt_b[l] = fm[l]; }
+    a.head = 21;
+    return a;
+}
+
+ArchDesc make_msg()
+{
+    ArchDesc a{};
+    a.id = PSG_PN2_ARCH_MSG; a.ns = 2; a.n_layers = PSG_PN2_MSG_NUM_LAYERS; a.sa_perm = false; a.fp4_big = true;
+    const int mlp[4][2][3] = {{{16, 16, 32}, {32, 32, 64}}, {{64, 64, 128}, {64, 96, 128}},
+                              {{128, 196, 256}, {128, 196, 256}}, {{256, 256, 512}, {256, 384, 512}}};
+    const double r[4][2] = {{0.05, 0.1}, {0.1, 0.2}, {0.2, 0.4}, {0.4, 0.8}};
+    // kernel configurations: every layer of a module must fit maxt tiles per wave (tiles = ceil(width / 32) * P / 32)
+    const int P[4][2] = {{128, 128}, {64, 64}, {32, 32}, {32, 32}}, NW[4][2] = {{4, 4}, {4, 8}, {8, 8}, {8, 8}};
+    const int mf[4][2] = {{1, 1}, {1, 1}, {1, 1}, {1, 2}};     // sa4 scale 1: 384 -> 12 tiles on 8 waves
+    const int mbk[4][2] = {{1, 1}, {2, 1}, {2, 2}, {3, 3}};    // first layers transposed: 99 -> 8 tiles, 259 -> 9, 515 -> 17
+    a.C[0] = 9;
+    int li = 0;
+    for (int l = 0; l < 4; ++l) {
+        int coff = 0;
+        for (int s = 0; s < 2; ++s) {
+            a.sc[l][s] = ScaleDesc{s == 0 ? 16 : 32, (float)(r[l][s] * r[l][s]), li, coff, P[l][s], NW[l][s], mf[l][s], mbk[l][s]};
+            int last = a.C[l] + 3;
+            for (int j = 0; j < 3; ++j) { a.cin[li] = last; a.cout[li] = mlp[l][s][j]; last = mlp[l][s][j]; ++li; }
+            coff += mlp[l][s][2];
+        }
+        a.C[l + 1] = coff;
+    }
+    // fp4, fp3, fp2, fp1 (state_dict order), then the head
+    const int fin[4] = {a.C[3] + a.C[4], a.C[2] + 256, a.C[1] + 256, 128};
+    const int fw[4][3] = {{256, 256, 0}, {256, 256, 0}, {256, 128, 0}, {128, 128, 128}};
+    const int fm[4] = {1, 2, 2, 1};   // by LVL: fp1 1; fp2 352 -> 11 tiles on 8 waves; fp3 512 -> 16; fp4 streamed
+    for (int q = 0; q < 4; ++q) {
+        const int lvl = 3 - q, n = q == 3 ? 3 : 2;
+        a.fp_first[lvl] = li; a.fp_count[lvl] = n; a.fp_maxt_b[lvl] = fm[lvl];
+        int last = fin[q];
+        for (int j = 0; j < n; ++j) { a.cin[li] = last; a.cout[li] = fw[q][j]; last = fw[q][j]; ++li; }
+    }
+    a.head = li;
+    a.cin[li] = 128; a.cout[li] = 128; ++li;
+    a.cin[li] = 128; a.cout[li] = NCLS; ++li;
+    return a;
+}
+
+const ArchDesc &arch_of(int id)
+{
+    static const ArchDesc ssg = make_ssg(), msg = make_msg();
+    return id == PSG_PN2_ARCH_MSG ? msg : ssg;
+}
 
 struct PackedLayer {
     float4 *wf = nullptr;  // forward packing  [mb(cout)][k8(cin)][64]
@@ -54,34 +141,37 @@ struct PackedLayer {
 
 struct psg_pn2_model {
     psg_ctx *ctx;
-    PackedLayer L[kNumReal];
+    const ArchDesc *arch;
+    PackedLayer L[MAXL];
     void *arena = nullptr;
 };
 
 struct psg_pn2_ws {
     psg_ctx *ctx;
+    const ArchDesc *arch;
     int B, N, F;          // batch, points per room, max forwards in the plan
     int Nl[5];            // points at level 0..4
     void *arena = nullptr;
     size_t bytes = 0;
-    // plan
+    // plan (per-scale tables are indexed [level][scale]; an SSG level has one scale)
     float *xyz0;          // [B][N][3]
     int32_t *fps[4];      // [F*B][S_l]
     float *xyz[5];        // xyz[l+1]: [F*B][S_l][3]; xyz[0] = xyz0
-    int32_t *gidx[4];     // [F*B][S_l][32]
+    int32_t *gidx[4][2];  // [F*B][S_l][K]
     int32_t *nn_idx[4];   // [F*B][N_l][3]
     float *nn_w[4];
     int32_t *inv_off[4];  // inverse 3-NN lists (CSR by coarse point): [F*B][S_l + 1]
     int2 *inv_ent[4];     // [F*B][3*N_l] {fine point, weight bits}, ascending fine point inside a list
     float *dint[4];       // [B][N_l][C2_l] interpolated-part gradient rows of fp_bwd level l
-    int32_t *ginv_off[4]; // inverse group lists (CSR by source point, lists sorted by grouped row): [F*B][N_l + 1]
-    int32_t *ginv_pos[4]; // [F*B][S_l*32] inverse permutation: slot of a grouped row in the concatenated lists
-    float *gsa[4];        // [B][S_l*32][CG_l] grouped-input gradient rows of sa_bwd level l (CG = 12, 64, 128, 256)
+    int32_t *ginv_off[4][2]; // inverse group lists (CSR by source point, lists sorted by grouped row): [F*B][N_l + 1]
+    int32_t *ginv_pos[4][2]; // [F*B][S_l*K] inverse permutation: slot of a grouped row in the concatenated lists
+    float *gsa[4][2];     // [B][S_l*K][CG_l] grouped-input gradient rows of sa_bwd level l (CG = 12, then C[l])
     int planned = 0;
     // activations of one forward
     float *act[7];        // l1..l4, fp4 out (64 pts), fp3 out (256), fp2 out (1024)
-    uint8_t *arg[4];
-    uint16_t *mask[kNumReal];
+    int actC[7];
+    uint8_t *arg[4][2];
+    uint16_t *mask[MAXL];
     float *logp, *dlogp;
     // gradients (every buffer has exactly one writer: nothing is zeroed or accumulated into)
     float *dact[7];
@@ -241,112 +331,147 @@ int launch_lds(psg_pn2_ws *ws, int tag, KernelT kern, dim3 grid, int threads, in
     return PSG_OK;
 }
 
-// points per workgroup / waves per workgroup of each module (forward and backward share P)
-template <int LVL> struct SaCfg;
-template <> struct SaCfg<0> { static constexpr int P = 128, NW = 4; };
-template <> struct SaCfg<1> { static constexpr int P = 64, NW = 4; };
-template <> struct SaCfg<2> { static constexpr int P = 32, NW = 4; };
-template <> struct SaCfg<3> { static constexpr int P = 32, NW = 8; };
-template <int LVL> struct FpCfg { static constexpr int P = 32, NW = 8; };
-template <> struct FpCfg<0> { static constexpr int P = 32, NW = 4; };
-// tiles a wave may hold across the in-place barrier of a backward layer: ceil(widest layer's tiles / waves)
-// (sa2 67->96: 6 tiles on 4 waves; sa3 131->160: 5 on 4; sa4 259->288: 9 on 8; fp2 320: 10 on 8; fp3 384: 12 on 8;
-// fp4 768: 24 on 8); every forward layer has at most one tile per wave
-constexpr int kSaBwdMaxT[4] = {1, 2, 2, 2};
-constexpr int kFpBwdMaxT[4] = {1, 2, 2, 3};
-
 inline int layer_blocks(int k8, int mb) { return std::max(k8, mb * 4); }
+inline int gsa_stride(const ArchDesc &A, int lvl) { return lvl == 0 ? 12 : A.C[lvl]; }
 
-template <int LVL>
-int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *x0, hipStream_t st)
+#define PSG_CFG_KEY(P, NW, KS, MT) ((P) * 10000 + (NW) * 1000 + (KS) * 10 + (MT))
+
+int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, const float *x0, hipStream_t st)
 {
-    constexpr int P = SaCfg<LVL>::P, NW = SaCfg<LVL>::NW;
-    const int B = ws->B, S = kS[LVL], Np = ws->Nl[LVL], D = kSaC[LVL];
-    const PackedLayer *L = &m->L[3 * LVL];
+    const ArchDesc &A = *m->arch;
+    const ScaleDesc &d = A.sc[lvl][sc];
+    const int B = ws->B, S = kS[lvl], Np = ws->Nl[lvl], D = A.C[lvl], KS = d.K, P = d.P, NW = d.NW;
+    const PackedLayer *L = &m->L[d.l0];
     const size_t prob = (size_t)fwd * B;
     SaFwdArgs a;
     static const int sa_diag = getenv("PSG_DIAG") ? atoi(getenv("PSG_DIAG")) : 0;
     a.diag = sa_diag;
-    a.xyz = LVL == 0 ? x0 : ws->xyz[LVL] + prob * Np * 3;
-    a.xyz_stride = LVL == 0 ? 9 : 3;
-    a.feat = LVL == 0 ? x0 : ws->act[LVL > 0 ? LVL - 1 : 0];
-    a.new_xyz = ws->xyz[LVL + 1] + prob * S * 3;
-    a.gidx = ws->gidx[LVL] + prob * S * K;
-    a.out = ws->act[LVL];
-    a.arg = ws->arg[LVL];
-    a.l1 = fwd_layer(L[0], true, ws->mask[3 * LVL]);
-    a.l2 = fwd_layer(L[1], true, ws->mask[3 * LVL + 1]);
+    a.xyz = lvl == 0 ? x0 : ws->xyz[lvl] + prob * Np * 3;
+    a.xyz_stride = lvl == 0 ? 9 : 3;
+    a.feat = lvl == 0 ? x0 : ws->act[lvl - 1];
+    a.new_xyz = ws->xyz[lvl + 1] + prob * S * 3;
+    a.gidx = ws->gidx[lvl][sc] + prob * S * KS;
+    a.out = ws->act[lvl];
+    a.ld_out = A.C[lvl + 1];
+    a.c_out = d.c_off;
+    a.arg = ws->arg[lvl][sc];
+    a.l1 = fwd_layer(L[0], true, ws->mask[d.l0]);
+    a.l2 = fwd_layer(L[1], true, ws->mask[d.l0 + 1]);
     a.w3 = L[2].wf; a.b3 = L[2].bias; a.k8_3 = L[2].k8f(); a.nb3 = L[2].mbf();
     a.D = D; a.Np = Np; a.S = S; a.C3 = L[2].cout;
     // one in-place activation buffer: the widest of the layers' K / M extents (psg_mlp.cuh)
     const int blocks = std::max(std::max(layer_blocks(a.l1.k8, a.l1.mb), layer_blocks(a.l2.k8, a.l2.mb)), a.k8_3) + PSG_LDS_SPARE;
-    if (a.l1.mb * (P / 32) > NW || a.l2.mb * (P / 32) > NW || a.nb3 * (P / 32) > 2 * NW) {
-        set_error("run_sa_fwd<%d>: more tiles than waves in a layer", LVL);
+    if (a.l1.mb * (P / 32) > d.maxt_f * NW || a.l2.mb * (P / 32) > d.maxt_f * NW || a.nb3 * (P / 32) > 2 * NW) {
+        set_error("run_sa_fwd level %d scale %d: more tiles than waves in a layer", lvl, sc);
         return PSG_ERR_STATE;
     }
-    return launch_lds(ws, TAG_SA_FWD + LVL, sa_fwd_kernel<P, NW>, dim3(S / (P / 32), B), NW * 64, blocks, Lds<P>::BLK, a, st);
+    const dim3 grid(S / (P / KS), B);
+    const int tag = TAG_SA_FWD + lvl;
+#define PSG_SA_FWD_CASE(P_, NW_, KS_, MT_) \
+    case PSG_CFG_KEY(P_, NW_, KS_, MT_): \
+        return launch_lds(ws, tag, sa_fwd_kernel<P_, NW_, KS_, MT_>, grid, NW_ * 64, blocks, Lds<P_>::BLK, a, st)
+    switch (PSG_CFG_KEY(P, NW, KS, d.maxt_f)) {
+        PSG_SA_FWD_CASE(128, 4, 32, 1);   // SSG sa1, MSG sa1 scale 1
+        PSG_SA_FWD_CASE(64, 4, 32, 1);    // SSG sa2
+        PSG_SA_FWD_CASE(32, 4, 32, 1);    // SSG sa3
+        PSG_SA_FWD_CASE(32, 8, 32, 1);    // SSG sa4, MSG sa3 scale 1
+        PSG_SA_FWD_CASE(128, 4, 16, 1);   // MSG sa1 scale 0
+        PSG_SA_FWD_CASE(64, 4, 16, 1);    // MSG sa2 scale 0
+        PSG_SA_FWD_CASE(64, 8, 32, 1);    // MSG sa2 scale 1
+        PSG_SA_FWD_CASE(32, 8, 16, 1);    // MSG sa3 / sa4 scale 0
+        PSG_SA_FWD_CASE(32, 8, 32, 2);    // MSG sa4 scale 1
+    }
+#undef PSG_SA_FWD_CASE
+    set_error("run_sa_fwd: no kernel for P=%d NW=%d K=%d MAXT=%d", P, NW, KS, d.maxt_f);
+    return PSG_ERR_STATE;
 }
 
-template <int LVL>
-int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *dx0, int c_lo, int c_hi, hipStream_t st)
+int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, int c_lo, int c_hi, hipStream_t st)
 {
-    constexpr int P = SaCfg<LVL>::P, NW = SaCfg<LVL>::NW;
-    const int B = ws->B, S = kS[LVL], Np = ws->Nl[LVL], D = kSaC[LVL];
-    const PackedLayer *L = &m->L[3 * LVL];
+    const ArchDesc &A = *m->arch;
+    const ScaleDesc &d = A.sc[lvl][sc];
+    const int B = ws->B, S = kS[lvl], Np = ws->Nl[lvl], D = A.C[lvl], KS = d.K, P = d.P, NW = d.NW;
+    const PackedLayer *L = &m->L[d.l0];
     const size_t prob = (size_t)fwd * B;
     SaBwdArgs a;
     static const int sa_diag = getenv("PSG_DIAG") ? atoi(getenv("PSG_DIAG")) : 0;
     a.diag = sa_diag;
-    a.dout = ws->dact[LVL];   // skip-link gradient rows written by fp_bwd level LVL + 1
+    a.ld = A.C[lvl + 1];
+    a.c_off = d.c_off;
+    a.dout = ws->dact[lvl];   // skip-link gradient rows written by fp_bwd level lvl + 1
     a.nninv_off = nullptr; a.nninv_ent = nullptr; a.dint = nullptr; a.n_fine = 0;
     a.ginv_off = nullptr; a.gsa = nullptr; a.g_rows = 0;
-    if (LVL < 3) {   // plus the transposed grouping of SA level LVL + 1, gathered through its inverse lists
-        a.g_rows = kS[LVL + 1] * K;
-        a.ginv_off = ws->ginv_off[LVL + 1] + prob * (S + 1);
-        a.gsa = ws->gsa[LVL + 1];
+    a.ginv_off2 = nullptr; a.gsa2 = nullptr; a.g_rows2 = 0;
+    if (lvl < 3) {   // plus the transposed grouping of SA level lvl + 1, gathered through its inverse lists
+        a.g_rows = kS[lvl + 1] * A.sc[lvl + 1][0].K;
+        a.ginv_off = ws->ginv_off[lvl + 1][0] + prob * (S + 1);
+        a.gsa = ws->gsa[lvl + 1][0];
+        if (A.ns > 1) {
+            a.g_rows2 = kS[lvl + 1] * A.sc[lvl + 1][1].K;
+            a.ginv_off2 = ws->ginv_off[lvl + 1][1] + prob * (S + 1);
+            a.gsa2 = ws->gsa[lvl + 1][1];
+        }
     }
-    if (P * (kSaC[LVL + 1] / 8) > 4 * NW * 64) {   // sa_bwd_kernel pre-loads exactly 4 arg-max tasks per thread
-        set_error("run_sa_bwd<%d>: %d max-pool tasks exceed 4 per thread", LVL, P * (kSaC[LVL + 1] / 8));
+    const int C3 = L[2].cout;
+    if (P * (C3 / 8) > 4 * NW * 64) {   // sa_bwd_kernel pre-loads at most 4 arg-max tasks per thread
+        set_error("run_sa_bwd level %d scale %d: %d max-pool tasks exceed 4 per thread", lvl, sc, P * (C3 / 8));
         return PSG_ERR_STATE;
     }
-    a.gsa_out = ws->gsa[LVL];
-    a.gpos_out = ws->ginv_pos[LVL] + prob * S * K;
-    a.cg_out = (LVL == 0 && c_hi - c_lo == 3) ? 4 : kGsaC[LVL];   // colour-only: compact float4 rows
-    if (LVL == 3) {   // l4_points feed only fp4: its gradient is gathered from fp4's interpolated-part rows
+    a.gsa_out = ws->gsa[lvl][sc];
+    a.gpos_out = ws->ginv_pos[lvl][sc] + prob * S * KS;
+    a.cg_out = (lvl == 0 && c_hi - c_lo == 3) ? 4 : gsa_stride(A, lvl);   // colour-only: compact float4 rows
+    if (lvl == 3) {   // l4_points feed only fp4: its gradient is gathered from fp4's interpolated-part rows
         a.dout = nullptr;
         a.nninv_off = ws->inv_off[3] + prob * (kS[3] + 1);
         a.nninv_ent = ws->inv_ent[3] + prob * ws->Nl[3] * 3;
         a.dint = ws->dint[3];
         a.n_fine = ws->Nl[3];
     }
-    a.arg = ws->arg[LVL];
-    a.gidx = ws->gidx[LVL] + prob * S * K;
-    a.l3t = bwd_layer(L[2], ws->mask[3 * LVL + 1]);
-    a.l2t = bwd_layer(L[1], ws->mask[3 * LVL]);
+    a.arg = ws->arg[lvl][sc];
+    a.gidx = ws->gidx[lvl][sc] + prob * S * KS;
+    a.l3t = bwd_layer(L[2], ws->mask[d.l0 + 1]);
+    a.l2t = bwd_layer(L[1], ws->mask[d.l0]);
     a.l1t = bwd_layer(L[0], nullptr);
-    a.D = D; a.Np = Np; a.S = S; a.C3 = L[2].cout;
+    a.D = D; a.Np = Np; a.S = S; a.C3 = C3;
     a.c_lo = c_lo; a.c_hi = c_hi;
-    constexpr int MAXT = kSaBwdMaxT[LVL];
     const int main_blocks = std::max(std::max(layer_blocks(a.l3t.k8, a.l3t.mb), layer_blocks(a.l2t.k8, a.l2t.mb)),
                                      layer_blocks(a.l1t.k8, a.l1t.mb)) + PSG_LDS_SPARE;
     a.dsrc_blk = main_blocks;   // the gathered pooled-output gradient is staged behind the activation buffer
-    const int blocks = main_blocks + ceil_div((P / 32) * a.C3, Lds<P>::BLK);
-    if (std::max(std::max(a.l3t.mb, a.l2t.mb), a.l1t.mb) * (P / 32) > MAXT * NW) {
-        set_error("run_sa_bwd<%d>: more than %d tiles per wave in a layer", LVL, MAXT);
+    const int blk_floats = P * 8 + PSG_LDS_PAD;
+    const int blocks = main_blocks + ceil_div((P / KS) * C3, blk_floats);
+    if (std::max(std::max(a.l3t.mb, a.l2t.mb), a.l1t.mb) * (P / 32) > d.maxt_b * NW) {
+        set_error("run_sa_bwd level %d scale %d: more than %d tiles per wave in a layer", lvl, sc, d.maxt_b);
         return PSG_ERR_STATE;
     }
-    return launch_lds(ws, TAG_SA_BWD + LVL, (sa_bwd_kernel<P, NW, MAXT>), dim3(S / (P / 32), B), NW * 64, blocks, Lds<P>::BLK, a, st);
+    const dim3 grid(S / (P / KS), B);
+    const int tag = TAG_SA_BWD + lvl;
+#define PSG_SA_BWD_CASE(P_, NW_, KS_, MT_) \
+    case PSG_CFG_KEY(P_, NW_, KS_, MT_): \
+        return launch_lds(ws, tag, (sa_bwd_kernel<P_, NW_, MT_, KS_>), grid, NW_ * 64, blocks, Lds<P_>::BLK, a, st)
+    switch (PSG_CFG_KEY(P, NW, KS, d.maxt_b)) {
+        PSG_SA_BWD_CASE(128, 4, 32, 1);   // SSG sa1, MSG sa1 scale 1
+        PSG_SA_BWD_CASE(64, 4, 32, 2);    // SSG sa2
+        PSG_SA_BWD_CASE(32, 4, 32, 2);    // SSG sa3
+        PSG_SA_BWD_CASE(32, 8, 32, 2);    // SSG sa4, MSG sa3 scale 1
+        PSG_SA_BWD_CASE(128, 4, 16, 1);   // MSG sa1 scale 0
+        PSG_SA_BWD_CASE(64, 4, 16, 2);    // MSG sa2 scale 0
+        PSG_SA_BWD_CASE(64, 8, 32, 1);    // MSG sa2 scale 1
+        PSG_SA_BWD_CASE(32, 8, 16, 2);    // MSG sa3 scale 0
+        PSG_SA_BWD_CASE(32, 8, 16, 3);    // MSG sa4 scale 0
+        PSG_SA_BWD_CASE(32, 8, 32, 3);    // MSG sa4 scale 1
+    }
+#undef PSG_SA_BWD_CASE
+    set_error("run_sa_bwd: no kernel for P=%d NW=%d K=%d MAXT=%d", P, NW, KS, d.maxt_b);
+    return PSG_ERR_STATE;
 }
 
 // FP module `LVL` (0 = fp1 ... 3 = fp4) upsamples level LVL+1 -> level LVL.
-// layer indices: fp4 12,13  fp3 14,15  fp2 16,17  fp1 18,19,20 (+ head 21,22 fused into fp1)
-const int kFpFirst[4] = {18, 16, 14, 12};
-const int kFpCount[4] = {3, 2, 2, 2};
-
 // activation slots: act[0..3] = l1..l4 (SA outputs); act[4] = fp4 out (level 3), act[5] = fp3 out
 // (level 2), act[6] = fp2 out (level 1)
 inline int fp_out_slot(int lvl) { return 7 - lvl; }          // lvl 3 -> 4, 2 -> 5, 1 -> 6
 inline int fp_in2_slot(int lvl) { return lvl == 3 ? 3 : fp_out_slot(lvl + 1); }
+template <int LVL> struct FpCfg { static constexpr int P = 32, NW = 8; };
+template <> struct FpCfg<0> { static constexpr int P = 32, NW = 4; };
 
 // PSG_FP1_WAVE=1 selects the wave-private fp1 + head kernels (psg_chain.cuh) instead of the workgroup-cooperative
 // ones.  Measured on MI355X at a 32-room device batch: forward 193 vs 193 us, backward 211 vs 189 us, so the
@@ -361,8 +486,10 @@ template <int LVL>
 int run_fp_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *logp, hipStream_t st)
 {
     constexpr int P = FpCfg<LVL>::P, NW = FpCfg<LVL>::NW;
+    const ArchDesc &A = *m->arch;
     const int B = ws->B, N = ws->Nl[LVL], S = ws->Nl[LVL + 1];
     const size_t prob = (size_t)fwd * B;
+    const int first = A.fp_first[LVL], head = A.head;
     if (LVL == 0 && fp1_wave()) {
         // fp1 + classifier head as a wave-private chain (psg_chain.cuh): one wave per 32 points, no barriers
         Fp1FwdArgs w;
@@ -371,11 +498,12 @@ int run_fp_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *logp, hipStream
         w.nn_w = ws->nn_w[0] + prob * N * 3;
         w.logp = logp;
         for (int i = 0; i < 4; ++i) {
-            const PackedLayer &L = m->L[18 + i];
-            w.mask[i] = (unsigned long long *)ws->mask[18 + i];
+            const int li = i < 3 ? first + i : head;
+            const PackedLayer &L = m->L[li];
+            w.mask[i] = (unsigned long long *)ws->mask[li];
             w.layer[i].w4 = L.wf4; w.layer[i].bias = L.bias; w.layer[i].k8 = L.k8f();
         }
-        w.head = fwd_layer(m->L[22], false, nullptr);
+        w.head = fwd_layer(m->L[head + 1], false, nullptr);
         w.N = N; w.S = S; w.n_cls = NCLS;
         ProfScope prof(ws, TAG_FP_FWD + 0, st);
         hipLaunchKernelGGL(fp1_fwd_wave_kernel, dim3(N / 32, B), dim3(64), (size_t)16 * WBLK * sizeof(float), st, w);
@@ -384,24 +512,24 @@ int run_fp_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *logp, hipStream
     }
     FpFwdArgs a;
     a.feat1 = LVL == 0 ? nullptr : ws->act[LVL > 0 ? LVL - 1 : 0];
-    a.C1 = LVL == 0 ? 0 : kSaC[LVL];
+    a.C1 = LVL == 0 ? 0 : A.C[LVL];
     a.feat2 = ws->act[fp_in2_slot(LVL)];
-    a.C2 = m->L[kFpFirst[LVL]].cin - a.C1;
+    a.C2 = m->L[first].cin - a.C1;
     a.nn_idx = ws->nn_idx[LVL] + prob * N * 3;
     a.nn_w = ws->nn_w[LVL] + prob * N * 3;
     a.N = N; a.S = S;
-    int nl = kFpCount[LVL];
+    int nl = A.fp_count[LVL];
     for (int i = 0; i < nl; ++i)
-        a.layer[i] = fwd_layer(m->L[kFpFirst[LVL] + i], true, ws->mask[kFpFirst[LVL] + i]);
+        a.layer[i] = fwd_layer(m->L[first + i], true, ws->mask[first + i]);
     a.out = nullptr; a.logp = nullptr; a.Cout = 0; a.n_cls = 0;
     if (LVL == 0) {
-        a.layer[nl] = fwd_layer(m->L[21], true, ws->mask[21]);
-        a.layer[nl + 1] = fwd_layer(m->L[22], false, nullptr);
+        a.layer[nl] = fwd_layer(m->L[head], true, ws->mask[head]);
+        a.layer[nl + 1] = fwd_layer(m->L[head + 1], false, nullptr);
         nl += 2;
         a.logp = logp; a.n_cls = NCLS;
     } else {
         a.out = ws->act[fp_out_slot(LVL)];
-        a.Cout = m->L[kFpFirst[LVL] + nl - 1].cout;
+        a.Cout = m->L[first + nl - 1].cout;
     }
     a.n_layers = nl;
     static const int diag = getenv("PSG_DIAG") ? atoi(getenv("PSG_DIAG")) : 0;
@@ -411,30 +539,39 @@ int run_fp_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *logp, hipStream
     if (diag & 2) for (int i = 0; i < nl; ++i) a.layer[i].mask = nullptr;
     if (diag & 64) for (int i = 0; i < nl; ++i) a.layer[i].k8 = 4;    // timing only: 1/4 .. 1/24 of the MFMAs
     if (diag & 128) for (int i = 0; i < nl; ++i) a.layer[i].relu = 0; // timing only: no ReLU/mask epilogue
+    const bool big = LVL == 3 && A.fp4_big;
     int blocks = 0;
     for (int i = 0; i < nl; ++i) {
-        blocks = std::max(blocks, layer_blocks(a.layer[i].k8, a.layer[i].mb));
+        // a streamed first layer holds at most 64 blocks of its input at a time (fp_fwd_kernel<.., BIG>)
+        const int k8 = (big && i == 0) ? std::min(a.layer[i].k8, 64) : a.layer[i].k8;
+        blocks = std::max(blocks, layer_blocks(k8, a.layer[i].mb));
         if (a.layer[i].mb * (P / 32) > NW) {
             set_error("run_fp_fwd<%d>: more tiles than waves in layer %d", LVL, i);
             return PSG_ERR_STATE;
         }
     }
     blocks += PSG_LDS_SPARE;
-    return launch_lds(ws, TAG_FP_FWD + LVL, fp_fwd_kernel<P, NW>, dim3(N / P, B), NW * 64, blocks, Lds<P>::BLK, a, st);
+    if constexpr (LVL == 3) if (big) {
+        if (a.C1 % 4 || a.C2 % 4 || (a.C1 % 512) || !a.feat1) { set_error("run_fp_fwd: streamed fp4 wants C1 a multiple of 512"); return PSG_ERR_STATE; }
+        return launch_lds(ws, TAG_FP_FWD + LVL, (fp_fwd_kernel<P, NW, true>), dim3(N / P, B), NW * 64, blocks, Lds<P>::BLK, a, st);
+    }
+    return launch_lds(ws, TAG_FP_FWD + LVL, (fp_fwd_kernel<P, NW, false>), dim3(N / P, B), NW * 64, blocks, Lds<P>::BLK, a, st);
 }
 
 template <int LVL>
 int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, const float *dlogp, hipStream_t st)
 {
     constexpr int P = FpCfg<LVL>::P, NW = FpCfg<LVL>::NW;
+    const ArchDesc &A = *m->arch;
     const int B = ws->B, N = ws->Nl[LVL], S = ws->Nl[LVL + 1];
     const size_t prob = (size_t)fwd * B;
+    const int first = A.fp_first[LVL], cnt = A.fp_count[LVL], head = A.head;
     if (LVL == 0 && fp1_wave()) {
         Fp1BwdArgs w;
         w.logp = logp; w.dlogp = dlogp;
-        for (int i = 0; i < 4; ++i) w.mask[i] = (const unsigned long long *)ws->mask[18 + i];
+        for (int i = 0; i < 4; ++i) w.mask[i] = (const unsigned long long *)ws->mask[i < 3 ? first + i : head];
         for (int i = 0; i < 5; ++i) {   // conv2^T, conv1^T, mlp2^T, mlp1^T, mlp0^T
-            const PackedLayer &L = m->L[22 - i];
+            const PackedLayer &L = m->L[i < 2 ? head + 1 - i : first + 4 - i];
             w.layer[i].w4 = L.wb4; w.layer[i].bias = nullptr; w.layer[i].k8 = round_up(L.k8b(), 4);
         }
         w.dint_out = ws->dint[0];
@@ -448,19 +585,18 @@ int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, con
     a.nn_idx = ws->nn_idx[LVL] + prob * N * 3;
     a.nn_w = ws->nn_w[LVL] + prob * N * 3;
     a.N = N; a.S = S;
-    a.C1 = LVL == 0 ? 0 : kSaC[LVL];
-    a.C2 = m->L[kFpFirst[LVL]].cin - a.C1;
+    a.C1 = LVL == 0 ? 0 : A.C[LVL];
+    a.C2 = m->L[first].cin - a.C1;
     a.dfeat1 = LVL == 0 ? nullptr : ws->dact[LVL > 0 ? LVL - 1 : 0];
     a.dint_out = ws->dint[LVL];
     a.nninv_off = nullptr; a.nninv_ent = nullptr; a.dint = nullptr; a.n_fine = 0;
-    const int first = kFpFirst[LVL], cnt = kFpCount[LVL];
     int nl = 0;
     a.dout = nullptr; a.mask_last = nullptr; a.logp = nullptr; a.dlogp = nullptr;
     a.Cout = 0; a.n_cls = 0; a.mb_last = 0;
     if (LVL == 0) {
         a.logp = logp; a.dlogp = dlogp; a.n_cls = NCLS;
-        a.layer[nl++] = bwd_layer(m->L[22], ws->mask[21]);            // conv2^T, then bn1/conv1 ReLU mask
-        a.layer[nl++] = bwd_layer(m->L[21], ws->mask[first + cnt - 1]); // conv1^T, then fp1 last ReLU mask
+        a.layer[nl++] = bwd_layer(m->L[head + 1], ws->mask[head]);          // conv2^T, then bn1/conv1 ReLU mask
+        a.layer[nl++] = bwd_layer(m->L[head], ws->mask[first + cnt - 1]);   // conv1^T, then fp1 last ReLU mask
     } else {
         // gradient of this module's output = transpose of the finer module's interpolation, gathered
         constexpr int LF = LVL > 0 ? LVL - 1 : 0;   // the finer FP level
@@ -475,17 +611,30 @@ int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, con
     for (int i = cnt - 1; i >= 0; --i)
         a.layer[nl++] = bwd_layer(m->L[first + i], i > 0 ? ws->mask[first + i - 1] : nullptr);
     a.n_layers = nl;
-    constexpr int MAXT = kFpBwdMaxT[LVL];
+    const bool big = LVL == 3 && A.fp4_big;
+    const int maxt = A.fp_maxt_b[LVL];
     int blocks = a.mb_last * 4;
     for (int i = 0; i < nl; ++i) {
+        if (big && i == nl - 1) {   // streamed last layer: its input plus a staging area of NW tiles
+            blocks = std::max(blocks, a.layer[i].k8 + NW * 4);
+            continue;
+        }
         blocks = std::max(blocks, layer_blocks(a.layer[i].k8, a.layer[i].mb));
-        if (a.layer[i].mb * (P / 32) > MAXT * NW) {
-            set_error("run_fp_bwd<%d>: more than %d tiles per wave in layer %d", LVL, MAXT, i);
+        if (a.layer[i].mb * (P / 32) > maxt * NW) {
+            set_error("run_fp_bwd<%d>: more than %d tiles per wave in layer %d", LVL, maxt, i);
             return PSG_ERR_STATE;
         }
     }
     blocks += PSG_LDS_SPARE;
-    return launch_lds(ws, TAG_FP_BWD + LVL, (fp_bwd_kernel<P, NW, MAXT>), dim3(N / P, B), NW * 64, blocks, Lds<P>::BLK, a, st);
+    const dim3 grid(N / P, B);
+    if constexpr (LVL == 3) if (big) return launch_lds(ws, TAG_FP_BWD + LVL, (fp_bwd_kernel<P, NW, 1, true>), grid, NW * 64, blocks, Lds<P>::BLK, a, st);
+    switch (maxt) {
+    case 1: return launch_lds(ws, TAG_FP_BWD + LVL, (fp_bwd_kernel<P, NW, 1, false>), grid, NW * 64, blocks, Lds<P>::BLK, a, st);
+    case 2: return launch_lds(ws, TAG_FP_BWD + LVL, (fp_bwd_kernel<P, NW, 2, false>), grid, NW * 64, blocks, Lds<P>::BLK, a, st);
+    case 3: return launch_lds(ws, TAG_FP_BWD + LVL, (fp_bwd_kernel<P, NW, 3, false>), grid, NW * 64, blocks, Lds<P>::BLK, a, st);
+    }
+    set_error("run_fp_bwd<%d>: no kernel for MAXT=%d", LVL, maxt);
+    return PSG_ERR_STATE;
 }
 
 __global__ void extract_xyz_kernel(const float *__restrict__ x0, float *__restrict__ xyz, size_t rows)
@@ -552,12 +701,14 @@ __global__ __launch_bounds__(256) void build_inv_nn_kernel(const int32_t *__rest
 // offsets of a CSR whose lists are sorted by grouped row, plus the inverse permutation `pos` (slot of a grouped row
 // in the concatenated lists): sa_bwd stores row r at slot pos[r], so a consumer reads the rows of one point
 // contiguously and in a fixed order.  (query_ball_point pads a group by repeating its first member, so a point
-// can occur several times in one group: every occurrence is listed, as autograd's index backward sums every
-// occurrence.)  One workgroup per problem, the whole list array staged in LDS (<= 32768 16-bit row ids + 8193 counters).
+// can occur several times in one group: autograd's index backward sums every occurrence; see the kernel body for
+// why only the first is listed.)  One workgroup per problem, the whole list array staged in LDS (<= 32768 16-bit row ids + 8193 counters).
 constexpr int INV_NT = 1024;
 __global__ __launch_bounds__(INV_NT) void build_inv_group_kernel(const int32_t *__restrict__ gidx, int n_rows, int n_src,
-                                                                 int32_t *__restrict__ inv_off, int32_t *__restrict__ inv_pos)
+                                                                 int ks, int32_t *__restrict__ inv_off,
+                                                                 int32_t *__restrict__ inv_pos)
 {
+    const int km = ks - 1;   // ks = samples per group, a power of two
     extern __shared__ int s_inv[];
     int *s_cnt = s_inv;               // [n_src + 1]
     unsigned short *s_ent = (unsigned short *)(s_inv + n_src + 1);   // [n_rows] row ids (< 32768: 16 bits)
@@ -571,7 +722,7 @@ __global__ __launch_bounds__(INV_NT) void build_inv_group_kernel(const int32_t *
     // max-pool's lowest-index tie rule never routes gradient to them, so their rows are exactly zero.  pos = -1
     // tells sa_bwd not to store them.  That also bounds a list by the number of GROUPS containing the point.
     for (int e = threadIdx.x; e < n_rows; e += INV_NT) {
-        const bool pad = (e & 31) != 0 && idx[e] == idx[e & ~31];
+        const bool pad = (e & km) != 0 && idx[e] == idx[e & ~km];
         if (!pad) atomicAdd(&s_cnt[idx[e]], 1);
         else pos[e] = -1;
     }
@@ -591,7 +742,7 @@ __global__ __launch_bounds__(INV_NT) void build_inv_group_kernel(const int32_t *
     }
     __syncthreads();
     for (int e = threadIdx.x; e < n_rows; e += INV_NT) {
-        const bool pad = (e & 31) != 0 && idx[e] == idx[e & ~31];
+        const bool pad = (e & km) != 0 && idx[e] == idx[e & ~km];
         if (!pad) s_ent[atomicAdd(&s_cnt[idx[e]], 1)] = (unsigned short)e;
     }
     __syncthreads();
@@ -614,8 +765,9 @@ __global__ __launch_bounds__(INV_NT) void build_inv_group_kernel(const int32_t *
 // COMPACT: rows are {c_lo, c_lo+1, c_lo+2, 0} float4 (attack loop), one thread per point; else rows of `cg` floats
 // indexed by channel, one thread per (point, channel).
 template <bool COMPACT>
-__global__ void dx0_gather_kernel(const int32_t *__restrict__ inv_off, const float *__restrict__ gsa, int B, int N,
-                                  int g_rows, int cg, int c_lo, int c_hi, float *__restrict__ dx0)
+__global__ void dx0_gather_kernel(const int32_t *__restrict__ inv_off, const float *__restrict__ gsa, int g_rows,
+                                  const int32_t *__restrict__ inv_off2, const float *__restrict__ gsa2, int g_rows2,
+                                  int B, int N, int cg, int c_lo, int c_hi, float *__restrict__ dx0)
 {
     const int nc = COMPACT ? 1 : c_hi - c_lo;
     const size_t total = (size_t)B * N * nc;
@@ -623,23 +775,29 @@ __global__ void dx0_gather_kernel(const int32_t *__restrict__ inv_off, const flo
         const int c = c_lo + (int)(t % nc);
         const size_t pq = t / nc;
         const int b = (int)(pq / N), q = (int)(pq - (size_t)b * N);
-        const int32_t *off = inv_off + (size_t)b * (N + 1) + q;
-        const int e1 = off[1];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int e = off[0]; e < e1; e += 8) {
-            if (COMPACT) {
-                float4 v[8];
+        for (int list = 0; list < 2; ++list) {   // the MSG network has a second scale of sa1 (after the first)
+            const int32_t *offs = list ? inv_off2 : inv_off;
+            if (!offs) break;
+            const float *rows = list ? gsa2 : gsa;
+            const int gr = list ? g_rows2 : g_rows;
+            const int32_t *off = offs + (size_t)b * (N + 1) + q;
+            const int e1 = off[1];
+            for (int e = off[0]; e < e1; e += 8) {
+                if (COMPACT) {
+                    float4 v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    v[u] = e + u < e1 ? *(const float4 *)(gsa + ((size_t)b * g_rows + e + u) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int u = 0; u < 8; ++u)
+                        v[u] = e + u < e1 ? *(const float4 *)(rows + ((size_t)b * gr + e + u) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; }
-            } else {
-                float v[8];
+                    for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; }
+                } else {
+                    float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = e + u < e1 ? gsa[((size_t)b * g_rows + e + u) * cg + c] : 0.0f;
+                    for (int u = 0; u < 8; ++u) v[u] = e + u < e1 ? rows[((size_t)b * gr + e + u) * cg + c] : 0.0f;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc.x += v[u];
+                    for (int u = 0; u < 8; ++u) acc.x += v[u];
+                }
             }
         }
         if (COMPACT) {
@@ -654,6 +812,7 @@ size_t ws_layout(psg_pn2_ws *ws, char *base)
 {
     Bump bp;
     bp.base = base;
+    const ArchDesc &A = *ws->arch;
     const int B = ws->B, F = ws->F;
     const size_t PR = (size_t)F * B;
     ws->xyz0 = bp.take<float>((size_t)B * ws->N * 3);
@@ -661,37 +820,47 @@ size_t ws_layout(psg_pn2_ws *ws, char *base)
     for (int l = 0; l < 4; ++l) {
         ws->fps[l] = bp.take<int32_t>(PR * kS[l]);
         ws->xyz[l + 1] = bp.take<float>(PR * kS[l] * 3);
-        ws->gidx[l] = bp.take<int32_t>(PR * kS[l] * K);
         ws->nn_idx[l] = bp.take<int32_t>(PR * ws->Nl[l] * 3);
         ws->nn_w[l] = bp.take<float>(PR * ws->Nl[l] * 3);
         ws->inv_off[l] = bp.take<int32_t>(PR * (kS[l] + 1));
         ws->inv_ent[l] = bp.take<int2>(PR * ws->Nl[l] * 3);
-        ws->ginv_off[l] = bp.take<int32_t>(PR * (ws->Nl[l] + 1));
-        ws->ginv_pos[l] = bp.take<int32_t>(PR * kS[l] * K);
+        for (int s = 0; s < A.ns; ++s) {
+            ws->gidx[l][s] = bp.take<int32_t>(PR * kS[l] * A.sc[l][s].K);
+            ws->ginv_off[l][s] = bp.take<int32_t>(PR * (ws->Nl[l] + 1));
+            ws->ginv_pos[l][s] = bp.take<int32_t>(PR * kS[l] * A.sc[l][s].K);
+        }
     }
-    for (int l = 0; l < 4; ++l) ws->gsa[l] = bp.take<float>((size_t)B * kS[l] * K * kGsaC[l]);
-    {
-        const int c2[4] = {128, 256, 256, 512};
-        for (int l = 0; l < 4; ++l) ws->dint[l] = bp.take<float>((size_t)B * ws->Nl[l] * c2[l]);
+    for (int l = 0; l < 4; ++l)
+        for (int s = 0; s < A.ns; ++s) ws->gsa[l][s] = bp.take<float>((size_t)B * kS[l] * A.sc[l][s].K * gsa_stride(A, l));
+    for (int l = 0; l < 4; ++l) {   // interpolated-part gradient rows of FP module l: C2 = its input minus the skip part
+        const int c2 = A.cin[A.fp_first[l]] - (l == 0 ? 0 : A.C[l]);
+        ws->dint[l] = bp.take<float>((size_t)B * ws->Nl[l] * c2);
     }
     const int actN[7] = {1024, 256, 64, 16, 64, 256, 1024};
-    const int actC[7] = {64, 128, 256, 512, 256, 256, 128};
-    for (int i = 0; i < 7; ++i) ws->act[i] = bp.take<float>((size_t)B * actN[i] * actC[i]);
-    for (int l = 0; l < 4; ++l) ws->arg[l] = bp.take<uint8_t>((size_t)B * kS[l] * actC[l]);
+    for (int i = 0; i < 4; ++i) ws->actC[i] = A.C[i + 1];
+    for (int lvl = 3; lvl >= 1; --lvl) ws->actC[7 - lvl] = A.cout[A.fp_first[lvl] + A.fp_count[lvl] - 1];
+    for (int i = 0; i < 7; ++i) ws->act[i] = bp.take<float>((size_t)B * actN[i] * ws->actC[i]);
+    for (int l = 0; l < 4; ++l)
+        for (int s = 0; s < A.ns; ++s) ws->arg[l][s] = bp.take<uint8_t>((size_t)B * kS[l] * A.c3(l, s));
     // ReLU masks: one uint16 per (32-channel block, point-lane): rows * mb(cout) * 2 entries
-    for (int i = 0; i < kNumReal; ++i) {
-        size_t rows;
-        if (i < 12) rows = (size_t)B * kS[i / 3] * K;
-        else if (i < 14) rows = (size_t)B * ws->Nl[3];
-        else if (i < 16) rows = (size_t)B * ws->Nl[2];
-        else if (i < 18) rows = (size_t)B * ws->Nl[1];
-        else rows = (size_t)B * ws->Nl[0];
-        ws->mask[i] = bp.take<uint16_t>(rows * ceil_div(kCout[i], 32) * 2);
-    }
+    for (int i = 0; i < A.n_layers; ++i) ws->mask[i] = nullptr;
+    for (int l = 0; l < 4; ++l)
+        for (int s = 0; s < A.ns; ++s)
+            for (int j = 0; j < 3; ++j) {
+                const int li = A.sc[l][s].l0 + j;
+                ws->mask[li] = bp.take<uint16_t>((size_t)B * kS[l] * A.sc[l][s].K * ceil_div(A.cout[li], 32) * 2);
+            }
+    for (int lvl = 0; lvl < 4; ++lvl)
+        for (int j = 0; j < A.fp_count[lvl]; ++j) {
+            const int li = A.fp_first[lvl] + j;
+            ws->mask[li] = bp.take<uint16_t>((size_t)B * ws->Nl[lvl] * ceil_div(A.cout[li], 32) * 2);
+        }
+    for (int li = A.head; li < A.head + 2; ++li)
+        ws->mask[li] = bp.take<uint16_t>((size_t)B * ws->Nl[0] * ceil_div(A.cout[li], 32) * 2);
     ws->logp = bp.take<float>((size_t)B * ws->N * NCLS);
     ws->dlogp = bp.take<float>((size_t)B * ws->N * NCLS);
     bp.off = (bp.off + 255) & ~(size_t)255;
-    for (int i = 0; i < 7; ++i) ws->dact[i] = bp.take<float>((size_t)B * actN[i] * actC[i]);
+    for (int i = 0; i < 7; ++i) ws->dact[i] = bp.take<float>((size_t)B * actN[i] * ws->actC[i]);
     ws->dx0 = bp.take<float>((size_t)B * ws->N * 9);
     bp.off = (bp.off + 255) & ~(size_t)255;
     ws->x0 = bp.take<float>((size_t)B * ws->N * 9);
@@ -703,36 +872,44 @@ size_t ws_layout(psg_pn2_ws *ws, char *base)
 }  // namespace
 
 // ================================================================================== C ABI: model
-extern "C" int psg_pn2_model_create(psg_ctx *ctx, const float *const *weights, const float *const *biases,
-                                    psg_pn2_model **out)
+extern "C" int psg_pn2_model_create_arch(psg_ctx *ctx, int arch, const float *const *weights,
+                                         const float *const *biases, int n_layers, psg_pn2_model **out)
 {
     PSG_REQUIRE(ctx && weights && biases && out, "psg_pn2_model_create: null argument");
+    PSG_REQUIRE(arch == PSG_PN2_ARCH_SSG || arch == PSG_PN2_ARCH_MSG, "psg_pn2_model_create: unknown architecture %d", arch);
+    const ArchDesc &A = arch_of(arch);
+    PSG_REQUIRE(n_layers == A.n_layers, "psg_pn2_model_create: architecture %d has %d layers, got %d", arch, A.n_layers, n_layers);
     PSG_CHECK_HIP(hipSetDevice(ctx->device));
     auto *m = new psg_pn2_model();
     m->ctx = ctx;
-    std::vector<std::vector<float>> wf(kNumReal), wb(kNumReal), bs(kNumReal), wf4(kNumReal), wb4(kNumReal);
+    m->arch = &A;
+    const int NLr = A.n_layers, fp1 = A.fp_first[0];
+    std::vector<std::vector<float>> wf(NLr), wb(NLr), bs(NLr), wf4(NLr), wb4(NLr);
+    std::vector<bool> sa_first(NLr, false);
+    for (int l = 0; l < 4; ++l)
+        for (int s = 0; s < A.ns; ++s) sa_first[A.sc[l][s].l0] = A.sa_perm;
     size_t total = 0;
-    for (int i = 0; i < kNumReal; ++i) {
+    for (int i = 0; i < NLr; ++i) {
         if (!weights[i] || !biases[i]) { delete m; set_error("psg_pn2_model_create: layer %d is null", i); return PSG_ERR_ARG; }
+        const int cin = A.cin[i], cout = A.cout[i];
         std::vector<int> perm;
-        const bool sa_first = i < 12 && i % 3 == 0;
-        if (sa_first) perm = sa_input_perm(kCin[i]);
-        wf[i] = pack_fwd(weights[i], kCin[i], kCout[i], sa_first ? &perm : nullptr);
-        wb[i] = pack_bwd(weights[i], kCin[i], kCout[i], sa_first ? &perm : nullptr);
-        bs[i].assign((size_t)ceil_div(kCout[i], 32) * 32, 0.0f);
-        std::copy(biases[i], biases[i] + kCout[i], bs[i].begin());
-        if (i >= 18) {   // fp1 + head run as wave-private chains: k8-major packings of the 128-wide sides
-            if (kCout[i] == 128) wf4[i] = k8_major(wf[i], 4, ceil_div(kCin[i], 8));
-            wb4[i] = k8_major_padded(wb[i], 4, ceil_div(kCout[i], 8), round_up(ceil_div(kCout[i], 8), 4));
+        if (sa_first[i]) perm = sa_input_perm(cin);
+        wf[i] = pack_fwd(weights[i], cin, cout, sa_first[i] ? &perm : nullptr);
+        wb[i] = pack_bwd(weights[i], cin, cout, sa_first[i] ? &perm : nullptr);
+        bs[i].assign((size_t)ceil_div(cout, 32) * 32, 0.0f);
+        std::copy(biases[i], biases[i] + cout, bs[i].begin());
+        if (i >= fp1 && i < fp1 + 3 || i >= A.head) {   // fp1 + head run as wave-private chains: k8-major packings of the 128-wide sides
+            if (cout == 128) wf4[i] = k8_major(wf[i], 4, ceil_div(cin, 8));
+            wb4[i] = k8_major_padded(wb[i], 4, ceil_div(cout, 8), round_up(ceil_div(cout, 8), 4));
         }
         total += ((wf[i].size() + wb[i].size() + bs[i].size() + wf4[i].size() + wb4[i].size()) * 4 + 5 * 256);
     }
     PSG_CHECK_HIP(hipMalloc(&m->arena, total));
     Bump bp;
     bp.base = (char *)m->arena;
-    for (int i = 0; i < kNumReal; ++i) {
+    for (int i = 0; i < NLr; ++i) {
         PackedLayer &L = m->L[i];
-        L.cin = kCin[i]; L.cout = kCout[i];
+        L.cin = A.cin[i]; L.cout = A.cout[i];
         L.wf = bp.take<float4>(wf[i].size() / 4);
         L.wb = bp.take<float4>(wb[i].size() / 4);
         L.bias = bp.take<float>(bs[i].size());
@@ -752,6 +929,12 @@ extern "C" int psg_pn2_model_create(psg_ctx *ctx, const float *const *weights, c
     return PSG_OK;
 }
 
+extern "C" int psg_pn2_model_create(psg_ctx *ctx, const float *const *weights, const float *const *biases,
+                                    psg_pn2_model **out)
+{
+    return psg_pn2_model_create_arch(ctx, PSG_PN2_ARCH_SSG, weights, biases, PSG_PN2_NUM_LAYERS, out);
+}
+
 extern "C" int psg_pn2_model_destroy(psg_pn2_model *m)
 {
     if (!m) return PSG_OK;
@@ -761,15 +944,16 @@ extern "C" int psg_pn2_model_destroy(psg_pn2_model *m)
 }
 
 // ============================================================================== C ABI: workspace
-extern "C" int psg_pn2_ws_create(psg_ctx *ctx, int batch, int n_point, int max_forwards, psg_pn2_ws **out)
+extern "C" int psg_pn2_ws_create_arch(psg_ctx *ctx, int arch, int batch, int n_point, int max_forwards, psg_pn2_ws **out)
 {
     PSG_REQUIRE(ctx && out, "psg_pn2_ws_create: null argument");
+    PSG_REQUIRE(arch == PSG_PN2_ARCH_SSG || arch == PSG_PN2_ARCH_MSG, "psg_pn2_ws_create: unknown architecture %d", arch);
     PSG_REQUIRE(batch > 0 && max_forwards > 0, "psg_pn2_ws_create: batch and max_forwards must be positive");
     PSG_REQUIRE(n_point >= 1024 && n_point <= 8192 && n_point % 128 == 0,
                 "psg_pn2_ws_create: n_point=%d must be a multiple of 128 in [1024, 8192]", n_point);
     PSG_CHECK_HIP(hipSetDevice(ctx->device));
     auto *ws = new psg_pn2_ws();
-    ws->ctx = ctx; ws->B = batch; ws->N = n_point; ws->F = max_forwards;
+    ws->ctx = ctx; ws->arch = &arch_of(arch); ws->B = batch; ws->N = n_point; ws->F = max_forwards;
     ws->Nl[0] = n_point;
     for (int l = 0; l < 4; ++l) ws->Nl[l + 1] = kS[l];
     ws->bytes = ws_layout(ws, nullptr);
@@ -782,6 +966,11 @@ extern "C" int psg_pn2_ws_create(psg_ctx *ctx, int batch, int n_point, int max_f
     ws_layout(ws, (char *)ws->arena);
     *out = ws;
     return PSG_OK;
+}
+
+extern "C" int psg_pn2_ws_create(psg_ctx *ctx, int batch, int n_point, int max_forwards, psg_pn2_ws **out)
+{
+    return psg_pn2_ws_create_arch(ctx, PSG_PN2_ARCH_SSG, batch, n_point, max_forwards, out);
 }
 
 extern "C" int psg_pn2_ws_destroy(psg_pn2_ws *ws)
@@ -854,15 +1043,16 @@ extern "C" int psg_pn2_plan_build(psg_pn2_ws *ws, const float *x0, const int32_t
             if ((rc = psg_gather_points(ws->ctx, ws->xyz[l], n_clouds, P, Np, 3, ws->fps[l], S, ws->xyz[l + 1], st)))
                 return rc;
         }
-        {
+        for (int sc = 0; sc < ws->arch->ns; ++sc) {
+            const ScaleDesc &d = ws->arch->sc[l][sc];
             ProfScope prof(ws, TAG_BALL, st);
-            if ((rc = psg_ball_query(ws->ctx, ws->xyz[l], n_clouds, ws->xyz[l + 1], P, Np, S, kRadius2[l], K,
-                                     ws->gidx[l], st)))
+            if ((rc = psg_ball_query(ws->ctx, ws->xyz[l], n_clouds, ws->xyz[l + 1], P, Np, S, d.r2, d.K,
+                                     ws->gidx[l][sc], st)))
                 return rc;
-            const size_t inv_lds = (size_t)(Np + 1) * 4 + (size_t)S * K * 2;
+            const size_t inv_lds = (size_t)(Np + 1) * 4 + (size_t)S * d.K * 2;
             if (inv_lds > 48 * 1024) PSG_CHECK_HIP(allow_big_lds((const void *)build_inv_group_kernel));
-            hipLaunchKernelGGL(build_inv_group_kernel, dim3(P), dim3(INV_NT), inv_lds, st, ws->gidx[l], S * K, Np,
-                               ws->ginv_off[l], ws->ginv_pos[l]);
+            hipLaunchKernelGGL(build_inv_group_kernel, dim3(P), dim3(INV_NT), inv_lds, st, ws->gidx[l][sc], S * d.K, Np, d.K,
+                               ws->ginv_off[l][sc], ws->ginv_pos[l][sc]);
             PSG_LAUNCH_CHECK();
         }
         {
@@ -885,10 +1075,11 @@ extern "C" const void *psg_pn2_plan_ptr(const psg_pn2_ws *ws, int what, int leve
     const size_t p = (size_t)forward * ws->B + room;
     switch (what) {
     case 0: return ws->fps[level] + p * kS[level];
-    case 1: return ws->gidx[level] + p * kS[level] * K;
+    case 1: return ws->gidx[level][0] + p * kS[level] * ws->arch->sc[level][0].K;
     case 2: return ws->nn_idx[level] + p * ws->Nl[level] * 3;
     case 3: return ws->nn_w[level] + p * ws->Nl[level] * 3;
     case 4: return ws->xyz[level + 1] + p * kS[level] * 3;
+    case 5: return ws->arch->ns > 1 ? ws->gidx[level][1] + p * kS[level] * ws->arch->sc[level][1].K : nullptr;
     default: return nullptr;
     }
 }
@@ -899,18 +1090,24 @@ extern "C" const float *psg_pn2_activation_ptr(const psg_pn2_ws *ws, int which)
     return ws->act[which];
 }
 
+extern "C" int psg_pn2_activation_channels(const psg_pn2_ws *ws, int which)
+{
+    if (!ws || which < 0 || which > 6) return 0;
+    return ws->actC[which];
+}
+
 // ================================================================================ forward / backward
 extern "C" int psg_pn2_forward(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *x0, float *logp_out,
                                float *l4_out, psg_stream stream)
 {
     PSG_REQUIRE(m && ws && x0 && logp_out, "psg_pn2_forward: null argument");
+    PSG_REQUIRE(m->arch == ws->arch, "psg_pn2_forward: model and workspace were created for different architectures");
     PSG_REQUIRE(fwd >= 0 && fwd < ws->planned, "psg_pn2_forward: plan slot %d not built (planned %d)", fwd, ws->planned);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if ((rc = run_sa_fwd<0>(m, ws, fwd, x0, st))) return rc;
-    if ((rc = run_sa_fwd<1>(m, ws, fwd, x0, st))) return rc;
-    if ((rc = run_sa_fwd<2>(m, ws, fwd, x0, st))) return rc;
-    if ((rc = run_sa_fwd<3>(m, ws, fwd, x0, st))) return rc;
+    for (int l = 0; l < 4; ++l)
+        for (int sc = 0; sc < m->arch->ns; ++sc)
+            if ((rc = run_sa_fwd(m, ws, l, sc, fwd, x0, st))) return rc;
     if ((rc = run_fp_fwd<3>(m, ws, fwd, nullptr, st))) return rc;
     if ((rc = run_fp_fwd<2>(m, ws, fwd, nullptr, st))) return rc;
     if ((rc = run_fp_fwd<1>(m, ws, fwd, nullptr, st))) return rc;
@@ -918,7 +1115,7 @@ extern "C" int psg_pn2_forward(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const 
     if (logp_out != ws->logp)
         PSG_CHECK_HIP(hipMemcpyAsync(logp_out, ws->logp, (size_t)ws->B * ws->N * NCLS * 4, hipMemcpyDeviceToDevice, st));
     if (l4_out)
-        PSG_CHECK_HIP(hipMemcpyAsync(l4_out, ws->act[3], (size_t)ws->B * 16 * 512 * 4, hipMemcpyDeviceToDevice, st));
+        PSG_CHECK_HIP(hipMemcpyAsync(l4_out, ws->act[3], (size_t)ws->B * 16 * ws->actC[3] * 4, hipMemcpyDeviceToDevice, st));
     ws->fwd_slot = fwd;
     return PSG_OK;
 }
@@ -926,28 +1123,32 @@ extern "C" int psg_pn2_forward(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const 
 static int backward_impl(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, const float *dlogp,
                          float *dx0, int c_lo, int c_hi, hipStream_t st)
 {
+    const ArchDesc &A = *m->arch;
     int rc;
     // no gradient buffer is accumulated into: every row has exactly one writer, consumers gather (fixed order)
     if ((rc = run_fp_bwd<0>(m, ws, fwd, logp, dlogp, st))) return rc;
     if ((rc = run_fp_bwd<1>(m, ws, fwd, nullptr, nullptr, st))) return rc;
     if ((rc = run_fp_bwd<2>(m, ws, fwd, nullptr, nullptr, st))) return rc;
     if ((rc = run_fp_bwd<3>(m, ws, fwd, nullptr, nullptr, st))) return rc;
-    if ((rc = run_sa_bwd<3>(m, ws, fwd, dx0, 0, kSaC[3], st))) return rc;
-    if ((rc = run_sa_bwd<2>(m, ws, fwd, dx0, 0, kSaC[2], st))) return rc;
-    if ((rc = run_sa_bwd<1>(m, ws, fwd, dx0, 0, kSaC[1], st))) return rc;
-    if ((rc = run_sa_bwd<0>(m, ws, fwd, dx0, c_lo, c_hi, st))) return rc;
+    for (int l = 3; l >= 0; --l)
+        for (int sc = 0; sc < A.ns; ++sc)
+            if ((rc = run_sa_bwd(m, ws, l, sc, fwd, l ? 0 : c_lo, l ? A.C[l] : c_hi, st))) return rc;
     {
         ProfScope prof(ws, TAG_ZERO, st);   // (tag kept: the slot that used to be the gradient memset)
         const bool compact = c_hi - c_lo == 3;
         const size_t total = (size_t)ws->B * ws->N * (compact ? 1 : c_hi - c_lo);
         const dim3 grid((unsigned)std::min<size_t>(8192, (total + 255) / 256));
-        const int32_t *off = ws->ginv_off[0] + (size_t)fwd * ws->B * (ws->N + 1);
+        const size_t po = (size_t)fwd * ws->B * (ws->N + 1);
+        const int32_t *off = ws->ginv_off[0][0] + po;
+        const int32_t *off2 = A.ns > 1 ? ws->ginv_off[0][1] + po : nullptr;
+        const float *gsa2 = A.ns > 1 ? ws->gsa[0][1] : nullptr;
+        const int gr = kS[0] * A.sc[0][0].K, gr2 = A.ns > 1 ? kS[0] * A.sc[0][1].K : 0;
         if (compact)
-            hipLaunchKernelGGL(dx0_gather_kernel<true>, grid, dim3(256), 0, st, off, ws->gsa[0], ws->B, ws->N, kS[0] * K, 4,
-                               c_lo, c_hi, dx0);
+            hipLaunchKernelGGL(dx0_gather_kernel<true>, grid, dim3(256), 0, st, off, ws->gsa[0][0], gr, off2, gsa2, gr2, ws->B,
+                               ws->N, 4, c_lo, c_hi, dx0);
         else
-            hipLaunchKernelGGL(dx0_gather_kernel<false>, grid, dim3(256), 0, st, off, ws->gsa[0], ws->B, ws->N, kS[0] * K,
-                               kGsaC[0], c_lo, c_hi, dx0);
+            hipLaunchKernelGGL(dx0_gather_kernel<false>, grid, dim3(256), 0, st, off, ws->gsa[0][0], gr, off2, gsa2, gr2, ws->B,
+                               ws->N, gsa_stride(A, 0), c_lo, c_hi, dx0);
         PSG_LAUNCH_CHECK();
     }
     return PSG_OK;
@@ -957,6 +1158,7 @@ extern "C" int psg_pn2_backward(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const
                                 psg_stream stream)
 {
     PSG_REQUIRE(m && ws && dlogp && dx0_out, "psg_pn2_backward: null argument");
+    PSG_REQUIRE(m->arch == ws->arch, "psg_pn2_backward: model and workspace were created for different architectures");
     if (ws->fwd_slot != fwd) {
         set_error("psg_pn2_backward: forward %d is not the one resident in the workspace (%d)", fwd, ws->fwd_slot);
         return PSG_ERR_STATE;
@@ -971,6 +1173,7 @@ extern "C" int psg_pn2_nb_attack(psg_pn2_model *m, psg_pn2_ws *ws, const float *
                                  int targeted, int target, float *adv_out, psg_stream stream)
 {
     PSG_REQUIRE(m && ws && images && starts && adv_out, "psg_pn2_nb_attack: null argument");
+    PSG_REQUIRE(m->arch == ws->arch, "psg_pn2_nb_attack: model and workspace were created for different architectures");
     PSG_REQUIRE(targeted || labels, "psg_pn2_nb_attack: labels required for the non-targeted attack");
     PSG_REQUIRE(iters > 0 && iters <= ws->F, "psg_pn2_nb_attack: iters=%d exceeds workspace capacity %d", iters, ws->F);
     hipStream_t st = (hipStream_t)stream;

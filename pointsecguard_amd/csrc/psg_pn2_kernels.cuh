@@ -18,19 +18,22 @@ struct SaFwdArgs {
     const float *xyz;      // [B][Np][xyz_stride], first 3 floats of a row = xyz
     const float *feat;     // [B][Np][D]
     const float *new_xyz;  // [B][S][3]
-    const int32_t *gidx;   // [B][S][32]
-    float *out;            // [B][S][C3]
+    const int32_t *gidx;   // [B][S][KS]
+    float *out;            // [B][S][ld_out], this module's C3 channels at column c_out (MSG scales share a row)
     uint8_t *arg;          // [B][S][C3] arg-max sample, 255 = no gradient (max <= 0)
     FwdLayer l1, l2;
     const float4 *w3;      // last layer, packed like FwdLayer::w, used as the B operand (flipped tile)
     const float *b3;
     int k8_3, nb3;
     int xyz_stride, D, Np, S, C3;
+    int ld_out, c_out;
     int diag;              // timing diagnostics only (PSG_DIAG env): skip sections, results are then wrong
 };
 
 struct SaBwdArgs {
-    const float *dout;    // [B][S][C3] (direct), or null when the gradient is gathered through nninv_*
+    // The pooled-output gradient of this module is columns [c_off, c_off + C3) of rows of `ld` floats (ld = all
+    // channels of the level: an MSG level concatenates its scales); dout, dint and gsa rows all have that stride.
+    const float *dout;    // [B][S][ld] (direct), or null when the gradient is gathered through nninv_*
     // gather form: dout[s][c] = sum over the fine points p whose 3-NN lists contain s of w * dint[p][c]
     const int32_t *nninv_off;   // [B][S+1]
     const int2 *nninv_ent;      // [B][3*n_fine] {fine point, weight bits}, sorted by fine point per list
@@ -38,13 +41,17 @@ struct SaBwdArgs {
     int n_fine;
     // grouping-transpose form: dout[s][c] += sum over the grouped rows e of the next SA level that gathered point s
     const int32_t *ginv_off;    // [B][S+1] or null: list of point s = rows [off[s], off[s+1]) of gsa
-    const float *gsa;           // [B][g_rows][C3] gradient rows written by the next level's sa_bwd IN LIST ORDER
+    const float *gsa;           // [B][g_rows][ld] gradient rows written by the next level's sa_bwd IN LIST ORDER
     int g_rows;
-    float *gsa_out;             // [B][S*32][cg_out]: this module's grouped-input gradient rows (plain stores), row
-    const int32_t *gpos_out;    // (group*32 + sample) stored at position gpos_out[row] = its slot in the consumer's lists
+    const int32_t *ginv_off2;   // second scale of the next level (MSG), or null
+    const float *gsa2;
+    int g_rows2;
+    int ld, c_off;
+    float *gsa_out;             // [B][S*KS][cg_out]: this module's grouped-input gradient rows (plain stores), row
+    const int32_t *gpos_out;    // (group*KS + sample) stored at position gpos_out[row] = its slot in the consumer's lists
     int cg_out;
     const uint8_t *arg;   // [B][S][C3]
-    const int32_t *gidx;  // [B][S][32]
+    const int32_t *gidx;  // [B][S][KS]
     BwdLayer l3t, l2t, l1t;
     int D, Np, S, C3;
     int c_lo, c_hi;       // feature channels [c_lo, c_hi) of the grouped-input gradient are scattered
@@ -89,11 +96,14 @@ struct FpBwdArgs {
 // LDS channel order of the grouped input: [feats(D), rel_xyz(3), zero pad to a multiple of 8]; the
 // first layer's weight columns are permuted accordingly at pack time (reference order is
 // [rel_xyz, feats], pointnet_util.py:137).
-template <int P, int NW>
+// KS = samples per group (32, or 16 for the small-radius scale of an MSG level: two groups per 32-point tile);
+// MAXT = tiles a wave may hold in the first two layers.
+template <int P, int NW, int KS = 32, int MAXT = 1>
 __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
 {
     using L = Lds<P>;
-    constexpr int G = P / 32, NT = NW * 64, NPART = NT / P;
+    static_assert(KS == 32 || KS == 16, "groups of 32 or 16 samples");
+    constexpr int G = P / KS, PB = P / 32, NT = NW * 64, NPART = NT / P;
     extern __shared__ float lds[];
     float *buf0 = lds;   // the one activation buffer (layers run in place)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -104,8 +114,8 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
 
     if (!(a.diag & 1)) {   // gather the P grouped points
         const int j = tid % P, part = tid / P;
-        const int s = s0 + (j >> 5);
-        const int src = a.gidx[((size_t)b * a.S + s) * 32 + (j & 31)];
+        const int s = s0 + j / KS;
+        const int src = a.gidx[((size_t)b * a.S + s) * KS + (j & (KS - 1))];
         const float *frow = a.feat + ((size_t)b * a.Np + src) * a.D;
         const float *xr = a.xyz + ((size_t)b * a.Np + src) * a.xyz_stride;
         const float *cr = a.new_xyz + ((size_t)b * a.S + s) * 3;
@@ -135,18 +145,18 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
     }
     __syncthreads();
     // biases of this wave's last-layer tiles: fetched now, so their latency is spent under the first two layers
-    // (every SA level has nb3 * G = 2 * NW last-layer tiles, i.e. two per wave)
+    // (an SSG level has nb3 * PB = 2 * NW last-layer tiles, i.e. two per wave; MSG scales have at most that)
     const int jj = lane & 31, h = lane >> 5;
     constexpr int T3 = 2;
     float bias3[T3];
 #pragma unroll
     for (int i = 0; i < T3; ++i) {
         const int task = wave + i * NW;
-        bias3[i] = task < a.nb3 * G ? a.b3[(task / G) * 32 + jj] : 0.0f;
+        bias3[i] = task < a.nb3 * PB ? a.b3[(task / PB) * 32 + jj] : 0.0f;
     }
-    if (!(a.diag & 8)) layer_fwd<P, NW, 1>(a.l1, buf0, wg);
+    if (!(a.diag & 8)) layer_fwd<P, NW, MAXT>(a.l1, buf0, wg);
     if (!(a.diag & 16)) __syncthreads();
-    if (!(a.diag & 8)) layer_fwd<P, NW, 1>(a.l2, buf0, wg);
+    if (!(a.diag & 8)) layer_fwd<P, NW, MAXT>(a.l2, buf0, wg);
     if (!(a.diag & 16)) __syncthreads();
     if (a.diag & 32) return;
 
@@ -155,37 +165,61 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
 #pragma unroll
     for (int i = 0; i < T3; ++i) {
         const int task = wave + i * NW;
-        if (task >= a.nb3 * G) break;
-        const int nb = task / G, g = task - nb * G;
+        if (task >= a.nb3 * PB) break;
+        const int nb = task / PB, g = task - nb * PB;   // g = 32-point tile of the workgroup
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = bias3[i];
         acc = tile_mac<L::BLK, true>(a.w3 + (size_t)nb * a.k8_3 * 64 + lane, a.k8_3, buf0 + (g * 32 + jj) * 8 + 4 * h,
                                      acc);
-        float best = -1.0f;
-        int bidx = 0;
+        if (KS == 32) {
+            float best = -1.0f;
+            int bidx = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = acc[r] > 0.0f ? acc[r] : 0.0f;
-            if (v > best) { best = v; bidx = acc_row(r, h); }
-        }
-        float ob = __shfl_xor(best, 32);
-        int oi = __shfl_xor(bidx, 32);
-        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-        if (h == 0) {
-            size_t o = ((size_t)b * a.S + s0 + g) * a.C3 + nb * 32 + jj;
-            a.out[o] = best;
-            a.arg[o] = best > 0.0f ? (uint8_t)bidx : (uint8_t)255;
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[r] > 0.0f ? acc[r] : 0.0f;
+                if (v > best) { best = v; bidx = acc_row(r, h); }
+            }
+            float ob = __shfl_xor(best, 32);
+            int oi = __shfl_xor(bidx, 32);
+            if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+            if (h == 0) {
+                const size_t row = (size_t)b * a.S + s0 + g;
+                a.out[row * a.ld_out + a.c_out + nb * 32 + jj] = best;
+                a.arg[row * a.C3 + nb * 32 + jj] = best > 0.0f ? (uint8_t)bidx : (uint8_t)255;
+            }
+        } else {
+            // two groups of 16 samples per tile: accumulators 0..7 hold points 0..15, 8..15 hold points 16..31
+            float best[2] = {-1.0f, -1.0f};
+            int bidx[2] = {0, 0};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[r] > 0.0f ? acc[r] : 0.0f;
+                if (v > best[r >> 3]) { best[r >> 3] = v; bidx[r >> 3] = acc_row(r, h) & 15; }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float ob = __shfl_xor(best[q], 32);
+                int oi = __shfl_xor(bidx[q], 32);
+                if (ob > best[q] || (ob == best[q] && oi < bidx[q])) { best[q] = ob; bidx[q] = oi; }
+            }
+            // lane half h writes group h of the tile
+            const float bv = h ? best[1] : best[0];
+            const int bi = h ? bidx[1] : bidx[0];
+            const size_t row = (size_t)b * a.S + s0 + 2 * g + h;
+            a.out[row * a.ld_out + a.c_out + nb * 32 + jj] = bv;
+            a.arg[row * a.C3 + nb * 32 + jj] = bv > 0.0f ? (uint8_t)bi : (uint8_t)255;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------ SA bwd
-template <int P, int NW, int MAXT>
+template <int P, int NW, int MAXT, int KS = 32>
 __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
 {
     using L = Lds<P>;
-    constexpr int G = P / 32, NT = NW * 64;
+    static_assert(KS == 32 || KS == 16, "groups of 32 or 16 samples");
+    constexpr int G = P / KS, NT = NW * 64;
     extern __shared__ float lds[];
     float *buf0 = lds;   // the one activation buffer (layers run in place)
     const int tid = threadIdx.x;
@@ -198,7 +232,7 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     // interpolated-part rows of the feature-propagation module that upsampled this level
     // arg-max bytes of this workgroup's groups: issued first, so their latency overlaps the gradient gather below
     const int nblk = a.C3 >> 3;
-    constexpr int NTASK = 4;   // (point, 8-channel block) tasks per thread: P * C3 / 8 / NT = 4 for every SA level
+    constexpr int NTASK = 4;   // (point, 8-channel block) tasks per thread: P * C3 / 8 / NT = 4 for every SSG level (<= 4 for MSG)
     uint2 am_pre[NTASK];
 #pragma unroll
     for (int i = 0; i < NTASK; ++i) {
@@ -206,7 +240,7 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
         am_pre[i] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
         if (t < P * nblk && !(a.diag & 1)) {
             const int pnt = t % P, blk = t / P;
-            am_pre[i] = *(const uint2 *)(a.arg + ((size_t)b * a.S + s0 + (pnt >> 5)) * a.C3 + blk * 8);
+            am_pre[i] = *(const uint2 *)(a.arg + ((size_t)b * a.S + s0 + pnt / KS) * a.C3 + blk * 8);
         }
     }
     // dout[s][c] = skip-link gradient (plain rows) + transposed 3-NN interpolation + transposed grouping of the
@@ -214,24 +248,37 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     float *dsrc = lds + (size_t)a.dsrc_blk * L::BLK;   // staging block(s) behind the activation buffer
     for (int t = tid; t < G * a.C3; t += NT) {
         const int g = t / a.C3, c = t - g * a.C3;
-        float acc = a.dout ? a.dout[((size_t)b * a.S + s0 + g) * a.C3 + c] : 0.0f;
+        const int cc = a.c_off + c;
+        float acc = a.dout ? a.dout[((size_t)b * a.S + s0 + g) * a.ld + cc] : 0.0f;
         if (a.nninv_off) {
             const int32_t *off = a.nninv_off + (size_t)b * (a.S + 1) + s0 + g;
             const int2 *ent = a.nninv_ent + (size_t)b * 3 * a.n_fine;
             for (int e = off[0]; e < off[1]; ++e) {
                 const int2 pe = ent[e];
-                acc += __int_as_float(pe.y) * a.dint[((size_t)b * a.n_fine + pe.x) * a.C3 + c];
+                acc += __int_as_float(pe.y) * a.dint[((size_t)b * a.n_fine + pe.x) * a.ld + cc];
             }
         }
         if (a.ginv_off) {
             // the producer stored its rows in list order: the rows of point s are contiguous, ascending grouped row
             const int32_t *off = a.ginv_off + (size_t)b * (a.S + 1) + s0 + g;
-            const float *rows = a.gsa + (size_t)b * a.g_rows * a.C3 + c;
+            const float *rows = a.gsa + (size_t)b * a.g_rows * a.ld + cc;
             const int e1 = off[1];
             for (int e = off[0]; e < e1; e += 8) {   // absent entries add +0.0f: still the ascending chain
                 float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = e + u < e1 ? rows[(size_t)(e + u) * a.C3] : 0.0f;
+                for (int u = 0; u < 8; ++u) v[u] = e + u < e1 ? rows[(size_t)(e + u) * a.ld] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+        }
+        if (a.ginv_off2) {   // second scale of the next (MSG) level, same scheme
+            const int32_t *off = a.ginv_off2 + (size_t)b * (a.S + 1) + s0 + g;
+            const float *rows = a.gsa2 + (size_t)b * a.g_rows2 * a.ld + cc;
+            const int e1 = off[1];
+            for (int e = off[0]; e < e1; e += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = e + u < e1 ? rows[(size_t)(e + u) * a.ld] : 0.0f;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc += v[u];
             }
@@ -246,7 +293,7 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
         const int t = tid + i * NT;
         if (t >= P * nblk || (a.diag & 1)) break;
         const int pnt = t % P, blk = t / P;
-        const int g = pnt >> 5, k = pnt & 31;
+        const int g = pnt / KS, k = pnt & (KS - 1);
         const uint2 am = am_pre[i];
         const float *dp = dsrc + (size_t)g * a.C3 + blk * 8;
         const float4 d0 = *(const float4 *)dp, d1 = *(const float4 *)(dp + 4);
@@ -275,8 +322,8 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     // are stored as plain rows; the consumer (previous level's sa_bwd, or dx0_gather_kernel) sums them through the
     // inverse group lists.  (LDS channel order is [feats, rel_xyz]: LDS channel c is feature channel c.)
     const int nc = a.c_hi - a.c_lo;
-    const int32_t *pos = a.gpos_out + (size_t)b * a.S * 32 + (size_t)s0 * 32;
-    float *orow = a.gsa_out + (size_t)b * a.S * 32 * a.cg_out;
+    const int32_t *pos = a.gpos_out + (size_t)b * a.S * KS + (size_t)s0 * KS;
+    float *orow = a.gsa_out + (size_t)b * a.S * KS * a.cg_out;
     if (a.cg_out == 4) {   // colour-only request of the attack loop: one 16-byte row {c_lo, c_lo+1, c_lo+2, 0} per lane
         for (int j = tid; j < P; j += NT) {
             const float4 v = make_float4(buf0[L::off(a.c_lo, j)], buf0[L::off(a.c_lo + 1, j)], buf0[L::off(a.c_lo + 2, j)], 0.0f);
@@ -291,7 +338,9 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
 }
 
 // ------------------------------------------------------------------------------------------ FP fwd
-template <int P, int NW>
+// BIG: the concatenated input does not fit LDS (MSG fp4: 512 + 1024 channels): the first layer's K is streamed
+// through the buffer in chunks of KC blocks, its accumulators staying in registers across the chunks.
+template <int P, int NW, bool BIG = false>
 __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
 {
     using L = Lds<P>;
@@ -308,7 +357,73 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
         a.dbg[wg * 4 + 0] = __builtin_amdgcn_s_memtime();
         a.dbg[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     }
-    if (!(a.diag & 1)) {
+    if (BIG) {
+        static_assert(!BIG || P == 32, "streamed first layer: one 32-point tile per workgroup");
+        constexpr int KC = 64;                       // blocks (of 8 channels) per chunk
+        constexpr int RG = NT / 32, JI = P / RG;
+        const int ql = tid & 31, rg = tid >> 5;
+        const int lane = tid & 63, wave = tid >> 6, jj = lane & 31, h = lane >> 5;
+        int i0[JI], i1[JI], i2[JI];
+        float w0[JI], w1[JI], w2[JI];
+#pragma unroll
+        for (int u = 0; u < JI; ++u) {
+            const size_t n = (size_t)b * a.N + n0 + rg + u * RG;
+            i0[u] = a.nn_idx[n * 3]; i1[u] = a.nn_idx[n * 3 + 1]; i2[u] = a.nn_idx[n * 3 + 2];
+            w0[u] = a.nn_w[n * 3]; w1[u] = a.nn_w[n * 3 + 1]; w2[u] = a.nn_w[n * 3 + 2];
+        }
+        const FwdLayer &L0 = a.layer[0];
+        const int ntask = L0.mb;                     // P == 32: one tile per 32 output channels
+        const int first = (wave + (int)(wg & (NW - 1))) & (NW - 1);
+        f32x16 c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+        for (int kb = 0; kb < L0.k8; kb += KC) {
+            const int nb = min(KC, L0.k8 - kb), c_lo = kb * 8, c_hi = (kb + nb) * 8;
+            // skip-link rows, channels [c_lo, min(c_hi, C1))
+#pragma unroll
+            for (int u = 0; u < JI; ++u) {
+                const int j = rg + u * RG;
+                const float4 *f4 = (const float4 *)(a.feat1 + ((size_t)b * a.N + n0 + j) * a.C1);
+                for (int q = (c_lo >> 2) + ql; 4 * q < min(c_hi, a.C1); q += 32) *(float4 *)(buf0 + L::off(4 * q - c_lo, j)) = f4[q];
+            }
+            // interpolated rows, concat channels [max(c_lo, C1), c_hi)
+#pragma unroll
+            for (int u = 0; u < JI; ++u) {
+                const int j = rg + u * RG;
+                const float4 *g0 = (const float4 *)(a.feat2 + ((size_t)b * a.S + i0[u]) * a.C2);
+                const float4 *g1 = (const float4 *)(a.feat2 + ((size_t)b * a.S + i1[u]) * a.C2);
+                const float4 *g2 = (const float4 *)(a.feat2 + ((size_t)b * a.S + i2[u]) * a.C2);
+                const int lo = max(c_lo, a.C1) - a.C1, hi = c_hi - a.C1;
+                for (int q = (lo >> 2) + ql; 4 * q < hi; q += 32) {
+                    const float4 u0 = g0[q], u1 = g1[q], u2 = g2[q];
+                    float4 r;
+                    r.x = u0.x * w0[u] + u1.x * w1[u] + u2.x * w2[u];
+                    r.y = u0.y * w0[u] + u1.y * w1[u] + u2.y * w2[u];
+                    r.z = u0.z * w0[u] + u1.z * w1[u] + u2.z * w2[u];
+                    r.w = u0.w * w0[u] + u1.w * w1[u] + u2.w * w2[u];
+                    *(float4 *)(buf0 + L::off(a.C1 + 4 * q - c_lo, j)) = r;
+                }
+            }
+            __syncthreads();
+            if (first < ntask)
+                c = tile_mac<L::BLK, false>(L0.w + ((size_t)first * L0.k8 + kb) * 64 + lane, nb, buf0 + jj * 8 + 4 * h, c);
+            __syncthreads();
+        }
+        if (first < ntask) {   // bias, ReLU, mask bits and write-back exactly like layer_fwd
+            const float *bp = L0.bias + first * 32 + 4 * h;
+            unsigned m = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                c[r] += bp[8 * (r >> 2) + (r & 3)];
+                const bool pos = c[r] > 0.0f;
+                c[r] = pos ? c[r] : 0.0f;
+                m |= (unsigned)pos << r;
+            }
+            if (L0.mask) L0.mask[(wg * ntask + first) * 64 + lane] = (uint16_t)m;
+            store_tile<P>(buf0, first, jj, h, c);
+        }
+        __syncthreads();
+    } else if (!(a.diag & 1)) {
         // 32 consecutive lanes read consecutive float4 of ONE source row (512 contiguous bytes per row group), so a
         // wave-wide load touches 8 cache lines instead of 64; neighbour indices / weights are broadcast loads.
         constexpr int RG = NT / 32, JI = P / RG;
@@ -350,7 +465,7 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
     __syncthreads();
     float *in = buf0;
     if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 0] = __builtin_amdgcn_s_memtime();
-    for (int l = 0; l < a.n_layers; ++l) {
+    for (int l = BIG ? 1 : 0; l < a.n_layers; ++l) {
         if (!(a.diag & 8)) layer_fwd<P, NW, 1>(a.layer[l], in, wg);
         if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 1 + 2 * l] = __builtin_amdgcn_s_memtime();
         if (!(a.diag & 16)) __syncthreads();
@@ -392,7 +507,9 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
 }
 
 // ------------------------------------------------------------------------------------------ FP bwd
-template <int P, int NW, int MAXT>
+// BIG: the gradient of the concatenated input does not fit LDS (MSG fp4: 1536 channels): the last transposed layer
+// is not run in place; NW output tiles at a time go through a staging area behind its input and out to HBM.
+template <int P, int NW, int MAXT, bool BIG = false>
 __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
 {
     using L = Lds<P>;
@@ -479,9 +596,35 @@ __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
     }
     __syncthreads();
     float *in = buf0;
-    for (int l = 0; l < a.n_layers; ++l) {
+    for (int l = 0; l < a.n_layers - (BIG ? 1 : 0); ++l) {
         layer_bwd<P, NW, MAXT>(a.layer[l], in, wg);
         __syncthreads();
+    }
+    if (BIG) {
+        static_assert(!BIG || P == 32, "streamed last layer: one 32-point tile per workgroup");
+        const BwdLayer &Lz = a.layer[a.n_layers - 1];   // first forward layer transposed: no mask behind it
+        float *stage = buf0 + (size_t)Lz.k8 * L::BLK;   // NW tiles = NW * 4 blocks behind the layer's input
+        const int jj = lane & 31, h = lane >> 5;
+        for (int t0 = 0; t0 < Lz.mb; t0 += NW) {
+            const int mb = t0 + wave;
+            if (mb < Lz.mb) {
+                f32x16 c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+                c = tile_mac<L::BLK, false>(Lz.w + (size_t)mb * Lz.k8 * 64 + lane, Lz.k8, buf0 + jj * 8 + 4 * h, c);
+                store_tile<P>(stage, wave, jj, h, c);
+            }
+            __syncthreads();
+            for (int t = tid; t < P * NW * 32; t += NT) {
+                const int j = t / (NW * 32), cc = t - j * (NW * 32), c = t0 * 32 + cc;
+                const float v = stage[L::off(cc, j)];
+                const size_t n = (size_t)b * a.N + n0 + j;
+                if (c < a.C1) a.dfeat1[n * a.C1 + c] = v;
+                else if (c < a.C1 + a.C2) a.dint_out[n * a.C2 + (c - a.C1)] = v;
+            }
+            __syncthreads();
+        }
+        return;
     }
     // `in` = gradient of the concat input [C1 skip rows | C2 interpolated rows][point]
     if (a.dfeat1) {

@@ -45,11 +45,11 @@ class _PN2Function(torch.autograd.Function):
         x0 = torch.empty(B, N, C, device=x.device, dtype=torch.float32)
         _lib.call("psg_to_point_major", runtime.ptr(xin), B, C, N, runtime.ptr(x0), runtime.stream())
         ws.plan_build(x0, starts, 1)
-        l4 = torch.empty(B, 16, 512, device=x.device, dtype=torch.float32)
+        l4 = torch.empty(B, 16, module.L4_CHANNELS, device=x.device, dtype=torch.float32)
         logp = ws.forward(model, 0, x0, l4=l4)
         module._generation += 1
         ctx.module, ctx.model, ctx.ws, ctx.generation = module, model, ws, module._generation
-        l4_points = l4.transpose(1, 2)  # [B,512,16] like the reference
+        l4_points = l4.transpose(1, 2)  # [B,512,16] (MSG: [B,1024,16]) like the reference
         ctx.mark_non_differentiable(l4_points)
         return logp, l4_points
 
@@ -67,6 +67,8 @@ class _PN2Function(torch.autograd.Function):
 
 
 class get_model(nn.Module):
+    L4_CHANNELS = 512
+
     def __init__(self, num_classes):
         super(get_model, self).__init__()
         if num_classes != runtime.NUM_CLASSES:

@@ -2,7 +2,7 @@
 
 Public names and argument meaning follow the reference (PointNet/models/pointnet_util.py):
 square_distance :19, index_points :43, farthest_point_sample :63, query_ball_point :87,
-sample_and_group :110, PointNetSetAbstraction :166, PointNetFeaturePropagation :270.
+sample_and_group :110, PointNetSetAbstraction :166, PointNetSetAbstractionMsg :210, PointNetFeaturePropagation :270.
 Every function takes CUDA tensors and runs a hand-written gfx950 kernel through libpsg.so; there is
 no PyTorch-op or CPU fallback.  Index results are int64 like the reference's.
 
@@ -75,6 +75,30 @@ class PointNetSetAbstraction(nn.Module):
 
     def forward(self, xyz, points):
         raise NotImplementedError("stand-alone PointNetSetAbstraction.forward is executed by the fused whole-network "
+                                  "kernels of get_model; call the parent get_model instead")
+
+
+class PointNetSetAbstractionMsg(nn.Module):
+    """Multi-scale grouping: one FPS sample, one ball query + shared MLP + max-pool per radius, channel concat
+    (pointnet_util.py:210-267 of the reference).  Parameter layout conv_blocks.{scale}.{layer} / bn_blocks.*"""
+
+    def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list):
+        super(PointNetSetAbstractionMsg, self).__init__()
+        self.npoint, self.radius_list, self.nsample_list = npoint, radius_list, nsample_list
+        self.conv_blocks = nn.ModuleList()
+        self.bn_blocks = nn.ModuleList()
+        for widths in mlp_list:
+            convs, bns = nn.ModuleList(), nn.ModuleList()
+            last_channel = in_channel + 3
+            for out_channel in widths:
+                convs.append(nn.Conv2d(last_channel, out_channel, 1))
+                bns.append(nn.BatchNorm2d(out_channel))
+                last_channel = out_channel
+            self.conv_blocks.append(convs)
+            self.bn_blocks.append(bns)
+
+    def forward(self, xyz, points):
+        raise NotImplementedError("stand-alone PointNetSetAbstractionMsg.forward is executed by the fused whole-network "
                                   "kernels of get_model; call the parent get_model instead")
 
 

@@ -12,6 +12,10 @@ SA_NPOINT = (1024, 256, 64, 16)   # PointNet/models/pointnet2_sem_seg.py:9-12 (r
 SA_RADIUS = (0.1, 0.2, 0.4, 0.8)
 NSAMPLE = 32
 NUM_CLASSES = 13
+ARCH_SSG, ARCH_MSG = 0, 1          # PSG_PN2_ARCH_* of include/psg.h
+ARCH_LAYERS = {ARCH_SSG: 23, ARCH_MSG: 35}
+MSG_NSAMPLE = (16, 32)             # PointNet/models/pointnet2_sem_seg_msg.py:10-13 (reference)
+ACT_POINTS = (1024, 256, 64, 16, 64, 256, 1024)
 ACT_SHAPES = ((1024, 64), (256, 128), (64, 256), (16, 512), (64, 256), (256, 256), (1024, 128))
 
 _ctx = {}
@@ -65,7 +69,7 @@ def _hip_memcpy_d2d(dst_ptr, src_ptr, nbytes):
         raise _lib.PsgError("hipMemcpyAsync failed with %d" % rc)
 
 
-def fold_state_dict(sd, eps=1e-5):
+def fold_state_dict(sd, eps=1e-5, msg=False):
     """Eval-mode BatchNorm folded into the preceding 1x1 conv, in the layer order of
     psg_pn2_model_create.  sd: mapping name -> tensor/ndarray with the reference's state_dict keys
     (sa{1-4}.mlp_convs.N.weight ..., fp{1-4}..., conv1, bn1, conv2).  fp64 math, fp32 result."""
@@ -86,7 +90,16 @@ def fold_state_dict(sd, eps=1e-5):
         return np.ascontiguousarray(w, np.float32), np.ascontiguousarray(b, np.float32)
 
     out = []
-    for name, nl in (("sa1", 3), ("sa2", 3), ("sa3", 3), ("sa4", 3), ("fp4", 2), ("fp3", 2), ("fp2", 2), ("fp1", 3)):
+    if msg:   # sa{l}.conv_blocks.{scale}.{j} / bn_blocks (pointnet_util.py:216-227 of the reference)
+        for l in range(1, 5):
+            for i in range(2):
+                for j in range(3):
+                    out.append(fold("sa%d.conv_blocks.%d.%d" % (l, i, j), "sa%d.bn_blocks.%d.%d" % (l, i, j)))
+    else:
+        for name in ("sa1", "sa2", "sa3", "sa4"):
+            for i in range(3):
+                out.append(fold("%s.mlp_convs.%d" % (name, i), "%s.mlp_bns.%d" % (name, i)))
+    for name, nl in (("fp4", 2), ("fp3", 2), ("fp2", 2), ("fp1", 3)):
         for i in range(nl):
             out.append(fold("%s.mlp_convs.%d" % (name, i), "%s.mlp_bns.%d" % (name, i)))
     out.append(fold("conv1", "bn1"))
@@ -97,16 +110,19 @@ def fold_state_dict(sd, eps=1e-5):
 class PN2Model:
     """Device-resident MFMA-packed weights of get_model (psg_pn2_model)."""
 
-    def __init__(self, folded, device=None):
-        if len(folded) != 23:
-            raise _lib.PsgError("expected 23 folded layers, got %d" % len(folded))
+    def __init__(self, folded, device=None, arch=ARCH_SSG):
+        n = ARCH_LAYERS[arch]
+        if len(folded) != n:
+            raise _lib.PsgError("expected %d folded layers, got %d" % (n, len(folded)))
         self.ctx = context(device)
+        self.arch = arch
         lib = _lib.load()
-        ws = (ctypes.c_void_p * 23)(*[w.ctypes.data_as(ctypes.c_void_p) for w, _ in folded])
-        bs = (ctypes.c_void_p * 23)(*[b.ctypes.data_as(ctypes.c_void_p) for _, b in folded])
+        ws = (ctypes.c_void_p * n)(*[w.ctypes.data_as(ctypes.c_void_p) for w, _ in folded])
+        bs = (ctypes.c_void_p * n)(*[b.ctypes.data_as(ctypes.c_void_p) for _, b in folded])
         self._keep = folded
         self.handle = ctypes.c_void_p()
-        _lib.check(lib.psg_pn2_model_create(self.ctx, ws, bs, ctypes.byref(self.handle)), "psg_pn2_model_create")
+        _lib.check(lib.psg_pn2_model_create_arch(self.ctx, arch, ws, bs, n, ctypes.byref(self.handle)),
+                   "psg_pn2_model_create_arch")
 
     def __del__(self):
         try:
@@ -120,12 +136,12 @@ class PN2Model:
 class PN2Workspace:
     """Geometry plan + activations + gradient buffers for a batch (psg_pn2_ws)."""
 
-    def __init__(self, batch, n_point, max_forwards, device=None):
+    def __init__(self, batch, n_point, max_forwards, device=None, arch=ARCH_SSG):
         self.ctx = context(device)
-        self.batch, self.n_point, self.max_forwards = batch, n_point, max_forwards
+        self.batch, self.n_point, self.max_forwards, self.arch = batch, n_point, max_forwards, arch
         self.handle = ctypes.c_void_p()
-        _lib.check(_lib.load().psg_pn2_ws_create(self.ctx, batch, n_point, max_forwards, ctypes.byref(self.handle)),
-                   "psg_pn2_ws_create")
+        _lib.check(_lib.load().psg_pn2_ws_create_arch(self.ctx, arch, batch, n_point, max_forwards,
+                                                      ctypes.byref(self.handle)), "psg_pn2_ws_create_arch")
         self.device = torch.device("cuda", torch.cuda.current_device())
 
     def __del__(self):
@@ -192,9 +208,11 @@ class PN2Workspace:
     # ---- read-back helpers (parity tests)
     def plan_tensor(self, what, level, forward, room):
         n_l = (self.n_point,) + SA_NPOINT
-        shape, dt = {0: ((SA_NPOINT[level],), torch.int32), 1: ((SA_NPOINT[level], NSAMPLE), torch.int32),
+        k0 = MSG_NSAMPLE[0] if self.arch == ARCH_MSG else NSAMPLE
+        shape, dt = {0: ((SA_NPOINT[level],), torch.int32), 1: ((SA_NPOINT[level], k0), torch.int32),
                      2: ((n_l[level], 3), torch.int32), 3: ((n_l[level], 3), torch.float32),
-                     4: ((SA_NPOINT[level], 3), torch.float32)}[what]
+                     4: ((SA_NPOINT[level], 3), torch.float32),
+                     5: ((SA_NPOINT[level], MSG_NSAMPLE[1]), torch.int32)}[what]
         src = _lib.load().psg_pn2_plan_ptr(self.handle, what, level, forward, room)
         if not src:
             raise _lib.PsgError("psg_pn2_plan_ptr: bad slice")
@@ -203,7 +221,7 @@ class PN2Workspace:
         return out
 
     def activation(self, which):
-        n, c = ACT_SHAPES[which]
+        n, c = ACT_POINTS[which], _lib.load().psg_pn2_activation_channels(self.handle, which)
         src = _lib.load().psg_pn2_activation_ptr(self.handle, which)
         out = torch.empty(self.batch, n, c, dtype=torch.float32, device=self.device)
         _hip_memcpy_d2d(out.data_ptr(), src, out.numel() * 4)

@@ -1,0 +1,215 @@
+"""GPU parity tests of the MSG network: the HIP path through the C ABI against the
+fixtures generated from the reference's pointnet2_sem_seg_msg (tests/golden/make_golden_msg.py) and against the CPU
+oracle (oracle/pn2_msg.py) on the same seeded inputs.  Same bars as test_gpu_parity.py: grouping indices bit-exact;
+activations / log-probs within 1e-4 (relative to the tensor's magnitude where that exceeds 1); colour gradient with
+identical zero pattern and >= 99.9 % sign agreement; teacher-forced attack steps bit-equal on >= 99.9 % of entries."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from pointsecguard_amd.synthetic import make_rooms, msg_state_dict, rule_labels
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-4
+
+
+def dev(a, dt=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dt is not None:
+        t = t.to(dt)
+    return t.cuda().contiguous()
+
+
+@pytest.fixture(scope="module")
+def room():
+    return dict(np.load(os.path.join(GOLD, "pn2msg_room.npz")))
+
+
+@pytest.fixture(scope="module")
+def nb():
+    return dict(np.load(os.path.join(GOLD, "pn2msg_nb.npz")))
+
+
+@pytest.fixture(scope="module")
+def sd(room):
+    return msg_state_dict(int(room["msg_seed"]))
+
+
+@pytest.fixture(scope="module")
+def model(sd):
+    from pointsecguard_amd import runtime
+    return runtime.PN2Model(runtime.fold_state_dict(sd, msg=True), arch=runtime.ARCH_MSG)
+
+
+@pytest.fixture(scope="module")
+def oracle(sd):
+    from oracle import pn2_msg
+    return pn2_msg.PN2MsgOracle(sd)
+
+
+@pytest.fixture(scope="module")
+def room_run(model, room):
+    from pointsecguard_amd import runtime
+    ws = runtime.PN2Workspace(1, 4096, 2, arch=runtime.ARCH_MSG)
+    x0 = dev(room["room"][None])
+    ws.plan_build(x0, dev(room["starts"].reshape(1, 4, 1), torch.int32), 1)
+    logp = ws.forward(model, 0, x0)
+    torch.cuda.synchronize()
+    return ws, x0, logp
+
+
+def test_msg_geometry_bit_exact(room_run, room):
+    ws, _, _ = room_run
+    for lvl in range(4):
+        assert np.array_equal(ws.plan_tensor(0, lvl, 0, 0).cpu().numpy(), room["fps%d" % lvl].astype(np.int32)), lvl
+        assert np.array_equal(ws.plan_tensor(1, lvl, 0, 0).cpu().numpy(), room["group%d_0" % lvl].astype(np.int32)), lvl
+        assert np.array_equal(ws.plan_tensor(5, lvl, 0, 0).cpu().numpy(), room["group%d_1" % lvl].astype(np.int32)), lvl
+
+
+def test_msg_forward_vs_reference(room_run, room):
+    ws, _, logp = room_run
+    for which, name in enumerate(("sa1", "sa2", "sa3", "sa4", "fp4", "fp3", "fp2")):
+        a = ws.activation(which)[0].cpu().numpy()
+        ref = room["act_" + name]
+        assert a.shape == ref.shape, name
+        assert np.abs(a - ref).max() <= TOL * max(1.0, np.abs(ref).max()), name
+    assert np.abs(logp[0].cpu().numpy() - room["logp"]).max() <= TOL
+
+
+def check_grad(ours, ref):
+    nz = ref != 0
+    assert np.array_equal(ours != 0, nz), "zero pattern of the colour gradient differs"
+    agree = np.sign(ours[nz]) == np.sign(ref[nz])
+    assert agree.mean() >= 0.999
+    if not agree.all():
+        assert np.abs(ref[nz][~agree]).max() <= 1e-3 * np.abs(ref).max()
+    rel = np.abs(ours - ref)[nz] / np.abs(ref[nz])
+    assert np.median(rel) < 1e-4
+
+
+def _ce_grad(logp, labels, n):
+    from pointsecguard_amd import _lib, runtime
+    rows = logp.shape[0] * logp.shape[1]
+    dlogp = torch.empty_like(logp)
+    cost = torch.zeros(1, device="cuda")
+    _lib.call("psg_ce_logp_grad", runtime.ptr(logp), runtime.ptr(labels), 0, rows, rows, 13, 1.0 / n,
+              runtime.ptr(dlogp), runtime.ptr(cost), runtime.stream())
+    return dlogp, cost
+
+
+def test_msg_backward_vs_reference(room_run, room, model):
+    ws, x0, logp = room_run
+    labels = dev(room["labels"].astype(np.int32)[None])
+    dlogp, cost = _ce_grad(logp, labels, 4096)
+    dx0 = ws.backward(model, 0, dlogp)
+    torch.cuda.synchronize()
+    assert abs(cost.item() - float(room["cost"])) < 1e-4
+    check_grad(dx0[0, :, 3:6].cpu().numpy(), room["dcolor"])
+
+
+def test_msg_l4_points(room_run, room, model):
+    """the second output of get_model.forward: l4_points [1024 channels x 16 points]"""
+    ws, x0, _ = room_run
+    l4 = torch.empty(1, 16, 1024, device="cuda")
+    ws.forward(model, 0, x0, l4=l4)
+    torch.cuda.synchronize()
+    assert np.abs(l4[0].cpu().numpy().T - room["l4"]).max() <= TOL * max(1.0, np.abs(room["l4"]).max())
+
+
+def test_msg_batch_vs_oracle(model, oracle):
+    """B = 3 rooms of 2048 points (another N than the fixture), full 9-channel gradient against the oracle."""
+    from oracle import pn2
+    from pointsecguard_amd import runtime
+    B, N = 3, 2048
+    rooms = make_rooms(B, 515, num_point=N)
+    labels = rule_labels(rooms)
+    torch.manual_seed(3)
+    starts = np.stack([torch.randint(0, n, (B,)).numpy() for n in (N, 1024, 256, 64)]).astype(np.int32)
+    ws = runtime.PN2Workspace(B, N, 1, arch=runtime.ARCH_MSG)
+    x0 = dev(rooms)
+    ws.plan_build(x0, dev(starts.reshape(1, 4, B), torch.int32), 1)
+    logp = ws.forward(model, 0, x0)
+    dlogp, _ = _ce_grad(logp, dev(labels.astype(np.int32)), N)
+    dx0 = ws.backward(model, 0, dlogp)
+    torch.cuda.synchronize()
+    for b in range(B):
+        geom = oracle.geometry(rooms[b, :, :3], starts[:, b])
+        for lvl in range(4):
+            assert np.array_equal(ws.plan_tensor(0, lvl, 0, b).cpu().numpy(), geom["fps"][lvl])
+            assert np.array_equal(ws.plan_tensor(1, lvl, 0, b).cpu().numpy(), geom["group"][lvl][0])
+            assert np.array_equal(ws.plan_tensor(5, lvl, 0, b).cpu().numpy(), geom["group"][lvl][1])
+        lp, cache = oracle.forward(rooms[b], geom)
+        assert np.abs(logp[b].cpu().numpy() - lp).max() <= TOL
+        dl, _ = pn2.nll_logp_grad(lp, labels[b], 1.0 / N)
+        check_grad(dx0[b, :, 3:6].cpu().numpy(), oracle.backward_color(cache, dl))
+
+
+def test_msg_nb_attack_steps_vs_reference(model, nb):
+    """Teacher-forced NB_attack iterations through the MSG network (see test_gpu_parity.py for the rationale)."""
+    from pointsecguard_amd import _lib, runtime
+    g = nb
+    rooms, iters = g["rooms"], int(g["iters"])
+    B = rooms.shape[0]
+    labels = dev(g["labels"].astype(np.int32))
+    x0 = dev(rooms)
+    ori = x0[:, :, 3:6].contiguous()
+    ws = runtime.PN2Workspace(B, 4096, iters, arch=runtime.ARCH_MSG)
+    ws.plan_build(x0, dev(g["starts"][1:1 + iters], torch.int32), iters)
+    for t in range(iters):
+        nxt = g["adv_color_final"] if t == iters - 1 else g["state_it%d" % (t + 1)]
+        x0[:, :, 3:6] = dev(np.ascontiguousarray(g["state_it%d" % t].transpose(0, 2, 1)))
+        logp = ws.forward(model, t, x0)
+        dlogp, _ = _ce_grad(logp, labels, 4096)
+        dx0 = ws.backward(model, t, dlogp)
+        _lib.call("psg_pgd_step", runtime.ptr(x0), runtime.ptr(dx0), runtime.ptr(ori), None, B, 4096,
+                  float(g["alpha"]), float(g["eps"]), 1.0, 1 if t == iters - 1 else 0, runtime.stream())
+        torch.cuda.synchronize()
+        got = np.ascontiguousarray(x0[:, :, 3:6].cpu().numpy().transpose(0, 2, 1))
+        same = (got.view(np.uint32) == nxt.view(np.uint32)).mean()
+        assert same >= 0.999, (t, same)
+
+
+def test_msg_fused_attack_and_module_api(nb, sd):
+    """The reference-shaped module (models.pointnet2_sem_seg_msg.get_model) under the reference-shaped NB_attack:
+    same result as the fused C-ABI loop fed the same FPS draws, deterministic, and inside the eps ball."""
+    from pointsecguard_amd import runtime
+    from pointsecguard_amd.attacks import torchattacks
+    from pointsecguard_amd.models import pointnet2_sem_seg_msg as msg
+    g = nb
+    iters, eps, alpha = int(g["iters"]), float(g["eps"]), float(g["alpha"])
+    net = msg.get_model(13).cuda().eval()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    images_np = np.ascontiguousarray(g["rooms"].transpose(0, 2, 1))
+    images = dev(images_np)
+    with torch.no_grad():
+        torch.manual_seed(int(g["seed_rng"]))
+        logp, l4 = net(images)
+    assert tuple(l4.shape) == (2, 1024, 16)
+    assert np.abs(logp.cpu().numpy() - g["clean_logp"]).max() <= TOL
+    torch.manual_seed(int(g["seed_rng"]))
+    net(images)   # consume the clean forward's draws like the fixture's run
+    atk = torchattacks.NB_attack(net, eps=eps, alpha=alpha, iters=iters)
+    adv = atk(images, g["labels"].astype(np.float64))
+    torch.cuda.synchronize()
+    out = adv.cpu().numpy()
+    assert np.array_equal(out[:, :3], images_np[:, :3]) and np.array_equal(out[:, 6:], images_np[:, 6:])
+    assert np.abs(out[:, 3:6] - images_np[:, 3:6]).max() <= eps + alpha + 1e-6
+    ws = runtime.PN2Workspace(2, 4096, iters, arch=runtime.ARCH_MSG)
+    fused = ws.nb_attack(net._packed(), images, dev(g["labels"].astype(np.int32)),
+                         dev(g["starts"][1:1 + iters], torch.int32), eps, alpha, iters)
+    torch.cuda.synchronize()
+    assert np.array_equal(fused.cpu().numpy().view(np.uint32), out.view(np.uint32))
+    same = (out[:, 3:6].view(np.uint32) == g["adv_color_final"].view(np.uint32)).mean()
+    assert same >= 0.9, same   # 6 free-running iterations: a few amplified sign flips at most
+
+
+def test_msg_arch_mismatch_is_refused(model):
+    from pointsecguard_amd import _lib, runtime
+    ws = runtime.PN2Workspace(1, 1024, 1)   # SSG workspace
+    x0 = dev(make_rooms(1, 1, num_point=1024))
+    ws.plan_build(x0, dev(np.zeros((1, 4, 1), np.int32)), 1)
+    with pytest.raises(_lib.PsgError):
+        ws.forward(model, 0, x0)
