@@ -75,9 +75,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=6)
-    ap.add_argument("--workload", default="pointnet2", choices=["pointnet2", "resgcn", "tarnu"],
+    ap.add_argument("--workload", default="pointnet2", choices=["pointnet2", "resgcn", "tarnu", "pointnet2_msg"],
                     help="pointnet2 = BASELINE configs[1] (headline metric); resgcn = configs[3] (secondary, ResGCN-28); "
-                         "tarnu = configs[2] (secondary, targeted NU attack, batch 32)")
+                         "tarnu = configs[2] (secondary, targeted NU attack, batch 32); pointnet2_msg = the headline "
+                         "attack on the multi-scale-grouping network (SURVEY 8f rank 2, secondary)")
     ap.add_argument("--coalesce", type=int, default=8,
                     help="consecutive steps (batches of 8 rooms) fused into one device batch per launch; rooms are "
                          "independent, so results are identical and small kernels get more workgroups")
@@ -91,6 +92,8 @@ def main():
         return main_resgcn(args)
     if args.workload == "tarnu":
         return main_tarnu(args)
+    if args.workload == "pointnet2_msg":
+        return main_msg(args)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -364,6 +367,73 @@ def main_resgcn(args):
                                      "batch=1 room x 4096 pts (BASELINE configs[3]); random-init weights",
                          "attacks_in_flight": conc},
               "tflops_effective": 2 * gmac * iters * batch * args.steps / elapsed / 1e3}
+    print(json.dumps(result), flush=True)
+    return result
+
+
+def main_msg(args):
+    """The headline attack (NB non-targeted PGD, eps=0.05, alpha=2/255, 40 iterations, batches of 8 rooms x 4096 points)
+    on pointnet2_sem_seg_msg (PointNet/models/pointnet2_sem_seg_msg.py of the reference), one MI355X, random-init
+    weights (no checkpoint of this variant ships).  Secondary line: BASELINE.json's metric is quoted on the SSG network."""
+    import torch
+    from pointsecguard_amd import runtime
+    from pointsecguard_amd.synthetic import MSG_FP, MSG_SA, make_rooms, msg_state_dict, rule_labels
+    torch.cuda.set_device(0)
+    model = runtime.PN2Model(runtime.fold_state_dict(msg_state_dict(77), msg=True), arch=runtime.ARCH_MSG)
+    G = max(1, min(args.coalesce, args.steps))
+    DB = BATCH * G
+    n_groups, n_warm = -(-args.steps // G), (-(-args.warmup // G) if args.warmup > 0 else 0)
+    conc = max(1, min(args.concurrency, n_groups))
+    streams = [torch.cuda.Stream() for _ in range(conc)]
+    wss = [runtime.PN2Workspace(DB, NPOINT, ITERS, arch=runtime.ARCH_MSG) for _ in range(conc)]
+    pool = []
+    for i in range(conc):
+        rooms = make_rooms(DB, 9000 + i)
+        images = torch.from_numpy(np.ascontiguousarray(rooms.transpose(0, 2, 1))).cuda()
+        labels = torch.from_numpy(rule_labels(rooms).astype(np.int32)).cuda()
+        torch.manual_seed(100 + i)
+        starts = torch.stack([torch.stack([torch.randint(0, n, (DB,)) for n in (NPOINT, 1024, 256, 64)])
+                              for _ in range(ITERS)]).to(torch.int32).cuda()
+        pool.append((images, labels, starts, torch.empty_like(images)))
+
+    def launch(i):
+        images, labels, starts, out = pool[i % conc]
+        with torch.cuda.stream(streams[i % conc]):
+            wss[i % conc].nb_attack(model, images, labels, starts, EPS, ALPHA, ITERS, out=out)
+
+    torch.cuda.synchronize()
+    for i in range(n_warm):
+        launch(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_groups):
+        launch(i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    rooms_done = DB * n_groups
+    # per-kernel HIP-event profile of one more (untimed) launch
+    wss[0].prof_enable(True)
+    launch(0)
+    torch.cuda.synchronize()
+    prof = {k: {"ms_total": round(v[0], 3), "launches": v[1]} for k, v in wss[0].prof_read().items()}
+    wss[0].prof_enable(False)
+    # algorithmic MACs per room per forward (the input-gradient pass has the same count)
+    mac = 0
+    for (cin, mlps), s_l in zip(MSG_SA, (1024, 256, 64, 16)):
+        for mlp, k in zip(mlps, (16, 32)):
+            mac += s_l * k * macs((cin + 3,) + tuple(mlp))
+    for (_, cin, mlp), n_l in zip(MSG_FP, (64, 256, 1024, 4096)):
+        mac += n_l * macs((cin,) + tuple(mlp))
+    mac += 4096 * macs((128, 128, 13))
+    result = {"metric": "attacked rooms/sec (PointNet++ MSG, 4096 pts, 40 PGD iters)", "value": rooms_done / elapsed,
+              "unit": "rooms/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": elapsed / (rooms_done / BATCH) * 1e3, "higher_is_better": True, "scaling": "weak",
+              "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "config": {"workload": "NB non-targeted PGD (eps=0.05, alpha=2/255, 40 iters) on PointNet++ MSG sem_seg "
+                                     "(pointnet2_sem_seg_msg), batch=8 rooms x 4096 pts; random-init weights",
+                         "device_batch_rooms": DB, "launches_in_flight_per_gpu": conc},
+              "tflops_effective": 2.0 * 2.0 * mac * ITERS * rooms_done / elapsed / 1e12,
+              "gmac_per_room_forward": mac / 1e9, "kernel_profile_one_launch": prof}
     print(json.dumps(result), flush=True)
     return result
 
