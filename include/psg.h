@@ -264,8 +264,20 @@ typedef struct psg_gcn_ws psg_gcn_ws;
  * [64][2C], bias, BN weight/bias/running_mean/running_var; fusion_block; prediction.0/.1 with BN; prediction.3).
  * n_tensors must equal 6*n_blocks + 20.  Blocking. */
 int psg_gcn_model_create(psg_ctx *ctx, const float *const *tensors, int n_tensors, int n_blocks, psg_gcn_model **out);
+/* The reference's configuration switches (ResGCN/sem_seg_dense/architecture.py:26-39 `opt.block`, gcn_lib/dense/
+ * torch_vertex.py:44-49 `opt.conv`): block = ResDynBlock2d / PlainDynBlock2d / DenseDynBlock2d, conv = EdgeConv2d /
+ * MRConv2d.  Same tensor order as psg_gcn_model_create with the reference's shapes for that configuration (dense:
+ * conv weight of block e is [64][2*64e], fusion_block [1024][64 n(n+1)/2], prediction.0 [512][1024 + 64 n(n+1)/2]). */
+#define PSG_GCN_BLOCK_RES 0
+#define PSG_GCN_BLOCK_PLAIN 1
+#define PSG_GCN_BLOCK_DENSE 2
+#define PSG_GCN_CONV_EDGE 0
+#define PSG_GCN_CONV_MR 1
+int psg_gcn_model_create_cfg(psg_ctx *ctx, const float *const *tensors, int n_tensors, int n_blocks, int block, int conv,
+                             psg_gcn_model **out);
 int psg_gcn_model_destroy(psg_gcn_model *model);
 int psg_gcn_ws_create(psg_ctx *ctx, int batch, int n_point, int n_blocks, psg_gcn_ws **out);
+int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n_blocks, int block, int conv, psg_gcn_ws **out);
 int psg_gcn_ws_destroy(psg_gcn_ws *ws);
 size_t psg_gcn_ws_bytes(const psg_gcn_ws *ws);
 

@@ -4,6 +4,8 @@ TEST INFRASTRUCTURE ONLY (see oracle/pn2.py).  Restates, relative to /root/refer
   gcn_lib/dense/torch_edge.py:32-79    pairwise_distance, dense_knn_matrix, DenseDilatedKnnGraph
   gcn_lib/dense/torch_nn.py:55-98      BasicConv (Conv -> ReLU -> BatchNorm), batched_index_select
   gcn_lib/dense/torch_vertex.py:23-100 EdgeConv2d (cat[x_i, x_j - x_i] -> conv -> max over k), ResDynBlock2d
+  gcn_lib/dense/torch_vertex.py:8-20, 74-85, 103-115   MRConv2d, PlainDynBlock2d, DenseDynBlock2d (the `conv` /
+                                       `block` switches of architecture.py:26-39)
   sem_seg_dense/architecture.py:58-68  DenseDeepGCN.forward
   sem_seg_dense/attacks/torchattacks/attacks/colper.py:17-39  NB_attack
 and the input-gradient backward autograd derives (kNN graphs are constants: computed under no_grad).
@@ -49,8 +51,9 @@ def _conv(sd, name):
 
 
 class GCNOracle:
-    def __init__(self, sd, n_blocks=28):
-        self.n_blocks = n_blocks
+    def __init__(self, sd, n_blocks=28, block="res", conv="edge"):
+        assert block in ("res", "plain", "dense") and conv in ("edge", "mr")
+        self.n_blocks, self.block, self.conv = n_blocks, block, conv
         self.edge = []
         for e in range(n_blocks):
             base = "head.gconv.nn" if e == 0 else "backbone.%d.body.gconv.nn" % (e - 1)
@@ -81,23 +84,39 @@ class GCNOracle:
         out = np.take_along_axis(y, arg[:, None, :], axis=1)[:, 0, :]
         return out.astype(F), (arg, act.reshape(n, K, -1))
 
+    def mr_conv(self, x, nbr, e):
+        """MRConv2d.forward (torch_vertex.py:16-20): BasicConv(cat[x, max_k (x_j - x_i)])."""
+        w, b, s, t = self.edge[e]
+        rel = x[nbr] - x[:, None, :]                    # [N,K,C]
+        arg = rel.argmax(axis=1)                        # first index on ties, like torch.max
+        mx = np.take_along_axis(rel, arg[:, None, :], axis=1)[:, 0, :]
+        y, act = self._basic(_c(np.concatenate([x, mx], axis=1)), w, b, s, t)
+        return y, (arg, act)
+
     def forward(self, x, graphs=None):
         """x [N,9] -> (logits [N,13], cache).  `graphs`: optional precomputed neighbour tables (teacher forcing)."""
         x = _c(x)
-        cache = {"x": x, "nbr": [], "ec": []}
+        cache = {"x": x, "nbr": [], "ec": [], "inp": []}
         feats = []
         cur = None
         for e in range(self.n_blocks):
             inp = x if e == 0 else cur
             if graphs is not None:
                 nbr = graphs[e]
+            else:   # dilation 1 + i for res / dense (architecture.py:23,28), 1 for plain (:36)
+                nbr = knn_dilated(x[:, :3] if e == 0 else cur, 1 if e == 0 or self.block == "plain" else e)
+            y, aux = (self.edge_conv if self.conv == "edge" else self.mr_conv)(inp, nbr, e)
+            if e == 0 or self.block == "plain":
+                cur = y                                   # PlainDynBlock2d: body(x) (torch_vertex.py:84-85)
+            elif self.block == "res":
+                cur = (y + cur).astype(F)                 # ResDynBlock2d: body(x) + x (torch_vertex.py:99-100)
             else:
-                nbr = knn_dilated(x[:, :3] if e == 0 else cur, 1 if e == 0 else e)
-            y, aux = self.edge_conv(inp, nbr, e)
-            cur = y if e == 0 else (y + cur).astype(F)   # ResDynBlock2d: body(x) + x (torch_vertex.py:99-100)
+                cur = _c(np.concatenate([cur, y], axis=1))   # DenseDynBlock2d: cat(x, body(x)) (torch_vertex.py:113-115)
             cache["nbr"].append(nbr)
             cache["ec"].append(aux)
+            cache["inp"].append(inp)
             feats.append(cur)
+        cache["widths"] = [f.shape[1] for f in feats]
         feats = _c(np.concatenate(feats, axis=1))
         fused, fact = self._basic(feats, *self.fusion)
         farg = fused.argmax(axis=0)
@@ -123,31 +142,73 @@ class GCNOracle:
         cols = np.arange(1024)
         gz = np.where(fact[farg, cols], gf * self.fusion[2], F(0)).astype(np.float64)
         np.add.at(dfeats, farg, (gz[:, None] * self.fusion[0].astype(np.float64)).astype(F))
+        if self.block != "res" or self.conv != "edge":
+            return self._backward_alt(cache, dfeats)
         G = dfeats[:, -64:].copy()
         dx = None
         for e in range(self.n_blocks - 1, -1, -1):
-            w, b, s, t = self.edge[e]
-            arg, act = cache["ec"][e]
-            nbr = cache["nbr"][e]
-            c = 9 if e == 0 else 64
-            win_act = np.take_along_axis(act, arg[:, None, :], axis=1)[:, 0, :]
-            gz = np.where(win_act, G * s, F(0)).astype(np.float64)            # [N,64] at the winning edge
-            # d/d(cat[x_i, x_j - x_i]) of the winning edge of every (vertex, channel)
-            dxi = np.zeros((n, c), np.float64)
-            dxj = np.zeros((n, c), np.float64)
-            w1, w2 = w[:, :c].astype(np.float64), w[:, c:].astype(np.float64)
-            for k in range(K):
-                gk = np.where(arg == k, gz, 0.0)                                # [N,64]
-                if not gk.any():
-                    continue
-                d1, d2 = gk @ w1, gk @ w2
-                dxi += d1 - d2
-                np.add.at(dxj, nbr[:, k], d2)
-            dprev = (dxi + dxj).astype(F)
+            dprev = self._edge_conv_bwd(cache, e, G)
             if e > 0:
                 G = (dfeats[:, 64 * (e - 1):64 * e] + G + dprev).astype(F)
             else:
                 dx = dprev
+        return dx
+
+    def _edge_conv_bwd(self, cache, e, G):
+        """d/d(input of EdgeConv e) given G = d/d(its output) [N,64]."""
+        n = cache["n"]
+        w, b, s, t = self.edge[e]
+        arg, act = cache["ec"][e]
+        nbr = cache["nbr"][e]
+        c = w.shape[1] // 2
+        win_act = np.take_along_axis(act, arg[:, None, :], axis=1)[:, 0, :]
+        gz = np.where(win_act, G * s, F(0)).astype(np.float64)            # [N,64] at the winning edge
+        # d/d(cat[x_i, x_j - x_i]) of the winning edge of every (vertex, channel)
+        dxi = np.zeros((n, c), np.float64)
+        dxj = np.zeros((n, c), np.float64)
+        w1, w2 = w[:, :c].astype(np.float64), w[:, c:].astype(np.float64)
+        for k in range(K):
+            gk = np.where(arg == k, gz, 0.0)                                # [N,64]
+            if not gk.any():
+                continue
+            d1, d2 = gk @ w1, gk @ w2
+            dxi += d1 - d2
+            np.add.at(dxj, nbr[:, k], d2)
+        return (dxi + dxj).astype(F)
+
+    def _mr_conv_bwd(self, cache, e, G):
+        """d/d(input of MRConv e): through BatchNorm, ReLU, the conv, then cat[x, max-relative]."""
+        w, b, s, t = self.edge[e]
+        arg, act = cache["ec"][e]
+        nbr = cache["nbr"][e]
+        c = w.shape[1] // 2
+        gz = np.where(act, G * s, F(0)).astype(np.float64)
+        dcat = gz @ w.astype(np.float64)                                    # [N,2C]
+        dx = dcat[:, :c] - dcat[:, c:]
+        j = nbr[np.arange(nbr.shape[0])[:, None], arg]                      # [N,C] winning neighbour per channel
+        np.add.at(dx, (j, np.broadcast_to(np.arange(c), j.shape)), dcat[:, c:])
+        return dx.astype(F)
+
+    def _backward_alt(self, cache, dfeats_cat):
+        """Backbone backward for the alternative blocks: walk the blocks downwards, d cur_e complete when reached."""
+        widths = cache["widths"]
+        offs = np.concatenate([[0], np.cumsum(widths)])
+        dcur = [dfeats_cat[:, offs[e]:offs[e + 1]].astype(np.float64) for e in range(self.n_blocks)]
+        conv_bwd = self._edge_conv_bwd if self.conv == "edge" else self._mr_conv_bwd
+        dx = None
+        for e in range(self.n_blocks - 1, -1, -1):
+            g = dcur[e].astype(F)
+            if self.block == "dense" and e > 0:
+                gy, gpass = g[:, -64:], g[:, :-64]
+            else:
+                gy, gpass = g, (g if (self.block == "res" and e > 0) else None)
+            dprev = conv_bwd(cache, e, _c(gy))
+            if e == 0:
+                dx = dprev
+            else:
+                dcur[e - 1] += dprev
+                if gpass is not None:
+                    dcur[e - 1] += gpass
         return dx
 
 

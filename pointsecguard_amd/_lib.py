@@ -56,8 +56,10 @@ SIGNATURES = {
     "psg_smooth_knn": (ci, [vp, ci, vp, ci, ci, ci, vp, vp, vp]),
     "psg_nu_adam_step": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, cf, ci, ci, ci, vp, vp]),
     "psg_gcn_model_create": (ci, [vp, ctypes.POINTER(vp), ci, ci, ctypes.POINTER(vp)]),
+    "psg_gcn_model_create_cfg": (ci, [vp, ctypes.POINTER(vp), ci, ci, ci, ci, ctypes.POINTER(vp)]),
     "psg_gcn_model_destroy": (ci, [vp]),
     "psg_gcn_ws_create": (ci, [vp, ci, ci, ci, ctypes.POINTER(vp)]),
+    "psg_gcn_ws_create_cfg": (ci, [vp, ci, ci, ci, ci, ci, ctypes.POINTER(vp)]),
     "psg_gcn_ws_destroy": (ci, [vp]),
     "psg_gcn_ws_bytes": (ctypes.c_size_t, [vp]),
     "psg_gcn_knn": (ci, [vp, vp, ci, ci, vp, vp]),

@@ -35,7 +35,7 @@ struct GemmArgs {
     uint32_t *mask_out;   // ReLU bits out: [rows][ceil(M/32)] words, or null
     const uint32_t *mask_in;  // multiply the result by these bits (backward through the producer's ReLU), or null
     int rows, K, M, ld_in, ld_w, ld_out, group_rows;
-    int accumulate;       // out += result
+    int accumulate;       // 1: out += result;  2: out = addend + result (out is not read)
     const float *addend;  // with accumulate: out = (out + addend[row][c]) + result  (rows of ld_add floats), or null
     int ld_add;
 };
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
                         float4 v = make_float4(vals[4 * g], vals[4 * g + 1], vals[4 * g + 2], vals[4 * g + 3]);
                         float4 *dst = (float4 *)(o + 8 * g);
                         if (a.accumulate) {
-                            float4 old = *dst;
+                            float4 old = a.accumulate == 1 ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
                             if (a.addend) {
                                 const float4 ad = *(const float4 *)(a.addend + (size_t)row * a.ld_add + c);
                                 old.x += ad.x; old.y += ad.y; old.z += ad.z; old.w += ad.w;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
                         for (int u = 0; u < 4; ++u)
                             if (c + u < a.M) {
                                 float *dst = o + 8 * g + u;
-                                float base = a.accumulate ? *dst : 0.0f;
+                                float base = a.accumulate == 1 ? *dst : 0.0f;
                                 if (a.accumulate && a.addend) base += a.addend[(size_t)row * a.ld_add + c + u];
                                 *dst = a.accumulate ? vals[4 * g + u] + base : vals[4 * g + u];
                             }

@@ -489,12 +489,80 @@ __global__ void scale_rows_kernel(const float *__restrict__ w, int M, int K, con
     if (t < (size_t)M * K) out[t] = w[t] * s_by_k[t % K];
 }
 
+// ---- MRConv2d vertex pass (torch_vertex.py:8-20): cat[v] = [x_v | max_k (x_nbr(v,k) - x_v)], first index on ties
+// like torch.max; arg = winning k.  One thread per (vertex, channel); C = 9, 64 or a multiple of 64.
+__global__ void mr_gather_fwd_kernel(const float *__restrict__ x, int ld, int C, const int32_t *__restrict__ nbr,
+                                     float *__restrict__ cat, uint8_t *__restrict__ arg, int N, size_t total)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c = (int)(t % C);
+    const size_t v = t / C;
+    const size_t room_base = (v / N) * N;
+    const float xv = x[v * ld + c];
+    const int32_t *nb = nbr + v * KNB;
+    float best = -INFINITY;
+    int bk = 0;
+#pragma unroll 4
+    for (int k = 0; k < KNB; ++k) {
+        const float r = x[(room_base + nb[k]) * ld + c] - xv;
+        if (r > best) { best = r; bk = k; }
+    }
+    cat[v * 2 * C + c] = xv;
+    cat[v * 2 * C + C + c] = best;
+    arg[t] = (uint8_t)bk;
+}
+
+// gz[v][o] = dy[v][o] * s_o where the conv output was positive (backward through BatchNorm and ReLU of a BasicConv)
+__global__ void mr_dz_kernel(const float *__restrict__ dy, int ld_dy, const uint32_t *__restrict__ mask,
+                             const float *__restrict__ scale, float *__restrict__ gz, size_t total)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int o = (int)(t % GC);
+    const size_t v = t / GC;
+    const bool act = (mask[v * 2 + (o >> 5)] >> (o & 31)) & 1u;
+    gz[t] = act ? dy[v * ld_dy + o] * scale[o] : 0.0f;
+}
+
+// d cat -> d x, own-vertex part: tgt[v][c] (+)= dcat[v][c] - dcat[v][C + c] (+ extra[v][c]);  `assign` overwrites.
+__global__ void mr_bwd_self_kernel(const float *__restrict__ dcat, int C, float *__restrict__ tgt, int ld_t,
+                                   const float *__restrict__ extra, int ld_e, int assign, size_t total)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c = (int)(t % C);
+    const size_t v = t / C;
+    float g = dcat[v * 2 * C + c] - dcat[v * 2 * C + C + c];
+    if (extra) g += extra[v * ld_e + c];
+    float *o = tgt + v * ld_t + c;
+    *o = assign ? g : *o + g;
+}
+
+// neighbour part: tgt[nbr(v, k*)][c] += dcat[v][C + c]  (launched after mr_bwd_self_kernel has finished)
+__global__ void mr_bwd_scatter_kernel(const float *__restrict__ dcat, int C, const int32_t *__restrict__ nbr,
+                                      const uint8_t *__restrict__ arg, float *__restrict__ tgt, int ld_t, int N, size_t total)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c = (int)(t % C);
+    const size_t v = t / C;
+    const float g = dcat[v * 2 * C + C + c];
+    if (g != 0.0f) {
+        const size_t j = (v / N) * N + nbr[v * KNB + arg[t]];
+        atomicAdd(tgt + j * ld_t + c, g);
+    }
+}
+
 struct EdgeLayer {
     float *wcat;    // [128][C]: rows 0..63 = W1 - W2, rows 64..127 = W2
     float *bcat;    // [128] = [b, 0]
     float *wcat_t;  // [C][128] (transpose, for the input gradient)
     float *scale, *shift;  // eval BatchNorm after the ReLU
+    float *w = nullptr, *b = nullptr;   // conv = mr: plain [64][2C] weight and [64] bias of the BasicConv
+    float *w_t = nullptr;               // conv = mr: [2C][64] transpose (input gradient)
     int C;
+    size_t arg_off = 0;                 // conv = mr: offset of this layer's arg-max bytes per vertex block (sum of C before it)
 };
 
 }  // namespace
@@ -502,6 +570,8 @@ struct EdgeLayer {
 struct psg_gcn_model {
     psg_ctx *ctx;
     int n_blocks;
+    int block = PSG_GCN_BLOCK_RES, conv = PSG_GCN_CONV_EDGE;   // architecture.py:26-39, torch_vertex.py:44-49
+    size_t arg_total = 0;                 // conv = mr: arg-max bytes per vertex over all layers
     std::vector<EdgeLayer> edge;
     float *wf, *bf, *sf, *tf;             // fusion 1792 -> 1024
     float *wp1, *bp1, *s1, *t1;           // prediction.0: 2816 -> 512 (columns: [fusion 1024 | feats 1792])
@@ -518,6 +588,10 @@ struct psg_gcn_model {
 struct psg_gcn_ws {
     psg_ctx *ctx;
     int B, N, NP2, n_blocks, fdim;
+    int block = PSG_GCN_BLOCK_RES, conv = PSG_GCN_CONV_EDGE;
+    int pq_w = 128;            // row width of pq / dpq: 128, or 2 * (widest conv input) for conv = mr
+    uint8_t *arg_mr = nullptr; // conv = mr: [sum_e C_e][B*N] winning neighbour of every (layer, vertex, channel)
+    uint32_t *mask_mr = nullptr; // conv = mr: [n_blocks][B*N][2] ReLU bits of every layer's conv output
     void *arena = nullptr;
     size_t bytes = 0;
     float *feats, *dfeats;     // [B*N][fdim]
@@ -614,10 +688,18 @@ int knn_graph(psg_gcn_ws *ws, const float *x, int ld, int C, int d, int32_t *out
 //   prediction.0: weight [512][1024 + 64*n_blocks], bias, bn x4 [512]
 //   prediction.1: weight [256][512], bias, bn x4 [256]
 //   prediction.3: weight [13][256], bias [13]
-extern "C" int psg_gcn_model_create(psg_ctx *ctx, const float *const *tensors, int n_tensors, int n_blocks,
-                                    psg_gcn_model **out)
+//
+// block = dense (DenseDynBlock2d, torch_vertex.py:103-115): EdgeConv e reads ALL earlier outputs (C = 64 e) and the
+// fusion / prediction.0 layers see every block's growing concatenation, i.e. output y_j of block j (64 channels)
+// occurs n_blocks - j times among their input columns (architecture.py:62-63 with :112-115).  Those duplicate columns
+// are summed on the host into one [.., 64 * n_blocks] weight: W_eff[:, y_j] = sum_{i >= j} W[:, copy of y_j in cur_i],
+// so everything downstream of the backbone is the same computation as for block = res.
+extern "C" int psg_gcn_model_create_cfg(psg_ctx *ctx, const float *const *tensors, int n_tensors, int n_blocks, int block,
+                                        int conv, psg_gcn_model **out)
 {
     PSG_REQUIRE(ctx && tensors && out, "psg_gcn_model_create: null argument");
+    PSG_REQUIRE(block >= PSG_GCN_BLOCK_RES && block <= PSG_GCN_BLOCK_DENSE, "psg_gcn_model_create: unknown block kind %d", block);
+    PSG_REQUIRE(conv == PSG_GCN_CONV_EDGE || conv == PSG_GCN_CONV_MR, "psg_gcn_model_create: unknown conv kind %d", conv);
     PSG_REQUIRE(n_blocks >= 1 && n_blocks <= 64, "psg_gcn_model_create: n_blocks out of range");
     PSG_REQUIRE(n_tensors == 6 * n_blocks + 6 + 6 + 6 + 2, "psg_gcn_model_create: expected %d tensors, got %d",
                 6 * n_blocks + 20, n_tensors);
@@ -625,9 +707,10 @@ extern "C" int psg_gcn_model_create(psg_ctx *ctx, const float *const *tensors, i
     PSG_CHECK_HIP(hipSetDevice(ctx->device));
     auto *m = new psg_gcn_model();
     m->ctx = ctx; m->n_blocks = n_blocks; m->fdim = GC * n_blocks;
+    m->block = block; m->conv = conv;
     int ti = 0;
     for (int e = 0; e < n_blocks; ++e) {
-        const int C = e == 0 ? 9 : GC;
+        const int C = e == 0 ? 9 : (block == PSG_GCN_BLOCK_DENSE ? GC * e : GC);
         const float *W = tensors[ti], *b = tensors[ti + 1];
         std::vector<float> s, t;
         bn_affine(tensors[ti + 2], tensors[ti + 3], tensors[ti + 4], tensors[ti + 5], GC, s, t);
@@ -647,15 +730,46 @@ extern "C" int psg_gcn_model_create(psg_ctx *ctx, const float *const *tensors, i
         L.C = C;
         L.wcat = dev_upload(m, wcat); L.bcat = dev_upload(m, bcat); L.wcat_t = dev_upload(m, wt);
         L.scale = dev_upload(m, s); L.shift = dev_upload(m, t);
+        if (conv == PSG_GCN_CONV_MR) {
+            std::vector<float> wplain(W, W + (size_t)GC * 2 * C), wtr((size_t)2 * C * GC);
+            for (int o = 0; o < GC; ++o)
+                for (int k = 0; k < 2 * C; ++k) wtr[(size_t)k * GC + o] = W[(size_t)o * 2 * C + k];
+            L.w = dev_upload(m, wplain); L.w_t = dev_upload(m, wtr);
+            L.b = dev_upload(m, std::vector<float>(b, b + GC));
+            L.arg_off = m->arg_total;
+            m->arg_total += (size_t)C;
+        }
         m->edge.push_back(L);
     }
     const int F = m->fdim;
     auto up = [&](const float *p, size_t n) { return dev_upload(m, std::vector<float>(p, p + n)); };
+    // fold the duplicated feature columns of a dense backbone (see above): src has `lead` leading columns kept as
+    // they are, then the concatenation cur_0 | cur_1 | ... with cur_i = y_0 .. y_i
+    std::vector<std::vector<float>> folded;
+    auto fold_dense = [&](const float *W, int rows, int lead) -> const float * {
+        if (block != PSG_GCN_BLOCK_DENSE) return W;
+        const int fd = GC * n_blocks * (n_blocks + 1) / 2;
+        std::vector<float> o((size_t)rows * (lead + F), 0.0f);
+        for (int r = 0; r < rows; ++r) {
+            const float *src = W + (size_t)r * (lead + fd);
+            float *dst = o.data() + (size_t)r * (lead + F);
+            for (int k = 0; k < lead; ++k) dst[k] = src[k];
+            std::vector<double> acc(F, 0.0);
+            int off = lead;
+            for (int i = 0; i < n_blocks; ++i) {
+                for (int k = 0; k < GC * (i + 1); ++k) acc[k] += (double)src[off + k];
+                off += GC * (i + 1);
+            }
+            for (int k = 0; k < F; ++k) dst[lead + k] = (float)acc[k];
+        }
+        folded.push_back(std::move(o));
+        return folded.back().data();
+    };
     std::vector<float> s, t;
-    m->wf = up(tensors[ti], (size_t)1024 * F); m->bf = up(tensors[ti + 1], 1024);
+    m->wf = up(fold_dense(tensors[ti], 1024, 0), (size_t)1024 * F); m->bf = up(tensors[ti + 1], 1024);
     bn_affine(tensors[ti + 2], tensors[ti + 3], tensors[ti + 4], tensors[ti + 5], 1024, s, t);
     m->sf = dev_upload(m, s); m->tf = dev_upload(m, t); ti += 6;
-    const float *W1 = tensors[ti];
+    const float *W1 = fold_dense(tensors[ti], 512, 1024);
     m->wp1 = up(W1, (size_t)512 * (1024 + F)); m->bp1 = up(tensors[ti + 1], 512);
     std::vector<float> s1v, t1v;
     bn_affine(tensors[ti + 2], tensors[ti + 3], tensors[ti + 4], tensors[ti + 5], 512, s1v, t1v);
@@ -685,6 +799,12 @@ extern "C" int psg_gcn_model_create(psg_ctx *ctx, const float *const *tensors, i
     return PSG_OK;
 }
 
+extern "C" int psg_gcn_model_create(psg_ctx *ctx, const float *const *tensors, int n_tensors, int n_blocks,
+                                    psg_gcn_model **out)
+{
+    return psg_gcn_model_create_cfg(ctx, tensors, n_tensors, n_blocks, PSG_GCN_BLOCK_RES, PSG_GCN_CONV_EDGE, out);
+}
+
 extern "C" int psg_gcn_model_destroy(psg_gcn_model *m)
 {
     if (!m) return PSG_OK;
@@ -694,15 +814,23 @@ extern "C" int psg_gcn_model_destroy(psg_gcn_model *m)
 }
 
 // ======================================================================================== workspace
-extern "C" int psg_gcn_ws_create(psg_ctx *ctx, int batch, int n_point, int n_blocks, psg_gcn_ws **out)
+extern "C" int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n_blocks, int block, int conv, psg_gcn_ws **out)
 {
     PSG_REQUIRE(ctx && out, "psg_gcn_ws_create: null argument");
+    PSG_REQUIRE(block >= PSG_GCN_BLOCK_RES && block <= PSG_GCN_BLOCK_DENSE && (conv == PSG_GCN_CONV_EDGE || conv == PSG_GCN_CONV_MR),
+                "psg_gcn_ws_create: unknown block / conv kind");
     PSG_REQUIRE(batch > 0 && n_blocks >= 1, "psg_gcn_ws_create: bad sizes");
     PSG_REQUIRE(n_point >= 16 * n_blocks && n_point <= 4096,
                 "psg_gcn_ws_create: n_point=%d must be in [k*max dilation = %d, 4096]", n_point, 16 * n_blocks);
     PSG_CHECK_HIP(hipSetDevice(ctx->device));
     auto *ws = new psg_gcn_ws();
     ws->ctx = ctx; ws->B = batch; ws->N = n_point; ws->n_blocks = n_blocks; ws->fdim = GC * n_blocks;
+    ws->block = block; ws->conv = conv;
+    // widest conv input (dense: all earlier outputs) and the total arg-max bytes per vertex of the mr layers
+    const int c_max = block == PSG_GCN_BLOCK_DENSE ? std::max(GC, GC * (n_blocks - 1)) : GC;
+    size_t arg_total = 9;
+    for (int e = 1; e < n_blocks; ++e) arg_total += block == PSG_GCN_BLOCK_DENSE ? (size_t)GC * e : (size_t)GC;
+    ws->pq_w = conv == PSG_GCN_CONV_MR ? std::max(128, 2 * c_max) : 128;
     ws->NP2 = 1;
     while (ws->NP2 < n_point) ws->NP2 <<= 1;
     const size_t R = (size_t)batch * n_point;
@@ -718,8 +846,12 @@ extern "C" int psg_gcn_ws_create(psg_ctx *ctx, int batch, int n_point, int n_blo
         ws->dfeats = (float *)take(R * ws->fdim * 4);
         ws->dist = (float *)take(R * n_point * 4);
         ws->sq = (float *)take(R * 4);
-        ws->pq = (float *)take(R * 128 * 4);
-        ws->dpq = (float *)take(R * 128 * 4);
+        ws->pq = (float *)take(R * ws->pq_w * 4);
+        ws->dpq = (float *)take(R * ws->pq_w * 4);
+        if (conv == PSG_GCN_CONV_MR) {
+            ws->arg_mr = (uint8_t *)take(R * arg_total);
+            ws->mask_mr = (uint32_t *)take((size_t)n_blocks * R * 2 * 4);
+        }
         ws->nbr = (int32_t *)take((size_t)n_blocks * R * KNB * 4);
         ws->arg = (uint8_t *)take((size_t)n_blocks * R * GC);
         ws->fused = (float *)take(R * 1024 * 4);
@@ -756,6 +888,11 @@ extern "C" int psg_gcn_ws_create(psg_ctx *ctx, int batch, int n_point, int n_blo
     }
     *out = ws;
     return PSG_OK;
+}
+
+extern "C" int psg_gcn_ws_create(psg_ctx *ctx, int batch, int n_point, int n_blocks, psg_gcn_ws **out)
+{
+    return psg_gcn_ws_create_cfg(ctx, batch, n_point, n_blocks, PSG_GCN_BLOCK_RES, PSG_GCN_CONV_EDGE, out);
 }
 
 extern "C" int psg_gcn_ws_destroy(psg_gcn_ws *ws)
@@ -800,7 +937,8 @@ extern "C" int psg_gcn_knn(psg_gcn_ws *ws, const float *x, int C, int dilation, 
 extern "C" int psg_gcn_forward(psg_gcn_model *m, psg_gcn_ws *ws, const float *x0, float *logits_out, psg_stream stream)
 {
     PSG_REQUIRE(m && ws && x0 && logits_out, "psg_gcn_forward: null argument");
-    PSG_REQUIRE(m->n_blocks == ws->n_blocks, "psg_gcn_forward: model/workspace block count mismatch");
+    PSG_REQUIRE(m->n_blocks == ws->n_blocks && m->block == ws->block && m->conv == ws->conv,
+                "psg_gcn_forward: model / workspace configuration mismatch");
     hipStream_t st = (hipStream_t)stream;
     const int B = ws->B, N = ws->N, F = ws->fdim;
     const size_t R = (size_t)B * N;
@@ -808,23 +946,41 @@ extern "C" int psg_gcn_forward(psg_gcn_model *m, psg_gcn_ws *ws, const float *x0
     int rc;
     hipLaunchKernelGGL(extract3_kernel, dim3(ceil_div((int)(R * 3), 256)), dim3(256), 0, st, x0, ws->xyz, R);
     PSG_LAUNCH_CHECK();
+    const bool dense = m->block == PSG_GCN_BLOCK_DENSE, res = m->block == PSG_GCN_BLOCK_RES, mr = m->conv == PSG_GCN_CONV_MR;
     for (int e = 0; e < m->n_blocks; ++e) {
         const EdgeLayer &L = m->edge[e];
         int32_t *nbr = ws->nbr + (size_t)e * R * KNB;
-        const float *xin = e == 0 ? x0 : ws->feats + (size_t)(e - 1) * GC;
+        // input of block e: the previous block's output (res / plain) or all earlier outputs (dense: a prefix of the rows)
+        const float *xin = e == 0 ? x0 : (dense ? ws->feats : ws->feats + (size_t)(e - 1) * GC);
         const int ld = e == 0 ? 9 : F;
-        // graph: xyz kNN for the head (architecture.py:59), feature-space kNN with dilation e for block e (:61-62)
+        // graph: xyz kNN for the head (architecture.py:59); feature-space kNN for block e with dilation e (res, dense:
+        // architecture.py:23,28) or 1 (plain, :36).  The norms of a 64-wide EdgeConv output come out of its max kernel.
+        const int dil = e == 0 || m->block == PSG_GCN_BLOCK_PLAIN ? 1 : e;
+        const bool have_sq = e > 0 && !mr && !dense;
         if (!ws->fixed_graphs && !(e == 0 && ws->head_graph_frozen) &&
-            (rc = knn_graph(ws, e == 0 ? ws->xyz : xin, e == 0 ? 3 : ld, e == 0 ? 3 : GC, e == 0 ? 1 : e, nbr, st, e > 0)))
+            (rc = knn_graph(ws, e == 0 ? ws->xyz : xin, e == 0 ? 3 : ld, e == 0 ? 3 : L.C, dil, nbr, st, have_sq)))
             return rc;
-        // [P | Q] = x . [W1 - W2 ; W2]^T + [b, 0]
-        GemmArgs a = gemm_args(xin, ld, L.wcat, L.C, ws->pq, 2 * GC, (int)R, L.C, 2 * GC);
-        a.bias = L.bcat;
-        if ((rc = launch_gemm<2, 2, EPI_LINEAR, false>(a, st))) return rc;
-        hipLaunchKernelGGL(edge_max_fwd_kernel, dim3(g256), dim3(256), 0, st, ws->pq, nbr, L.scale, L.shift,
-                           e == 0 ? nullptr : xin, F, ws->feats + (size_t)e * GC, F, ws->arg + (size_t)e * R * GC, N,
-                           R * GC, ws->fixed_graphs ? nullptr : ws->sq);
-        PSG_LAUNCH_CHECK();
+        float *yout = ws->feats + (size_t)e * GC;
+        if (!mr) {
+            // [P | Q] = x . [W1 - W2 ; W2]^T + [b, 0]
+            GemmArgs a = gemm_args(xin, ld, L.wcat, L.C, ws->pq, 2 * GC, (int)R, L.C, 2 * GC);
+            a.bias = L.bcat;
+            if ((rc = launch_gemm<2, 2, EPI_LINEAR, false>(a, st))) return rc;
+            hipLaunchKernelGGL(edge_max_fwd_kernel, dim3(g256), dim3(256), 0, st, ws->pq, nbr, L.scale, L.shift,
+                               (e == 0 || !res) ? nullptr : xin, F, yout, F, ws->arg + (size_t)e * R * GC, N,
+                               R * GC, (ws->fixed_graphs || dense) ? nullptr : ws->sq);
+            PSG_LAUNCH_CHECK();
+        } else {
+            // MRConv2d: BasicConv(cat[x, max_k (x_j - x_i)]) per vertex (+ x for a residual block)
+            const size_t tot = R * (size_t)L.C;
+            hipLaunchKernelGGL(mr_gather_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, xin, ld, L.C, nbr,
+                               ws->pq, ws->arg_mr + L.arg_off * R, N, tot);
+            PSG_LAUNCH_CHECK();
+            GemmArgs a = gemm_args(ws->pq, 2 * L.C, L.w, 2 * L.C, yout, F, (int)R, 2 * L.C, GC);
+            a.bias = L.b; a.scale = L.scale; a.shift = L.shift; a.mask_out = ws->mask_mr + (size_t)e * R * 2;
+            if (res && e > 0) { a.accumulate = 2; a.addend = xin; a.ld_add = F; }
+            if ((rc = launch_gemm<2, 2, EPI_RELU_AFFINE, false>(a, st))) return rc;
+        }
     }
     // fusion: Conv(F -> 1024) + ReLU + BN, global max over the room
     {
@@ -864,11 +1020,61 @@ extern "C" int psg_gcn_forward(psg_gcn_model *m, psg_gcn_ws *ws, const float *x0
     return PSG_OK;
 }
 
+// Backbone backward of the alternative blocks / convolutions.  dfeats[:, slice e] holds d loss / d y_e from the fusion
+// and prediction layers; walking e downwards, every block adds its input gradient into the slice(s) it read, so a
+// slice is complete when its block is reached:
+//   res:    d x_{e-1} += d x_e + conv_e^T(d x_e)        plain:  d y_{e-1} += conv_e^T(d y_e)
+//   dense:  d y_j     += conv_e^T(d y_e)[:, y_j]  for every j < e
+static int backward_alt(psg_gcn_model *m, psg_gcn_ws *ws, float *dx0_out, hipStream_t st)
+{
+    const int N = ws->N, F = ws->fdim;
+    const size_t R = (size_t)ws->B * N;
+    const int g256 = ceil_div((int)(R * GC), 256);
+    const bool dense = m->block == PSG_GCN_BLOCK_DENSE, res = m->block == PSG_GCN_BLOCK_RES, mr = m->conv == PSG_GCN_CONV_MR;
+    int rc;
+    for (int e = m->n_blocks - 1; e >= 0; --e) {
+        const EdgeLayer &L = m->edge[e];
+        const float *dy = ws->dfeats + (size_t)e * GC;                       // rows of F floats
+        float *tgt = e == 0 ? dx0_out : (dense ? ws->dfeats : ws->dfeats + (size_t)(e - 1) * GC);
+        const int ld_t = e == 0 ? 9 : F;
+        const int32_t *nbr = ws->nbr + (size_t)e * R * KNB;
+        if (!mr) {
+            PSG_CHECK_HIP(hipMemsetAsync(ws->dpq, 0, R * 2 * GC * 4, st));
+            hipLaunchKernelGGL(edge_max_bwd_kernel, dim3(g256), dim3(256), 0, st, dy, F, nbr, ws->arg + (size_t)e * R * GC,
+                               L.scale, ws->dpq, N, R * GC);
+            PSG_LAUNCH_CHECK();
+            GemmArgs a = gemm_args(ws->dpq, 2 * GC, L.wcat_t, 2 * GC, tgt, ld_t, (int)R, 2 * GC, L.C);
+            if (e > 0) {
+                a.accumulate = 1;
+                if (res) { a.addend = dy; a.ld_add = F; }
+            }
+            if ((rc = launch_gemm<2, 2, EPI_LINEAR, false>(a, st))) return rc;
+        } else {
+            hipLaunchKernelGGL(mr_dz_kernel, dim3(g256), dim3(256), 0, st, dy, F, ws->mask_mr + (size_t)e * R * 2, L.scale,
+                               ws->gcur, R * GC);
+            PSG_LAUNCH_CHECK();
+            GemmArgs a = gemm_args(ws->gcur, GC, L.w_t, GC, ws->dpq, 2 * L.C, (int)R, GC, 2 * L.C);
+            if ((rc = launch_gemm<2, 2, EPI_LINEAR, false>(a, st))) return rc;
+            const size_t tot = R * (size_t)L.C;
+            const unsigned grid = (unsigned)((tot + 255) / 256);
+            hipLaunchKernelGGL(mr_bwd_self_kernel, dim3(grid), dim3(256), 0, st, ws->dpq, L.C, tgt, ld_t,
+                               (res && e > 0) ? dy : nullptr, F, e == 0 ? 1 : 0, tot);
+            PSG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(mr_bwd_scatter_kernel, dim3(grid), dim3(256), 0, st, ws->dpq, L.C, nbr,
+                               ws->arg_mr + L.arg_off * R, tgt, ld_t, N, tot);
+            PSG_LAUNCH_CHECK();
+        }
+    }
+    return PSG_OK;
+}
+
 extern "C" int psg_gcn_backward(psg_gcn_model *m, psg_gcn_ws *ws, const float *dlogits, float *dx0_out,
                                 psg_stream stream)
 {
     PSG_REQUIRE(m && ws && dlogits && dx0_out, "psg_gcn_backward: null argument");
     if (!ws->have_fwd) { set_error("psg_gcn_backward: no forward is resident in the workspace"); return PSG_ERR_STATE; }
+    PSG_REQUIRE(m->n_blocks == ws->n_blocks && m->block == ws->block && m->conv == ws->conv,
+                "psg_gcn_backward: model / workspace configuration mismatch");
     hipStream_t st = (hipStream_t)stream;
     const int B = ws->B, N = ws->N, F = ws->fdim;
     const size_t R = (size_t)B * N;
@@ -901,6 +1107,7 @@ extern "C" int psg_gcn_backward(psg_gcn_model *m, psg_gcn_ws *ws, const float *d
     hipLaunchKernelGGL(fusion_bwd_kernel, dim3(1024, B), dim3(256), 0, st, ws->gfvec, ws->farg, ws->mask_f, m->sf, m->wf, F,
                        1024, N, ws->dfeats);
     PSG_LAUNCH_CHECK();
+    if (m->block != PSG_GCN_BLOCK_RES || m->conv != PSG_GCN_CONV_EDGE) return backward_alt(m, ws, dx0_out, st);
     // backbone in reverse: G_e = d/d x_e
     PSG_CHECK_HIP(hipMemcpy2DAsync(ws->gcur, GC * 4, ws->dfeats + (size_t)(m->n_blocks - 1) * GC, (size_t)F * 4, GC * 4, R,
                                    hipMemcpyDeviceToDevice, st));

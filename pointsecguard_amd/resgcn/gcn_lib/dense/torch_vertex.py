@@ -1,5 +1,5 @@
 """Graph-convolution modules with the reference's names and parameter layout
-(ResGCN/gcn_lib/dense/torch_vertex.py:23-100).  They carry the parameters; DenseDeepGCN executes them through
+(ResGCN/gcn_lib/dense/torch_vertex.py:8-115).  They carry the parameters; DenseDeepGCN executes them through
 libpsg as whole-network kernels."""
 from torch import nn
 
@@ -20,12 +20,26 @@ class EdgeConv2d(nn.Module):
         raise NotImplementedError("EdgeConv2d.forward is " + _MSG)
 
 
+class MRConv2d(nn.Module):
+    """Max-relative graph convolution: BasicConv(cat[x, max_j (x_j - x_i)]) (torch_vertex.py:8-20)."""
+
+    def __init__(self, in_channels, out_channels, act="relu", norm=None, bias=True):
+        super(MRConv2d, self).__init__()
+        self.nn = BasicConv([in_channels * 2, out_channels], act, norm, bias)
+
+    def forward(self, x, edge_index):
+        raise NotImplementedError("MRConv2d.forward is " + _MSG)
+
+
 class GraphConv2d(nn.Module):
     def __init__(self, in_channels, out_channels, conv="edge", act="relu", norm=None, bias=True):
         super(GraphConv2d, self).__init__()
-        if conv != "edge":
-            raise NotImplementedError("conv:{} is not supported (default 'edge' only)".format(conv))
-        self.gconv = EdgeConv2d(in_channels, out_channels, act, norm, bias)
+        if conv == "edge":
+            self.gconv = EdgeConv2d(in_channels, out_channels, act, norm, bias)
+        elif conv == "mr":
+            self.gconv = MRConv2d(in_channels, out_channels, act, norm, bias)
+        else:
+            raise NotImplementedError("conv:{} is not supported".format(conv))
 
     def forward(self, x, edge_index):
         return self.gconv(x, edge_index)
@@ -58,19 +72,27 @@ class ResDynBlock2d(nn.Module):
         raise NotImplementedError("ResDynBlock2d.forward is " + _MSG)
 
 
-def _unsupported(name, where):
-    class _Unsupported(nn.Module):
-        """Importable so that `from gcn_lib.dense import ...` lines of the reference keep working; constructing it says
-        which configuration is missing (alternative blocks are not implemented)."""
+class PlainDynBlock2d(nn.Module):
+    """Plain dynamic graph-convolution block: body(x) (torch_vertex.py:74-85)."""
 
-        def __init__(self, *args, **kwargs):
-            raise NotImplementedError("%s (%s) is not implemented: the gfx950 kernels cover the reference's attack "
-                                      "configuration (EdgeConv2d inside ResDynBlock2d)" % (name, where))
+    def __init__(self, in_channels, kernel_size=9, dilation=1, conv="edge", act="relu", norm=None, bias=True,
+                 stochastic=False, epsilon=0.0, knn="matrix"):
+        super(PlainDynBlock2d, self).__init__()
+        self.body = DynConv2d(in_channels, in_channels, kernel_size, dilation, conv, act, norm, bias, stochastic,
+                              epsilon, knn)
 
-    _Unsupported.__name__ = _Unsupported.__qualname__ = name
-    return _Unsupported
+    def forward(self, x):
+        raise NotImplementedError("PlainDynBlock2d.forward is " + _MSG)
 
 
-MRConv2d = _unsupported("MRConv2d", "torch_vertex.py:8-20")
-PlainDynBlock2d = _unsupported("PlainDynBlock2d", "torch_vertex.py:74-85")
-DenseDynBlock2d = _unsupported("DenseDynBlock2d", "torch_vertex.py:103-115")
+class DenseDynBlock2d(nn.Module):
+    """Dense dynamic graph-convolution block: cat(x, body(x)) (torch_vertex.py:103-115)."""
+
+    def __init__(self, in_channels, out_channels=64, kernel_size=9, dilation=1, conv="edge", act="relu", norm=None,
+                 bias=True, stochastic=False, epsilon=0.0, knn="matrix"):
+        super(DenseDynBlock2d, self).__init__()
+        self.body = DynConv2d(in_channels, out_channels, kernel_size, dilation, conv, act, norm, bias, stochastic,
+                              epsilon, knn)
+
+    def forward(self, x):
+        raise NotImplementedError("DenseDynBlock2d.forward is " + _MSG)

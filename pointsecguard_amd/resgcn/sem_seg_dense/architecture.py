@@ -7,7 +7,11 @@ import torch
 from torch.nn import Sequential as Seq
 
 from pointsecguard_amd import _lib, runtime
-from pointsecguard_amd.resgcn.gcn_lib.dense import BasicConv, DenseDilatedKnnGraph, GraphConv2d, ResDynBlock2d
+from pointsecguard_amd.resgcn.gcn_lib.dense import (BasicConv, DenseDilatedKnnGraph, DenseDynBlock2d, GraphConv2d,
+                                                    PlainDynBlock2d, ResDynBlock2d)
+
+BLOCKS = {"res": runtime.GCN_BLOCK_RES, "plain": runtime.GCN_BLOCK_PLAIN, "dense": runtime.GCN_BLOCK_DENSE}
+CONVS = {"edge": runtime.GCN_CONV_EDGE, "mr": runtime.GCN_CONV_MR}
 
 
 class _GCNFunction(torch.autograd.Function):
@@ -45,17 +49,31 @@ class DenseDeepGCN(torch.nn.Module):
         channels, k = opt.n_filters, opt.k
         act, norm, bias = opt.act, opt.norm, opt.bias
         epsilon, stochastic, conv = opt.epsilon, opt.stochastic, opt.conv
-        if (channels, k, conv, opt.block.lower(), opt.in_channels, opt.n_classes) != (64, 16, "edge", "res", 9, 13):
-            raise NotImplementedError("the gfx950 kernels implement the reference's default configuration "
-                                      "(n_filters=64, k=16, conv='edge', block='res', in_channels=9, n_classes=13)")
+        block = opt.block.lower() if opt.block.lower() in ("res", "dense") else "plain"   # architecture.py:26-39
+        if (channels, k, opt.in_channels, opt.n_classes) != (64, 16, 9, 13) or conv not in CONVS:
+            raise NotImplementedError("the gfx950 kernels implement n_filters=64, k=16, in_channels=9, n_classes=13 with "
+                                      "conv in ('edge', 'mr') and block in ('res', 'dense', plain)")
         if epsilon != 0 or opt.dropout != 0:
             raise NotImplementedError("epsilon / dropout must be 0 (attack path runs in eval mode)")
         self.n_blocks = opt.n_blocks
+        self.block_kind, self.conv_kind = BLOCKS[block], CONVS[conv]
+        c_growth = channels
         self.knn = DenseDilatedKnnGraph(k, 1, stochastic, epsilon)
+        self._knn_stochastic = bool(stochastic)
         self.head = GraphConv2d(opt.in_channels, channels, conv, act, norm, bias)
-        self.backbone = Seq(*[ResDynBlock2d(channels, k, 1 + i, conv, act, norm, bias, stochastic, epsilon)
-                              for i in range(self.n_blocks - 1)])
-        fusion_dims = int(channels + channels * (self.n_blocks - 1))
+        if block == "res":
+            self.backbone = Seq(*[ResDynBlock2d(channels, k, 1 + i, conv, act, norm, bias, stochastic, epsilon)
+                                  for i in range(self.n_blocks - 1)])
+            fusion_dims = int(channels + c_growth * (self.n_blocks - 1))
+        elif block == "dense":
+            self.backbone = Seq(*[DenseDynBlock2d(channels + c_growth * i, c_growth, k, 1 + i, conv, act, norm, bias,
+                                                  stochastic, epsilon) for i in range(self.n_blocks - 1)])
+            fusion_dims = int((channels + channels + c_growth * (self.n_blocks - 1)) * self.n_blocks // 2)
+        else:
+            stochastic = False
+            self.backbone = Seq(*[PlainDynBlock2d(channels, k, 1, conv, act, norm, bias, stochastic, epsilon)
+                                  for i in range(self.n_blocks - 1)])
+            fusion_dims = int(channels + c_growth * (self.n_blocks - 1))
         self.fusion_block = BasicConv([fusion_dims, 1024], act, norm, bias)
         self.prediction = Seq(*[BasicConv([fusion_dims + 1024, 512], act, norm, bias),
                                 BasicConv([512, 256], act, norm, bias),
@@ -79,15 +97,26 @@ class DenseDeepGCN(torch.nn.Module):
         key = tuple((t.data_ptr(), t._version) for t in tensors)
         if self._psg_model is None or key != self._psg_key:
             sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
-            self._psg_model = runtime.GCNModel(sd, self.n_blocks)
+            self._psg_model = runtime.GCNModel(sd, self.n_blocks, block=self.block_kind, conv=self.conv_kind)
             self._psg_key = key
         return self._psg_model
 
     def _workspace(self, batch, n_point):
         key = (batch, n_point)
         if key not in self._psg_ws:
-            self._psg_ws[key] = runtime.GCNWorkspace(batch, n_point, self.n_blocks)
+            self._psg_ws[key] = runtime.GCNWorkspace(batch, n_point, self.n_blocks, block=self.block_kind,
+                                                     conv=self.conv_kind)
         return self._psg_ws[key]
+
+    def rng_draws_per_forward(self):
+        """torch.rand(1) draws of one reference forward: every stochastic DenseDilated.forward draws one even in eval
+        (torch_edge.py:21); knn is called twice on xyz (architecture.py:59-60) + once per backbone block (plain blocks
+        are built with stochastic=False, architecture.py:34)."""
+        return (2 if self._knn_stochastic else 0) + (self.n_blocks - 1 if self.stochastic else 0)
+
+    def consume_rng(self, n_forward):
+        for _ in range(n_forward * self.rng_draws_per_forward()):
+            torch.rand(1)
 
     def forward(self, inputs):
         if self.training:
@@ -95,9 +124,5 @@ class DenseDeepGCN(torch.nn.Module):
         runtime.require_cuda(inputs, "inputs")
         if inputs.dim() != 4 or inputs.shape[1] != 9 or inputs.shape[3] != 1:
             raise ValueError("expected inputs [B, 9, N, 1], got %s" % (tuple(inputs.shape),))
-        if self.stochastic:
-            # the reference draws torch.rand(1) in every DenseDilated.forward even in eval (torch_edge.py:21):
-            # knn is called twice on xyz (architecture.py:59-60) + once per backbone block
-            for _ in range(2 + self.n_blocks - 1):
-                torch.rand(1)
+        self.consume_rng(1)
         return _GCNFunction.apply(inputs, self)

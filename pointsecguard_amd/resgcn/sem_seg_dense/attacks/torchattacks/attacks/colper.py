@@ -28,9 +28,7 @@ class NB_attack(Attack):
         B, C, N, _ = images.shape
         x = images[:, :, :, 0].contiguous()
         labels = labels.detach().to(self.device).to(torch.int32).contiguous()
-        if net.stochastic:
-            for _ in range(self.iters * (2 + net.n_blocks - 1)):
-                torch.rand(1)                        # RNG parity: one draw per DenseDilated.forward
+        net.consume_rng(self.iters)                  # RNG parity: one draw per stochastic DenseDilated.forward
         net._generation += 1
         adv = net._workspace(B, N).nb_attack(net._packed(), x, labels, self.eps, self.alpha, self.iters)
         return adv.unsqueeze(-1)

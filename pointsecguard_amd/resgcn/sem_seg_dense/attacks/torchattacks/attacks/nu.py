@@ -58,9 +58,7 @@ def gcn_nu_attack(atk, images, labels, mask=None, target=None, neighbour=10, tar
 
     for step in range(atk.steps):
         _lib.call("psg_nu_tanh_color", runtime.ptr(w), runtime.ptr(mask_d), B, N, runtime.ptr(x0), st())
-        if net.stochastic:
-            for _ in range(2 + net.n_blocks - 1):
-                torch.rand(1)
+        net.consume_rng(1)
         logits = ws.forward(model, x0)
         scal.zero_()
         _lib.call("psg_gcn_f_loss_grad", runtime.ptr(logits), runtime.ptr(labels_d), int(target) if use_target else 0,

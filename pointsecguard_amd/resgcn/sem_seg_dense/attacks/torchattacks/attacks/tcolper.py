@@ -36,9 +36,7 @@ class tar_NB_attack(Attack):
             return out.unsqueeze(-1)
 
         for i in range(self.iters):
-            if net.stochastic:
-                for _ in range(2 + net.n_blocks - 1):
-                    torch.rand(1)
+            net.consume_rng(1)
             logits = ws.forward(model, x0)
             pred = logits.argmax(dim=2)
             target_acc = pred[:, mask_b].eq(int(self.target)).sum().item() / float(mask_b.sum().item())

@@ -316,15 +316,19 @@ def gcn_tensor_list(sd, n_blocks):
     return out
 
 
+GCN_BLOCK_RES, GCN_BLOCK_PLAIN, GCN_BLOCK_DENSE = 0, 1, 2   # PSG_GCN_BLOCK_* / PSG_GCN_CONV_* of include/psg.h
+GCN_CONV_EDGE, GCN_CONV_MR = 0, 1
+
+
 class GCNModel:
-    def __init__(self, sd, n_blocks, device=None):
+    def __init__(self, sd, n_blocks, device=None, block=GCN_BLOCK_RES, conv=GCN_CONV_EDGE):
         self.ctx = context(device)
-        self.n_blocks = n_blocks
+        self.n_blocks, self.block, self.conv = n_blocks, block, conv
         self._keep = gcn_tensor_list(sd, n_blocks)
         arr = (ctypes.c_void_p * len(self._keep))(*[t.ctypes.data_as(ctypes.c_void_p) for t in self._keep])
         self.handle = ctypes.c_void_p()
-        _lib.check(_lib.load().psg_gcn_model_create(self.ctx, arr, len(self._keep), n_blocks, ctypes.byref(self.handle)),
-                   "psg_gcn_model_create")
+        _lib.check(_lib.load().psg_gcn_model_create_cfg(self.ctx, arr, len(self._keep), n_blocks, block, conv,
+                                                        ctypes.byref(self.handle)), "psg_gcn_model_create_cfg")
 
     def __del__(self):
         try:
@@ -336,12 +340,12 @@ class GCNModel:
 
 
 class GCNWorkspace:
-    def __init__(self, batch, n_point, n_blocks, device=None):
+    def __init__(self, batch, n_point, n_blocks, device=None, block=GCN_BLOCK_RES, conv=GCN_CONV_EDGE):
         self.ctx = context(device)
         self.batch, self.n_point, self.n_blocks = batch, n_point, n_blocks
         self.handle = ctypes.c_void_p()
-        _lib.check(_lib.load().psg_gcn_ws_create(self.ctx, batch, n_point, n_blocks, ctypes.byref(self.handle)),
-                   "psg_gcn_ws_create")
+        _lib.check(_lib.load().psg_gcn_ws_create_cfg(self.ctx, batch, n_point, n_blocks, block, conv,
+                                                     ctypes.byref(self.handle)), "psg_gcn_ws_create_cfg")
         self.device = torch.device("cuda", torch.cuda.current_device())
 
     def __del__(self):

@@ -109,3 +109,32 @@ def msg_state_dict(seed):
     bn("bn1", 128)
     conv("conv2", 128, NUM_CLASSES, 1)
     return sd
+
+
+def gcn_state_dict(seed, n_blocks, block="res", conv="edge"):
+    """Seeded random weights for DenseDeepGCN(opt) (n_filters=64, k=16, in_channels=9, 13 classes) with the reference's
+    state_dict keys and shapes for the given `block` / `conv` switches (ResGCN/sem_seg_dense/architecture.py:20-45):
+    He-scaled conv weights, small biases and non-trivial eval BatchNorm statistics."""
+    rng = np.random.RandomState(int(seed))
+    sd = {}
+
+    def basic(name, cin, cout, norm=True):
+        sd[name + ".0.weight"] = (rng.standard_normal((cout, cin, 1, 1)) * np.sqrt(2.0 / cin)).astype(np.float32)
+        sd[name + ".0.bias"] = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+        if norm:   # BasicConv = Conv2d, ReLU, BatchNorm2d  -> the norm is sub-module 2
+            sd[name + ".2.weight"] = rng.uniform(0.8, 1.2, cout).astype(np.float32)
+            sd[name + ".2.bias"] = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+            sd[name + ".2.running_mean"] = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+            sd[name + ".2.running_var"] = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+            sd[name + ".2.num_batches_tracked"] = np.array(1, np.int64)
+
+    basic("head.gconv.nn", 18, 64)
+    for i in range(n_blocks - 1):
+        cin = 64 * (i + 1) if block == "dense" else 64
+        basic("backbone.%d.body.gconv.nn" % i, 2 * cin, 64)
+    fdim = 64 * n_blocks * (n_blocks + 1) // 2 if block == "dense" else 64 * n_blocks
+    basic("fusion_block", fdim, 1024)
+    basic("prediction.0", fdim + 1024, 512)
+    basic("prediction.1", 512, 256)
+    basic("prediction.3", 256, NUM_CLASSES, norm=False)
+    return sd
