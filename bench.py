@@ -84,6 +84,10 @@ def main():
                          "independent, so results are identical and small kernels get more workgroups")
     ap.add_argument("--nu-steps", type=int, default=100, help="tarnu workload: optimiser step cap per attack")
     ap.add_argument("--gcn-concurrency", type=int, default=3, help="resgcn workload: attacks in flight (streams)")
+    ap.add_argument("--gcn-block", default="res", choices=["res", "plain", "dense"],
+                    help="resgcn workload: backbone block (architecture.py:26-39 of the reference); default = BASELINE's")
+    ap.add_argument("--gcn-conv", default="edge", choices=["edge", "mr"], help="resgcn workload: graph convolution")
+    ap.add_argument("--gcn-blocks", type=int, default=28, help="resgcn workload: number of blocks (BASELINE: 28)")
     ap.add_argument("--concurrency", type=int, default=3,
                     help="device batches in flight per GPU (one HIP stream + workspace each)")
     args = ap.parse_args()
@@ -308,33 +312,20 @@ def main_resgcn(args):
     import torch
     from pointsecguard_amd import runtime
     from pointsecguard_amd.synthetic import make_rooms, rule_labels
-    n_blocks, iters, batch = 28, 50, 1
-    rng = np.random.default_rng(7)
-    sd = {}
-
-    def conv(name, cout, cin):
-        sd[name + ".weight"] = (rng.standard_normal((cout, cin)) * np.sqrt(2.0 / cin)).astype(np.float32)
-        sd[name + ".bias"] = np.zeros(cout, np.float32)
-
-    def bn(name, c):
-        sd[name + ".weight"] = np.ones(c, np.float32); sd[name + ".bias"] = np.zeros(c, np.float32)
-        sd[name + ".running_mean"] = (rng.standard_normal(c) * 0.1).astype(np.float32)
-        sd[name + ".running_var"] = (1.0 + 0.1 * rng.random(c)).astype(np.float32)
-
-    for e in range(n_blocks):
-        base = "head.gconv.nn" if e == 0 else "backbone.%d.body.gconv.nn" % (e - 1)
-        conv(base + ".0", 64, 18 if e == 0 else 128); bn(base + ".2", 64)
+    from pointsecguard_amd.synthetic import gcn_state_dict
+    n_blocks, iters, batch = args.gcn_blocks, 50, 1
+    default_cfg = (args.gcn_block, args.gcn_conv, n_blocks) == ("res", "edge", 28)
+    sd = gcn_state_dict(7, n_blocks, args.gcn_block, args.gcn_conv)
     F = 64 * n_blocks
-    conv("fusion_block.0", 1024, F); bn("fusion_block.2", 1024)
-    conv("prediction.0.0", 512, F + 1024); bn("prediction.0.2", 512)
-    conv("prediction.1.0", 256, 512); bn("prediction.1.2", 256)
-    conv("prediction.3.0", 13, 256)
+    BLOCKS = {"res": runtime.GCN_BLOCK_RES, "plain": runtime.GCN_BLOCK_PLAIN, "dense": runtime.GCN_BLOCK_DENSE}
+    CONVS = {"edge": runtime.GCN_CONV_EDGE, "mr": runtime.GCN_CONV_MR}
+    cfg = dict(block=BLOCKS[args.gcn_block], conv=CONVS[args.gcn_conv])
     torch.cuda.set_device(0)
-    model = runtime.GCNModel(sd, n_blocks)
+    model = runtime.GCNModel(sd, n_blocks, **cfg)
     # rooms are independent and a single 4096-point room cannot fill 256 CUs with its small per-vertex GEMMs: several
     # attacks are kept in flight, one HIP stream + workspace each (the same thing bench's PointNet++ path does)
     conc = max(1, min(args.gcn_concurrency, args.steps))
-    wss = [runtime.GCNWorkspace(batch, NPOINT, n_blocks) for _ in range(conc)]
+    wss = [runtime.GCNWorkspace(batch, NPOINT, n_blocks, **cfg) for _ in range(conc)]
     streams = [torch.cuda.Stream() for _ in range(conc)]
     n_steps = args.steps + args.warmup
     rooms = [make_rooms(batch, 5000 + s) for s in range(n_steps)]
@@ -359,14 +350,17 @@ def main_resgcn(args):
     n = NPOINT
     gmac = (27 * n * n * 64 + n * n * 3 + 28 * n * 64 * 128 * 2 + n * F * 1024 + n * F * 512 * 2 + n * 512 * 256 * 2 +
             n * 256 * 13 * 2) / 1e9
-    result = {"metric": "attacked rooms/sec (ResGCN-28, 4096 pts, 50 PGD iters)", "value": batch * args.steps / elapsed,
+    name = "ResGCN-%d" % n_blocks + ("" if (args.gcn_block, args.gcn_conv) == ("res", "edge") else
+                                      " block=%s conv=%s" % (args.gcn_block, args.gcn_conv))
+    result = {"metric": "attacked rooms/sec (%s, 4096 pts, 50 PGD iters)" % name, "value": batch * args.steps / elapsed,
               "unit": "rooms/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
               "dtype": "f32", "data": "synthetic",
-              "config": {"workload": "ResGCN-28 dense sem_seg NB non-targeted PGD (eps=0.3, alpha=2/255, 50 iters), kNN k=16, "
-                                     "batch=1 room x 4096 pts (BASELINE configs[3]); random-init weights",
+              "config": {"workload": name + " dense sem_seg NB non-targeted PGD (eps=0.3, alpha=2/255, 50 iters), kNN k=16, "
+                                     "batch=1 room x 4096 pts (%s); random-init weights" % (
+                                         "BASELINE configs[3]" if default_cfg else "configuration switch of configs[3]"),
                          "attacks_in_flight": conc},
-              "tflops_effective": 2 * gmac * iters * batch * args.steps / elapsed / 1e3}
+              "tflops_effective": 2 * gmac * iters * batch * args.steps / elapsed / 1e3 if default_cfg else None}
     print(json.dumps(result), flush=True)
     return result
 
