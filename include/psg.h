@@ -308,6 +308,18 @@ int psg_gcn_set_graphs(psg_gcn_ws *ws, const int32_t *nbr, psg_stream stream);
 const int32_t *psg_gcn_edge_ptr(const psg_gcn_ws *ws, int block);
 const float *psg_gcn_feats_ptr(const psg_gcn_ws *ws);
 
+/* ------------------------------------------------------------------------------------------
+ * RandLA-Net input pipeline (first piece): exact k-nearest neighbours of 3-D points.
+ * Replaces DataProcessing.knn_search (RandLA-Net/helper_tool.py:158-167) = nearest_neighbors.knn_batch(support,
+ * query, k, omp=True) (utils/nearest_neighbors/knn_.cxx:103-134, nanoflann kd-tree + OpenMP on the host).
+ * support [batch][n_support][3], query [batch][n_query][3] device fp32; out_idx [batch][n_query][k] int32: the k
+ * support points nearest to each query in ascending (squared distance, index) order, 1 <= k <= 16.  Distances are
+ * evaluated like nanoflann's L2 metric, so neighbour sets equal the reference's (order may differ among exact ties,
+ * where nanoflann's order depends on its tree traversal).
+ * ------------------------------------------------------------------------------------------ */
+int psg_knn_points(psg_ctx *ctx, const float *support, const float *query, int batch, int n_support, int n_query, int k,
+                   int32_t *out_idx, psg_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,7 @@ SIGNATURES = {
     "psg_gcn_set_graphs": (ci, [vp, vp, vp]),
     "psg_gcn_edge_ptr": (vp, [vp, ci]),
     "psg_gcn_feats_ptr": (vp, [vp]),
+    "psg_knn_points": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "psg_seg_stats": (ci, [vp, vp, ci, ci, vp, vp, vp]),
     "psg_vote_add": (ci, [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]),
     "psg_vote_stats": (ci, [vp, vp, ci, ci, vp, vp, vp]),

@@ -898,7 +898,7 @@ extern "C" int psg_pn2_model_create_arch(psg_ctx *ctx, int arch, const float *co
         wb[i] = pack_bwd(weights[i], cin, cout, sa_first[i] ? &perm : nullptr);
         bs[i].assign((size_t)ceil_div(cout, 32) * 32, 0.0f);
         std::copy(biases[i], biases[i] + cout, bs[i].begin());
-        if (i >= fp1 && i < fp1 + 3 || i >= A.head) {   // fp1 + head run as wave-private chains: k8-major packings of the 128-wide sides
+        if ((i >= fp1 && i < fp1 + 3) || i >= A.head) {   // fp1 + head run as wave-private chains: k8-major packings of the 128-wide sides
             if (cout == 128) wf4[i] = k8_major(wf[i], 4, ceil_div(cin, 8));
             wb4[i] = k8_major_padded(wb[i], 4, ceil_div(cout, 8), round_up(ceil_div(cout, 8), 4));
         }
