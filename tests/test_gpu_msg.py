@@ -213,3 +213,55 @@ def test_msg_arch_mismatch_is_refused(model):
     ws.plan_build(x0, dev(np.zeros((1, 4, 1), np.int32)), 1)
     with pytest.raises(_lib.PsgError):
         ws.forward(model, 0, x0)
+
+
+def test_msg_nu_step_vs_oracle(model, oracle):
+    """One NU_attack optimiser step (tanh-space Adam, f-loss + Smooth + L2) through the MSG network against the CPU
+    oracle's restatement of the same step (oracle/attacks.py: nu_step is generic in the network oracle)."""
+    from oracle import attacks as oatk
+    from pointsecguard_amd import runtime
+    from test_gpu_nu import nu_step_gpu
+    N, c, kappa, lr, nb = 2048, 0.1, 0.0, 0.01, 10
+    rooms = make_rooms(1, 616, num_point=N)
+    labels = rule_labels(rooms)
+    torch.manual_seed(9)
+    starts = np.stack([torch.randint(0, n, (1,)).numpy() for n in (N, 1024, 256, 64)]).astype(np.int32)[None]   # [1,4,1]
+    images = np.ascontiguousarray(rooms.transpose(0, 2, 1))
+    w0 = oatk.inverse_tanh_space(images[:, 3:6]).astype(np.float32)          # [1,3,N]
+    zeros = np.zeros_like(w0)
+    ref = oatk.nu_step(oracle, images, images.copy(), w0, zeros, zeros, 1, labels, starts[0], c, kappa, lr, nb)
+    ws = runtime.PN2Workspace(1, N, 1, arch=runtime.ARCH_MSG)
+    x0 = dev(rooms)
+    ori = x0[:, :, 3:6].contiguous()
+    ws.plan_build(x0, dev(starts, torch.int32), 1)
+    w = dev(np.ascontiguousarray(w0.transpose(0, 2, 1)))
+    r = nu_step_gpu(ws, model, x0, ori, w, torch.zeros_like(w), torch.zeros_like(w), 1, dev(labels.astype(np.int32)), None,
+                    None, c, kappa, lr, nb, 0)
+    assert abs(r["cost"] - ref["cost"]) <= 1e-4 * abs(ref["cost"]) + 0.02
+    got_g, ref_g = r["grad"].transpose(0, 2, 1), ref["grad_w"]
+    rel = np.abs(got_g - ref_g) / (np.abs(ref_g) + 1e-12)
+    assert np.median(rel) < 1e-3
+    assert (np.abs(got_g - ref_g) <= 1e-2 * np.abs(ref_g).max()).mean() >= 0.99
+    assert (np.abs(r["w"].transpose(0, 2, 1) - ref["w"]) <= 1e-4).mean() >= 0.99
+
+
+def test_msg_whole_scene_harness(tmp_path, sd):
+    """The whole-scene evaluation loop with the MSG classifier under NB_attack: runs, is reproducible,
+    and sees every scene point once per vote pool."""
+    from pointsecguard_amd import harness
+    from pointsecguard_amd.attacks import torchattacks
+    from pointsecguard_amd.models import pointnet2_sem_seg_msg as msg
+    from test_gpu_harness import synth_scene
+    ds = harness.ScannetDatasetWholeScene(None, block_points=1024, scenes={"Area_5_a.npy": synth_scene(21, 4000, 1.4, 1.2)})
+    net = msg.get_model(13).cuda().eval()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    res = []
+    for rep in range(2):
+        np.random.seed(4)
+        torch.manual_seed(4)
+        res.append(harness.evaluate_whole_scene(net, ds, lambda m: torchattacks.NB_attack(m, eps=0.1, alpha=0.05, iters=2),
+                                                batch_size=4, num_votes=1, log_path=str(tmp_path / ("l%d.txt" % rep)),
+                                                log=lambda *_: None))
+    assert np.array_equal(res[0]["counters"], res[1]["counters"])
+    assert res[0]["counters"][0][0].sum() == 4000 and res[0]["counters"][1][0].sum() == 4000
+    assert (tmp_path / "l0.txt").read_text() == (tmp_path / "l1.txt").read_text()
