@@ -83,6 +83,10 @@ def main():
                     help="consecutive steps (batches of 8 rooms) fused into one device batch per launch; rooms are "
                          "independent, so results are identical and small kernels get more workgroups")
     ap.add_argument("--nu-steps", type=int, default=100, help="tarnu workload: optimiser step cap per attack")
+    ap.add_argument("--nu-concurrency", type=int, default=3,
+                    help="tarnu workload: attacks in flight, one host thread + HIP stream + model instance each (an NU "
+                         "step reads one scalar tensor back for the reference's early-exit test; a second attack fills "
+                         "the GPU while the first one's host thread waits for it)")
     ap.add_argument("--gcn-concurrency", type=int, default=3, help="resgcn workload: attacks in flight (streams)")
     ap.add_argument("--gcn-block", default="res", choices=["res", "plain", "dense"],
                     help="resgcn workload: backbone block (architecture.py:26-39 of the reference); default = BASELINE's")
@@ -445,9 +449,14 @@ def main_tarnu(args):
     from pointsecguard_amd.synthetic import make_rooms, rule_labels
     batch = 32
     sd = dict(np.load(os.path.join(ROOT, "tests", "golden", "pn2_weights.npz")))
-    net = get_model(13)
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    net = net.cuda().eval()
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    conc = max(1, min(args.nu_concurrency, args.steps))
+    nets, streams = [], [torch.cuda.Stream() for _ in range(conc)]
+    for _ in range(conc):
+        net = get_model(13)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(net.cuda().eval())
     n_steps = args.steps + args.warmup
     rooms = [make_rooms(batch, 7000 + s, structured=True) for s in range(n_steps)]
     labels = [rule_labels(r) for r in rooms]
@@ -456,22 +465,40 @@ def main_tarnu(args):
     # early exit (`target_acc > 0.9`, a ratio the reference inflates by the batch size) fires after 1-2 steps at
     # batch 32, which would time the plan build instead of the optimiser steps
     src_cls, target = 2, None
-    opt_steps = [0]
+    opt_steps, lock = [0], threading.Lock()
+
+    def count(**kw):
+        with lock:
+            opt_steps[0] += 1
 
     def attack(i):
+        slot = i % conc
         mask = labels[i][0] == src_cls                          # the harness masks by the first room's labels (mask[0])
-        atk = torchattacks.tar_NU_attack(net, c=1, kappa=0, steps=args.nu_steps, lr=0.01, target=target, mask=mask)
-        return nu_mod.nu_attack(atk, d_images[i], labels[i].astype(np.float64), mask, target, 5, targeted_variant=True,
-                                trace=lambda **kw: opt_steps.__setitem__(0, opt_steps[0] + 1))
+        with torch.cuda.stream(streams[slot]):
+            atk = torchattacks.tar_NU_attack(nets[slot], c=1, kappa=0, steps=args.nu_steps, lr=0.01, target=target, mask=mask)
+            out = nu_mod.nu_attack(atk, d_images[i], labels[i].astype(np.float64), mask, target, 5, targeted_variant=True,
+                                   trace=count)
+            streams[slot].synchronize()
+        return out
+
+    def run(lo, hi):
+        # slot = i % conc: attacks of one slot run in order on that slot's thread, so a model instance is never shared
+        def worker(slot):
+            for i in range(lo + ((slot - lo) % conc), hi, conc):
+                attack(i)
+        if conc == 1:
+            worker(lo % conc)
+            return
+        with ThreadPoolExecutor(max_workers=conc) as pool:
+            list(pool.map(worker, range(conc)))
 
     torch.manual_seed(0)
-    for i in range(args.warmup):
-        attack(i)
+    torch.cuda.synchronize()
+    run(0, args.warmup)
     torch.cuda.synchronize()
     opt_steps[0] = 0
     t0 = time.perf_counter()
-    for i in range(args.warmup, n_steps):
-        attack(i)
+    run(args.warmup, n_steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     result = {"metric": "attacked rooms/sec (tar_NU, 4096 pts, <= %d Adam steps)" % args.nu_steps,
@@ -480,7 +507,7 @@ def main_tarnu(args):
               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
               "config": {"workload": "tar_NU_attack (c=1, kappa=0, lr=0.01, neighbour=5) on PointNet++ SSG sem_seg, batch=32 "
                                      "rooms x 4096 pts (BASELINE configs[2]); fitted fixture weights",
-                         "optimizer_steps_cap": args.nu_steps},
+                         "optimizer_steps_cap": args.nu_steps, "attacks_in_flight": conc},
               "optimizer_steps_per_sec": opt_steps[0] / elapsed, "optimizer_steps_run": opt_steps[0],
               "room_steps_per_sec": batch * opt_steps[0] / elapsed}
     print(json.dumps(result), flush=True)
