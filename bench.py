@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--no-reference", action="store_true",
+                    help="skip the uncoalesced 8-room reference run (profiling passes: keeps every launch of a kernel "
+                         "at the same device batch, so per-launch averages mean something)")
     ap.add_argument("--workload", default="pointnet2", choices=["pointnet2", "resgcn", "tarnu", "pointnet2_msg"],
                     help="pointnet2 = BASELINE configs[1] (headline metric); resgcn = configs[3] (secondary, ResGCN-28); "
                          "tarnu = configs[2] (secondary, targeted NU attack, batch 32); pointnet2_msg = the headline "
@@ -92,6 +95,7 @@ def main():
                     help="resgcn workload: backbone block (architecture.py:26-39 of the reference); default = BASELINE's")
     ap.add_argument("--gcn-conv", default="edge", choices=["edge", "mr"], help="resgcn workload: graph convolution")
     ap.add_argument("--gcn-blocks", type=int, default=28, help="resgcn workload: number of blocks (BASELINE: 28)")
+    ap.add_argument("--gcn-batch", type=int, default=1, help="resgcn workload: rooms per attack call (BASELINE configs[3]: 1..4)")
     ap.add_argument("--concurrency", type=int, default=3,
                     help="device batches in flight per GPU (one HIP stream + workspace each)")
     args = ap.parse_args()
@@ -214,7 +218,7 @@ def main():
         value = total_rooms / elapsed
         # ---- for reference: the same attack launched one 8-room step at a time (no coalescing), 2 in flight
         ref8 = None
-        if G > 1:
+        if G > 1 and not args.no_reference:
             ws8 = [runtime.PN2Workspace(BATCH, NPOINT, ITERS) for _ in range(2)]
             x8 = [d_images[n_warm][i * BATCH:(i + 1) * BATCH].contiguous() for i in range(min(4, G))]
             l8 = [d_labels[n_warm][i * BATCH:(i + 1) * BATCH].contiguous() for i in range(min(4, G))]
@@ -284,12 +288,12 @@ def main():
 FP1_FWD_BYTES_PER_ROOM = 1024 * 128 * 4 + 4096 * 3 * 8 + 4096 * 13 * 4 + 4 * (4096 // 32) * 4 * 64 * 2
 
 # HIP symbols of the modules whose kernel instantiation is unique (PMC rows are keyed by symbol, not by module)
-PMC_SYMBOL = {"fp1_head_fwd": "void psg::fp_fwd_kernel<32, 4>(psg::FpFwdArgs)",
-              "fp1_head_bwd": "void psg::fp_bwd_kernel<32, 4>(psg::FpBwdArgs)",
-              "sa1_fwd": "void psg::sa_fwd_kernel<128, 4>(psg::SaFwdArgs)",
-              "sa1_bwd": "void psg::sa_bwd_kernel<128, 4>(psg::SaBwdArgs)",
-              "sa2_fwd": "void psg::sa_fwd_kernel<64, 4>(psg::SaFwdArgs)",
-              "sa2_bwd": "void psg::sa_bwd_kernel<64, 4>(psg::SaBwdArgs)"}
+PMC_SYMBOL = {"fp1_head_fwd": "void psg::fp_fwd_kernel<32, 4, false>(psg::FpFwdArgs)",
+              "fp1_head_bwd": "void psg::fp_bwd_kernel<32, 4, 1, false>(psg::FpBwdArgs)",
+              "sa1_fwd": "void psg::sa_fwd_kernel<128, 4, 32, 1>(psg::SaFwdArgs)",
+              "sa1_bwd": "void psg::sa_bwd_kernel<128, 4, 1, 32>(psg::SaBwdArgs)",
+              "sa2_fwd": "void psg::sa_fwd_kernel<64, 4, 32, 1>(psg::SaFwdArgs)",
+              "sa2_bwd": "void psg::sa_bwd_kernel<64, 4, 2, 32>(psg::SaBwdArgs)"}
 
 
 def pmc_traffic(tag, device_batch):
@@ -317,7 +321,7 @@ def main_resgcn(args):
     from pointsecguard_amd import runtime
     from pointsecguard_amd.synthetic import make_rooms, rule_labels
     from pointsecguard_amd.synthetic import gcn_state_dict
-    n_blocks, iters, batch = args.gcn_blocks, 50, 1
+    n_blocks, iters, batch = args.gcn_blocks, 50, args.gcn_batch
     default_cfg = (args.gcn_block, args.gcn_conv, n_blocks) == ("res", "edge", 28)
     sd = gcn_state_dict(7, n_blocks, args.gcn_block, args.gcn_conv)
     F = 64 * n_blocks
@@ -361,7 +365,7 @@ def main_resgcn(args):
               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
               "dtype": "f32", "data": "synthetic",
               "config": {"workload": name + " dense sem_seg NB non-targeted PGD (eps=0.3, alpha=2/255, 50 iters), kNN k=16, "
-                                     "batch=1 room x 4096 pts (%s); random-init weights" % (
+                                     "batch=%d room(s) x 4096 pts per call (%s); random-init weights" % (batch, 
                                          "BASELINE configs[3]" if default_cfg else "configuration switch of configs[3]"),
                          "attacks_in_flight": conc},
               "tflops_effective": 2 * gmac * iters * batch * args.steps / elapsed / 1e3 if default_cfg else None}
