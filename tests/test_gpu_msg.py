@@ -265,3 +265,25 @@ def test_msg_whole_scene_harness(tmp_path, sd):
     assert np.array_equal(res[0]["counters"], res[1]["counters"])
     assert res[0]["counters"][0][0].sum() == 4000 and res[0]["counters"][1][0].sum() == 4000
     assert (tmp_path / "l0.txt").read_text() == (tmp_path / "l1.txt").read_text()
+
+
+def test_msg_bit_reproducible_and_stream_safe(model, nb):
+    """No floating-point atomics on this path either: two fused attacks give bit-identical results, also when a second
+    attack runs concurrently on another stream with its own workspace."""
+    from pointsecguard_amd import runtime
+    g = nb
+    iters = 4
+    images = dev(np.ascontiguousarray(g["rooms"].transpose(0, 2, 1)))
+    labels = dev(g["labels"].astype(np.int32))
+    starts = dev(g["starts"][1:1 + iters], torch.int32)
+    ws = [runtime.PN2Workspace(2, 4096, iters, arch=runtime.ARCH_MSG) for _ in range(2)]
+    ref = ws[0].nb_attack(model, images, labels, starts, 0.05, 2 / 255, iters).clone()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs = []
+    for i in range(2):
+        with torch.cuda.stream(streams[i]):
+            outs.append(ws[i].nb_attack(model, images, labels, starts, 0.05, 2 / 255, iters))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, ref)
