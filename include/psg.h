@@ -320,6 +320,42 @@ const float *psg_gcn_feats_ptr(const psg_gcn_ws *ws);
 int psg_knn_points(psg_ctx *ctx, const float *support, const float *query, int batch, int n_support, int n_query, int k,
                    int32_t *out_idx, psg_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * RandLA-Net: inference graph, colour gradient and BIM attack for ONE cloud per
+ * workspace (ConfigS3DIS.val_batch_size = 1), 5 levels, k = 16, 13 classes.  Replaces Network.inference
+ * (RandLA-Net/RandLANet.py:150-190 with :323-410) and the BIM loop of ares/ares/attack/bim.py:66-116,190-236.
+ * PARITY UNPINNED: the reference is a TensorFlow-1 graph that cannot run in this environment; the checker is a
+ * source-reading restatement (oracle/randla_net.py).
+ * tensors: 6 HOST pointers per layer in forward order (pointsecguard_amd.synthetic.randla_layer_specs: fc0; per encoder
+ * level mlp1, LFAmlp1, LFAatt_pooling_1fc, LFAatt_pooling_1mlp, LFAmlp2, LFAatt_pooling_2fc, LFAatt_pooling_2mlp, mlp2,
+ * shortcut; decoder_0; Decoder_layer_0..4; fc1, fc2, fc): weight [cout][cin], bias or NULL, BatchNorm gamma, beta,
+ * moving mean, moving variance or NULL (eps 1e-6, folded on the host).
+ * ------------------------------------------------------------------------------------------ */
+#define PSG_RLA_NUM_LAYERS 55
+typedef struct psg_rla_model psg_rla_model;
+typedef struct psg_rla_ws psg_rla_ws;
+int psg_rla_model_create(psg_ctx *ctx, const float *const *tensors, int n_tensors, psg_rla_model **out);
+int psg_rla_model_destroy(psg_rla_model *model);
+int psg_rla_ws_create(psg_ctx *ctx, int n_points, psg_rla_ws **out);
+int psg_rla_ws_destroy(psg_rla_ws *ws);
+size_t psg_rla_ws_bytes(const psg_rla_ws *ws);
+/* xyz [n_points][3] device: builds the index pyramid of main_S3DIS.py:198-207 (psg_knn_points) and the relative
+ * position encodings.  Sub-sampling is the reference's: the first n / ratio points of each level. */
+int psg_rla_set_cloud(psg_rla_ws *ws, const float *xyz, psg_stream stream);
+/* what: 0 neighbour idx [n_l][16], 1 up-sampling idx [n_l]; device pointers into the workspace (tests) */
+const int32_t *psg_rla_index_ptr(const psg_rla_ws *ws, int what, int level);
+/* features [n_points][6] = (xyz, rgb) -> logits [n_points][13] */
+int psg_rla_forward(psg_rla_model *model, psg_rla_ws *ws, const float *features, float *logits_out, psg_stream stream);
+/* d loss / d logits -> d loss / d features [n_points][6] (through the feature path only: the relative-position branch
+ * is constant for a colour attack); consumes the resident forward */
+int psg_rla_backward(psg_rla_model *model, psg_rla_ws *ws, const float *dlogits, float *dfeatures_out, psg_stream stream);
+/* the attack's loss (bim.py:110-116) and its gradient w.r.t. the logits; loss_out (nullable) device scalar */
+int psg_rla_colper_grad(const float *logits, const int32_t *labels, int n, float *dlogits, float *loss_out, psg_stream stream);
+/* `iters` BIM updates (goal 'ut') of the colour half of `features`; l2_metric 0: l_inf, 1: l_2 (bim.py:84-98);
+ * builds the cloud's geometry itself.  adv_features_out [n_points][6]. */
+int psg_rla_bim_attack(psg_rla_model *model, psg_rla_ws *ws, const float *features, const int32_t *labels, float eps,
+                       float alpha, int iters, int l2_metric, float *adv_features_out, psg_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,17 @@ SIGNATURES = {
     "psg_gcn_edge_ptr": (vp, [vp, ci]),
     "psg_gcn_feats_ptr": (vp, [vp]),
     "psg_knn_points": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "psg_rla_model_create": (ci, [vp, ctypes.POINTER(vp), ci, ctypes.POINTER(vp)]),
+    "psg_rla_model_destroy": (ci, [vp]),
+    "psg_rla_ws_create": (ci, [vp, ci, ctypes.POINTER(vp)]),
+    "psg_rla_ws_destroy": (ci, [vp]),
+    "psg_rla_ws_bytes": (ctypes.c_size_t, [vp]),
+    "psg_rla_set_cloud": (ci, [vp, vp, vp]),
+    "psg_rla_index_ptr": (vp, [vp, ci, ci]),
+    "psg_rla_forward": (ci, [vp, vp, vp, vp, vp]),
+    "psg_rla_backward": (ci, [vp, vp, vp, vp, vp]),
+    "psg_rla_colper_grad": (ci, [vp, vp, ci, vp, vp, vp]),
+    "psg_rla_bim_attack": (ci, [vp, vp, vp, vp, cf, cf, ci, ci, vp, vp]),
     "psg_seg_stats": (ci, [vp, vp, ci, ci, vp, vp, vp]),
     "psg_vote_add": (ci, [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]),
     "psg_vote_stats": (ci, [vp, vp, ci, ci, vp, vp, vp]),

@@ -21,7 +21,7 @@
 
 namespace psg {
 
-enum GemmEpi { EPI_LINEAR = 0, EPI_RELU_AFFINE = 1, EPI_KNN_DIST = 2 };
+enum GemmEpi { EPI_LINEAR = 0, EPI_RELU_AFFINE = 1, EPI_KNN_DIST = 2, EPI_LRELU = 3 };   // LRELU: leaky_relu(0.2), sign bits to mask_out
 
 struct GemmArgs {
     const float *in;      // [rows][ld_in]
@@ -229,11 +229,16 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
                         z = pos ? z : 0.0f;
                         if (a.scale && c < a.M) z = z * a.scale[c] + a.shift[c];
                     }
+                    if (EPI == EPI_LRELU) {
+                        const bool pos = z > 0.0f;
+                        mbits |= (unsigned)pos << cl;
+                        z = pos ? z : 0.2f * z;
+                    }
                     if (!((min_bits >> cl) & 1u)) z = 0.0f;
                 }
                 vals[r] = z;
             }
-            if (EPI == EPI_RELU_AFFINE && a.mask_out) {
+            if ((EPI == EPI_RELU_AFFINE || EPI == EPI_LRELU) && a.mask_out) {
                 const unsigned other = __shfl_xor(mbits, 32);
                 if (h == 0 && row < a.rows && cbase < a.M) a.mask_out[(size_t)row * ((a.M + 31) >> 5) + (cbase >> 5)] = mbits | other;
             }

@@ -1,0 +1,788 @@
+// RandLA-Net inference graph + input (colour) gradient + BIM attack loop on gfx950.
+//
+// Restates RandLA-Net/RandLANet.py:150-190 (inference) and :323-410 (dilated_res_block, building_block,
+// relative_pos_encoding, random_sample, nearest_interpolation, gather_neighbour, att_pooling) of the reference, whose
+// 1x1 convolutions are conv + bias -> batch_normalization(eps 1e-6) -> leaky_relu(0.2) (helper_tf_util.py:115-170), and
+// the BIM update of ares/ares/attack/bim.py:66-98 with its "colper" loss (:110-116).  One cloud per workspace
+// (ConfigS3DIS.val_batch_size = 1, helper_tool.py:52), 5 levels, k = 16.
+//
+// Every 1x1 convolution is one launch of the fp32-MFMA row GEMM (psg_gemm.cuh) with the BatchNorm affine folded into
+// the weights on the host and bias + leaky_relu (+ sign bits for the backward pass) in its epilogue; the per-edge
+// attention scores are GEMMs over the [N*16, d] neighbour rows.  Around them: small HBM-bound kernels for the relative
+// position encoding, neighbour gather / concat, softmax-over-neighbours pooling and its gradient, random-sample max
+// pooling, nearest interpolation, and the transposes of the gathers (float atomics: several edges point at one vertex).
+// The xyz branch of the local feature aggregation (relative positions and their two MLPs) does not depend on colour:
+// it runs in the forward pass, but the colour attack never differentiates through it.
+#include <vector>
+
+#include "psg_common.h"
+#include "psg_gemm.cuh"
+
+using namespace psg;
+
+namespace {
+
+constexpr int RL = 5;            // encoder levels
+constexpr int RK = 16;           // neighbours
+constexpr int RNCLS = 13;
+const int kDout[RL] = {16, 64, 128, 256, 512};
+const int kRatio[RL] = {4, 4, 4, 4, 2};
+constexpr float kSlope = 0.2f;
+
+struct RLayer {
+    float *w = nullptr;    // [cout][cin]  BatchNorm scale folded in
+    float *wt = nullptr;   // [cin][cout]
+    float *b = nullptr;    // [cout] folded bias, or null
+    int cin = 0, cout = 0;
+};
+
+template <int EPI>
+int rl_gemm(const GemmArgs &a, hipStream_t st)
+{
+    dim3 grid(ceil_div(a.rows, 128), ceil_div(a.M, 128));
+    if ((size_t)grid.x * grid.y < 256) {   // few 128-wide tiles: 64 x 64 tiles, one MFMA tile per wave
+        dim3 small(ceil_div(a.rows, 64), ceil_div(a.M, 64));
+        hipLaunchKernelGGL((gemm_rows_kernel<2, 2, EPI, false, 1, 1>), small, dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((gemm_rows_kernel<2, 2, EPI, false>), grid, dim3(256), 0, st, a);
+    }
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+GemmArgs rl_args(const float *in, int ld_in, const float *w, int ld_w, float *out, int ld_out, int rows, int K, int M)
+{
+    GemmArgs a;
+    a.in = in; a.w = w; a.bias = nullptr; a.gbias = nullptr; a.scale = nullptr; a.shift = nullptr; a.sq = nullptr;
+    a.out = out; a.mask_out = nullptr; a.mask_in = nullptr;
+    a.rows = rows; a.K = K; a.M = M; a.ld_in = ld_in; a.ld_w = ld_w; a.ld_out = ld_out; a.group_rows = 1;
+    a.accumulate = 0; a.addend = nullptr; a.ld_add = 0;
+    return a;
+}
+
+// out = [leaky_relu](in . W^T + b), sign bits to `mask` ([rows][ceil(cout/32)] words) when given
+int conv_fwd(const RLayer &L, const float *in, int ld_in, float *out, int ld_out, int rows, bool act, uint32_t *mask,
+             hipStream_t st)
+{
+    GemmArgs a = rl_args(in, ld_in, L.w, L.cin, out, ld_out, rows, L.cin, L.cout);
+    a.bias = L.b;
+    a.mask_out = mask;
+    return act ? rl_gemm<EPI_LRELU>(a, st) : rl_gemm<EPI_LINEAR>(a, st);
+}
+
+// g[row][c] *= (bit ? 1 : slope): gradient through leaky_relu, in place
+__global__ void lrelu_bwd_kernel(float *__restrict__ g, int ld, const uint32_t *__restrict__ mask, int M, size_t total)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const size_t row = t / M;
+    const int c = (int)(t - row * M);
+    const bool pos = (mask[row * ((M + 31) >> 5) + (c >> 5)] >> (c & 31)) & 1u;
+    if (!pos) g[row * ld + c] *= kSlope;
+}
+
+// din (+)= dz . W   (dz already multiplied by the activation's derivative)
+int conv_bwd(const RLayer &L, const float *dz, int ld_dz, float *din, int ld_din, int rows, int accumulate, hipStream_t st)
+{
+    GemmArgs a = rl_args(dz, ld_dz, L.wt, L.cout, din, ld_din, rows, L.cout, L.cin);
+    a.accumulate = accumulate;
+    return rl_gemm<EPI_LINEAR>(a, st);
+}
+
+int lrelu_bwd(float *g, int ld, const uint32_t *mask, int rows, int M, hipStream_t st)
+{
+    const size_t total = (size_t)rows * M;
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g, ld, mask, M, total);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+// relative_pos_encoding (RandLANet.py:347-353): [dist, xyz_i - xyz_j, xyz_i, xyz_j] per edge
+__global__ void relpos_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ neigh, size_t edges, float *__restrict__ out)
+{
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= edges) return;
+    const size_t i = e / RK;
+    const int j = neigh[e];
+    const float xi = xyz[3 * i], yi = xyz[3 * i + 1], zi = xyz[3 * i + 2];
+    const float xj = xyz[3 * (size_t)j], yj = xyz[3 * (size_t)j + 1], zj = xyz[3 * (size_t)j + 2];
+    const float rx = xi - xj, ry = yi - yj, rz = zi - zj;
+    float *o = out + e * 10;
+    o[0] = sqrtf(rx * rx + ry * ry + rz * rz);
+    o[1] = rx; o[2] = ry; o[3] = rz; o[4] = xi; o[5] = yi; o[6] = zi; o[7] = xj; o[8] = yj; o[9] = zj;
+}
+
+// cat[e][0:h] = f[neigh[e]][0:h]; cat[e][h:2h] = fxyz[e][0:h]     (gather_neighbour + concat, RandLANet.py:337-339)
+__global__ void gather_concat_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh, const float *__restrict__ fxyz,
+                                     int h, size_t total, float *__restrict__ cat)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int d = 2 * h;
+    const size_t e = t / d;
+    const int c = (int)(t - e * d);
+    cat[t] = c < h ? f[(size_t)neigh[e] * h + c] : fxyz[e * h + (c - h)];
+}
+
+// att_pooling core (RandLANet.py:403-405): scores -> softmax over the 16 neighbours (kept in place of the scores),
+// agg[n][c] = sum_k cat[n][k][c] * a[n][k][c].  One thread per (point, channel).
+__global__ void att_pool_fwd_kernel(const float *__restrict__ cat, float *__restrict__ s, int d, size_t total, float *__restrict__ agg)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const size_t n = t / d;
+    const int c = (int)(t - n * d);
+    float v[RK];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < RK; ++k) { v[k] = s[(n * RK + k) * d + c]; m = fmaxf(m, v[k]); }
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < RK; ++k) { v[k] = expf(v[k] - m); sum += v[k]; }
+    const float inv = 1.0f / sum;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        const float a = v[k] * inv;
+        s[(n * RK + k) * d + c] = a;
+        acc += cat[(n * RK + k) * d + c] * a;
+    }
+    agg[t] = acc;
+}
+
+// gradient of the pooling: dcat = a * dagg (direct path); ds = a * (g - sum_j a_j g_j), g = cat * dagg (softmax path)
+__global__ void att_pool_bwd_kernel(const float *__restrict__ cat, const float *__restrict__ a, const float *__restrict__ dagg, int d,
+                                    size_t total, float *__restrict__ dcat, float *__restrict__ ds)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const size_t n = t / d;
+    const int c = (int)(t - n * d);
+    const float g0 = dagg[t];
+    float av[RK], gv[RK];
+    float dot = 0.0f;
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        av[k] = a[(n * RK + k) * d + c];
+        gv[k] = cat[(n * RK + k) * d + c] * g0;
+        dot += av[k] * gv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        dcat[(n * RK + k) * d + c] = av[k] * g0;
+        ds[(n * RK + k) * d + c] = av[k] * (gv[k] - dot);
+    }
+}
+
+// transpose of the neighbour gather: df[neigh[e]][c] += dcat[e][c] for c < h (the xyz half carries no colour gradient)
+__global__ void gather_bwd_kernel(const float *__restrict__ dcat, const int32_t *__restrict__ neigh, int h, size_t total,
+                                  float *__restrict__ df)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const size_t e = t / h;
+    const int c = (int)(t - e * h);
+    const float g = dcat[e * 2 * h + c];
+    if (g != 0.0f) atomicAdd(df + (size_t)neigh[e] * h + c, g);
+}
+
+// enc = leaky_relu(a + b), sign bits out (dilated_res_block, RandLANet.py:330)
+__global__ void add_lrelu_kernel(const float *__restrict__ a, const float *__restrict__ b, int M, size_t total, float *__restrict__ out,
+                                 uint32_t *__restrict__ mask)
+{
+    // one wave per 64 consecutive channels of a row: M is a multiple of 32
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t < total;
+    const float z = live ? a[t] + b[t] : 0.0f;
+    const bool pos = z > 0.0f;
+    if (live) out[t] = pos ? z : kSlope * z;
+    const unsigned long long bal = __ballot(pos && live);
+    const int lane = threadIdx.x & 63;
+    if (live && (lane & 31) == 0) {
+        const size_t row = t / M;
+        const int c = (int)(t - row * M);
+        mask[row * (M >> 5) + (c >> 5)] = (uint32_t)(bal >> (lane & 32));
+    }
+}
+
+// random_sample (RandLANet.py:356-371): out[n'][c] = max_k f[pool[n'][k]][c], arg = first winning k
+__global__ void pool_max_fwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ pool, int C, size_t total,
+                                    float *__restrict__ out, uint8_t *__restrict__ arg)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const size_t n = t / C;
+    const int c = (int)(t - n * C);
+    float best = -INFINITY;
+    int bk = 0;
+#pragma unroll 4
+    for (int k = 0; k < RK; ++k) {
+        const float v = f[(size_t)pool[n * RK + k] * C + c];
+        if (v > best) { best = v; bk = k; }
+    }
+    out[t] = best;
+    arg[t] = (uint8_t)bk;
+}
+
+__global__ void pool_max_bwd_kernel(const float *__restrict__ dout, const int32_t *__restrict__ pool, const uint8_t *__restrict__ arg,
+                                    int C, size_t total, float *__restrict__ df)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const size_t n = t / C;
+    const int c = (int)(t - n * C);
+    const float g = dout[t];
+    if (g != 0.0f) atomicAdd(df + (size_t)pool[n * RK + arg[t]] * C + c, g);
+}
+
+// decoder input: cat[n] = [skip[n] | coarse[up[n]]]   (nearest_interpolation + concat, RandLANet.py:172-174)
+__global__ void interp_concat_kernel(const float *__restrict__ skip, int cs, const float *__restrict__ coarse, int cc,
+                                     const int32_t *__restrict__ up, size_t total, float *__restrict__ cat)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int w = cs + cc;
+    const size_t n = t / w;
+    const int c = (int)(t - n * w);
+    cat[t] = c < cs ? skip[n * cs + c] : coarse[(size_t)up[n] * cc + (c - cs)];
+}
+
+// its transpose: dskip[n] += dcat[n][:cs] (one writer per element), dcoarse[up[n]] += dcat[n][cs:] (atomics)
+__global__ void interp_concat_bwd_kernel(const float *__restrict__ dcat, int cs, int cc, const int32_t *__restrict__ up, size_t total,
+                                         float *__restrict__ dskip, float *__restrict__ dcoarse)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int w = cs + cc;
+    const size_t n = t / w;
+    const int c = (int)(t - n * w);
+    const float g = dcat[t];
+    if (c < cs) dskip[n * cs + c] += g;
+    else if (g != 0.0f) atomicAdd(dcoarse + (size_t)up[n] * cc + (c - cs), g);
+}
+
+// "colper" loss of the BIM attack (bim.py:110-116): sum_n max(0, max_k((1 - onehot) * z)_k - z_y); gradient w.r.t. z
+__global__ void colper_grad_kernel(const float *__restrict__ z, const int32_t *__restrict__ y, int n, float *__restrict__ dz,
+                                   float *__restrict__ loss)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float l = 0.0f;
+    if (i < n) {
+        const float *zi = z + (size_t)i * RNCLS;
+        const int yi = y[i];
+        float other = 0.0f;          // the masked entry of the true class is 0 and takes part in the max
+        int oi = yi;
+        for (int k = 0; k < RNCLS; ++k)
+            if (k != yi && zi[k] > other) { other = zi[k]; oi = k; }
+        const float real = zi[yi];
+        const bool on = other - real > 0.0f;
+        l = on ? other - real : 0.0f;
+        for (int k = 0; k < RNCLS; ++k) dz[(size_t)i * RNCLS + k] = 0.0f;
+        if (on) {
+            dz[(size_t)i * RNCLS + yi] = -1.0f;
+            if (oi != yi) dz[(size_t)i * RNCLS + oi] = 1.0f;
+        }
+    }
+    if (loss) {
+        for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+        if ((threadIdx.x & 63) == 0 && l != 0.0f) atomicAdd(loss, l);
+    }
+}
+
+// BIM update of the colours (bim.py:84-98), goal 'ut' (ascent).  l_inf: clip(adv + alpha*sign(g), x-eps, x+eps);
+// l_2: x + clip_by_norm(adv - x + alpha * g/|g|, eps); then clip to [0, 1].  norms[0] = |g|^2, norms[1] = |delta|^2.
+__global__ void sq_norm_kernel(const float *__restrict__ a, int ld, int c0, size_t n, float *__restrict__ out)
+{
+    float s = 0.0f;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * 3; t += (size_t)gridDim.x * blockDim.x) {
+        const float v = a[(t / 3) * ld + c0 + (t % 3)];
+        s += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+__global__ void bim_linf_kernel(float *__restrict__ feat, const float *__restrict__ dfeat, const float *__restrict__ ori, size_t n,
+                                float alpha, float eps)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 3) return;
+    const size_t i = t / 3;
+    const int c = (int)(t % 3);
+    const float g = dfeat[i * 6 + 3 + c], x = ori[t];
+    const float sg = g > 0.0f ? 1.0f : (g < 0.0f ? -1.0f : 0.0f);
+    float v = feat[i * 6 + 3 + c] + alpha * sg;
+    v = fminf(fmaxf(v, x - eps), x + eps);
+    feat[i * 6 + 3 + c] = fminf(fmaxf(v, 0.0f), 1.0f);
+}
+
+__global__ void bim_l2_delta_kernel(const float *__restrict__ feat, const float *__restrict__ dfeat, const float *__restrict__ ori,
+                                    size_t n, float alpha, const float *__restrict__ gnorm2, float *__restrict__ delta)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 3) return;
+    const size_t i = t / 3;
+    const int c = (int)(t % 3);
+    const float gn = fmaxf(1e-12f, sqrtf(gnorm2[0]));
+    delta[t] = feat[i * 6 + 3 + c] - ori[t] + alpha * (dfeat[i * 6 + 3 + c] / gn);
+}
+
+__global__ void bim_l2_apply_kernel(float *__restrict__ feat, const float *__restrict__ ori, const float *__restrict__ delta, size_t n,
+                                    float eps, const float *__restrict__ dnorm2)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 3) return;
+    const size_t i = t / 3;
+    const int c = (int)(t % 3);
+    const float dn = sqrtf(dnorm2[0]);
+    const float scale = dn > eps ? eps / dn : 1.0f;
+    feat[i * 6 + 3 + c] = fminf(fmaxf(ori[t] + delta[t] * scale, 0.0f), 1.0f);
+}
+
+__global__ void copy_cols_kernel(const float *__restrict__ src, int ld_s, int c0, int nc, size_t rows, float *__restrict__ dst, int ld_d, int d0)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * nc) return;
+    const size_t r = t / nc;
+    const int c = (int)(t % nc);
+    dst[r * ld_d + d0 + c] = src[r * ld_s + c0 + c];
+}
+
+inline unsigned blocks_for(size_t total) { return (unsigned)((total + 255) / 256); }
+
+struct EncLayers { RLayer mlp1, lfa_mlp1, att1_fc, att1_mlp, lfa_mlp2, att2_fc, att2_mlp, mlp2, shortcut; };
+
+}  // namespace
+
+struct psg_rla_model {
+    psg_ctx *ctx;
+    RLayer fc0, decoder0, dec[RL], fc1, fc2, fc;
+    EncLayers enc[RL];
+    std::vector<void *> allocs;
+};
+
+struct LevelBuf {
+    int n = 0, n_sub = 0, d = 0, h = 0, d_in = 0;
+    const float *xyz = nullptr;
+    int32_t *neigh = nullptr, *up = nullptr;   // [n][16], [n][1]; pool = the first n_sub rows of neigh
+    float *relpos, *fxyz1, *fxyz2;             // [n*16][10], [n*16][h] x2
+    float *fpc, *cat1, *a1, *agg1, *fagg1, *cat2, *a2, *agg2, *fagg2, *m2, *sc, *enc, *samp;
+    uint32_t *m_fpc, *m_fagg1, *m_fagg2, *m_enc;
+    uint8_t *arg;
+    float *d_enc, *d_samp;                     // gradients w.r.t. enc [n][2d] and samp [n_sub][2d]
+    float *d_fpc, *d_fagg1;                    // [n][h]
+};
+
+struct psg_rla_ws {
+    psg_ctx *ctx;
+    int N = 0;
+    void *arena = nullptr;
+    size_t bytes = 0;
+    float *xyz_all;                 // the five levels' points are prefixes of the cloud (first N / ratio points)
+    LevelBuf lv[RL];
+    float *f0; uint32_t *m_f0;      // fc0 output [N][8]
+    float *dec0; uint32_t *m_dec0;  // decoder_0 output [n5][1024]
+    float *dec_cat[RL], *dec_out[RL]; uint32_t *m_dec[RL];
+    float *fc1o, *fc2o; uint32_t *m_fc1, *m_fc2;
+    float *logits, *dlogits;
+    float *scratch_a, *scratch_b;   // [max edges * d] gradient scratch (dcat / ds), also decoder d_cat
+    float *d_f0, *d_dec0, *d_dec_out[RL], *d_fc1o, *d_fc2o;
+    float *feat, *dfeat, *ori, *delta, *norms;   // attack state: [N][6], [N][6], [N][3], [N][3], [4]
+    int32_t *labels;
+    bool cloud_set = false, have_fwd = false;
+};
+
+namespace {
+
+template <typename T> T *upload(psg_rla_model *m, const std::vector<T> &h)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, h.size() * sizeof(T)) != hipSuccess) return nullptr;
+    (void)hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    m->allocs.push_back(p);
+    return (T *)p;
+}
+
+// tensors[6 * i .. 6 * i + 5] = weight [cout][cin], bias or null, bn gamma, beta, mean, var or null
+RLayer make_layer(psg_rla_model *m, const float *const *t, int cin, int cout)
+{
+    std::vector<float> w((size_t)cout * cin), wt((size_t)cin * cout), b(cout, 0.0f);
+    for (int o = 0; o < cout; ++o) {
+        double s = 1.0, sh = 0.0;
+        if (t[2]) { s = (double)t[2][o] / sqrt((double)t[5][o] + 1e-6); sh = (double)t[3][o] - (double)t[4][o] * s; }
+        for (int k = 0; k < cin; ++k) {
+            const float v = (float)((double)t[0][(size_t)o * cin + k] * s);
+            w[(size_t)o * cin + k] = v;
+            wt[(size_t)k * cout + o] = v;
+        }
+        b[o] = (float)((t[1] ? (double)t[1][o] : 0.0) * s + sh);
+    }
+    RLayer L;
+    L.cin = cin; L.cout = cout;
+    L.w = upload(m, w); L.wt = upload(m, wt);
+    L.b = (t[1] || t[2]) ? upload(m, b) : nullptr;
+    return L;
+}
+
+}  // namespace
+
+extern "C" int psg_rla_model_create(psg_ctx *ctx, const float *const *tensors, int n_tensors, psg_rla_model **out)
+{
+    PSG_REQUIRE(ctx && tensors && out, "psg_rla_model_create: null argument");
+    PSG_REQUIRE(n_tensors == 6 * PSG_RLA_NUM_LAYERS, "psg_rla_model_create: expected %d tensors (6 per layer), got %d",
+                6 * PSG_RLA_NUM_LAYERS, n_tensors);
+    PSG_CHECK_HIP(hipSetDevice(ctx->device));
+    auto *m = new psg_rla_model();
+    m->ctx = ctx;
+    for (int l = 0; l < PSG_RLA_NUM_LAYERS; ++l)
+        if (!tensors[6 * l]) { delete m; set_error("psg_rla_model_create: weight of layer %d is null", l); return PSG_ERR_ARG; }
+    int li = 0;
+    auto next = [&](int cin, int cout) {
+        RLayer L = make_layer(m, tensors + 6 * li, cin, cout);
+        ++li;
+        return L;
+    };
+    m->fc0 = next(6, 8);
+    int d_in = 8;
+    for (int i = 0; i < RL; ++i) {
+        const int d = kDout[i], h = d / 2;
+        EncLayers &E = m->enc[i];
+        E.mlp1 = next(d_in, h); E.lfa_mlp1 = next(10, h); E.att1_fc = next(d, d); E.att1_mlp = next(d, h);
+        E.lfa_mlp2 = next(h, h); E.att2_fc = next(d, d); E.att2_mlp = next(d, d); E.mlp2 = next(d, 2 * d);
+        E.shortcut = next(d_in, 2 * d);
+        d_in = 2 * d;
+    }
+    m->decoder0 = next(d_in, d_in);
+    const int enc_c[RL + 1] = {2 * kDout[0], 2 * kDout[0], 2 * kDout[1], 2 * kDout[2], 2 * kDout[3], 2 * kDout[4]};
+    int feat = d_in;
+    for (int j = 0; j < RL; ++j) {
+        const int skip = enc_c[RL - 1 - j];
+        m->dec[j] = next(skip + feat, skip);
+        feat = skip;
+    }
+    m->fc1 = next(feat, 64); m->fc2 = next(64, 32); m->fc = next(32, RNCLS);
+    for (void *p : m->allocs)
+        if (!p) { set_error("psg_rla_model_create: device allocation failed"); return PSG_ERR_HIP; }
+    *out = m;
+    return PSG_OK;
+}
+
+extern "C" int psg_rla_model_destroy(psg_rla_model *m)
+{
+    if (!m) return PSG_OK;
+    for (void *p : m->allocs) (void)hipFree(p);
+    delete m;
+    return PSG_OK;
+}
+
+extern "C" int psg_rla_ws_create(psg_ctx *ctx, int n_points, psg_rla_ws **out)
+{
+    PSG_REQUIRE(ctx && out, "psg_rla_ws_create: null argument");
+    PSG_REQUIRE(n_points >= 8192 && n_points <= 65536 && n_points % 512 == 0,
+                "psg_rla_ws_create: n_points=%d must be a multiple of 512 in [8192, 65536] (five sub-samplings, >= 16 points left)", n_points);
+    PSG_CHECK_HIP(hipSetDevice(ctx->device));
+    auto *ws = new psg_rla_ws();
+    ws->ctx = ctx; ws->N = n_points;
+    for (int pass = 0; pass < 2; ++pass) {
+        size_t off = 0;
+        auto take = [&](size_t bytes) {
+            off = (off + 255) & ~(size_t)255;
+            char *p = pass ? (char *)ws->arena + off : nullptr;
+            off += bytes;
+            return (void *)p;
+        };
+        const size_t N = n_points;
+        ws->xyz_all = (float *)take(N * 3 * 4);
+        int n = n_points, d_in = 8;
+        size_t max_edge = 0;
+        for (int i = 0; i < RL; ++i) {
+            LevelBuf &L = ws->lv[i];
+            L.n = n; L.n_sub = n / kRatio[i]; L.d = kDout[i]; L.h = L.d / 2; L.d_in = d_in;
+            L.xyz = ws->xyz_all;
+            const size_t E = (size_t)n * RK, d = L.d, h = L.h;
+            max_edge = std::max(max_edge, E * d);
+            L.neigh = (int32_t *)take(E * 4); L.up = (int32_t *)take((size_t)n * 4);
+            L.relpos = (float *)take(E * 10 * 4); L.fxyz1 = (float *)take(E * h * 4); L.fxyz2 = (float *)take(E * h * 4);
+            L.fpc = (float *)take((size_t)n * h * 4); L.cat1 = (float *)take(E * d * 4); L.a1 = (float *)take(E * d * 4);
+            L.agg1 = (float *)take((size_t)n * d * 4); L.fagg1 = (float *)take((size_t)n * h * 4);
+            L.cat2 = (float *)take(E * d * 4); L.a2 = (float *)take(E * d * 4); L.agg2 = (float *)take((size_t)n * d * 4);
+            L.fagg2 = (float *)take((size_t)n * d * 4); L.m2 = (float *)take((size_t)n * 2 * d * 4);
+            L.sc = (float *)take((size_t)n * 2 * d * 4); L.enc = (float *)take((size_t)n * 2 * d * 4);
+            L.samp = (float *)take((size_t)L.n_sub * 2 * d * 4);
+            L.m_fpc = (uint32_t *)take((size_t)n * ceil_div((int)h, 32) * 4); L.m_fagg1 = (uint32_t *)take((size_t)n * ceil_div((int)h, 32) * 4);
+            L.m_fagg2 = (uint32_t *)take((size_t)n * ceil_div((int)d, 32) * 4); L.m_enc = (uint32_t *)take((size_t)n * (2 * d / 32) * 4);
+            L.arg = (uint8_t *)take((size_t)L.n_sub * 2 * d);
+            L.d_enc = (float *)take((size_t)n * 2 * d * 4); L.d_samp = (float *)take((size_t)L.n_sub * 2 * d * 4);
+            L.d_fpc = (float *)take((size_t)n * h * 4); L.d_fagg1 = (float *)take((size_t)n * h * 4);
+            n = L.n_sub; d_in = 2 * L.d;
+        }
+        const int n5 = ws->lv[RL - 1].n_sub;
+        ws->f0 = (float *)take(N * 8 * 4); ws->m_f0 = (uint32_t *)take(N * 4);
+        ws->dec0 = (float *)take((size_t)n5 * 1024 * 4); ws->m_dec0 = (uint32_t *)take((size_t)n5 * 32 * 4);
+        int feat = 1024;
+        for (int j = 0; j < RL; ++j) {
+            const LevelBuf &L = ws->lv[RL - 1 - j];        // decoder layer j produces features at level RL-1-j's points
+            const int skip = j == RL - 1 ? 2 * kDout[0] : 2 * kDout[RL - 2 - j];
+            ws->dec_cat[j] = (float *)take((size_t)L.n * (skip + feat) * 4);
+            ws->dec_out[j] = (float *)take((size_t)L.n * skip * 4);
+            ws->m_dec[j] = (uint32_t *)take((size_t)L.n * ceil_div(skip, 32) * 4);
+            ws->d_dec_out[j] = (float *)take((size_t)L.n * skip * 4);
+            max_edge = std::max(max_edge, (size_t)L.n * (skip + feat));
+            feat = skip;
+        }
+        ws->fc1o = (float *)take(N * 64 * 4); ws->fc2o = (float *)take(N * 32 * 4);
+        ws->m_fc1 = (uint32_t *)take(N * 2 * 4); ws->m_fc2 = (uint32_t *)take(N * 4);
+        ws->logits = (float *)take(N * RNCLS * 4); ws->dlogits = (float *)take(N * RNCLS * 4);
+        ws->scratch_a = (float *)take(max_edge * 4); ws->scratch_b = (float *)take(max_edge * 4);
+        ws->d_f0 = (float *)take(N * 8 * 4); ws->d_dec0 = (float *)take((size_t)n5 * 1024 * 4);
+        ws->d_fc1o = (float *)take(N * 64 * 4); ws->d_fc2o = (float *)take(N * 32 * 4);
+        ws->feat = (float *)take(N * 6 * 4); ws->dfeat = (float *)take(N * 6 * 4); ws->ori = (float *)take(N * 3 * 4);
+        ws->delta = (float *)take(N * 3 * 4); ws->norms = (float *)take(4 * 4); ws->labels = (int32_t *)take(N * 4);
+        if (!pass) {
+            ws->bytes = (off + 255) & ~(size_t)255;
+            hipError_t e = hipMalloc(&ws->arena, ws->bytes);
+            if (e != hipSuccess) {
+                set_error("psg_rla_ws_create: hipMalloc(%zu) failed: %s", ws->bytes, hipGetErrorString(e));
+                delete ws;
+                return PSG_ERR_HIP;
+            }
+        }
+    }
+    *out = ws;
+    return PSG_OK;
+}
+
+extern "C" int psg_rla_ws_destroy(psg_rla_ws *ws)
+{
+    if (!ws) return PSG_OK;
+    if (ws->arena) (void)hipFree(ws->arena);
+    delete ws;
+    return PSG_OK;
+}
+
+extern "C" size_t psg_rla_ws_bytes(const psg_rla_ws *ws) { return ws ? ws->bytes : 0; }
+
+// The index pyramid of the reference's tf_map (main_S3DIS.py:198-207) and the relative position encodings, from the
+// cloud in ws->xyz_all.
+static int build_pyramid(psg_rla_ws *ws, psg_stream stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    for (int i = 0; i < RL; ++i) {
+        LevelBuf &L = ws->lv[i];
+        if ((rc = psg_knn_points(ws->ctx, L.xyz, L.xyz, 1, L.n, L.n, RK, L.neigh, stream))) return rc;
+        if ((rc = psg_knn_points(ws->ctx, L.xyz, L.xyz, 1, L.n_sub, L.n, 1, L.up, stream))) return rc;   // sub_points = first n_sub points
+        const size_t E = (size_t)L.n * RK;
+        hipLaunchKernelGGL(relpos_kernel, dim3(blocks_for(E)), dim3(256), 0, st, L.xyz, L.neigh, E, L.relpos);
+        PSG_LAUNCH_CHECK();
+    }
+    ws->cloud_set = true;
+    ws->have_fwd = false;
+    return PSG_OK;
+}
+
+extern "C" int psg_rla_set_cloud(psg_rla_ws *ws, const float *xyz, psg_stream stream)
+{
+    PSG_REQUIRE(ws && xyz, "psg_rla_set_cloud: null argument");
+    PSG_CHECK_HIP(hipMemcpyAsync(ws->xyz_all, xyz, (size_t)ws->N * 3 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return build_pyramid(ws, stream);
+}
+
+extern "C" const int32_t *psg_rla_index_ptr(const psg_rla_ws *ws, int what, int level)
+{
+    if (!ws || level < 0 || level >= RL) return nullptr;
+    return what == 0 ? ws->lv[level].neigh : (what == 1 ? ws->lv[level].up : nullptr);
+}
+
+extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *features, float *logits_out, psg_stream stream)
+{
+    PSG_REQUIRE(m && ws && features && logits_out, "psg_rla_forward: null argument");
+    if (!ws->cloud_set) { set_error("psg_rla_forward: psg_rla_set_cloud has not been called"); return PSG_ERR_STATE; }
+    hipStream_t st = (hipStream_t)stream;
+    const int N = ws->N;
+    int rc;
+    if ((rc = conv_fwd(m->fc0, features, 6, ws->f0, 8, N, true, ws->m_f0, st))) return rc;
+    const float *fin = ws->f0;
+    for (int i = 0; i < RL; ++i) {
+        LevelBuf &L = ws->lv[i];
+        const EncLayers &E = m->enc[i];
+        const int n = L.n, d = L.d, h = L.h;
+        const size_t ne = (size_t)n * RK;
+        if ((rc = conv_fwd(E.mlp1, fin, L.d_in, L.fpc, h, n, true, L.m_fpc, st))) return rc;
+        if ((rc = conv_fwd(E.lfa_mlp1, L.relpos, 10, L.fxyz1, h, (int)ne, true, nullptr, st))) return rc;
+        hipLaunchKernelGGL(gather_concat_kernel, dim3(blocks_for(ne * d)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, h, ne * d, L.cat1);
+        PSG_LAUNCH_CHECK();
+        if ((rc = conv_fwd(E.att1_fc, L.cat1, d, L.a1, d, (int)ne, false, nullptr, st))) return rc;
+        hipLaunchKernelGGL(att_pool_fwd_kernel, dim3(blocks_for((size_t)n * d)), dim3(256), 0, st, L.cat1, L.a1, d, (size_t)n * d, L.agg1);
+        PSG_LAUNCH_CHECK();
+        if ((rc = conv_fwd(E.att1_mlp, L.agg1, d, L.fagg1, h, n, true, L.m_fagg1, st))) return rc;
+        if ((rc = conv_fwd(E.lfa_mlp2, L.fxyz1, h, L.fxyz2, h, (int)ne, true, nullptr, st))) return rc;
+        hipLaunchKernelGGL(gather_concat_kernel, dim3(blocks_for(ne * d)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, h, ne * d, L.cat2);
+        PSG_LAUNCH_CHECK();
+        if ((rc = conv_fwd(E.att2_fc, L.cat2, d, L.a2, d, (int)ne, false, nullptr, st))) return rc;
+        hipLaunchKernelGGL(att_pool_fwd_kernel, dim3(blocks_for((size_t)n * d)), dim3(256), 0, st, L.cat2, L.a2, d, (size_t)n * d, L.agg2);
+        PSG_LAUNCH_CHECK();
+        if ((rc = conv_fwd(E.att2_mlp, L.agg2, d, L.fagg2, d, n, true, L.m_fagg2, st))) return rc;
+        if ((rc = conv_fwd(E.mlp2, L.fagg2, d, L.m2, 2 * d, n, false, nullptr, st))) return rc;
+        if ((rc = conv_fwd(E.shortcut, fin, L.d_in, L.sc, 2 * d, n, false, nullptr, st))) return rc;
+        hipLaunchKernelGGL(add_lrelu_kernel, dim3(blocks_for((size_t)n * 2 * d)), dim3(256), 0, st, L.m2, L.sc, 2 * d, (size_t)n * 2 * d,
+                           L.enc, L.m_enc);
+        PSG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(blocks_for((size_t)L.n_sub * 2 * d)), dim3(256), 0, st, L.enc, L.neigh, 2 * d,
+                           (size_t)L.n_sub * 2 * d, L.samp, L.arg);
+        PSG_LAUNCH_CHECK();
+        fin = L.samp;
+    }
+    const int n5 = ws->lv[RL - 1].n_sub;
+    if ((rc = conv_fwd(m->decoder0, ws->lv[RL - 1].samp, 1024, ws->dec0, 1024, n5, true, ws->m_dec0, st))) return rc;
+    const float *feat = ws->dec0;
+    int cfeat = 1024;
+    for (int j = 0; j < RL; ++j) {
+        const LevelBuf &L = ws->lv[RL - 1 - j];
+        const float *skip = j == RL - 1 ? ws->lv[0].enc : ws->lv[RL - 2 - j].samp;
+        const int cs = m->dec[j].cout;
+        hipLaunchKernelGGL(interp_concat_kernel, dim3(blocks_for((size_t)L.n * (cs + cfeat))), dim3(256), 0, st, skip, cs, feat, cfeat,
+                           L.up, (size_t)L.n * (cs + cfeat), ws->dec_cat[j]);
+        PSG_LAUNCH_CHECK();
+        if ((rc = conv_fwd(m->dec[j], ws->dec_cat[j], cs + cfeat, ws->dec_out[j], cs, L.n, true, ws->m_dec[j], st))) return rc;
+        feat = ws->dec_out[j];
+        cfeat = cs;
+    }
+    if ((rc = conv_fwd(m->fc1, feat, cfeat, ws->fc1o, 64, N, true, ws->m_fc1, st))) return rc;
+    if ((rc = conv_fwd(m->fc2, ws->fc1o, 64, ws->fc2o, 32, N, true, ws->m_fc2, st))) return rc;
+    if ((rc = conv_fwd(m->fc, ws->fc2o, 32, ws->logits, RNCLS, N, false, nullptr, st))) return rc;
+    if (logits_out != ws->logits)
+        PSG_CHECK_HIP(hipMemcpyAsync(logits_out, ws->logits, (size_t)N * RNCLS * 4, hipMemcpyDeviceToDevice, st));
+    ws->have_fwd = true;
+    return PSG_OK;
+}
+
+extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *dlogits, float *dfeatures_out, psg_stream stream)
+{
+    PSG_REQUIRE(m && ws && dlogits && dfeatures_out, "psg_rla_backward: null argument");
+    if (!ws->have_fwd) { set_error("psg_rla_backward: no forward is resident in the workspace"); return PSG_ERR_STATE; }
+    hipStream_t st = (hipStream_t)stream;
+    const int N = ws->N;
+    int rc;
+    // head
+    if ((rc = conv_bwd(m->fc, dlogits, RNCLS, ws->d_fc2o, 32, N, 0, st))) return rc;
+    if ((rc = lrelu_bwd(ws->d_fc2o, 32, ws->m_fc2, N, 32, st))) return rc;
+    if ((rc = conv_bwd(m->fc2, ws->d_fc2o, 32, ws->d_fc1o, 64, N, 0, st))) return rc;
+    if ((rc = lrelu_bwd(ws->d_fc1o, 64, ws->m_fc1, N, 64, st))) return rc;
+    if ((rc = conv_bwd(m->fc1, ws->d_fc1o, 64, ws->d_dec_out[RL - 1], m->fc1.cin, N, 0, st))) return rc;
+    // gradient accumulators of the encoder outputs: every one starts at zero and collects its consumers
+    for (int i = 0; i < RL; ++i) {
+        LevelBuf &L = ws->lv[i];
+        PSG_CHECK_HIP(hipMemsetAsync(L.d_enc, 0, (size_t)L.n * 2 * L.d * 4, st));
+        PSG_CHECK_HIP(hipMemsetAsync(L.d_samp, 0, (size_t)L.n_sub * 2 * L.d * 4, st));
+    }
+    const int n5 = ws->lv[RL - 1].n_sub;
+    PSG_CHECK_HIP(hipMemsetAsync(ws->d_dec0, 0, (size_t)n5 * 1024 * 4, st));
+    // decoder, last layer first
+    for (int j = RL - 1; j >= 0; --j) {
+        const LevelBuf &L = ws->lv[RL - 1 - j];
+        const int cs = m->dec[j].cout, cfeat = m->dec[j].cin - cs;
+        float *dout = ws->d_dec_out[j];
+        if ((rc = lrelu_bwd(dout, cs, ws->m_dec[j], L.n, cs, st))) return rc;
+        if ((rc = conv_bwd(m->dec[j], dout, cs, ws->scratch_a, cs + cfeat, L.n, 0, st))) return rc;
+        float *dskip = j == RL - 1 ? ws->lv[0].d_enc : ws->lv[RL - 2 - j].d_samp;
+        float *dcoarse = j == 0 ? ws->d_dec0 : ws->d_dec_out[j - 1];
+        if (j > 0) PSG_CHECK_HIP(hipMemsetAsync(dcoarse, 0, (size_t)ws->lv[RL - j].n * cfeat * 4, st));
+        hipLaunchKernelGGL(interp_concat_bwd_kernel, dim3(blocks_for((size_t)L.n * (cs + cfeat))), dim3(256), 0, st, ws->scratch_a, cs,
+                           cfeat, L.up, (size_t)L.n * (cs + cfeat), dskip, dcoarse);
+        PSG_LAUNCH_CHECK();
+    }
+    if ((rc = lrelu_bwd(ws->d_dec0, 1024, ws->m_dec0, n5, 1024, st))) return rc;
+    if ((rc = conv_bwd(m->decoder0, ws->d_dec0, 1024, ws->lv[RL - 1].d_samp, 1024, n5, 1, st))) return rc;
+    // encoder, deepest level first
+    for (int i = RL - 1; i >= 0; --i) {
+        LevelBuf &L = ws->lv[i];
+        const EncLayers &E = m->enc[i];
+        const int n = L.n, d = L.d, h = L.h;
+        const size_t ne = (size_t)n * RK;
+        float *din = i == 0 ? ws->d_f0 : ws->lv[i - 1].d_samp;    // gradient of this level's input features
+        hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(blocks_for((size_t)L.n_sub * 2 * d)), dim3(256), 0, st, L.d_samp, L.neigh, L.arg,
+                           2 * d, (size_t)L.n_sub * 2 * d, L.d_enc);
+        PSG_LAUNCH_CHECK();
+        if ((rc = lrelu_bwd(L.d_enc, 2 * d, L.m_enc, n, 2 * d, st))) return rc;
+        if ((rc = conv_bwd(E.shortcut, L.d_enc, 2 * d, din, L.d_in, n, i == 0 ? 0 : 1, st))) return rc;
+        float *g_fagg2 = L.agg2;   // forward buffers that are dead by now serve as gradient buffers of the same shape
+        if ((rc = conv_bwd(E.mlp2, L.d_enc, 2 * d, g_fagg2, d, n, 0, st))) return rc;
+        if ((rc = lrelu_bwd(g_fagg2, d, L.m_fagg2, n, d, st))) return rc;
+        float *g_agg2 = L.fagg2;
+        if ((rc = conv_bwd(E.att2_mlp, g_fagg2, d, g_agg2, d, n, 0, st))) return rc;
+        hipLaunchKernelGGL(att_pool_bwd_kernel, dim3(blocks_for((size_t)n * d)), dim3(256), 0, st, L.cat2, L.a2, g_agg2, d, (size_t)n * d,
+                           ws->scratch_a, ws->scratch_b);
+        PSG_LAUNCH_CHECK();
+        if ((rc = conv_bwd(E.att2_fc, ws->scratch_b, d, ws->scratch_a, d, (int)ne, 1, st))) return rc;
+        PSG_CHECK_HIP(hipMemsetAsync(L.d_fagg1, 0, (size_t)n * h * 4, st));
+        hipLaunchKernelGGL(gather_bwd_kernel, dim3(blocks_for(ne * h)), dim3(256), 0, st, ws->scratch_a, L.neigh, h, ne * h, L.d_fagg1);
+        PSG_LAUNCH_CHECK();
+        if ((rc = lrelu_bwd(L.d_fagg1, h, L.m_fagg1, n, h, st))) return rc;
+        float *g_agg1 = L.agg1;
+        if ((rc = conv_bwd(E.att1_mlp, L.d_fagg1, h, g_agg1, d, n, 0, st))) return rc;
+        hipLaunchKernelGGL(att_pool_bwd_kernel, dim3(blocks_for((size_t)n * d)), dim3(256), 0, st, L.cat1, L.a1, g_agg1, d, (size_t)n * d,
+                           ws->scratch_a, ws->scratch_b);
+        PSG_LAUNCH_CHECK();
+        if ((rc = conv_bwd(E.att1_fc, ws->scratch_b, d, ws->scratch_a, d, (int)ne, 1, st))) return rc;
+        PSG_CHECK_HIP(hipMemsetAsync(L.d_fpc, 0, (size_t)n * h * 4, st));
+        hipLaunchKernelGGL(gather_bwd_kernel, dim3(blocks_for(ne * h)), dim3(256), 0, st, ws->scratch_a, L.neigh, h, ne * h, L.d_fpc);
+        PSG_LAUNCH_CHECK();
+        if ((rc = lrelu_bwd(L.d_fpc, h, L.m_fpc, n, h, st))) return rc;
+        if ((rc = conv_bwd(E.mlp1, L.d_fpc, h, din, L.d_in, n, 1, st))) return rc;
+    }
+    if ((rc = lrelu_bwd(ws->d_f0, 8, ws->m_f0, N, 8, st))) return rc;
+    if ((rc = conv_bwd(m->fc0, ws->d_f0, 8, dfeatures_out, 6, N, 0, st))) return rc;
+    ws->have_fwd = false;   // agg / fagg buffers were reused as gradient scratch
+    return PSG_OK;
+}
+
+extern "C" int psg_rla_colper_grad(const float *logits, const int32_t *labels, int n, float *dlogits, float *loss_out, psg_stream stream)
+{
+    PSG_REQUIRE(logits && labels && dlogits && n > 0, "psg_rla_colper_grad: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (loss_out) PSG_CHECK_HIP(hipMemsetAsync(loss_out, 0, 4, st));
+    hipLaunchKernelGGL(colper_grad_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, logits, labels, n, dlogits, loss_out);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+// BIM (ares/ares/attack/bim.py:190-236): `iters` gradient steps on the colour half of the features of one cloud.
+extern "C" int psg_rla_bim_attack(psg_rla_model *m, psg_rla_ws *ws, const float *features, const int32_t *labels, float eps,
+                                  float alpha, int iters, int l2_metric, float *adv_features_out, psg_stream stream)
+{
+    PSG_REQUIRE(m && ws && features && labels && adv_features_out && iters > 0, "psg_rla_bim_attack: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t N = ws->N;
+    int rc;
+    PSG_CHECK_HIP(hipMemcpyAsync(ws->feat, features, N * 6 * 4, hipMemcpyDeviceToDevice, st));
+    PSG_CHECK_HIP(hipMemcpyAsync(ws->labels, labels, N * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, features, 6, 3, 3, N, ws->ori, 3, 0);
+    PSG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, features, 6, 0, 3, N, ws->xyz_all, 3, 0);
+    PSG_LAUNCH_CHECK();
+    if ((rc = build_pyramid(ws, stream))) return rc;        // geometry: once per cloud, the attack moves colours only
+    for (int it = 0; it < iters; ++it) {
+        if ((rc = psg_rla_forward(m, ws, ws->feat, ws->logits, stream))) return rc;
+        if ((rc = psg_rla_colper_grad(ws->logits, ws->labels, (int)N, ws->dlogits, nullptr, stream))) return rc;
+        if ((rc = psg_rla_backward(m, ws, ws->dlogits, ws->dfeat, stream))) return rc;
+        if (!l2_metric) {
+            hipLaunchKernelGGL(bim_linf_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, ws->feat, ws->dfeat, ws->ori, N, alpha, eps);
+            PSG_LAUNCH_CHECK();
+        } else {
+            PSG_CHECK_HIP(hipMemsetAsync(ws->norms, 0, 16, st));
+            hipLaunchKernelGGL(sq_norm_kernel, dim3(256), dim3(256), 0, st, ws->dfeat, 6, 3, N, ws->norms);
+            PSG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(bim_l2_delta_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, ws->feat, ws->dfeat, ws->ori, N, alpha,
+                               ws->norms, ws->delta);
+            PSG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(sq_norm_kernel, dim3(256), dim3(256), 0, st, ws->delta, 3, 0, N, ws->norms + 1);
+            PSG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(bim_l2_apply_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, ws->feat, ws->ori, ws->delta, N, eps,
+                               ws->norms + 1);
+            PSG_LAUNCH_CHECK();
+        }
+    }
+    PSG_CHECK_HIP(hipMemcpyAsync(adv_features_out, ws->feat, N * 6 * 4, hipMemcpyDeviceToDevice, st));
+    return PSG_OK;
+}

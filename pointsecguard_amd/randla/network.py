@@ -1,0 +1,115 @@
+"""RandLA-Net on the MI355X: thin object layer over the psg_rla_* C ABI (csrc/psg_randla_net.hip).
+
+Restates Network.inference of RandLA-Net/RandLANet.py:150-190 (eval mode) and the BIM colour attack of
+ares/ares/attack/bim.py of the reference; one cloud per workspace like the reference's validation batches.  PARITY
+UNPINNED: the reference's TensorFlow-1 graph cannot run here (see oracle/randla_net.py).  `params` is a mapping with
+the keys of pointsecguard_amd.synthetic.randla_layer_specs: name.weight [cout, cin], name.bias, name.bn.{gamma, beta,
+mean, var} (a TF checkpoint maps onto it by transposing each [1, 1, cin, cout] kernel).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from pointsecguard_amd import _lib, runtime
+from pointsecguard_amd.synthetic import randla_layer_specs
+
+NUM_CLASSES = 13
+
+
+def tensor_list(params):
+    out = []
+    for name, cin, cout, bn in randla_layer_specs():
+        w = np.ascontiguousarray(params[name + ".weight"], np.float32)
+        if w.shape != (cout, cin):
+            raise ValueError("%s.weight has shape %s, expected %s" % (name, w.shape, (cout, cin)))
+        row = [w, params.get(name + ".bias")]
+        row += [params.get(name + ".bn." + k) for k in ("gamma", "beta", "mean", "var")] if bn else [None] * 4
+        out += [None if t is None else np.ascontiguousarray(t, np.float32) for t in row]
+    return out
+
+
+class RandLAModel:
+    def __init__(self, params, device=None):
+        self.ctx = runtime.context(device)
+        self._keep = tensor_list(params)
+        arr = (ctypes.c_void_p * len(self._keep))(*[None if t is None else t.ctypes.data_as(ctypes.c_void_p) for t in self._keep])
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.load().psg_rla_model_create(self.ctx, arr, len(self._keep), ctypes.byref(self.handle)),
+                   "psg_rla_model_create")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().psg_rla_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class RandLAWorkspace:
+    def __init__(self, n_points, device=None):
+        self.ctx = runtime.context(device)
+        self.n_points = n_points
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.load().psg_rla_ws_create(self.ctx, n_points, ctypes.byref(self.handle)), "psg_rla_ws_create")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().psg_rla_ws_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    @property
+    def nbytes(self):
+        return _lib.load().psg_rla_ws_bytes(self.handle)
+
+    def set_cloud(self, xyz):
+        runtime.require_cuda(xyz, "xyz", torch.float32)
+        assert tuple(xyz.shape) == (self.n_points, 3)
+        _lib.call("psg_rla_set_cloud", self.handle, runtime.ptr(xyz), runtime.stream())
+
+    def index(self, what, level):
+        n = self.n_points
+        for r in (4, 4, 4, 4, 2)[:level]:
+            n //= r
+        shape = (n, 16) if what == 0 else (n,)
+        src = _lib.load().psg_rla_index_ptr(self.handle, what, level)
+        out = torch.empty(shape, dtype=torch.int32, device=self.device)
+        runtime._hip_memcpy_d2d(out.data_ptr(), src, out.numel() * 4)
+        return out
+
+    def forward(self, model, features):
+        runtime.require_cuda(features, "features", torch.float32)
+        assert tuple(features.shape) == (self.n_points, 6)
+        logits = torch.empty(self.n_points, NUM_CLASSES, dtype=torch.float32, device=features.device)
+        _lib.call("psg_rla_forward", model.handle, self.handle, runtime.ptr(features), runtime.ptr(logits), runtime.stream())
+        return logits
+
+    def backward(self, model, dlogits):
+        runtime.require_cuda(dlogits, "dlogits", torch.float32)
+        dfeat = torch.empty(self.n_points, 6, dtype=torch.float32, device=dlogits.device)
+        _lib.call("psg_rla_backward", model.handle, self.handle, runtime.ptr(dlogits), runtime.ptr(dfeat), runtime.stream())
+        return dfeat
+
+    def bim_attack(self, model, features, labels, eps, alpha, iters, metric="l_inf"):
+        runtime.require_cuda(features, "features", torch.float32)
+        runtime.require_cuda(labels, "labels", torch.int32)
+        out = torch.empty_like(features)
+        _lib.call("psg_rla_bim_attack", model.handle, self.handle, runtime.ptr(features), runtime.ptr(labels), float(eps),
+                  float(alpha), int(iters), 1 if metric == "l_2" else 0, runtime.ptr(out), runtime.stream())
+        return out
+
+
+def colper_grad(logits, labels):
+    """The BIM attack's loss and its gradient w.r.t. the logits (device)."""
+    runtime.require_cuda(logits, "logits", torch.float32)
+    runtime.require_cuda(labels, "labels", torch.int32)
+    d = torch.empty_like(logits)
+    loss = torch.zeros(1, dtype=torch.float32, device=logits.device)
+    _lib.call("psg_rla_colper_grad", runtime.ptr(logits), runtime.ptr(labels), logits.shape[0], runtime.ptr(d), runtime.ptr(loss),
+              runtime.stream())
+    return loss, d

@@ -138,3 +138,50 @@ def gcn_state_dict(seed, n_blocks, block="res", conv="edge"):
     basic("prediction.1", 512, 256)
     basic("prediction.3", 256, NUM_CLASSES, norm=False)
     return sd
+
+
+# RandLA-Net for S3DIS (RandLA-Net/helper_tool.py:41-60 ConfigS3DIS, RandLANet.py:150-190 of the reference)
+RANDLA_D_OUT = (16, 64, 128, 256, 512)
+RANDLA_RATIOS = (4, 4, 4, 4, 2)
+
+
+def randla_layer_specs(d_out=RANDLA_D_OUT, n_classes=NUM_CLASSES):
+    """[(name, cin, cout, has_bn)] of every weight layer in forward order.  Names follow the reference's scopes
+    (RandLANet.py:150-190, 323-345, 396-410): fc0; Encoder_layer_i{mlp1, LFAmlp1, LFAatt_pooling_1fc, LFAatt_pooling_1mlp,
+    LFAmlp2, LFAatt_pooling_2fc, LFAatt_pooling_2mlp, mlp2, shortcut}; decoder_0; Decoder_layer_j; fc1, fc2, fc."""
+    specs = [("fc0", 6, 8, True)]
+    d_in = 8
+    for i, d in enumerate(d_out):
+        p = "Encoder_layer_%d" % i
+        specs += [(p + "mlp1", d_in, d // 2, True), (p + "LFAmlp1", 10, d // 2, True),
+                  (p + "LFAatt_pooling_1fc", d, d, False), (p + "LFAatt_pooling_1mlp", d, d // 2, True),
+                  (p + "LFAmlp2", d // 2, d // 2, True), (p + "LFAatt_pooling_2fc", d, d, False),
+                  (p + "LFAatt_pooling_2mlp", d, d, True), (p + "mlp2", d, 2 * d, True), (p + "shortcut", d_in, 2 * d, True)]
+        d_in = 2 * d
+    specs.append(("decoder_0", d_in, d_in, True))
+    enc_c = [2 * d_out[0]] + [2 * d for d in d_out]          # channels of f_encoder_list: enc_0, samp_0 .. samp_4
+    feat = d_in
+    for j in range(len(d_out)):
+        skip = enc_c[-j - 2]
+        specs.append(("Decoder_layer_%d" % j, skip + feat, skip, True))
+        feat = skip
+    specs += [("fc1", feat, 64, True), ("fc2", 64, 32, True), ("fc", 32, n_classes, False)]
+    return specs
+
+
+def randla_params(seed):
+    """Seeded random parameters {name.weight [cout, cin], name.bias (absent for the attention fc), name.bn.{gamma,
+    beta, mean, var}} for the network above (no checkpoint ships with the reference)."""
+    rng = np.random.RandomState(int(seed))
+    out = {}
+    for name, cin, cout, bn in randla_layer_specs():
+        out[name + ".weight"] = (rng.standard_normal((cout, cin)) * np.sqrt(1.0 / cin)).astype(np.float32)
+        if "att_pooling" in name and name.endswith("fc"):
+            continue                                          # tf.layers.dense(..., use_bias=False) (RandLANet.py:402)
+        out[name + ".bias"] = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+        if bn:
+            out[name + ".bn.gamma"] = rng.uniform(0.8, 1.2, cout).astype(np.float32)
+            out[name + ".bn.beta"] = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+            out[name + ".bn.mean"] = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+            out[name + ".bn.var"] = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    return out

@@ -1,0 +1,125 @@
+"""RandLA-Net network: the HIP path against the source-reading torch restatement
+(oracle/randla_net.py; PARITY UNPINNED: the TensorFlow-1 reference cannot run here).  Tolerances: logits 2e-4 relative to
+their magnitude, loss 1e-4 relative, colour gradient 1e-3 of its maximum on >= 99.5 % of entries (a max-pool or
+leaky-ReLU sign that flips on a last-bit difference moves single entries visibly), BIM colours after teacher-forced
+steps equal on >= 99.5 % of entries."""
+import numpy as np
+import pytest
+
+from oracle import randla, randla_net
+from pointsecguard_amd.synthetic import randla_layer_specs, randla_params
+
+N = 8192
+
+
+@pytest.fixture(scope="module")
+def cloud():
+    rng = np.random.default_rng(12)
+    xyz = (rng.random((1, N, 3), dtype=np.float32) * np.array([4, 3, 3], np.float32)).astype(np.float32)
+    rgb = rng.random((N, 3), dtype=np.float32)
+    labels = rng.integers(0, 13, N)
+    pts, neigh, pools, ups = randla.pyramid(xyz)
+    pyr = ([p[0] for p in pts], [n[0] for n in neigh], [p[0] for p in pools], [u[0] for u in ups])
+    return xyz[0], rgb, labels, pyr
+
+
+def test_layer_specs_and_oracle_shapes(cloud):
+    specs = randla_layer_specs()
+    assert len(specs) == 55 and specs[0] == ("fc0", 6, 8, True) and specs[-1] == ("fc", 32, 13, False)
+    assert [s for s in specs if s[0] == "Decoder_layer_0"][0][1:3] == (1536, 512)
+    xyz, rgb, labels, pyr = cloud
+    orc = randla_net.RandLAOracle(randla_params(3))
+    loss, logits, g = randla_net.loss_and_grad(orc, xyz, rgb, labels, pyr)
+    assert logits.shape == (N, 13) and g.shape == (N, 3) and np.isfinite(logits).all() and loss > 0
+    # finite-difference check of the restatement's gradient along a random direction, on a float64 copy of the network
+    import torch
+    o64 = randla_net.RandLAOracle(randla_params(3), dtype=torch.float64)
+    _, _, g64 = randla_net.loss_and_grad(o64, xyz, rgb, labels, pyr)
+    assert np.abs(g64 - g).max() <= 1e-3 * np.abs(g64).max()
+    rng = np.random.default_rng(0)
+    dirn = rng.standard_normal(rgb.shape)
+    h = 1e-6
+    lp, _, _ = randla_net.loss_and_grad(o64, xyz, rgb.astype(np.float64) + h * dirn, labels, pyr)
+    lm, _, _ = randla_net.loss_and_grad(o64, xyz, rgb.astype(np.float64) - h * dirn, labels, pyr)
+    fd, an = (lp - lm) / (2 * h), float((g64 * dirn).sum())
+    assert abs(fd - an) <= 1e-3 * max(abs(an), 1.0), (fd, an)
+
+
+def test_bim_step_rules():
+    xs = np.full((4, 3), 0.5, np.float32)
+    g = np.array([[1, -1, 0], [2, 2, 2], [-3, 0, 1], [0, 0, 0]], np.float32)
+    out = randla_net.bim_step(xs, xs, g, eps=0.05, alpha=0.1)
+    assert np.allclose(out, xs + 0.05 * np.sign(g))
+    out = randla_net.bim_step(xs, xs, g, eps=10.0, alpha=0.1, metric="l_2")
+    assert np.isclose(np.linalg.norm(out - xs), 0.1, rtol=1e-5)
+    out = randla_net.bim_step(xs, xs, g, eps=0.03, alpha=0.1, metric="l_2")
+    assert np.isclose(np.linalg.norm(out - xs), 0.03, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def dev(a, dt=None):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dt is not None:
+        t = t.to(dt)
+    return t.cuda().contiguous()
+
+
+@pytest.fixture(scope="module")
+def gpu(cloud):
+    from pointsecguard_amd.randla import network
+    params = randla_params(3)
+    return network.RandLAModel(params), network.RandLAWorkspace(N), randla_net.RandLAOracle(params)
+
+
+@pytest.mark.gpu
+def test_gpu_forward_backward_vs_oracle(cloud, gpu):
+    import torch
+    from pointsecguard_amd.randla import network
+    xyz, rgb, labels, pyr = cloud
+    model, ws, orc = gpu
+    ws.set_cloud(dev(xyz))
+    for lvl in range(5):
+        assert np.array_equal(ws.index(0, lvl).cpu().numpy(), pyr[1][lvl])
+        assert np.array_equal(ws.index(1, lvl).cpu().numpy(), pyr[3][lvl][:, 0])
+    feats = dev(np.concatenate([xyz, rgb], 1))
+    logits = ws.forward(model, feats)
+    loss_ref, logits_ref, g_ref = randla_net.loss_and_grad(orc, xyz, rgb, labels, pyr)
+    assert np.abs(logits.cpu().numpy() - logits_ref).max() <= 2e-4 * max(1.0, np.abs(logits_ref).max())
+    loss, dl = network.colper_grad(logits, dev(labels.astype(np.int32)))
+    assert abs(loss.item() - loss_ref) <= 1e-4 * abs(loss_ref)
+    df = ws.backward(model, dl).cpu().numpy()
+    torch.cuda.synchronize()
+    g = df[:, 3:6]
+    ok = np.abs(g - g_ref) <= 1e-3 * np.abs(g_ref).max()
+    assert ok.mean() >= 0.995, ok.mean()
+    assert np.abs(g - g_ref).max() <= 0.05 * np.abs(g_ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric,eps,alpha", [("l_inf", 0.08, 0.02), ("l_2", 3.0, 1.0)])
+def test_gpu_bim_attack_vs_oracle(cloud, gpu, metric, eps, alpha):
+    """Three BIM updates, the oracle teacher-forced with the GPU's colours after every step."""
+    import torch
+    xyz, rgb, labels, pyr = cloud
+    model, ws, orc = gpu
+    feats0 = np.concatenate([xyz, rgb], 1)
+    lab = dev(labels.astype(np.int32))
+    cur = rgb.copy()
+    for it in range(1, 4):
+        adv = ws.bim_attack(model, dev(feats0), lab, eps, alpha, it, metric=metric).cpu().numpy()
+        torch.cuda.synchronize()
+        assert np.array_equal(adv[:, :3], xyz)
+        _, _, g = randla_net.loss_and_grad(orc, xyz, cur, labels, pyr)
+        want = randla_net.bim_step(rgb, cur, g, eps, alpha, metric)
+        # l_2: the GPU re-runs the earlier steps (float atomics: rounding-level differences) and every entry is scaled by
+        # the clip-by-norm factor, so the comparison is to 1e-4 instead of 1e-5
+        same = np.abs(adv[:, 3:6] - want) <= (1e-5 if metric == "l_inf" else 1e-4)
+        assert same.mean() >= 0.995, (it, same.mean())   # (an l_2 step is proportional to the gradient VALUE: the
+        # entries whose gradient differs in a max-pool / leaky-ReLU flip differ here too)
+        cur = adv[:, 3:6].copy()
+    if metric == "l_inf":
+        assert np.abs(cur - rgb).max() <= eps + 1e-6
+    else:
+        assert np.linalg.norm((cur - rgb).astype(np.float64)) <= eps * (1 + 1e-5)
+    assert cur.min() >= 0.0 and cur.max() <= 1.0
