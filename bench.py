@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--no-reference", action="store_true",
                     help="skip the uncoalesced 8-room reference run (profiling passes: keeps every launch of a kernel "
                          "at the same device batch, so per-launch averages mean something)")
-    ap.add_argument("--workload", default="pointnet2", choices=["pointnet2", "resgcn", "tarnu", "pointnet2_msg"],
+    ap.add_argument("--workload", default="pointnet2", choices=["pointnet2", "resgcn", "tarnu", "pointnet2_msg", "randla"],
                     help="pointnet2 = BASELINE configs[1] (headline metric); resgcn = configs[3] (secondary, ResGCN-28); "
                          "tarnu = configs[2] (secondary, targeted NU attack, batch 32); pointnet2_msg = the headline "
                          "attack on the multi-scale-grouping network (SURVEY 8f rank 2, secondary)")
@@ -86,6 +86,7 @@ def main():
                     help="consecutive steps (batches of 8 rooms) fused into one device batch per launch; rooms are "
                          "independent, so results are identical and small kernels get more workgroups")
     ap.add_argument("--nu-steps", type=int, default=100, help="tarnu workload: optimiser step cap per attack")
+    ap.add_argument("--randla-iters", type=int, default=10, help="randla workload: BIM iterations per attacked cloud")
     ap.add_argument("--nu-concurrency", type=int, default=3,
                     help="tarnu workload: attacks in flight, one host thread + HIP stream + model instance each (an NU "
                          "step reads one scalar tensor back for the reference's early-exit test; a second attack fills "
@@ -106,6 +107,8 @@ def main():
         return main_tarnu(args)
     if args.workload == "pointnet2_msg":
         return main_msg(args)
+    if args.workload == "randla":
+        return main_randla(args)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -436,6 +439,70 @@ def main_msg(args):
                          "device_batch_rooms": DB, "launches_in_flight_per_gpu": conc},
               "tflops_effective": 2.0 * 2.0 * mac * ITERS * rooms_done / elapsed / 1e12,
               "gmac_per_room_forward": mac / 1e9, "kernel_profile_one_launch": prof}
+    print(json.dumps(result), flush=True)
+    return result
+
+
+def main_randla(args):
+    """BASELINE configs[4] family (secondary): BIM colour attack (l_inf, goal 'ut') on RandLA-Net, one 40 960-point cloud
+    per call (ConfigS3DIS.val_batch_size = 1), --randla-iters gradient steps per attack, geometry (5-level k-NN pyramid)
+    rebuilt per cloud; random-init weights (no checkpoint ships), a step = one attacked cloud."""
+    import torch
+    from pointsecguard_amd.randla import network
+    from pointsecguard_amd.synthetic import randla_layer_specs, randla_params
+    torch.cuda.set_device(0)
+    n_pts, iters = 40960, args.randla_iters
+    model = network.RandLAModel(randla_params(3))
+    conc = max(1, min(args.concurrency, args.steps))
+    wss = [network.RandLAWorkspace(n_pts) for _ in range(conc)]
+    streams = [torch.cuda.Stream() for _ in range(conc)]
+    n_steps = args.steps + args.warmup
+    rng = np.random.default_rng(4)
+    clouds = []
+    for _ in range(min(n_steps, 8)):
+        xyz = (rng.random((n_pts, 3), dtype=np.float32) * np.array([8, 6, 3], np.float32)).astype(np.float32)
+        feats = torch.from_numpy(np.concatenate([xyz, rng.random((n_pts, 3), dtype=np.float32)], 1)).cuda()
+        clouds.append((feats, torch.from_numpy(rng.integers(0, 13, n_pts).astype(np.int32)).cuda()))
+
+    def step(i):
+        f, y = clouds[i % len(clouds)]
+        with torch.cuda.stream(streams[i % conc]):
+            wss[i % conc].bim_attack(model, f, y, 0.05, 0.01, iters)
+
+    torch.cuda.synchronize()
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_steps):
+        step(i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # algorithmic MACs of one forward (the input-gradient pass has about the same count minus the xyz branch)
+    mac, n = 0, n_pts
+    rows = {}
+    for name, cin, cout, _ in randla_layer_specs():
+        if name.startswith("Encoder_layer_"):
+            lvl = int(name[len("Encoder_layer_")])
+            nl = n_pts // (4 ** lvl)
+            r = nl * 16 if ("LFAmlp" in name or name.endswith("fc")) else nl
+        elif name == "decoder_0":
+            r = n_pts // 512
+        elif name.startswith("Decoder_layer_"):
+            r = n_pts // (4 ** (4 - int(name[-1])))
+        else:
+            r = n_pts
+        mac += r * cin * cout
+    result = {"metric": "attacked clouds/sec (RandLA-Net, 40960 pts, %d BIM iters)" % iters, "value": args.steps / elapsed,
+              "unit": "clouds/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "dtype": "f32", "data": "synthetic",
+              "config": {"workload": "BIM l_inf colour attack (eps=0.05, alpha=0.01, %d iters) on RandLA-Net, 1 cloud x 40960 pts "
+                                     "per call; random-init weights; parity unpinned (TF1 reference)" % iters,
+                         "attacks_in_flight": conc},
+              "ms_per_iteration": elapsed / args.steps / iters * 1e3,
+              "gmac_per_cloud_forward": mac / 1e9,
+              "tflops_effective": 2.0 * 2.0 * mac * iters * args.steps / elapsed / 1e12}
     print(json.dumps(result), flush=True)
     return result
 

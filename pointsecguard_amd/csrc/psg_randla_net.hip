@@ -390,6 +390,7 @@ struct psg_rla_ws {
     float *feat, *dfeat, *ori, *delta, *norms;   // attack state: [N][6], [N][6], [N][3], [N][3], [4]
     int32_t *labels;
     bool cloud_set = false, have_fwd = false;
+    const void *xyz_branch_model = nullptr;   // the model whose xyz-branch features (fxyz1 / fxyz2) are resident
 };
 
 namespace {
@@ -578,6 +579,7 @@ static int build_pyramid(psg_rla_ws *ws, psg_stream stream)
     }
     ws->cloud_set = true;
     ws->have_fwd = false;
+    ws->xyz_branch_model = nullptr;
     return PSG_OK;
 }
 
@@ -603,20 +605,23 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
     int rc;
     if ((rc = conv_fwd(m->fc0, features, 6, ws->f0, 8, N, true, ws->m_f0, st))) return rc;
     const float *fin = ws->f0;
+    const bool xyz_ready = ws->xyz_branch_model == (const void *)m;
     for (int i = 0; i < RL; ++i) {
         LevelBuf &L = ws->lv[i];
         const EncLayers &E = m->enc[i];
         const int n = L.n, d = L.d, h = L.h;
         const size_t ne = (size_t)n * RK;
         if ((rc = conv_fwd(E.mlp1, fin, L.d_in, L.fpc, h, n, true, L.m_fpc, st))) return rc;
-        if ((rc = conv_fwd(E.lfa_mlp1, L.relpos, 10, L.fxyz1, h, (int)ne, true, nullptr, st))) return rc;
+        if (!xyz_ready) {   // the xyz branch depends on the cloud and the weights only: once per (cloud, model)
+            if ((rc = conv_fwd(E.lfa_mlp1, L.relpos, 10, L.fxyz1, h, (int)ne, true, nullptr, st))) return rc;
+            if ((rc = conv_fwd(E.lfa_mlp2, L.fxyz1, h, L.fxyz2, h, (int)ne, true, nullptr, st))) return rc;
+        }
         hipLaunchKernelGGL(gather_concat_kernel, dim3(blocks_for(ne * d)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, h, ne * d, L.cat1);
         PSG_LAUNCH_CHECK();
         if ((rc = conv_fwd(E.att1_fc, L.cat1, d, L.a1, d, (int)ne, false, nullptr, st))) return rc;
         hipLaunchKernelGGL(att_pool_fwd_kernel, dim3(blocks_for((size_t)n * d)), dim3(256), 0, st, L.cat1, L.a1, d, (size_t)n * d, L.agg1);
         PSG_LAUNCH_CHECK();
         if ((rc = conv_fwd(E.att1_mlp, L.agg1, d, L.fagg1, h, n, true, L.m_fagg1, st))) return rc;
-        if ((rc = conv_fwd(E.lfa_mlp2, L.fxyz1, h, L.fxyz2, h, (int)ne, true, nullptr, st))) return rc;
         hipLaunchKernelGGL(gather_concat_kernel, dim3(blocks_for(ne * d)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, h, ne * d, L.cat2);
         PSG_LAUNCH_CHECK();
         if ((rc = conv_fwd(E.att2_fc, L.cat2, d, L.a2, d, (int)ne, false, nullptr, st))) return rc;
@@ -654,6 +659,7 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
     if (logits_out != ws->logits)
         PSG_CHECK_HIP(hipMemcpyAsync(logits_out, ws->logits, (size_t)N * RNCLS * 4, hipMemcpyDeviceToDevice, st));
     ws->have_fwd = true;
+    ws->xyz_branch_model = m;
     return PSG_OK;
 }
 
