@@ -36,9 +36,75 @@ struct RLayer {
     int cin = 0, cout = 0;
 };
 
+// Skinny layers (K, M <= 32: everything at level 0 -- 8/16-wide features over 40 960 points or 655 360 edge rows): the
+// MFMA row GEMM would spend a 128-column tile on 8-32 useful columns, so these run one row per thread on the vector
+// pipe with the weights in LDS (broadcast reads): ~K*M FMAs per row against 4 (K + M) bytes of traffic, i.e.
+// bandwidth-bound, which is the floor for these shapes.  Same epilogue semantics as gemm_rows_kernel.
+template <int EPI>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(GemmArgs a)
+{
+    __shared__ float s_w[32 * 32 + 32];
+    for (int t = threadIdx.x; t < a.M * a.K; t += 256) s_w[t] = a.w[(size_t)(t / a.K) * a.ld_w + (t % a.K)];
+    if (threadIdx.x < 32) s_w[1024 + threadIdx.x] = (a.bias && (int)threadIdx.x < a.M) ? a.bias[threadIdx.x] : 0.0f;
+    __syncthreads();
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.rows) return;
+    float x[32];
+    const float *in = a.in + (size_t)row * a.ld_in;
+    if (((a.K | a.ld_in) & 3) == 0) {   // 16-byte loads: a wave then reads its 64 rows as whole cache lines
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+            const float4 v = 4 * k4 < a.K ? *(const float4 *)(in + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            x[4 * k4] = v.x; x[4 * k4 + 1] = v.y; x[4 * k4 + 2] = v.z; x[4 * k4 + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) x[k] = k < a.K ? in[k] : 0.0f;
+    }
+    float *out = a.out + (size_t)row * a.ld_out;
+    unsigned bits = 0;
+    const bool vec_out = ((a.M | a.ld_out) & 3) == 0;
+    for (int m0 = 0; m0 < a.M; m0 += 4) {
+        float z[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = m0 + u;
+            float acc = 0.0f;
+            if (m < a.M) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k)
+                    if (k < a.K) acc += x[k] * s_w[m * a.K + k];
+                acc += s_w[1024 + m];
+                if (EPI == EPI_LRELU) {
+                    const bool pos = acc > 0.0f;
+                    bits |= (unsigned)pos << m;
+                    acc = pos ? acc : 0.2f * acc;
+                }
+            }
+            z[u] = acc;
+        }
+        if (vec_out) {
+            float4 *o4 = (float4 *)(out + m0);
+            float4 v = make_float4(z[0], z[1], z[2], z[3]);
+            if (a.accumulate == 1) { const float4 o = *o4; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *o4 = v;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (m0 + u < a.M) out[m0 + u] = a.accumulate == 1 ? out[m0 + u] + z[u] : z[u];
+        }
+    }
+    if (EPI == EPI_LRELU && a.mask_out) a.mask_out[row] = bits;
+}
+
 template <int EPI>
 int rl_gemm(const GemmArgs &a, hipStream_t st)
 {
+    if (a.M <= 32 && a.K <= 32 && a.rows >= 4096 && !a.addend && !a.gbias && !a.mask_in) {
+        hipLaunchKernelGGL(skinny_gemm_kernel<EPI>, dim3(ceil_div(a.rows, 256)), dim3(256), 0, st, a);
+        PSG_LAUNCH_CHECK();
+        return PSG_OK;
+    }
     dim3 grid(ceil_div(a.rows, 128), ceil_div(a.M, 128));
     if ((size_t)grid.x * grid.y < 256) {   // few 128-wide tiles: 64 x 64 tiles, one MFMA tile per wave
         dim3 small(ceil_div(a.rows, 64), ceil_div(a.M, 64));
