@@ -28,6 +28,9 @@ constexpr int RNCLS = 13;
 const int kDout[RL] = {16, 64, 128, 256, 512};
 const int kRatio[RL] = {4, 4, 4, 4, 2};
 constexpr float kSlope = 0.2f;
+#ifndef RL_SMALL_TILE_BELOW
+#define RL_SMALL_TILE_BELOW 256
+#endif
 
 struct RLayer {
     float *w = nullptr;    // [cout][cin]  BatchNorm scale folded in
@@ -106,7 +109,7 @@ int rl_gemm(const GemmArgs &a, hipStream_t st)
         return PSG_OK;
     }
     dim3 grid(ceil_div(a.rows, 128), ceil_div(a.M, 128));
-    if ((size_t)grid.x * grid.y < 256) {   // few 128-wide tiles: 64 x 64 tiles, one MFMA tile per wave
+    if ((size_t)grid.x * grid.y < RL_SMALL_TILE_BELOW) {   // few 128-wide tiles: 64 x 64 tiles, one MFMA tile per wave
         dim3 small(ceil_div(a.rows, 64), ceil_div(a.M, 64));
         hipLaunchKernelGGL((gemm_rows_kernel<2, 2, EPI, false, 1, 1>), small, dim3(256), 0, st, a);
     } else {
