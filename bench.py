@@ -86,7 +86,8 @@ def main():
                     help="consecutive steps (batches of 8 rooms) fused into one device batch per launch; rooms are "
                          "independent, so results are identical and small kernels get more workgroups")
     ap.add_argument("--nu-steps", type=int, default=100, help="tarnu workload: optimiser step cap per attack")
-    ap.add_argument("--randla-iters", type=int, default=10, help="randla workload: BIM iterations per attacked cloud")
+    ap.add_argument("--randla-iters", type=int, default=100,
+                    help="randla workload: BIM iterations per attacked cloud (BASELINE configs[4]: 100)")
     ap.add_argument("--nu-concurrency", type=int, default=3,
                     help="tarnu workload: attacks in flight, one host thread + HIP stream + model instance each (an NU "
                          "step reads one scalar tensor back for the reference's early-exit test; a second attack fills "
@@ -444,9 +445,9 @@ def main_msg(args):
 
 
 def main_randla(args):
-    """BASELINE configs[4] family (secondary): BIM colour attack (l_inf, goal 'ut') on RandLA-Net, one 40 960-point cloud
-    per call (ConfigS3DIS.val_batch_size = 1), --randla-iters gradient steps per attack, geometry (5-level k-NN pyramid)
-    rebuilt per cloud; random-init weights (no checkpoint ships), a step = one attacked cloud."""
+    """BASELINE configs[4] (secondary): BIM colour attack (l_inf, goal 'ut') on RandLA-Net, one 40 960-point cloud per
+    call (ConfigS3DIS.val_batch_size = 1), 100 gradient steps per attack (--randla-iters), geometry (5-level k-NN
+    pyramid) rebuilt per cloud; random-init weights (no checkpoint ships), a step = one attacked cloud; this GPU only."""
     import torch
     from pointsecguard_amd.randla import network
     from pointsecguard_amd.synthetic import randla_layer_specs, randla_params

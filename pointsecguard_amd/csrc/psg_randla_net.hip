@@ -13,6 +13,7 @@
 // pooling, nearest interpolation, and the transposes of the gathers (float atomics: several edges point at one vertex).
 // The xyz branch of the local feature aggregation (relative positions and their two MLPs) does not depend on colour:
 // it runs in the forward pass, but the colour attack never differentiates through it.
+#include <cstdlib>
 #include <vector>
 
 #include "psg_common.h"
@@ -460,6 +461,12 @@ struct psg_rla_ws {
     int32_t *labels;
     bool cloud_set = false, have_fwd = false;
     const void *xyz_branch_model = nullptr;   // the model whose xyz-branch features (fxyz1 / fxyz2) are resident
+    // hipGraph of one BIM iteration (forward, loss gradient, backward, update: ~150 short launches), valid for the
+    // (model, eps, alpha, metric) below; every captured kernel works on workspace buffers, so it is cloud-independent
+    hipGraphExec_t bim_exec = nullptr;
+    const void *bim_model = nullptr;
+    float bim_eps = 0.f, bim_alpha = 0.f;
+    int bim_metric = -1;
 };
 
 namespace {
@@ -625,6 +632,7 @@ extern "C" int psg_rla_ws_create(psg_ctx *ctx, int n_points, psg_rla_ws **out)
 extern "C" int psg_rla_ws_destroy(psg_rla_ws *ws)
 {
     if (!ws) return PSG_OK;
+    if (ws->bim_exec) (void)hipGraphExecDestroy(ws->bim_exec);
     if (ws->arena) (void)hipFree(ws->arena);
     delete ws;
     return PSG_OK;
@@ -837,10 +845,11 @@ extern "C" int psg_rla_bim_attack(psg_rla_model *m, psg_rla_ws *ws, const float 
     hipLaunchKernelGGL(copy_cols_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, features, 6, 0, 3, N, ws->xyz_all, 3, 0);
     PSG_LAUNCH_CHECK();
     if ((rc = build_pyramid(ws, stream))) return rc;        // geometry: once per cloud, the attack moves colours only
-    for (int it = 0; it < iters; ++it) {
-        if ((rc = psg_rla_forward(m, ws, ws->feat, ws->logits, stream))) return rc;
-        if ((rc = psg_rla_colper_grad(ws->logits, ws->labels, (int)N, ws->dlogits, nullptr, stream))) return rc;
-        if ((rc = psg_rla_backward(m, ws, ws->dlogits, ws->dfeat, stream))) return rc;
+    auto iteration = [&]() -> int {
+        int r;
+        if ((r = psg_rla_forward(m, ws, ws->feat, ws->logits, stream))) return r;
+        if ((r = psg_rla_colper_grad(ws->logits, ws->labels, (int)N, ws->dlogits, nullptr, stream))) return r;
+        if ((r = psg_rla_backward(m, ws, ws->dlogits, ws->dfeat, stream))) return r;
         if (!l2_metric) {
             hipLaunchKernelGGL(bim_linf_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, ws->feat, ws->dfeat, ws->ori, N, alpha, eps);
             PSG_LAUNCH_CHECK();
@@ -857,7 +866,41 @@ extern "C" int psg_rla_bim_attack(psg_rla_model *m, psg_rla_ws *ws, const float 
                                ws->norms + 1);
             PSG_LAUNCH_CHECK();
         }
+        return PSG_OK;
+    };
+    // The first iteration runs eagerly (it computes the xyz branch and sets kernel attributes outside any capture); the
+    // others enqueue the same launches with the same arguments, so they are captured once into a hipGraph kept in the
+    // workspace and replayed: one graph launch instead of ~150 kernel launches per iteration, which is what lets several
+    // long attacks on different streams actually overlap (the host would otherwise spend its time filling one stream's
+    // queue).  Capture is impossible on the legacy default stream; the loop then stays eager.
+    if ((rc = iteration())) return rc;
+    int it = 1;
+    static const bool use_graph = !(getenv("PSG_RLA_NO_GRAPH") && atoi(getenv("PSG_RLA_NO_GRAPH")));
+    if (use_graph && iters - it >= 2) {
+        if (ws->bim_exec && (ws->bim_model != (const void *)m || ws->bim_eps != eps || ws->bim_alpha != alpha || ws->bim_metric != l2_metric)) {
+            PSG_CHECK_HIP(hipStreamSynchronize(st));
+            (void)hipGraphExecDestroy(ws->bim_exec);
+            ws->bim_exec = nullptr;
+        }
+        if (!ws->bim_exec) {
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int crc = iteration();
+                hipGraph_t graph = nullptr;
+                const hipError_t e = hipStreamEndCapture(st, &graph);
+                if (crc == PSG_OK && e == hipSuccess && graph) {
+                    if (hipGraphInstantiate(&ws->bim_exec, graph, nullptr, nullptr, 0) != hipSuccess) ws->bim_exec = nullptr;
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+                if (crc != PSG_OK) return crc;
+                ws->bim_model = m; ws->bim_eps = eps; ws->bim_alpha = alpha; ws->bim_metric = l2_metric;
+            }
+            (void)hipGetLastError();   // a refused capture (legacy stream) is not an error of this call
+        }
+        if (ws->bim_exec)
+            for (; it < iters; ++it) PSG_CHECK_HIP(hipGraphLaunch(ws->bim_exec, st));
     }
+    for (; it < iters; ++it)
+        if ((rc = iteration())) return rc;
     PSG_CHECK_HIP(hipMemcpyAsync(adv_features_out, ws->feat, N * 6 * 4, hipMemcpyDeviceToDevice, st));
     return PSG_OK;
 }
