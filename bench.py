@@ -68,6 +68,68 @@ def cpu_baseline(sd, rooms, labels, starts, iters_sample):
                 rooms.shape[0], iters_sample, ITERS, dt)}
 
 
+class Ranks:
+    """One process per GPU (torch.distributed.run): RANK / LOCAL_RANK / WORLD_SIZE from the environment, RCCL
+    (backend "nccl") for the barrier and the max-over-ranks time; PSG_BENCH_BACKEND=gloo lets several ranks share one
+    GPU to rehearse the multi-rank path on a single-GPU box (RCCL refuses two ranks on one device).  Work is sharded
+    by rank with no data-path collective: every rank attacks its own rooms / clouds (weak scaling)."""
+
+    def __init__(self, args):
+        import torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if args.gpus > 1 and self.world != args.gpus:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (
+                args.gpus, args.gpus))
+        backend = os.environ.get("PSG_BENCH_BACKEND", "nccl")
+        self.dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(self.dev_index)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev_index))
+            else:
+                dist.init_process_group(backend)
+            self.dist = dist
+
+    def fence(self):
+        import torch
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, fn):
+        """barrier + synchronize, fn(), barrier + synchronize; returns the MAX elapsed seconds over ranks."""
+        import torch
+        self.fence()
+        t0 = time.perf_counter()
+        fn()
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        if self.dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    def sum(self, x):
+        import torch
+        if self.dist is None:
+            return x
+        t = torch.tensor([float(x)], dtype=torch.float64, device="cuda")
+        self.dist.all_reduce(t)
+        return float(t.item())
+
+    def done(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -332,7 +394,7 @@ def main_resgcn(args):
     BLOCKS = {"res": runtime.GCN_BLOCK_RES, "plain": runtime.GCN_BLOCK_PLAIN, "dense": runtime.GCN_BLOCK_DENSE}
     CONVS = {"edge": runtime.GCN_CONV_EDGE, "mr": runtime.GCN_CONV_MR}
     cfg = dict(block=BLOCKS[args.gcn_block], conv=CONVS[args.gcn_conv])
-    torch.cuda.set_device(0)
+    R = Ranks(args)
     model = runtime.GCNModel(sd, n_blocks, **cfg)
     # rooms are independent and a single 4096-point room cannot fill 256 CUs with its small per-vertex GEMMs: several
     # attacks are kept in flight, one HIP stream + workspace each (the same thing bench's PointNet++ path does)
@@ -340,7 +402,7 @@ def main_resgcn(args):
     wss = [runtime.GCNWorkspace(batch, NPOINT, n_blocks, **cfg) for _ in range(conc)]
     streams = [torch.cuda.Stream() for _ in range(conc)]
     n_steps = args.steps + args.warmup
-    rooms = [make_rooms(batch, 5000 + s) for s in range(n_steps)]
+    rooms = [make_rooms(batch, 5000 + 1000 * R.rank + s) for s in range(n_steps)]
     d_images = [torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 1))).cuda() for r in rooms]
     d_labels = [torch.from_numpy(rule_labels(r).astype(np.int32)).cuda() for r in rooms]
     d_adv = [torch.empty_like(x) for x in d_images]
@@ -349,31 +411,28 @@ def main_resgcn(args):
         with torch.cuda.stream(streams[i % conc]):
             wss[i % conc].nb_attack(model, d_images[i], d_labels[i], 0.3, 2 / 255, iters, out=d_adv[i])
 
-    torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, n_steps):
-        step(i)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = R.timed(lambda: [step(i) for i in range(args.warmup, n_steps)])
+    world = R.world
     # algorithmic FLOPs per PGD iteration per room (kNN distance GEMMs + split EdgeConv + fusion/prediction + transposes)
     n = NPOINT
     gmac = (27 * n * n * 64 + n * n * 3 + 28 * n * 64 * 128 * 2 + n * F * 1024 + n * F * 512 * 2 + n * 512 * 256 * 2 +
             n * 256 * 13 * 2) / 1e9
     name = "ResGCN-%d" % n_blocks + ("" if (args.gcn_block, args.gcn_conv) == ("res", "edge") else
                                       " block=%s conv=%s" % (args.gcn_block, args.gcn_conv))
-    result = {"metric": "attacked rooms/sec (%s, 4096 pts, 50 PGD iters)" % name, "value": batch * args.steps / elapsed,
-              "unit": "rooms/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+    result = {"metric": "attacked rooms/sec (%s, 4096 pts, 50 PGD iters)" % name, "value": batch * args.steps * world / elapsed,
+              "unit": "rooms/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
               "dtype": "f32", "data": "synthetic",
               "config": {"workload": name + " dense sem_seg NB non-targeted PGD (eps=0.3, alpha=2/255, 50 iters), kNN k=16, "
                                      "batch=%d room(s) x 4096 pts per call (%s); random-init weights" % (batch, 
                                          "BASELINE configs[3]" if default_cfg else "configuration switch of configs[3]"),
                          "attacks_in_flight": conc},
-              "tflops_effective": 2 * gmac * iters * batch * args.steps / elapsed / 1e3 if default_cfg else None}
-    print(json.dumps(result), flush=True)
+              "tflops_effective": 2 * gmac * iters * batch * args.steps * world / elapsed / 1e3 if default_cfg else None}
+    if R.rank == 0:
+        print(json.dumps(result), flush=True)
+    R.done()
     return result
 
 
@@ -384,7 +443,7 @@ def main_msg(args):
     import torch
     from pointsecguard_amd import runtime
     from pointsecguard_amd.synthetic import MSG_FP, MSG_SA, make_rooms, msg_state_dict, rule_labels
-    torch.cuda.set_device(0)
+    R = Ranks(args)
     model = runtime.PN2Model(runtime.fold_state_dict(msg_state_dict(77), msg=True), arch=runtime.ARCH_MSG)
     G = max(1, min(args.coalesce, args.steps))
     DB = BATCH * G
@@ -394,7 +453,7 @@ def main_msg(args):
     wss = [runtime.PN2Workspace(DB, NPOINT, ITERS, arch=runtime.ARCH_MSG) for _ in range(conc)]
     pool = []
     for i in range(conc):
-        rooms = make_rooms(DB, 9000 + i)
+        rooms = make_rooms(DB, 9000 + 100 * R.rank + i)
         images = torch.from_numpy(np.ascontiguousarray(rooms.transpose(0, 2, 1))).cuda()
         labels = torch.from_numpy(rule_labels(rooms).astype(np.int32)).cuda()
         torch.manual_seed(100 + i)
@@ -407,16 +466,10 @@ def main_msg(args):
         with torch.cuda.stream(streams[i % conc]):
             wss[i % conc].nb_attack(model, images, labels, starts, EPS, ALPHA, ITERS, out=out)
 
-    torch.cuda.synchronize()
     for i in range(n_warm):
         launch(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(n_groups):
-        launch(i)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    rooms_done = DB * n_groups
+    elapsed = R.timed(lambda: [launch(i) for i in range(n_groups)])
+    rooms_done = DB * n_groups * R.world
     # per-kernel HIP-event profile of one more (untimed) launch
     wss[0].prof_enable(True)
     launch(0)
@@ -432,33 +485,36 @@ def main_msg(args):
         mac += n_l * macs((cin,) + tuple(mlp))
     mac += 4096 * macs((128, 128, 13))
     result = {"metric": "attacked rooms/sec (PointNet++ MSG, 4096 pts, 40 PGD iters)", "value": rooms_done / elapsed,
-              "unit": "rooms/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-              "ms_per_step": elapsed / (rooms_done / BATCH) * 1e3, "higher_is_better": True, "scaling": "weak",
+              "unit": "rooms/s", "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": elapsed / (DB * n_groups / BATCH) * 1e3, "higher_is_better": True, "scaling": "weak",
               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
               "config": {"workload": "NB non-targeted PGD (eps=0.05, alpha=2/255, 40 iters) on PointNet++ MSG sem_seg "
                                      "(pointnet2_sem_seg_msg), batch=8 rooms x 4096 pts; random-init weights",
                          "device_batch_rooms": DB, "launches_in_flight_per_gpu": conc},
               "tflops_effective": 2.0 * 2.0 * mac * ITERS * rooms_done / elapsed / 1e12,
               "gmac_per_room_forward": mac / 1e9, "kernel_profile_one_launch": prof}
-    print(json.dumps(result), flush=True)
+    if R.rank == 0:
+        print(json.dumps(result), flush=True)
+    R.done()
     return result
 
 
 def main_randla(args):
     """BASELINE configs[4] (secondary): BIM colour attack (l_inf, goal 'ut') on RandLA-Net, one 40 960-point cloud per
     call (ConfigS3DIS.val_batch_size = 1), 100 gradient steps per attack (--randla-iters), geometry (5-level k-NN
-    pyramid) rebuilt per cloud; random-init weights (no checkpoint ships), a step = one attacked cloud; this GPU only."""
+    pyramid) rebuilt per cloud; random-init weights (no checkpoint ships), a step = one attacked cloud; clouds sharded
+    by rank (data-parallel, no collective on the data path)."""
     import torch
     from pointsecguard_amd.randla import network
     from pointsecguard_amd.synthetic import randla_layer_specs, randla_params
-    torch.cuda.set_device(0)
+    R = Ranks(args)
     n_pts, iters = 40960, args.randla_iters
     model = network.RandLAModel(randla_params(3))
     conc = max(1, min(args.concurrency, args.steps))
     wss = [network.RandLAWorkspace(n_pts) for _ in range(conc)]
     streams = [torch.cuda.Stream() for _ in range(conc)]
     n_steps = args.steps + args.warmup
-    rng = np.random.default_rng(4)
+    rng = np.random.default_rng(4 + R.rank)
     clouds = []
     for _ in range(min(n_steps, 8)):
         xyz = (rng.random((n_pts, 3), dtype=np.float32) * np.array([8, 6, 3], np.float32)).astype(np.float32)
@@ -470,15 +526,10 @@ def main_randla(args):
         with torch.cuda.stream(streams[i % conc]):
             wss[i % conc].bim_attack(model, f, y, 0.05, 0.01, iters)
 
-    torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, n_steps):
-        step(i)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = R.timed(lambda: [step(i) for i in range(args.warmup, n_steps)])
+    world = R.world
     # algorithmic MACs of one forward (the input-gradient pass has about the same count minus the xyz branch)
     mac, n = 0, n_pts
     rows = {}
@@ -494,8 +545,8 @@ def main_randla(args):
         else:
             r = n_pts
         mac += r * cin * cout
-    result = {"metric": "attacked clouds/sec (RandLA-Net, 40960 pts, %d BIM iters)" % iters, "value": args.steps / elapsed,
-              "unit": "clouds/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+    result = {"metric": "attacked clouds/sec (RandLA-Net, 40960 pts, %d BIM iters)" % iters, "value": args.steps * world / elapsed,
+              "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
               "dtype": "f32", "data": "synthetic",
               "config": {"workload": "BIM l_inf colour attack (eps=0.05, alpha=0.01, %d iters) on RandLA-Net, 1 cloud x 40960 pts "
@@ -503,8 +554,10 @@ def main_randla(args):
                          "attacks_in_flight": conc},
               "ms_per_iteration": elapsed / args.steps / iters * 1e3,
               "gmac_per_cloud_forward": mac / 1e9,
-              "tflops_effective": 2.0 * 2.0 * mac * iters * args.steps / elapsed / 1e12}
-    print(json.dumps(result), flush=True)
+              "tflops_effective": 2.0 * 2.0 * mac * iters * args.steps * world / elapsed / 1e12}
+    if R.rank == 0:
+        print(json.dumps(result), flush=True)
+    R.done()
     return result
 
 
@@ -523,6 +576,7 @@ def main_tarnu(args):
     sd = dict(np.load(os.path.join(ROOT, "tests", "golden", "pn2_weights.npz")))
     import threading
     from concurrent.futures import ThreadPoolExecutor
+    R = Ranks(args)
     conc = max(1, min(args.nu_concurrency, args.steps))
     nets, streams = [], [torch.cuda.Stream() for _ in range(conc)]
     for _ in range(conc):
@@ -530,7 +584,7 @@ def main_tarnu(args):
         net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         nets.append(net.cuda().eval())
     n_steps = args.steps + args.warmup
-    rooms = [make_rooms(batch, 7000 + s, structured=True) for s in range(n_steps)]
+    rooms = [make_rooms(batch, 7000 + 1000 * R.rank + s, structured=True) for s in range(n_steps)]
     labels = [rule_labels(r) for r in rooms]
     d_images = [torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 1))).cuda() for r in rooms]
     # target=None selects the reference's `non_f` branch (target.py:100-104): with a target class the harness'
@@ -564,25 +618,25 @@ def main_tarnu(args):
         with ThreadPoolExecutor(max_workers=conc) as pool:
             list(pool.map(worker, range(conc)))
 
-    torch.manual_seed(0)
-    torch.cuda.synchronize()
+    torch.manual_seed(R.rank)
     run(0, args.warmup)
     torch.cuda.synchronize()
     opt_steps[0] = 0
-    t0 = time.perf_counter()
-    run(args.warmup, n_steps)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = R.timed(lambda: run(args.warmup, n_steps))
+    world = R.world
+    total_opt = R.sum(opt_steps[0])
     result = {"metric": "attacked rooms/sec (tar_NU, 4096 pts, <= %d Adam steps)" % args.nu_steps,
-              "value": batch * args.steps / elapsed, "unit": "rooms/s", "n_gpus": 1, "steps": args.steps,
+              "value": batch * args.steps * world / elapsed, "unit": "rooms/s", "n_gpus": world, "steps": args.steps,
               "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
               "config": {"workload": "tar_NU_attack (c=1, kappa=0, lr=0.01, neighbour=5) on PointNet++ SSG sem_seg, batch=32 "
                                      "rooms x 4096 pts (BASELINE configs[2]); fitted fixture weights",
                          "optimizer_steps_cap": args.nu_steps, "attacks_in_flight": conc},
-              "optimizer_steps_per_sec": opt_steps[0] / elapsed, "optimizer_steps_run": opt_steps[0],
-              "room_steps_per_sec": batch * opt_steps[0] / elapsed}
-    print(json.dumps(result), flush=True)
+              "optimizer_steps_per_sec": total_opt / elapsed, "optimizer_steps_run": int(total_opt),
+              "room_steps_per_sec": batch * total_opt / elapsed}
+    if R.rank == 0:
+        print(json.dumps(result), flush=True)
+    R.done()
     return result
 
 
