@@ -109,6 +109,11 @@ int rl_gemm(const GemmArgs &a, hipStream_t st)
         PSG_LAUNCH_CHECK();
         return PSG_OK;
     }
+    if (a.M <= 64 && a.rows >= 32768) {   // 64 output channels (level 1): 256-row x 64-column workgroup tiles, no wasted half tile
+        hipLaunchKernelGGL((gemm_rows_kernel<4, 1, EPI, false>), dim3(ceil_div(a.rows, 256), 1), dim3(256), 0, st, a);
+        PSG_LAUNCH_CHECK();
+        return PSG_OK;
+    }
     dim3 grid(ceil_div(a.rows, 128), ceil_div(a.M, 128));
     if ((size_t)grid.x * grid.y < RL_SMALL_TILE_BELOW) {   // few 128-wide tiles: 64 x 64 tiles, one MFMA tile per wave
         dim3 small(ceil_div(a.rows, 64), ceil_div(a.M, 64));
@@ -457,6 +462,7 @@ struct psg_rla_ws {
     float *logits, *dlogits;
     float *scratch_a, *scratch_b;   // [max edges * d] gradient scratch (dcat / ds), also decoder d_cat
     float *d_f0, *d_dec0, *d_dec_out[RL], *d_fc1o, *d_fc2o;
+    char *acc = nullptr; size_t acc_bytes = 0;   // the contiguous block of gradient accumulators
     float *feat, *dfeat, *ori, *delta, *norms;   // attack state: [N][6], [N][6], [N][3], [N][3], [4]
     int32_t *labels;
     bool cloud_set = false, have_fwd = false;
@@ -589,8 +595,6 @@ extern "C" int psg_rla_ws_create(psg_ctx *ctx, int n_points, psg_rla_ws **out)
             L.m_fpc = (uint32_t *)take((size_t)n * ceil_div((int)h, 32) * 4); L.m_fagg1 = (uint32_t *)take((size_t)n * ceil_div((int)h, 32) * 4);
             L.m_fagg2 = (uint32_t *)take((size_t)n * ceil_div((int)d, 32) * 4); L.m_enc = (uint32_t *)take((size_t)n * (2 * d / 32) * 4);
             L.arg = (uint8_t *)take((size_t)L.n_sub * 2 * d);
-            L.d_enc = (float *)take((size_t)n * 2 * d * 4); L.d_samp = (float *)take((size_t)L.n_sub * 2 * d * 4);
-            L.d_fpc = (float *)take((size_t)n * h * 4); L.d_fagg1 = (float *)take((size_t)n * h * 4);
             n = L.n_sub; d_in = 2 * L.d;
         }
         const int n5 = ws->lv[RL - 1].n_sub;
@@ -603,7 +607,6 @@ extern "C" int psg_rla_ws_create(psg_ctx *ctx, int n_points, psg_rla_ws **out)
             ws->dec_cat[j] = (float *)take((size_t)L.n * (skip + feat) * 4);
             ws->dec_out[j] = (float *)take((size_t)L.n * skip * 4);
             ws->m_dec[j] = (uint32_t *)take((size_t)L.n * ceil_div(skip, 32) * 4);
-            ws->d_dec_out[j] = (float *)take((size_t)L.n * skip * 4);
             max_edge = std::max(max_edge, (size_t)L.n * (skip + feat));
             feat = skip;
         }
@@ -611,7 +614,25 @@ extern "C" int psg_rla_ws_create(psg_ctx *ctx, int n_points, psg_rla_ws **out)
         ws->m_fc1 = (uint32_t *)take(N * 2 * 4); ws->m_fc2 = (uint32_t *)take(N * 4);
         ws->logits = (float *)take(N * RNCLS * 4); ws->dlogits = (float *)take(N * RNCLS * 4);
         ws->scratch_a = (float *)take(max_edge * 4); ws->scratch_b = (float *)take(max_edge * 4);
-        ws->d_f0 = (float *)take(N * 8 * 4); ws->d_dec0 = (float *)take((size_t)n5 * 1024 * 4);
+        ws->d_f0 = (float *)take(N * 8 * 4);
+        // gradient accumulators (targets of atomics / of several consumers): one contiguous block, zeroed by ONE memset
+        // at the start of a backward pass instead of ~25 small ones spread over it
+        off = (off + 255) & ~(size_t)255;
+        const size_t acc_begin = off;
+        for (int i = 0; i < RL; ++i) {
+            LevelBuf &L = ws->lv[i];
+            L.d_enc = (float *)take((size_t)L.n * 2 * L.d * 4); L.d_samp = (float *)take((size_t)L.n_sub * 2 * L.d * 4);
+            L.d_fpc = (float *)take((size_t)L.n * L.h * 4); L.d_fagg1 = (float *)take((size_t)L.n * L.h * 4);
+        }
+        ws->d_dec0 = (float *)take((size_t)n5 * 1024 * 4);
+        for (int j = 0; j < RL; ++j) {
+            const LevelBuf &L = ws->lv[RL - 1 - j];
+            const int skip = j == RL - 1 ? 2 * kDout[0] : 2 * kDout[RL - 2 - j];
+            ws->d_dec_out[j] = (float *)take((size_t)L.n * skip * 4);
+        }
+        off = (off + 255) & ~(size_t)255;
+        ws->acc = pass ? (char *)ws->arena + acc_begin : nullptr;
+        ws->acc_bytes = off - acc_begin;
         ws->d_fc1o = (float *)take(N * 64 * 4); ws->d_fc2o = (float *)take(N * 32 * 4);
         ws->feat = (float *)take(N * 6 * 4); ws->dfeat = (float *)take(N * 6 * 4); ws->ori = (float *)take(N * 3 * 4);
         ws->delta = (float *)take(N * 3 * 4); ws->norms = (float *)take(4 * 4); ws->labels = (int32_t *)take(N * 4);
@@ -752,15 +773,11 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
     if ((rc = lrelu_bwd(ws->d_fc2o, 32, ws->m_fc2, N, 32, st))) return rc;
     if ((rc = conv_bwd(m->fc2, ws->d_fc2o, 32, ws->d_fc1o, 64, N, 0, st))) return rc;
     if ((rc = lrelu_bwd(ws->d_fc1o, 64, ws->m_fc1, N, 64, st))) return rc;
+    // every gradient accumulator starts at zero and collects its consumers (one memset for the whole block; the last
+    // decoder layer's gradient, written next by a plain GEMM store, lies in it too)
+    PSG_CHECK_HIP(hipMemsetAsync(ws->acc, 0, ws->acc_bytes, st));
     if ((rc = conv_bwd(m->fc1, ws->d_fc1o, 64, ws->d_dec_out[RL - 1], m->fc1.cin, N, 0, st))) return rc;
-    // gradient accumulators of the encoder outputs: every one starts at zero and collects its consumers
-    for (int i = 0; i < RL; ++i) {
-        LevelBuf &L = ws->lv[i];
-        PSG_CHECK_HIP(hipMemsetAsync(L.d_enc, 0, (size_t)L.n * 2 * L.d * 4, st));
-        PSG_CHECK_HIP(hipMemsetAsync(L.d_samp, 0, (size_t)L.n_sub * 2 * L.d * 4, st));
-    }
     const int n5 = ws->lv[RL - 1].n_sub;
-    PSG_CHECK_HIP(hipMemsetAsync(ws->d_dec0, 0, (size_t)n5 * 1024 * 4, st));
     // decoder, last layer first
     for (int j = RL - 1; j >= 0; --j) {
         const LevelBuf &L = ws->lv[RL - 1 - j];
@@ -770,7 +787,6 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         if ((rc = conv_bwd(m->dec[j], dout, cs, ws->scratch_a, cs + cfeat, L.n, 0, st))) return rc;
         float *dskip = j == RL - 1 ? ws->lv[0].d_enc : ws->lv[RL - 2 - j].d_samp;
         float *dcoarse = j == 0 ? ws->d_dec0 : ws->d_dec_out[j - 1];
-        if (j > 0) PSG_CHECK_HIP(hipMemsetAsync(dcoarse, 0, (size_t)ws->lv[RL - j].n * cfeat * 4, st));
         hipLaunchKernelGGL(interp_concat_bwd_kernel, dim3(blocks_for((size_t)L.n * (cs + cfeat))), dim3(256), 0, st, ws->scratch_a, cs,
                            cfeat, L.up, (size_t)L.n * (cs + cfeat), dskip, dcoarse);
         PSG_LAUNCH_CHECK();
@@ -798,7 +814,6 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
                            ws->scratch_a, ws->scratch_b);
         PSG_LAUNCH_CHECK();
         if ((rc = conv_bwd(E.att2_fc, ws->scratch_b, d, ws->scratch_a, d, (int)ne, 1, st))) return rc;
-        PSG_CHECK_HIP(hipMemsetAsync(L.d_fagg1, 0, (size_t)n * h * 4, st));
         hipLaunchKernelGGL(gather_bwd_kernel, dim3(blocks_for(ne * h)), dim3(256), 0, st, ws->scratch_a, L.neigh, h, ne * h, L.d_fagg1);
         PSG_LAUNCH_CHECK();
         if ((rc = lrelu_bwd(L.d_fagg1, h, L.m_fagg1, n, h, st))) return rc;
@@ -808,7 +823,6 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
                            ws->scratch_a, ws->scratch_b);
         PSG_LAUNCH_CHECK();
         if ((rc = conv_bwd(E.att1_fc, ws->scratch_b, d, ws->scratch_a, d, (int)ne, 1, st))) return rc;
-        PSG_CHECK_HIP(hipMemsetAsync(L.d_fpc, 0, (size_t)n * h * 4, st));
         hipLaunchKernelGGL(gather_bwd_kernel, dim3(blocks_for(ne * h)), dim3(256), 0, st, ws->scratch_a, L.neigh, h, ne * h, L.d_fpc);
         PSG_LAUNCH_CHECK();
         if ((rc = lrelu_bwd(L.d_fpc, h, L.m_fpc, n, h, st))) return rc;
