@@ -63,11 +63,50 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.0f;
 
+    constexpr int NI = BR * 8 / 256, NWL = BN * 8 / 256;
+    // plain (non-ASC) path: the global loads of step k0 + 32 are issued right after the barrier that publishes step k0 in
+    // LDS, so they are in flight under that step's MFMAs (register double buffering; one LDS buffer)
+    float4 vi[NI], vw[NWL];
+    auto load_plain = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int t = tid + u * 256, r = t >> 3, q = t & 7, k = k0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + r < a.rows) {
+                const float *p = a.in + (size_t)(row0 + r) * a.ld_in + k;
+                if (k + 3 < a.K && ((a.ld_in & 3) == 0)) v = *(const float4 *)p;
+                else {
+                    if (k < a.K) v.x = p[0];
+                    if (k + 1 < a.K) v.y = p[1];
+                    if (k + 2 < a.K) v.z = p[2];
+                    if (k + 3 < a.K) v.w = p[3];
+                }
+            }
+            vi[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < NWL; ++u) {
+            const int t = tid + u * 256, r = t >> 3, q = t & 7, k = k0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col0 + r < a.M) {
+                const float *p = a.w + (size_t)(col0 + r) * a.ld_w + k;
+                if (k + 3 < a.K && ((a.ld_w & 3) == 0)) v = *(const float4 *)p;
+                else {
+                    if (k < a.K) v.x = p[0];
+                    if (k + 1 < a.K) v.y = p[1];
+                    if (k + 2 < a.K) v.z = p[2];
+                    if (k + 3 < a.K) v.w = p[3];
+                }
+            }
+            vw[u] = v;
+        }
+    };
+    if constexpr (!ASC_K) load_plain(0);
+
     for (int k0 = 0; k0 < a.K; k0 += 32) {
         // ---- stage in[row0.., k0..k0+31] and w[col0.., k0..k0+31] (zero filled outside the matrices).  All global
         // loads of the step are issued into registers first, then written to LDS: otherwise every 16-byte piece
         // pays its own round trip (a 16-workgroup GEMM went from 34 us to a few us with this).
-        constexpr int NI = BR * 8 / 256, NWL = BN * 8 / 256;
         if constexpr (ASC_K) {
             // ascending-k layout: one thread moves a whole 8-chunk (two 16-byte loads) and writes it as two
             // ds_write_b128 {k0,k2,k4,k6} {k1,k3,k5,k7} (the first version scattered it with eight ds_write_b32)
@@ -120,39 +159,6 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
                 *(float4 *)(d + 4) = make_float4(wa2[u][0].y, wa2[u][0].w, wa2[u][1].y, wa2[u][1].w);
             }
         } else {
-        float4 vi[NI], vw[NWL];
-#pragma unroll
-        for (int u = 0; u < NI; ++u) {
-            const int t = tid + u * 256, r = t >> 3, q = t & 7, k = k0 + 4 * q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + r < a.rows) {
-                const float *p = a.in + (size_t)(row0 + r) * a.ld_in + k;
-                if (k + 3 < a.K && ((a.ld_in & 3) == 0)) v = *(const float4 *)p;
-                else {
-                    if (k < a.K) v.x = p[0];
-                    if (k + 1 < a.K) v.y = p[1];
-                    if (k + 2 < a.K) v.z = p[2];
-                    if (k + 3 < a.K) v.w = p[3];
-                }
-            }
-            vi[u] = v;
-        }
-#pragma unroll
-        for (int u = 0; u < NWL; ++u) {
-            const int t = tid + u * 256, r = t >> 3, q = t & 7, k = k0 + 4 * q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col0 + r < a.M) {
-                const float *p = a.w + (size_t)(col0 + r) * a.ld_w + k;
-                if (k + 3 < a.K && ((a.ld_w & 3) == 0)) v = *(const float4 *)p;
-                else {
-                    if (k < a.K) v.x = p[0];
-                    if (k + 1 < a.K) v.y = p[1];
-                    if (k + 2 < a.K) v.z = p[2];
-                    if (k + 3 < a.K) v.w = p[3];
-                }
-            }
-            vw[u] = v;
-        }
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
             const int t = tid + u * 256, r = t >> 3, q = t & 7;
@@ -185,6 +191,9 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
         }
         }
         __syncthreads();
+        if constexpr (!ASC_K) {
+            if (k0 + 32 < a.K) load_plain(k0 + 32);
+        }
 #pragma unroll
         for (int k8 = 0; k8 < 4; ++k8) {
             float4 wa[TI], xb[TQ];
