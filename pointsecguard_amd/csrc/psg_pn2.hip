@@ -656,45 +656,64 @@ __global__ void gather_starts_kernel(const int32_t *__restrict__ starts, int32_t
     if (p < P) out[p] = starts[((size_t)(p / B) * 4 + level) * B + (p % B)];
 }
 
+constexpr int INV_NT = 1024;
+
 // Inverse of the 3-NN tables: for every coarse point the (fine point, weight) pairs that interpolate from it,
 // as CSR sorted by fine point, so the backward pass can GATHER (fixed summation order, no atomics) what the
 // reference's autograd scatter-adds (index_points backward, pointnet_util.py:308).
-__global__ __launch_bounds__(256) void build_inv_nn_kernel(const int32_t *__restrict__ nn_idx, const float *__restrict__ nn_w,
-                                                           int N, int S, int32_t *__restrict__ inv_off,
-                                                           int2 *__restrict__ inv_ent)
+// One workgroup per problem; counters and the whole entry array are staged in LDS (3 N 16-bit fine indices + 3 N
+// weights + S + 1 counters: 78 KiB at N = 4096, S = 1024), so the per-list sort never touches HBM and the lists leave
+// the CU as one coalesced stream (the first version sorted in global memory: 640 MB of traffic per launch).
+__global__ __launch_bounds__(INV_NT) void build_inv_nn_kernel(const int32_t *__restrict__ nn_idx, const float *__restrict__ nn_w,
+                                                              int N, int S, int32_t *__restrict__ inv_off,
+                                                              int2 *__restrict__ inv_ent)
 {
-    extern __shared__ int s_cnt[];   // [S + 1]
+    extern __shared__ int s_nn[];
+    int *s_cnt = s_nn;                                         // [S + 1]
+    float *s_wt = (float *)(s_nn + S + 1);                     // [3 N]
+    unsigned short *s_fine = (unsigned short *)(s_wt + 3 * N); // [3 N] fine point of every entry (< 8192)
     const size_t p = blockIdx.x;
     const int32_t *idx = nn_idx + p * N * 3;
     const float *w = nn_w + p * N * 3;
     int32_t *off = inv_off + p * (S + 1);
     int2 *ent = inv_ent + p * N * 3;
-    for (int i = threadIdx.x; i <= S; i += 256) s_cnt[i] = 0;
+    for (int i = threadIdx.x; i <= S; i += INV_NT) s_cnt[i] = 0;
     __syncthreads();
-    for (int e = threadIdx.x; e < 3 * N; e += 256) atomicAdd(&s_cnt[idx[e]], 1);
+    for (int e = threadIdx.x; e < 3 * N; e += INV_NT) atomicAdd(&s_cnt[idx[e]], 1);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int i = 0; i < S; ++i) { const int c = s_cnt[i]; s_cnt[i] = run; off[i] = run; run += c; }
-        off[S] = run;
-        s_cnt[S] = run;
+    if (threadIdx.x < 64) {   // exclusive scan by one wave: 64 contiguous chunks, then a scan of the chunk sums
+        const int lane = threadIdx.x, chunk = (S + 63) / 64, lo = min(S, lane * chunk), hi = min(S, lo + chunk);
+        int sum = 0;
+        for (int i = lo; i < hi; ++i) sum += s_cnt[i];
+        int incl = sum;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        int run = incl - sum;
+        for (int i = lo; i < hi; ++i) { const int c = s_cnt[i]; s_cnt[i] = run; off[i] = run; run += c; }
+        if (lane == 63) { off[S] = incl; s_cnt[S] = incl; }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 3 * N; e += 256) {
+    for (int e = threadIdx.x; e < 3 * N; e += INV_NT) {
         const int pos = atomicAdd(&s_cnt[idx[e]], 1);
-        ent[pos] = make_int2(e / 3, __float_as_int(w[e]));
+        s_fine[pos] = (unsigned short)(e / 3);
+        s_wt[pos] = w[e];
     }
     __syncthreads();
     // after the fill s_cnt[i] == end of list i; start = end of list i-1 (0 for i == 0)
-    for (int i = threadIdx.x; i < S; i += 256) {
+    for (int i = threadIdx.x; i < S; i += INV_NT) {
         const int lo = i ? s_cnt[i - 1] : 0, hi = s_cnt[i];
-        for (int a = lo + 1; a < hi; ++a) {   // insertion sort by fine point (lists are short)
-            const int2 key = ent[a];
+        for (int a = lo + 1; a < hi; ++a) {   // insertion sort by fine point (the fill order above is not deterministic)
+            const unsigned short kf = s_fine[a];
+            const float kw = s_wt[a];
             int q = a - 1;
-            while (q >= lo && ent[q].x > key.x) { ent[q + 1] = ent[q]; --q; }
-            ent[q + 1] = key;
+            while (q >= lo && s_fine[q] > kf) { s_fine[q + 1] = s_fine[q]; s_wt[q + 1] = s_wt[q]; --q; }
+            s_fine[q + 1] = kf; s_wt[q + 1] = kw;
         }
     }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 3 * N; e += INV_NT) ent[e] = make_int2((int)s_fine[e], __float_as_int(s_wt[e]));
 }
 
 // Inverse of the group tables: for every source point the grouped rows (group*32 + sample) that gathered it, as
@@ -703,7 +722,6 @@ __global__ __launch_bounds__(256) void build_inv_nn_kernel(const int32_t *__rest
 // contiguously and in a fixed order.  (query_ball_point pads a group by repeating its first member, so a point
 // can occur several times in one group: autograd's index backward sums every occurrence; see the kernel body for
 // why only the first is listed.)  One workgroup per problem, the whole list array staged in LDS (<= 32768 16-bit row ids + 8193 counters).
-constexpr int INV_NT = 1024;
 __global__ __launch_bounds__(INV_NT) void build_inv_group_kernel(const int32_t *__restrict__ gidx, int n_rows, int n_src,
                                                                  int ks, int32_t *__restrict__ inv_off,
                                                                  int32_t *__restrict__ inv_pos)
@@ -1060,7 +1078,9 @@ extern "C" int psg_pn2_plan_build(psg_pn2_ws *ws, const float *x0, const int32_t
             if ((rc = psg_three_nn(ws->ctx, ws->xyz[l], n_clouds, ws->xyz[l + 1], P, Np, S, ws->nn_idx[l], ws->nn_w[l],
                                    st)))
                 return rc;
-            hipLaunchKernelGGL(build_inv_nn_kernel, dim3(P), dim3(256), (size_t)(S + 1) * 4, st, ws->nn_idx[l], ws->nn_w[l],
+            const size_t nn_lds = (size_t)(S + 1) * 4 + (size_t)3 * Np * 6;
+            if (nn_lds > 48 * 1024) PSG_CHECK_HIP(allow_big_lds((const void *)build_inv_nn_kernel));
+            hipLaunchKernelGGL(build_inv_nn_kernel, dim3(P), dim3(INV_NT), nn_lds, st, ws->nn_idx[l], ws->nn_w[l],
                                Np, S, ws->inv_off[l], ws->inv_ent[l]);
             PSG_LAUNCH_CHECK();
         }
