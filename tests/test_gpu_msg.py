@@ -287,3 +287,30 @@ def test_msg_bit_reproducible_and_stream_safe(model, nb):
     torch.cuda.synchronize()
     for o in outs:
         assert torch.equal(o, ref)
+
+
+@pytest.mark.parametrize("n_point,batch", [(1024, 2), (8192, 1)])
+def test_msg_smallest_and_largest_clouds(model, oracle, n_point, batch):
+    """Workspace limits (1024 / 8192 points): geometry bit-exact, log-probs and colour gradient against the oracle."""
+    from oracle import pn2
+    from pointsecguard_amd import runtime
+    rooms = make_rooms(batch, 900 + n_point, num_point=n_point)
+    labels = rule_labels(rooms)
+    torch.manual_seed(n_point)
+    starts = np.stack([torch.randint(0, n, (batch,)).numpy() for n in (n_point, 1024, 256, 64)]).astype(np.int32)
+    ws = runtime.PN2Workspace(batch, n_point, 1, arch=runtime.ARCH_MSG)
+    x0 = dev(rooms)
+    ws.plan_build(x0, dev(starts.reshape(1, 4, batch), torch.int32), 1)
+    logp = ws.forward(model, 0, x0)
+    dlogp, _ = _ce_grad(logp, dev(labels.astype(np.int32)), n_point)
+    dx0 = ws.backward(model, 0, dlogp)
+    torch.cuda.synchronize()
+    for b in range(batch):
+        geom = oracle.geometry(rooms[b, :, :3], starts[:, b])
+        for lvl in range(4):
+            assert np.array_equal(ws.plan_tensor(1, lvl, 0, b).cpu().numpy(), geom["group"][lvl][0])
+            assert np.array_equal(ws.plan_tensor(5, lvl, 0, b).cpu().numpy(), geom["group"][lvl][1])
+        lp, cache = oracle.forward(rooms[b], geom)
+        assert np.abs(logp[b].cpu().numpy() - lp).max() <= TOL
+        dl, _ = pn2.nll_logp_grad(lp, labels[b], 1.0 / n_point)
+        check_grad(dx0[b, :, 3:6].cpu().numpy(), oracle.backward_color(cache, dl))
