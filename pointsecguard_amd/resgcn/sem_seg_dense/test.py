@@ -64,3 +64,19 @@ def random_noise(model, loader, opt, noise_range=1.0, log=True):
                                                                    np.mean(mious[i])))
     return dict(dis=dis, acc=acc, adv_acc=adv_acc, mious=mious, adv_mious=adv_mious, Is=Is, Us=Us, adv_Is=adv_Is,
                 adv_Us=adv_Us, log=path)
+
+
+def attack(model, test_loader, opt):
+    """The `--attack` dispatcher of the reference's test.py:33-45."""
+    from .attacks import NB_attack_exp, NU_attack_exp, tar_NB_attack_exp, tar_NU_attack_exp
+    if opt.attack == 'random':
+        return random_noise(model, test_loader, opt)
+    if opt.attack == 'NU_attack':
+        return NU_attack_exp(model, test_loader, opt)
+    if opt.attack == 'tar_NU_attack':
+        return tar_NU_attack_exp(model, test_loader, opt)
+    if opt.attack == 'NB_attack':
+        return NB_attack_exp(model, test_loader, opt)
+    if opt.attack == 'tar_NB_attack':
+        return tar_NB_attack_exp(model, test_loader, opt)
+    raise ValueError("unknown attack %r" % (opt.attack,))

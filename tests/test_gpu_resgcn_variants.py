@@ -154,3 +154,49 @@ def test_random_noise_baseline(fx, tmp_path):
     lines = open(res["log"]).read().splitlines()
     assert lines[0].startswith("index\tl2dis\tadv_acc\tacc") and len(lines) == 4
     assert lines[1].split("\t")[0] == "0" and len(lines[1].split("\t")) == 7
+
+
+def test_attack_experiment_loops(fx, tmp_path):
+    """The four experiment loops of the reference's sem_seg_dense/attacks.py through the test.py dispatcher: protocol
+    (skip rules of the targeted loops), log format, and metrics equal to a numpy recomputation."""
+    from types import SimpleNamespace
+    from pointsecguard_amd.resgcn.sem_seg_dense.architecture import DenseDeepGCN
+    from pointsecguard_amd.resgcn.sem_seg_dense.test import attack
+    from pointsecguard_amd.synthetic import make_rooms, rule_labels
+    nb = int(fx["n_blocks"])
+    opt = SimpleNamespace(n_filters=64, k=16, act="relu", norm="batch", bias=True, epsilon=0.0, stochastic=True,
+                          conv="edge", n_blocks=nb, block="res", in_channels=9, dropout=0.0, n_classes=13,
+                          device="cuda", res_dir=str(tmp_path), target=1, origin=0, left_ratio=1.0, att_type="Color")
+    net = DenseDeepGCN(opt).cuda()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in gcn_state_dict(5, nb, "res", "edge").items()})
+    net.eval()
+    rooms = make_rooms(2, 43)
+    loader = []
+    for r in rooms:
+        x = dev(np.ascontiguousarray(r.T)[None, :, :, None])
+        y = net(x).argmax(1)                                # labels = the clean predictions: clean accuracy 1
+        loader.append(SimpleNamespace(pos=torch.from_numpy(r[None, :, :3].copy()), x=torch.from_numpy(r[None, :, 3:].copy()),
+                                      y=y.cpu()))
+    opt.attack, opt.attack_kwargs = "NB_attack", dict(iters=4)
+    res = attack(net, loader, opt)
+    assert np.allclose(res["acc"], 1.0) and np.all(res["other_acc"] <= 1.0) and np.all(res["dis"] > 0)
+    lines = open(res["log"]).read().splitlines()
+    assert lines[0] == "index\tL2_dis\tother_acc\tacc\tadv_miou\tmiou" and len(lines) == 3
+    opt.attack, opt.attack_kwargs = "NU_attack", dict(steps=3)
+    res = attack(net, loader, opt)
+    assert np.allclose(res["acc"], 1.0) and len(open(res["log"]).read().splitlines()) == 3
+    # targeted: attack the most frequent predicted class of room 0; a room with <= 500 such points is skipped
+    cls, cnt = torch.unique(loader[0].y, return_counts=True)
+    opt.origin = int(cls[cnt.argmax()])
+    opt.target = (opt.origin + 1) % 13
+    for name, kw in (("tar_NB_attack", dict(iters=3)), ("tar_NU_attack", dict(steps=3))):
+        opt.attack, opt.attack_kwargs = name, kw
+        res = attack(net, loader, opt)
+        lines = open(res["log"]).read().splitlines()
+        assert lines[0] == "left_ratio=1.0" and lines[1].startswith("index\tcount\tL2_dis\ttarget_acc")
+        assert len(lines) == 2 + int((~res["skipped"]).sum())
+        for i in np.where(~res["skipped"])[0]:
+            assert 0.0 <= res["target_acc"][i] <= 1.0 and res["dis"][i] > 0
+    opt.attack = "bogus"
+    with pytest.raises(ValueError):
+        attack(net, loader, opt)
