@@ -24,6 +24,8 @@ CLASSES = ['ceiling', 'floor', 'wall', 'beam', 'column', 'window', 'door', 'tabl
            'board', 'clutter']   # NB_nontarget_test_semseg.py:35
 LOG_HEADER = "index\tL2_dis\tadv_acc\tacc\tadv_miou\tmiou\n"            # :110
 LOG_ROW = "%d\t%.3f\t%.5f\t%.5f\t%.5f\t\t%.5f\n"                         # :213-215
+TARGETED_LOG_HEADER = "ori\tindex\tL2_dis\tcount\t target acc\tadv_acc\tacc\tadv_miou\tmiou\n"      # NB_target_test_semseg.py:93
+TARGETED_LOG_ROW = "%d\t%d\t%.3f\t%d\t%.5f\t%.5f\t%.5f\t%.5f\t\t%.5f\n"                          # :226-229
 
 
 class ScannetDatasetWholeScene:
@@ -162,7 +164,7 @@ def _miou(counters):
 
 
 def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_votes=1, log_path=None, rank=0, world=1,
-                         log=print):
+                         log=print, targeted=None):
     """The reference's evaluation loop (NB_nontarget_test_semseg.py:126-291) with the per-point work on the GPU.
 
     classifier: an eval-mode `get_model` on the GPU; make_attack(classifier) -> a torchattacks attack object (e.g.
@@ -170,9 +172,15 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
     PointNet/test_semseg.py (the "adversarial" columns then repeat the clean ones); dataset: ScannetDatasetWholeScene.
     Scenes are dealt round-robin to ranks; the int64 counters are summed over ranks at the end.  Returns a dict with
     the totals the reference prints (:272-291) and per-scene mIoUs; TSV rows go to `log_path` (rank-suffixed when
-    world > 1) in the reference's format."""
+    world > 1) in the reference's format.
+
+    targeted = dict(origin=o, target=t) selects the protocol of the targeted scripts (NB_target_test_semseg.py:157-229,
+    NU_target_test_semseg.py): per batch mask = (labels == origin), no attack when the batch holds no such point, the
+    attack is built per batch as make_attack(classifier, target, mask[0]) (the reference passes the FIRST block's mask,
+    :177), and the TSV rows carry origin, count and the target accuracy over the masked points (:226-229); rows are only
+    written for attacked batches."""
     dev = next(classifier.parameters()).device
-    attack = make_attack(classifier) if make_attack is not None else None
+    attack = make_attack(classifier) if (make_attack is not None and targeted is None) else None
     n_pt = dataset.block_points
     total = torch.zeros(2, 3, NUM_CLASSES, dtype=torch.int64, device=dev)   # [clean | adversarial][seen, correct, union]
     scene_rows = []
@@ -180,7 +188,7 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
     if log_path is not None:
         path = log_path if world == 1 else "%s.rank%d" % (log_path, rank)
         fh = open(path, "w")
-        fh.write(LOG_HEADER)
+        fh.write(LOG_HEADER if targeted is None else TARGETED_LOG_HEADER)
     my_scenes = shard_scenes(list(range(len(dataset))), rank, world)
     for si in my_scenes:
         labels_np = dataset.semantic_labels_list[si]
@@ -200,8 +208,15 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
                 smpw = torch.from_numpy(scene_smpw[lo:hi].astype(np.float32)).to(dev)
                 seg_pred, _ = classifier(torch_data)
                 seg_pred = seg_pred.detach().contiguous()
-                if attack is not None:
-                    adv_images = attack(torch_data, gt_np)
+                count, mask_np = 0, None
+                if targeted is not None:
+                    mask_np = gt_np == targeted["origin"]
+                    count = int(mask_np.sum())
+                    batch_attack = make_attack(classifier, targeted["target"], mask_np[0]) if count else None
+                else:
+                    batch_attack = attack
+                if batch_attack is not None:
+                    adv_images = batch_attack(torch_data, gt_np)
                     adv_seg_pred, _ = classifier(adv_images)
                     adv_seg_pred = adv_seg_pred.detach().contiguous()
                 else:
@@ -214,8 +229,16 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
                 rows = float((hi - lo) * n_pt)
                 acc = float(c_clean[1].sum().item()) / rows
                 adv_acc = float(c_adv[1].sum().item()) / rows
-                line = LOG_ROW % (sbatch, float(dis.item()), adv_acc, acc, _miou(c_adv), _miou(c_clean))
-                if fh is not None:
+                if targeted is None:
+                    line = LOG_ROW % (sbatch, float(dis.item()), adv_acc, acc, _miou(c_adv), _miou(c_clean))
+                elif count:
+                    m = torch.from_numpy(mask_np).to(dev)
+                    target_acc = float((adv_seg_pred.argmax(dim=2)[m] == targeted["target"]).sum().item()) / count
+                    line = TARGETED_LOG_ROW % (targeted["origin"], sbatch, float(dis.item()), count, target_acc, adv_acc, acc,
+                                               _miou(c_adv), _miou(c_clean))
+                else:
+                    line = None
+                if fh is not None and line is not None:
                     fh.write(line)
         c_scene = vote_stats(pool, scene_labels)
         c_scene_adv = vote_stats(adv_pool, scene_labels)

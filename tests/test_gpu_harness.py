@@ -133,3 +133,34 @@ def test_whole_scene_sharded_over_ranks(tmp_path):
     a, b = json.load(open(one)), json.load(open(two))
     assert a["counters"] == b["counters"]
     assert a["miou"] == b["miou"] and a["adv_miou"] == b["adv_miou"]
+
+
+def test_whole_scene_targeted_protocol(tmp_path, weights_sd):
+    """The targeted scripts' protocol (NB_target_test_semseg.py): per-batch mask of the origin class, batches without it
+    are not attacked and not logged, extra columns; colours outside the first block's mask never move."""
+    from pointsecguard_amd import harness
+    from pointsecguard_amd.attacks import torchattacks
+    from pointsecguard_amd.models.pointnet2_sem_seg import get_model
+    ds = harness.ScannetDatasetWholeScene(None, block_points=1024, scenes={"Area_5_a.npy": synth_scene(31, 5000, 1.6, 1.2)})
+    net = get_model(13).cuda().eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in weights_sd.items()})
+    labels = ds.semantic_labels_list[0]
+    origin = int(np.bincount(labels.astype(np.int64)).argmax())
+    np.random.seed(5)
+    torch.manual_seed(5)
+    path = tmp_path / "tar.txt"
+    seen = []
+
+    def make(m, target, mask):
+        seen.append(int(mask.sum()))
+        return torchattacks.tar_NB_attack(m, eps=0.5, alpha=0.1, iters=3, target=target, mask=mask)
+
+    res = harness.evaluate_whole_scene(net, ds, make, batch_size=2, log_path=str(path), log=lambda *_: None,
+                                       targeted=dict(origin=origin, target=(origin + 1) % 13))
+    rows = path.read_text().splitlines()
+    assert rows[0] == "ori\tindex\tL2_dis\tcount\t target acc\tadv_acc\tacc\tadv_miou\tmiou"
+    assert len(rows) - 1 == len(seen) and len(seen) >= 1
+    for r in rows[1:]:
+        f = r.split("\t")
+        assert len(f) == 10 and int(f[0]) == origin and int(f[3]) > 0 and 0.0 <= float(f[4]) <= 1.0
+    assert res["counters"][0][0].sum() == 5000
