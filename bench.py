@@ -72,19 +72,23 @@ class Ranks:
     """One process per GPU (torch.distributed.run): RANK / LOCAL_RANK / WORLD_SIZE from the environment, RCCL
     (backend "nccl") for the barrier and the max-over-ranks time; PSG_BENCH_BACKEND=gloo lets several ranks share one
     GPU to rehearse the multi-rank path on a single-GPU box (RCCL refuses two ranks on one device).  Work is sharded
-    by rank with no data-path collective: every rank attacks its own rooms / clouds (weak scaling)."""
+    by rank with no data-path collective: every rank attacks its own rooms / clouds (weak scaling).
+    `cuda=False` (the launch rehearsal only, see main_rehearse) keeps every torch.cuda call out."""
 
-    def __init__(self, args):
+    def __init__(self, args, cuda=True):
         import torch
         self.rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        if args.gpus > 1 and self.world != args.gpus:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (
-                args.gpus, args.gpus))
-        backend = os.environ.get("PSG_BENCH_BACKEND", "nccl")
-        self.dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(self.dev_index)
+        self.cuda = cuda
+        if args.gpus != self.world:
+            raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: start it plainly (python bench.py --gpus N "
+                             "launches its own ranks) or with torch.distributed.run --nproc-per-node N" % (args.gpus, self.world))
+        backend = os.environ.get("PSG_BENCH_BACKEND", "nccl") if cuda else "gloo"
+        self.device = "cuda" if cuda else "cpu"
+        if cuda:
+            self.dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(self.dev_index)
         self.dist = None
         if self.world > 1:
             import torch.distributed as dist
@@ -97,10 +101,12 @@ class Ranks:
 
     def fence(self):
         import torch
-        torch.cuda.synchronize()
+        if self.cuda:
+            torch.cuda.synchronize()
         if self.dist is not None:
             self.dist.barrier()
-        torch.cuda.synchronize()
+        if self.cuda:
+            torch.cuda.synchronize()
 
     def timed(self, fn):
         """barrier + synchronize, fn(), barrier + synchronize; returns the MAX elapsed seconds over ranks."""
@@ -111,7 +117,7 @@ class Ranks:
         self.fence()
         elapsed = time.perf_counter() - t0
         if self.dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed
@@ -120,7 +126,7 @@ class Ranks:
         import torch
         if self.dist is None:
             return x
-        t = torch.tensor([float(x)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([float(x)], dtype=torch.float64, device=self.device)
         self.dist.all_reduce(t)
         return float(t.item())
 
@@ -128,6 +134,39 @@ class Ranks:
         if self.dist is not None:
             self.dist.barrier()
             self.dist.destroy_process_group()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: start the N ranks ourselves, one process per GPU, as
+    children of THIS process (which has not imported torch, let alone touched a GPU: nothing is re-exec'ed), relay
+    their output (rank 0 prints the JSON line) and exit with the launcher's code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    proc = subprocess.Popen(cmd, env=env)
+    raise SystemExit(proc.wait())
+
+
+def main_rehearse(args):
+    """PSG_BENCH_REHEARSE=1: the launch / rendezvous / barrier / max-over-ranks / rank-0-prints plumbing of every
+    workload with NO device work (CPU test of `python bench.py --gpus 2`, gloo).  The line says so and carries no value."""
+    R = Ranks(args, cuda=False)
+    elapsed = R.timed(lambda: time.sleep(0.002 * args.steps * (1 + R.rank)))
+    units = R.sum(args.steps)
+    result = {"metric": "rehearsal", "rehearsal": True, "value": None, "n_gpus": R.world, "steps": args.steps,
+              "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "units_all_ranks": units,
+              "workload": args.workload}
+    if R.rank == 0:
+        print(json.dumps(result), flush=True)
+    R.done()
+    return result
 
 
 def main():
@@ -164,6 +203,10 @@ def main():
                     help="device batches in flight per GPU (one HIP stream + workspace each)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+    if os.environ.get("PSG_BENCH_REHEARSE") == "1":
+        return main_rehearse(args)
     if args.workload == "resgcn":
         return main_resgcn(args)
     if args.workload == "tarnu":
@@ -173,25 +216,8 @@ def main():
     if args.workload == "randla":
         return main_randla(args)
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (
-            args.gpus, args.gpus))
-    # one rank per GPU; PSG_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the multi-rank path on a
-    # single-GPU box (RCCL refuses two ranks on one device)
-    backend = os.environ.get("PSG_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend)
+    R = Ranks(args)
+    rank, world, dist = R.rank, R.world, R.dist
 
     from pointsecguard_amd import runtime
     from pointsecguard_amd.synthetic import make_rooms, rule_labels
@@ -241,22 +267,7 @@ def main():
     for i in range(n_warm):
         step(i)
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
-    t0 = time.perf_counter()
-    for i in range(n_warm, n_all):
-        step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = R.timed(lambda: [step(i) for i in range(n_warm, n_all)])
 
     # ---- attack statistics over the timed steps: clean vs adversarial accuracy / mIoU (RCCL all-reduce of counters)
     clean = torch.zeros(3, 13, dtype=torch.int64, device="cuda")
@@ -343,9 +354,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(sd, rooms[n_warm][:BATCH], labels[n_warm][:BATCH],
                                                   starts[n_warm][:, :, :BATCH], args.cpu_iters)
         print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    R.done()
     return result
 
 

@@ -70,3 +70,37 @@ def test_counter_all_reduce_gloo_world2():
     m = sharding.metrics_from_counters(total)
     assert abs(m["acc"] - (expect[1].sum() / expect[0].sum())) < 1e-12
     assert 0 < m["miou"] < 1 and 0 < m["micro_iou"] < 1
+
+
+def _run_bench(extra_args, env_extra):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra_args, env=env, capture_output=True,
+                         text=True, timeout=300)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, [json.loads(l) for l in lines]
+
+
+def test_bench_plain_gpus2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` exactly as the driver types it (no torch.distributed.run, no WORLD_SIZE): bench.py
+    starts the two ranks itself and relays rank 0's single JSON line.  PSG_BENCH_REHEARSE=1 keeps device work out
+    (there is no GPU here): launch, rendezvous, barriers, max-over-ranks time and the rank-0 print are the real code."""
+    for workload in ("pointnet2", "resgcn", "tarnu"):
+        out, lines = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", workload],
+                                {"PSG_BENCH_REHEARSE": "1"})
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert len(lines) == 1, out.stdout
+        line = lines[0]
+        assert line["rehearsal"] is True and line["value"] is None and line["n_gpus"] == 2 and line["units_all_ranks"] == 8
+        # rank 1 sleeps twice as long as rank 0: the reported time is the MAX over ranks
+        assert line["ms_per_step"] >= 3.9
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    out, lines = _run_bench(["--gpus", "1", "--steps", "2"], {"PSG_BENCH_REHEARSE": "1", "WORLD_SIZE": "2", "RANK": "0",
+                                                              "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "1"})
+    assert out.returncode != 0 and not lines
