@@ -331,12 +331,15 @@ __global__ __launch_bounds__(KS_WAVES * 64) void knn_select_kernel(const float *
     if (lane < k) out[row * k + lane] = (int32_t)(cand[(size_t)lane * d] & 0xFFFull);
 }
 
+#include "psg_knn_fused.cuh"
+
 // ---- EdgeConv edge pass (forward): y[i][c] = max_k ( s_c * relu(P[i][c] + Q[nbr(i,k)][c]) + t_c ) (+ residual)
 // One thread per (vertex, channel), channel fastest: the 64 lanes of a wave read one 256-byte Q row.
 __global__ void edge_max_fwd_kernel(const float *__restrict__ pq, const int32_t *__restrict__ nbr,
                                     const float *__restrict__ scale, const float *__restrict__ shift,
                                     const float *__restrict__ resid, int ld_res, float *__restrict__ out, int ld_out,
-                                    uint8_t *__restrict__ arg, int N, size_t total, float *__restrict__ sq_out)
+                                    uint8_t *__restrict__ arg, int N, size_t total, float *__restrict__ sq_out,
+                                    float *__restrict__ xp_out)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -359,6 +362,10 @@ __global__ void edge_max_fwd_kernel(const float *__restrict__ pq, const int32_t 
     if (resid) best += resid[v * ld_res + c];
     out[v * ld_out + c] = best;
     arg[t] = (uint8_t)(bk | (bact ? 0x80 : 0));
+    if (xp_out) {   // the next block's kNN reads the features in MFMA operand order (psg_knn_fused.cuh)
+        const int s4 = c >> 2, g4 = c & 3;
+        xp_out[(v >> 4) * 1024 + (size_t)((((s4 >> 2) * 64) + (int)(v & 15) + 16 * g4) * 4 + (s4 & 3))] = best;
+    }
     if (sq_out) {
         // squared norm of the vertex's 64 new features for the next block's kNN, in torch.sum's order for 64
         // contiguous floats (sumsq_rows_kernel): u_c = x_c^2 + x_{c+32}^2, t_l = ((u_l + u_{8+l}) + u_{16+l}) + u_{24+l},
@@ -597,6 +604,8 @@ struct psg_gcn_ws {
     float *feats, *dfeats;     // [B*N][fdim]
     float *dist;               // [B*N][N]
     float *sq;                 // [B*N]
+    float *xp;                 // [B*N][64] the current block's features in MFMA operand order (fused kNN)
+    bool knn_fused = true;     // PSG_GCN_KNN=matrix: the round-1 path (distance matrix in HBM + selection kernel)
     float *pq, *dpq;           // [B*N][128]
     int32_t *nbr;              // [n_blocks][B*N][16]
     uint8_t *arg;              // [n_blocks][B*N][64]
@@ -658,10 +667,50 @@ __global__ void extract_color3_kernel(const float *__restrict__ x0, float *__res
     if (t < rows * 3) ori[t] = x0[(t / 3) * 9 + 3 + (t % 3)];
 }
 
+bool knn_fused_ok(const psg_gcn_ws *ws, int C, int d)
+{
+    return ws->knn_fused && C == 64 && (ws->N % 16) == 0 && ws->N <= 4096 && (KNB - 1) * d + 1 <= 496;
+}
+
+int knn_fused_launch(psg_gcn_ws *ws, int d, int32_t *out, hipStream_t st)
+{
+    KnnFusedArgs a;
+    a.xp = ws->xp; a.sq = ws->sq; a.out = out; a.N = ws->N; a.k = KNB; a.d = d;
+    a.KK = (KNB - 1) * d + 1;
+    a.M = 64;
+    while (a.M < a.KK) a.M <<= 1;
+    const int npl = a.KK > 406 ? 10 : knn_fused_class(a.KK);
+    const int cap = npl == 10 ? 624 : 64 * npl;
+    const int slack = cap - a.KK;
+    a.TOL = slack / 8;
+    a.LOW = a.KK + slack / 4;
+    a.HIGH = cap - std::min(48, slack / 3);
+    const dim3 grid((unsigned)((size_t)ws->B * ws->N / KF_Q)), block(KF_WAVES * 64);
+    const size_t lds = knn_fused_lds_bytes(npl);
+    switch (npl) {
+    case 2: hipLaunchKernelGGL(knn_fused_kernel<2>, grid, block, lds, st, a); break;
+    case 4: hipLaunchKernelGGL(knn_fused_kernel<4>, grid, block, lds, st, a); break;
+    case 6: hipLaunchKernelGGL(knn_fused_kernel<6>, grid, block, lds, st, a); break;
+    default: hipLaunchKernelGGL(knn_fused_kernel<10>, grid, block, lds, st, a); break;
+    }
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+// have_sq: ws->sq (and, on the fused path, ws->xp) already hold the norms / operand copy of x (the forward pass gets
+// them from the producing edge_max_fwd kernel)
 int knn_graph(psg_gcn_ws *ws, const float *x, int ld, int C, int d, int32_t *out, hipStream_t st, bool have_sq = false)
 {
     const size_t rows = (size_t)ws->B * ws->N;
-    if (!have_sq) {   // (the forward pass gets the norms of a block's output from its edge_max_fwd kernel)
+    if (knn_fused_ok(ws, C, d)) {
+        if (!have_sq) {
+            hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)ceil_div((int)(rows * 64), 256)), dim3(256), 0, st, x, ld, rows,
+                               ws->xp, ws->sq);
+            PSG_LAUNCH_CHECK();
+        }
+        return knn_fused_launch(ws, d, out, st);
+    }
+    if (!have_sq) {
         hipLaunchKernelGGL(sumsq_rows_kernel, dim3(ceil_div((int)rows, 256)), dim3(256), 0, st, x, ld, C, rows, ws->sq);
         PSG_LAUNCH_CHECK();
     }
@@ -826,6 +875,15 @@ extern "C" int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n
     auto *ws = new psg_gcn_ws();
     ws->ctx = ctx; ws->B = batch; ws->N = n_point; ws->n_blocks = n_blocks; ws->fdim = GC * n_blocks;
     ws->block = block; ws->conv = conv;
+    {
+        const char *kv = getenv("PSG_GCN_KNN");
+        ws->knn_fused = !(kv && std::string(kv) == "matrix");
+        // the largest class of the fused kNN kernel needs 80 KB of dynamic LDS (set once, outside any stream capture)
+        PSG_CHECK_HIP(hipFuncSetAttribute((const void *)knn_fused_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)knn_fused_lds_bytes(6)));
+        PSG_CHECK_HIP(hipFuncSetAttribute((const void *)knn_fused_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)knn_fused_lds_bytes(10)));
+    }
     // widest conv input (dense: all earlier outputs) and the total arg-max bytes per vertex of the mr layers
     const int c_max = block == PSG_GCN_BLOCK_DENSE ? std::max(GC, GC * (n_blocks - 1)) : GC;
     size_t arg_total = 9;
@@ -846,6 +904,7 @@ extern "C" int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n
         ws->dfeats = (float *)take(R * ws->fdim * 4);
         ws->dist = (float *)take(R * n_point * 4);
         ws->sq = (float *)take(R * 4);
+        ws->xp = (float *)take(R * 64 * 4);
         ws->pq = (float *)take(R * ws->pq_w * 4);
         ws->dpq = (float *)take(R * ws->pq_w * 4);
         if (conv == PSG_GCN_CONV_MR) {
@@ -968,7 +1027,9 @@ extern "C" int psg_gcn_forward(psg_gcn_model *m, psg_gcn_ws *ws, const float *x0
             if ((rc = launch_gemm<2, 2, EPI_LINEAR, false>(a, st))) return rc;
             hipLaunchKernelGGL(edge_max_fwd_kernel, dim3(g256), dim3(256), 0, st, ws->pq, nbr, L.scale, L.shift,
                                (e == 0 || !res) ? nullptr : xin, F, yout, F, ws->arg + (size_t)e * R * GC, N,
-                               R * GC, (ws->fixed_graphs || dense) ? nullptr : ws->sq);
+                               R * GC, (ws->fixed_graphs || dense) ? nullptr : ws->sq,
+                               (!ws->fixed_graphs && !dense && e + 1 < m->n_blocks &&
+                                knn_fused_ok(ws, GC, m->block == PSG_GCN_BLOCK_PLAIN ? 1 : e + 1)) ? ws->xp : nullptr);
             PSG_LAUNCH_CHECK();
         } else {
             // MRConv2d: BasicConv(cat[x, max_k (x_j - x_i)]) per vertex (+ x for a residual block)

@@ -140,6 +140,22 @@ def gcn_state_dict(seed, n_blocks, block="res", conv="edge"):
     return sd
 
 
+def gcn28_state_dict():
+    """State dict of the 28-block ResGCN used by the BASELINE-size fixture (tests/golden/gcn28_room.npz) and by bench.py's
+    resgcn workload: gcn_state_dict(7, 28) for the two big matrices (fusion_block.0.weight, prediction.0.0.weight: 13 MB
+    that stay a seeded recipe) and, for everything else, the values a short fit of the reference network produced
+    (tests/golden/gcn28_weights_small.npz, written by tests/golden/make_golden_big.py: fit_gcn28).  Random residual blocks
+    alone blow the features up by 1e5 over 28 blocks."""
+    import os
+    sd = gcn_state_dict(7, 28)
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "gcn28_weights_small.npz")
+    small = np.load(path)
+    for k in small.files:
+        assert k in sd and sd[k].shape == small[k].shape, k
+        sd[k] = small[k]
+    return sd
+
+
 # RandLA-Net for S3DIS (RandLA-Net/helper_tool.py:41-60 ConfigS3DIS, RandLANet.py:150-190 of the reference)
 RANDLA_D_OUT = (16, 64, 128, 256, 512)
 RANDLA_RATIOS = (4, 4, 4, 4, 2)
