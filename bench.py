@@ -395,10 +395,11 @@ def main_resgcn(args):
     import torch
     from pointsecguard_amd import runtime
     from pointsecguard_amd.synthetic import make_rooms, rule_labels
-    from pointsecguard_amd.synthetic import gcn_state_dict
+    from pointsecguard_amd.synthetic import gcn28_state_dict, gcn_state_dict
     n_blocks, iters, batch = args.gcn_blocks, 50, args.gcn_batch
     default_cfg = (args.gcn_block, args.gcn_conv, n_blocks) == ("res", "edge", 28)
-    sd = gcn_state_dict(7, n_blocks, args.gcn_block, args.gcn_conv)
+    # default configuration: the fitted 28-block weights of the BASELINE-size parity fixture (tests/golden/gcn28_room.npz)
+    sd = gcn28_state_dict() if default_cfg else gcn_state_dict(7, n_blocks, args.gcn_block, args.gcn_conv)
     F = 64 * n_blocks
     BLOCKS = {"res": runtime.GCN_BLOCK_RES, "plain": runtime.GCN_BLOCK_PLAIN, "dense": runtime.GCN_BLOCK_DENSE}
     CONVS = {"edge": runtime.GCN_CONV_EDGE, "mr": runtime.GCN_CONV_MR}
@@ -435,8 +436,9 @@ def main_resgcn(args):
               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
               "dtype": "f32", "data": "synthetic",
               "config": {"workload": name + " dense sem_seg NB non-targeted PGD (eps=0.3, alpha=2/255, 50 iters), kNN k=16, "
-                                     "batch=%d room(s) x 4096 pts per call (%s); random-init weights" % (batch, 
-                                         "BASELINE configs[3]" if default_cfg else "configuration switch of configs[3]"),
+                                     "batch=%d room(s) x 4096 pts per call (%s); %s weights" % (batch, 
+                                         "BASELINE configs[3]" if default_cfg else "configuration switch of configs[3]",
+                                         "fitted fixture (synthetic.gcn28_state_dict)" if default_cfg else "random-init"),
                          "attacks_in_flight": conc},
               "tflops_effective": 2 * gmac * iters * batch * args.steps * world / elapsed / 1e3 if default_cfg else None}
     if R.rank == 0:

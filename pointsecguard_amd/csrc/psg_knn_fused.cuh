@@ -1,41 +1,64 @@
 // Matrix-free dilated kNN graph in feature space (C = 64): distances, running top-(15 d + 1) selection and the final
-// ordering in ONE kernel; the [N x N] distance matrix never exists (the round-1 path wrote 64 MB per block and re-read
+// ranks in ONE kernel; the [N x N] distance matrix never exists (the round-1 path wrote 64 MB per block and re-read
 // it).  Reference: ResGCN/gcn_lib/dense/torch_edge.py:32-59 (pairwise_distance, dense_knn_matrix: topk(-dist, k*d)) and
 // :19-29 (DenseDilated: every d-th of the sorted neighbours).
 //
 // Included by psg_resgcn.hip inside its anonymous namespace, after the wave helpers (key_of, wave_sum_u32,
 // wave_sort_keys, ...) it shares with the round-1 selection kernel.
 //
-// Work split.  A workgroup (4 waves) owns 16 QUERY points of one room and streams all N candidates of that room past
-// them; wave w takes candidate pairs-of-tiles w, w + 4, ... (32 candidates per step).  Distance tiles come from
-// v_mfma_f32_16x16x4_f32 with A = 16 candidates x K and B = K x 16 queries, so lane l holds, for query l & 15, the four
-// candidates 4 (l >> 4) + r: the query sits on the lane and everything that follows is per-lane work.  The dot product is
-// the ascending-k fmaf chain from 0 (16 chained MFMAs, k = 4 s + (l >> 4) inside step s: the same chain as a CPU sgemm,
-// SURVEY.md 8a'), the distance is (|x_i|^2 + (-2 x_i.x_j)) + |x_j|^2 with torch's rounding; equal features give
-// bit-equal distances, as with the round-1 GEMM.
+// Work split.  A workgroup of 16 waves owns 16 QUERY points of one room and streams all N candidates of that room past
+// them; wave w takes candidate pairs-of-tiles w, w + 16, ... (32 candidates per wave and step, 512 per workgroup and
+// step).  Four waves share a SIMD: while one waits for its operands, an LDS atomic or a barrier, the others keep the
+// matrix pipe busy (the first version had one wave per SIMD and spent 2.7x the MFMA time in the stream, everything else
+// latency-exposed on top).  Distance tiles come from v_mfma_f32_16x16x4_f32 with A = 16 candidates x K and B = K x 16
+// queries, so lane l holds, for query l & 15, the four candidates 4 (l >> 4) + r: the query sits on the lane and
+// everything that follows is per-lane work.  The dot product is the ascending-k fmaf chain from 0 (16 chained MFMAs,
+// k = 4 s + (l >> 4) inside step s; tools/mfma_chain_probe.hip: bit-identical to the host's fmaf chain on 409 600 dots),
+// the distance is (|x_i|^2 + (-2 x_i.x_j)) + |x_j|^2 with torch's rounding: equal features give bit-equal distances.
 // Operands are read straight from L2 in MFMA operand order ("xp": [point / 16][4][64 lanes] float4, element e of
 // lane l in quarter i = feature 4 (4 i + e) + (l >> 4) of point (l & 15)), one coalesced 1-KiB load per quarter; the
-// producer of the features (edge_max_fwd_kernel) writes that copy, knn_prep_kernel does it for the stand-alone entry
-// point.  The next step's operands are in flight under this step's MFMAs.
+// producer of the features (edge_max_fwd_kernel) writes that copy, knn_prep_kernel does it for the stand-alone entry.
 //
-// Selection.  Per query row a buffer of CAP composite keys (distance key << 12 | candidate index: ascending distance,
-// lowest index first, a strict total order) lives in LDS together with a threshold tau.  A candidate is appended iff
-// its key <= tau; slots come from one LDS atomic per lane and step.  When a row runs full the workgroup PRUNES it: a
-// wave finds (bisection on the distance value, counting with DPP wave sums) a new tau with KK <= #(keys <= tau) <=
-// KK + TOL and compacts the row in place.  tau is always the KK-th smallest of the candidates seen so far or larger, so
-// the buffer always contains the true top-KK of what has been seen: exact, for any input order.  Expected appends per
-// row ~ KK (1 + ln(N / KK)) for random order.  If an append would overflow CAP the step is rolled back, every row is
-// pruned exactly to KK and the step's candidates are committed one accumulator register at a time (at most 16 appends
-// per row between checks, KK + 16 <= CAP): slow, but it terminates and is correct for adversarial orders and for
-// massive ties (ties are ordered by index, so an exact prune always reaches KK).
-// After the stream each row is cut to [KK, M], bitonic-sorted by its wave in registers and ranks 0, d, 2d, .. emitted.
+// Selection.  Per query row a buffer of CAP = 1024 composite keys (distance key << 12 | candidate index: ascending
+// distance, lowest index first, a strict total order) lives in LDS (128 KB per workgroup, one workgroup per CU) with a
+// threshold tau.  A candidate is appended iff its key <= tau; slots come from one LDS atomic per lane and step.  When
+// a row gets close to full the workgroup PRUNES: one wave per row finds (regula falsi on the distance value, counting
+// with DPP wave sums) a new tau with KK <= #(keys <= tau) <= KK + TOL and compacts the row in place.  tau is never below
+// the KK-th smallest key seen so far, so the buffer always contains the true top-KK of what has been seen: exact for any
+// input order.  Everything is admitted until the first prune (after 1024 candidates); after it a row receives
+// ~KK ln(N / 1024) more keys, so typical rows are pruned once or twice.  If an append would overflow CAP (adversarial
+// orders) the step is rolled back, every row is cut to exactly KK and the step's candidates are committed one
+// accumulator register at a time (<= 64 appends per row between checks, KK + 64 <= CAP): slow, but it terminates and is
+// exact; ties are ordered by index, so an exact cut always reaches KK.
+//
+// Final ranks.  Only ranks 0, d, .., 15 d are wanted, so the row is not sorted (a 512-key bitonic sort through
+// ds_bpermute cost 34k cycles per row): the <= 512 survivors are binned by distance (1024 linear bins, a monotone map, so
+// bin order = key order), an exclusive scan gives every bin its first rank, the bins that contain a wanted rank are
+// flagged, their few members ("finalists") are collected and each finalist counts the finalists of its own bin below it:
+// first rank of the bin + that count is its exact rank.  More than 256 finalists (hundreds of equal distances) fall
+// back to the bitonic sort.
 #pragma once
 
-constexpr int KF_WAVES = 4;
+constexpr int KF_WAVES = 16;
 constexpr int KF_Q = 16;        // query rows per workgroup (one 16-column MFMA tile)
 constexpr int KF_STEP = 32;     // candidates per wave and step: two 16-row MFMA tiles (two independent accumulators)
+constexpr int KF_CAP = 1024;    // composite keys per row buffer
+constexpr int KF_NPL = KF_CAP / 64;
+constexpr int KF_FIN = 512;     // the final ranking works on <= 512 survivors; the row's upper half is its scratch
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// Diagnostic build only (make EXTRA=-DPSG_KF_STAMP, tools/knn_stamp.py): per-phase cycle sums of wave 0 of every
+// workgroup, written to a buffer no other code reads.  Phases: 0 stream (operands + MFMA + keys + slot allocation),
+// 1 wait at the step barrier, 2 appends, 3 prune events, 4 final ranks, 5 number of prune events, 6 roll-backs.
+#ifdef PSG_KF_STAMP
+__device__ unsigned long long g_kf_stamps[8];
+#define KF_T(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define KF_ACC(i, t1, t0) kf_sum[i] += (t1) - (t0)
+#else
+#define KF_T(var)
+#define KF_ACC(i, t1, t0)
+#endif
 
 struct KnnFusedArgs {
     const float *xp;   // [rows / 16][4][64] float4, operand order (see above); rows = B * N
@@ -43,9 +66,9 @@ struct KnnFusedArgs {
     int32_t *out;      // [rows][k]
     int N;             // points per room, multiple of 16
     int k, d;
-    int KK;            // (k - 1) d + 1 keys decide the output
-    int M;             // sort size: power of two >= KK, <= CAP
-    int HIGH, LOW, TOL;   // prune when an append leaves a row above HIGH; rows above LOW are cut to [KK, KK + TOL]
+    int KK;            // (k - 1) d + 1 keys decide the output (<= 448)
+    unsigned magic;    // ceil(2^18 / d): x / d = (x * magic) >> 18 for x < 2^18 / d
+    int LOW, TOL;      // a prune event cuts the rows above LOW to [KK, KK + TOL]
 };
 
 // xp / sq for the stand-alone entry point: one wave per point, lane = feature (C = 64)
@@ -73,13 +96,15 @@ __global__ void knn_prep_kernel(const float *__restrict__ x, int ld, size_t rows
     }
 }
 
-__device__ __forceinline__ unsigned long long wave_minmax_u64(unsigned long long v, bool want_max)
+// inclusive prefix sum over the 64 lanes (row scans by DPP row_shr, then the row totals by row_bcast)
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const unsigned long long o = ((unsigned long long)__shfl_xor((unsigned)(v >> 32), m) << 32) | __shfl_xor((unsigned)v, m);
-        v = want_max ? (o > v ? o : v) : (o < v ? o : v);
-    }
+    v += dpp_get<0x111, 0xF>(v);   // row_shr:1 (lanes shifted in from outside the row read 0)
+    v += dpp_get<0x112, 0xF>(v);   // row_shr:2
+    v += dpp_get<0x114, 0xF>(v);   // row_shr:4
+    v += dpp_get<0x118, 0xF>(v);   // row_shr:8: inclusive scan inside each row of 16 lanes
+    v += dpp_get<0x142, 0xA>(v);   // row_bcast15: rows 1, 3 += total of the row before
+    v += dpp_get<0x143, 0xC>(v);   // row_bcast31: rows 2, 3 += total of rows 0..1
     return v;
 }
 
@@ -95,28 +120,35 @@ __device__ __forceinline__ unsigned prune_row(unsigned long long *ent, unsigned 
         const unsigned e = (unsigned)(i * 64 + lane);
         v[i] = e < T ? ent[e] : ~0ull;
     }
-    unsigned long long mn = v[0], mx = 0ull;
+    // bracket from the 32-bit distance keys (DPP reductions; a 64-bit min / max through ds_bpermute cost ~3k cycles)
+    unsigned kmn = 0xFFFFFFFFu, kmx = 0u;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-        mn = v[i] < mn ? v[i] : mn;
-        mx = (v[i] != ~0ull && v[i] > mx) ? v[i] : mx;
+        const unsigned kq = (unsigned)(v[i] >> 12);
+        kmn = kq < kmn ? kq : kmn;
+        kmx = (v[i] != ~0ull && kq > kmx) ? kq : kmx;
     }
-    mn = wave_minmax_u64(mn, false);
-    mx = wave_minmax_u64(mx, true);
-    // invariant: #(v <= lo) < KK <= #(v <= hi) = c_hi
-    unsigned long long lo = mn - 1ull, hi = mx;
-    unsigned c_hi = T;
+    kmn = ~wave_max_u32(~kmn);
+    kmx = wave_max_u32(kmx);
+    // invariant: #(v <= lo) = c_lo < KK <= #(v <= hi) = c_hi
+    unsigned long long lo = ((unsigned long long)kmn << 12) - 1ull, hi = ((unsigned long long)kmx << 12) | 0xFFFull;
+    unsigned c_hi = T, c_lo = 0, it = 0;
     while (c_hi > KK + tol && hi - lo > 1ull) {
-        // midpoint in DISTANCE space (the integer keys between a ~0 self distance and the populated binades would
-        // cost ~10 extra halvings), all indices admitted at that distance; integer midpoint when that does not split
-        const float dm = 0.5f * dist_of((unsigned)(lo >> 12)) + 0.5f * dist_of((unsigned)(hi >> 12));
+        // probe in DISTANCE space: interpolate the wanted count between the bracket's counts (regula falsi; every third
+        // probe the plain midpoint, so one-sided convergence cannot stall), all indices admitted at that distance;
+        // integer midpoint of the composite keys when the distance probe does not split the bracket (ties)
+        const float dl = dist_of((unsigned)(lo >> 12)), dh = dist_of((unsigned)(hi >> 12));
+        float frac = ((float)(KK + (tol >> 1)) + 0.5f - (float)c_lo) / (float)(c_hi - c_lo);
+        frac = (it % 3u == 2u) ? 0.5f : fminf(fmaxf(frac, 0.02f), 0.98f);
+        ++it;
+        const float dm = dl + (dh - dl) * frac;
         unsigned long long mid = ((unsigned long long)key_of(dm) << 12) | 0xFFFull;
         if (!(mid > lo && mid < hi)) mid = lo + ((hi - lo) >> 1);
         unsigned c = 0;
 #pragma unroll
         for (int i = 0; i < NPL; ++i) c += v[i] <= mid ? 1u : 0u;
         c = wave_sum_u32(c);
-        if (c < KK) lo = mid;
+        if (c < KK) { lo = mid; c_lo = c; }
         else { hi = mid; c_hi = c; }
     }
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -132,15 +164,125 @@ __device__ __forceinline__ unsigned prune_row(unsigned long long *ent, unsigned 
     return c_hi;
 }
 
-template <int NPL>
+__device__ __forceinline__ unsigned kf_bin(unsigned long long comp, float dmin, float scale)
+{
+    const float t = (dist_of((unsigned)(comp >> 12)) - dmin) * scale;
+    return (unsigned)fminf(fmaxf(t, 0.0f), 1023.0f);      // (NaN -> 0: fmaxf returns the other operand)
+}
+
+// Ranks 0, d, .., (k-1) d of a row's T >= KK composite keys (see the header).  One wave; `row` has KF_CAP slots.
+__device__ __forceinline__ void final_ranks(unsigned long long *row, unsigned T, const KnnFusedArgs &a, unsigned *scratch_cnt,
+                                            int32_t *out, int lane)
+{
+    const unsigned KK = (unsigned)a.KK;
+    if (T > (unsigned)KF_FIN) {
+        unsigned long long thr;
+        const unsigned room = (unsigned)KF_FIN - KK;
+        T = prune_row<KF_NPL>(row, T, KK, room < 64u ? room : 64u, lane, thr);
+    }
+    wave_lds_fence();
+    constexpr int NV = KF_FIN / 64;
+    unsigned long long v[NV];
+    unsigned kmn = 0xFFFFFFFFu, kmx = 0u;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const unsigned e = (unsigned)(i * 64 + lane);
+        v[i] = e < T ? row[e] : ~0ull;
+        const unsigned kq = (unsigned)(v[i] >> 12);
+        kmn = kq < kmn ? kq : kmn;
+        kmx = (v[i] != ~0ull && kq > kmx) ? kq : kmx;
+    }
+    kmn = ~wave_max_u32(~kmn);
+    kmx = wave_max_u32(kmx);
+    const float dmin = dist_of(kmn), dmax = dist_of(kmx);
+    const float scale = dmax > dmin ? 1023.0f / (dmax - dmin) : 0.0f;
+    unsigned *hist = (unsigned *)(row + KF_FIN);          // 512 words = 1024 16-bit bins
+    unsigned long long *fin = row + KF_FIN + 256;         // 256 finalists
+    ((uint4 *)hist)[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
+    ((uint4 *)hist)[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
+    if (lane == 0) *scratch_cnt = 0u;
+    wave_lds_fence();
+    unsigned bin[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        bin[i] = kf_bin(v[i], dmin, scale);
+        if (v[i] != ~0ull) atomicAdd(&hist[bin[i] >> 1], 1u << (16 * (bin[i] & 1u)));
+    }
+    wave_lds_fence();
+    // lane owns bins 16 lane .. 16 lane + 15 (words 8 lane .. 8 lane + 7)
+    uint4 w0 = ((const uint4 *)hist)[2 * lane], w1 = ((const uint4 *)hist)[2 * lane + 1];
+    unsigned w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    unsigned tot = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tot += (w[j] & 0xFFFFu) + (w[j] >> 16);
+    unsigned start = wave_incl_scan_u32(tot) - tot;      // first rank of the lane's first bin
+    const unsigned d = (unsigned)a.d, last = (unsigned)(a.k - 1) * d;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        unsigned nw = 0;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const unsigned h = hlf ? (w[j] >> 16) : (w[j] & 0xFFFFu);
+            unsigned hw = h;
+            if (h) {
+                const unsigned m = (((start + d - 1u) * a.magic) >> 18) * d;      // first multiple of d >= start
+                if (m < start + h && m <= last) hw = 0x8000u | start;             // flagged: holds the bin's first rank
+            }
+            nw |= hw << (16 * hlf);
+            start += h;
+        }
+        w[j] = nw;
+    }
+    ((uint4 *)hist)[2 * lane] = make_uint4(w[0], w[1], w[2], w[3]);
+    ((uint4 *)hist)[2 * lane + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (v[i] != ~0ull) {
+            const unsigned hw = (hist[bin[i] >> 1] >> (16 * (bin[i] & 1u))) & 0xFFFFu;
+            if (hw & 0x8000u) {
+                const unsigned pos = atomicAdd(scratch_cnt, 1u);
+                if (pos < 256u) fin[pos] = ((unsigned long long)(hw & 0x7FFFu) << 44) | v[i];
+            }
+        }
+    }
+    wave_lds_fence();
+    const unsigned F = *scratch_cnt;
+    if (F > 256u) {
+        // hundreds of equal distances: sort the survivors (padding sorts last)
+        for (unsigned t = T + lane; t < (unsigned)KF_FIN; t += 64) row[t] = ~0ull;
+        wave_lds_fence();
+        wave_sort_keys<KF_FIN / 64>(row, lane);
+        wave_lds_fence();
+        if (lane < a.k) out[lane] = (int32_t)(row[(size_t)lane * d] & 0xFFFull);
+        return;
+    }
+    const unsigned long long m44 = (1ull << 44) - 1ull;
+    for (unsigned f = lane; f < F; f += 64) {
+        const unsigned long long x = fin[f];
+        const unsigned st = (unsigned)(x >> 44);
+        const unsigned long long xc = x & m44;
+        unsigned rank = st;
+        for (unsigned g = 0; g < F; ++g) {
+            const unsigned long long y = fin[g];
+            rank += ((unsigned)(y >> 44) == st && (y & m44) < xc) ? 1u : 0u;
+        }
+        const unsigned t = (rank * a.magic) >> 18;
+        if (t * d == rank && t < (unsigned)a.k) out[t] = (int32_t)(xc & 0xFFFull);
+    }
+}
+
 __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a)
 {
-    constexpr int CAP = NPL == 10 ? 624 : 64 * NPL;
+    constexpr int CAP = KF_CAP;
+    constexpr int PER_STEP = KF_WAVES * KF_STEP;                             // candidates per workgroup and step
     extern __shared__ __attribute__((aligned(16))) unsigned char kf_smem[];
     unsigned long long *ent = (unsigned long long *)kf_smem;                 // [KF_Q][CAP]
-    unsigned long long *tau = ent + KF_Q * CAP;                              // [KF_Q]
-    unsigned *cnt = (unsigned *)(tau + KF_Q);                                // [KF_Q]
+    unsigned *tau_k = (unsigned *)(ent + KF_Q * CAP);                        // [KF_Q] threshold: distance key ..
+    unsigned *tau_i = tau_k + KF_Q;                                          // [KF_Q] .. and index (ties)
+    unsigned *cnt = tau_i + KF_Q;                                            // [KF_Q]
     unsigned *flag = cnt + KF_Q;                                             // [3][2]: overflow, prune (by step % 3)
+    unsigned *fcnt = flag + 8;                                               // [KF_WAVES] finalists per row
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 15, g = lane >> 4;
@@ -151,7 +293,15 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
     const size_t qrow = (size_t)blockIdx.x * KF_Q + q;
     const unsigned KK = (unsigned)a.KK;
 
-    if (tid < KF_Q) { tau[tid] = ~0ull - 1ull; cnt[tid] = 0u; }   // (~0ull marks a candidate beyond N: never admitted)
+    if (tid < KF_Q) { tau_k[tid] = 0xFFFFFFFFu; tau_i[tid] = 0xFFFu; cnt[tid] = 0u; }      // everything is admitted
+    // the four waves of a SIMD get different priorities: the matrix pipe serves them one after the other instead of
+    // interleaving them, so one wave's key / append work overlaps the next wave's MFMAs
+    switch (wave >> 2) {
+    case 0: __builtin_amdgcn_s_setprio(3); break;
+    case 1: __builtin_amdgcn_s_setprio(2); break;
+    case 2: __builtin_amdgcn_s_setprio(1); break;
+    default: break;
+    }
     if (tid < 6) flag[tid] = 0u;
 
     const float4 *xp4 = (const float4 *)a.xp;
@@ -164,28 +314,24 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
     const int n_pairs = (a.N + KF_STEP - 1) / KF_STEP;                       // candidate pairs-of-tiles in the room
     const int n_steps = (n_pairs + KF_WAVES - 1) / KF_WAVES;
     const int last_tile = tiles_per_room - 1;
-
-    float4 an0[4], an1[4], sn0, sn1;
-    auto load_step = [&](int step) {
-        const int pair = step * KF_WAVES + wave;
-        const int t0 = min(2 * pair, last_tile), t1 = min(2 * pair + 1, last_tile);   // clamped: masked out below
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            an0[i] = xp4[((tile0 + t0) * 4 + i) * 64 + lane];
-            an1[i] = xp4[((tile0 + t1) * 4 + i) * 64 + lane];
-        }
-        sn0 = sq4[t0 * 4 + g];
-        sn1 = sq4[t1 * 4 + g];
-    };
-    load_step(0);
     __syncthreads();
 
+#ifdef PSG_KF_STAMP
+    unsigned long long kf_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int step = 0; step < n_steps; ++step) {
+        KF_T(t_a);
+        // (a register prefetch of the next step's operands was tried: 128 VGPRs + 22 spilled, 25 % slower; four waves per
+        // SIMD cover the L2 latency of these loads instead)
+        const int pair = step * KF_WAVES + wave;
+        const int t0 = min(2 * pair, last_tile), t1 = min(2 * pair + 1, last_tile);   // clamped: masked out below
         float4 a0[4], a1[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { a0[i] = an0[i]; a1[i] = an1[i]; }
-        const float4 s0 = sn0, s1 = sn1;
-        if (step + 1 < n_steps) load_step(step + 1);
+        for (int i = 0; i < 4; ++i) {
+            a0[i] = xp4[((tile0 + t0) * 4 + i) * 64 + lane];
+            a1[i] = xp4[((tile0 + t1) * 4 + i) * 64 + lane];
+        }
+        const float4 s0 = sq4[t0 * 4 + g], s1 = sq4[t1 * 4 + g];
 
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -199,74 +345,98 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i].w, bq[i].w, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i].w, bq[i].w, acc1, 0, 0, 0);
         }
-
-        // ---- composite keys of the lane's 8 (query, candidate) pairs
-        const int pair = step * KF_WAVES + wave;
-        const int c0 = pair * KF_STEP + 4 * g;              // candidates c0 + r (tile 0) and c0 + 16 + r (tile 1)
-        unsigned long long comp[8];
         const float sj[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+
+        // ---- distance keys of the lane's 8 (query, candidate) pairs; admitted iff (key, index) <= tau
+        const int c0 = pair * KF_STEP + 4 * g;              // candidates c0 + r (tile 0) and c0 + 16 + r (tile 1)
+        unsigned key[8];
+        const unsigned tk = tau_k[q], ti = tau_i[q];
+        unsigned mask = 0;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const float z = r < 4 ? acc0[r] : acc1[r - 4];
-            const int c = c0 + (r < 4 ? r : 12 + r);
             // (|x_i|^2 + (-2 x_i.x_j)) + |x_j|^2, torch_edge.py:41-43 (-2 z is exact, so the fma rounds once like the add)
-            const float dist = __fadd_rn(__fmaf_rn(-2.0f, z, sqi), sj[r]);
-            comp[r] = c < a.N ? (((unsigned long long)key_of(dist) << 12) | (unsigned)c) : ~0ull;
+            key[r] = key_of(__fadd_rn(__fmaf_rn(-2.0f, z, sqi), sj[r]));
+            const unsigned c = (unsigned)(c0 + (r < 4 ? r : 12 + r));
+            mask |= ((key[r] < tk || (key[r] == tk && c <= ti)) ? 1u : 0u) << r;
         }
-        const unsigned long long tq = tau[q];
-        unsigned mask = 0;
+        if (pair * KF_STEP + KF_STEP > a.N) {               // ragged tail (wave-uniform): candidates beyond N never pass
 #pragma unroll
-        for (int r = 0; r < 8; ++r) mask |= (comp[r] <= tq ? 1u : 0u) << r;
+            for (int r = 0; r < 8; ++r)
+                if (c0 + (r < 4 ? r : 12 + r) >= a.N) mask &= ~(1u << r);
+        }
         const unsigned n = (unsigned)__popc(mask);
         unsigned base = 0;
         if (n) base = atomicAdd(&cnt[q], n);
+        // room the NEXT step may need: about PER_STEP * KK / (candidates seen) keys per row, doubled, at most PER_STEP
+        const unsigned need = 2u * KK / (unsigned)(step + 1) + 32u;
+        const unsigned high = (unsigned)CAP - (need < (unsigned)PER_STEP ? need : (unsigned)PER_STEP);
         const int ph = step % 3;
         if (__ballot(n && base + n > (unsigned)CAP) && lane == 0) flag[2 * ph] = 1u;
-        if (__ballot(n && base + n > (unsigned)a.HIGH) && lane == 0) flag[2 * ph + 1] = 1u;
-        __syncthreads();
+        if (__ballot(n && base + n > high) && lane == 0) flag[2 * ph + 1] = 1u;
+        KF_T(t_b);
+        // (not __syncthreads(): that would also wait for the operand loads in flight; only LDS traffic must have landed)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        KF_T(t_c);
+        KF_ACC(0, t_b, t_a);
+        KF_ACC(1, t_c, t_b);
         const unsigned f_ovf = flag[2 * ph], f_prune = flag[2 * ph + 1];
         if (tid == 0) { flag[2 * ((step + 2) % 3)] = 0u; flag[2 * ((step + 2) % 3) + 1] = 0u; }
 
         if (!f_ovf) {
 #pragma unroll
             for (int r = 0; r < 8; ++r)
-                if ((mask >> r) & 1u) ent[q * CAP + base + __popc(mask & ((1u << r) - 1u))] = comp[r];
-            if (f_prune) {
+                if ((mask >> r) & 1u)
+                    ent[q * CAP + base + __popc(mask & ((1u << r) - 1u))] =
+                        ((unsigned long long)key[r] << 12) | (unsigned)(c0 + (r < 4 ? r : 12 + r));
+            KF_T(t_d);
+            KF_ACC(2, t_d, t_c);
+            if (f_prune && step + 1 < n_steps) {
                 __syncthreads();
-                for (int qq = wave; qq < KF_Q; qq += KF_WAVES) {
-                    const unsigned T = cnt[qq];
+                {
+                    const unsigned T = cnt[wave];            // one wave per row
                     if (T > (unsigned)a.LOW) {
                         unsigned long long thr;
-                        const unsigned c = prune_row<NPL>(ent + qq * CAP, T, KK, (unsigned)a.TOL, lane, thr);
-                        if (lane == 0) { cnt[qq] = c; tau[qq] = thr; }
+                        const unsigned c = prune_row<KF_NPL>(ent + wave * CAP, T, KK, (unsigned)a.TOL, lane, thr);
+                        if (lane == 0) { cnt[wave] = c; tau_k[wave] = (unsigned)(thr >> 12); tau_i[wave] = (unsigned)thr & 0xFFFu; }
                     }
                 }
                 __syncthreads();
+#ifdef PSG_KF_STAMP
+                KF_T(t_e);
+                KF_ACC(3, t_e, t_d);
+                kf_sum[5] += 1;
+#endif
             }
         } else {
-            // ---- overflow (rare): roll the step back, cut every row to exactly KK, commit one register at a time
+#ifdef PSG_KF_STAMP
+            kf_sum[6] += 1;
+#endif
+            // ---- overflow (adversarial orders): roll the step back, cut every row to exactly KK, commit one register
+            // at a time (<= 64 appends per row between checks)
             if (n) atomicSub(&cnt[q], n);
             __syncthreads();
-            for (int qq = wave; qq < KF_Q; qq += KF_WAVES) {
-                const unsigned T = cnt[qq];
+            {
+                const unsigned T = cnt[wave];
                 if (T > KK) {
                     unsigned long long thr;
-                    const unsigned c = prune_row<NPL>(ent + qq * CAP, T, KK, 0u, lane, thr);
-                    if (lane == 0) { cnt[qq] = c; tau[qq] = thr; }
+                    const unsigned c = prune_row<KF_NPL>(ent + wave * CAP, T, KK, 0u, lane, thr);
+                    if (lane == 0) { cnt[wave] = c; tau_k[wave] = (unsigned)(thr >> 12); tau_i[wave] = (unsigned)thr & 0xFFFu; }
                 }
             }
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const bool pass = comp[r] <= tau[q];
-                if (pass) ent[q * CAP + atomicAdd(&cnt[q], 1u)] = comp[r];     // <= 16 per row: KK + 16 <= CAP
+                const unsigned c = (unsigned)(c0 + (r < 4 ? r : 12 + r));
+                const bool pass = (int)c < a.N && (key[r] < tau_k[q] || (key[r] == tau_k[q] && c <= tau_i[q]));
+                if (pass) ent[q * CAP + atomicAdd(&cnt[q], 1u)] = ((unsigned long long)key[r] << 12) | c;
                 __syncthreads();
-                for (int qq = wave; qq < KF_Q; qq += KF_WAVES) {
-                    const unsigned T = cnt[qq];
-                    if (T + 16u > (unsigned)CAP) {
+                {
+                    const unsigned T = cnt[wave];
+                    if (T + 64u > (unsigned)CAP) {
                         unsigned long long thr;
-                        const unsigned c = prune_row<NPL>(ent + qq * CAP, T, KK, 0u, lane, thr);
-                        if (lane == 0) { cnt[qq] = c; tau[qq] = thr; }
+                        const unsigned c = prune_row<KF_NPL>(ent + wave * CAP, T, KK, 0u, lane, thr);
+                        if (lane == 0) { cnt[wave] = c; tau_k[wave] = (unsigned)(thr >> 12); tau_i[wave] = (unsigned)thr & 0xFFFu; }
                     }
                 }
                 __syncthreads();
@@ -274,41 +444,14 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
         }
     }
     __syncthreads();
-
-    // ---- final order: cut to [KK, M], pad, sort, emit every d-th
-    const unsigned M = (unsigned)a.M;
-    for (int qq = wave; qq < KF_Q; qq += KF_WAVES) {
-        unsigned long long *row = ent + qq * CAP;
-        unsigned T = cnt[qq];
-        if (T > M) {
-            unsigned long long thr;
-            T = prune_row<NPL>(row, T, KK, M - KK, lane, thr);
-        }
-        wave_lds_fence();
-        for (unsigned t = T + lane; t < M; t += 64) row[t] = ~0ull;
-        wave_lds_fence();
-        switch (M) {
-        case 64: wave_sort_keys<1>(row, lane); break;
-        case 128: wave_sort_keys<2>(row, lane); break;
-        case 256: wave_sort_keys<4>(row, lane); break;
-        default: wave_sort_keys<8>(row, lane); break;
-        }
-        wave_lds_fence();
-        if (lane < a.k) a.out[((size_t)blockIdx.x * KF_Q + qq) * a.k + lane] = (int32_t)(row[(size_t)lane * a.d] & 0xFFFull);
-    }
+    KF_T(t_f);
+    final_ranks(ent + wave * CAP, cnt[wave], a, fcnt + wave, a.out + ((size_t)blockIdx.x * KF_Q + wave) * a.k, lane);
+#ifdef PSG_KF_STAMP
+    KF_T(t_g);
+    KF_ACC(4, t_g, t_f);
+    if (tid == 0)
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_kf_stamps[i], kf_sum[i]);
+#endif
 }
 
-inline size_t knn_fused_lds_bytes(int npl)
-{
-    const int cap = npl == 10 ? 624 : 64 * npl;
-    return (size_t)KF_Q * cap * 8 + KF_Q * 8 + KF_Q * 4 + 6 * 4;
-}
-
-// class of a dilation: the smallest buffer with room for M and a useful amount of slack
-inline int knn_fused_class(int KK)
-{
-    if (KK <= 46) return 2;      // CAP 128
-    if (KK <= 136) return 4;     // CAP 256
-    if (KK <= 256) return 6;     // CAP 384
-    return 10;                   // CAP 624 (KK <= 406 + ...)
-}
+inline size_t knn_fused_lds_bytes() { return (size_t)KF_Q * KF_CAP * 8 + KF_Q * 8 + KF_Q * 4 + (8 + KF_WAVES) * 4; }

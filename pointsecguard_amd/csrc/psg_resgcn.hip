@@ -62,6 +62,9 @@ GemmArgs gemm_args(const float *in, int ld_in, const float *w, int ld_w, float *
 // 8 lanes x 4 accumulators (two passes of 32), lane-wise ((a0+a1)+a2)+a3, then the 8 lanes left to right.
 __global__ void sumsq_rows_kernel(const float *__restrict__ x, int ld, int C, size_t rows, float *__restrict__ out)
 {
+    // (this file is compiled with -ffp-contract=off: hipcc's __fmul_rn / __fadd_rn are plain operators, and with the
+    // default contraction they were fused into v_pk_fma_f32 - norms one ulp off torch's for some rows, which showed as
+    // 1-4 different neighbour rows per 4096-point graph)
     size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const float *p = x + r * ld;
@@ -669,30 +672,21 @@ __global__ void extract_color3_kernel(const float *__restrict__ x0, float *__res
 
 bool knn_fused_ok(const psg_gcn_ws *ws, int C, int d)
 {
-    return ws->knn_fused && C == 64 && (ws->N % 16) == 0 && ws->N <= 4096 && (KNB - 1) * d + 1 <= 496;
+    return ws->knn_fused && C == 64 && (ws->N % 16) == 0 && ws->N <= 4096 && (KNB - 1) * d + 1 <= 448;
 }
 
 int knn_fused_launch(psg_gcn_ws *ws, int d, int32_t *out, hipStream_t st)
 {
+    static_assert(KF_WAVES == KF_Q, "one wave per query row in the prune / final phases");
     KnnFusedArgs a;
     a.xp = ws->xp; a.sq = ws->sq; a.out = out; a.N = ws->N; a.k = KNB; a.d = d;
     a.KK = (KNB - 1) * d + 1;
-    a.M = 64;
-    while (a.M < a.KK) a.M <<= 1;
-    const int npl = a.KK > 406 ? 10 : knn_fused_class(a.KK);
-    const int cap = npl == 10 ? 624 : 64 * npl;
-    const int slack = cap - a.KK;
-    a.TOL = slack / 8;
+    a.magic = (unsigned)(((1u << 18) + (unsigned)d - 1u) / (unsigned)d);
+    const int slack = KF_CAP - a.KK;
+    a.TOL = slack / 16;
     a.LOW = a.KK + slack / 4;
-    a.HIGH = cap - std::min(48, slack / 3);
     const dim3 grid((unsigned)((size_t)ws->B * ws->N / KF_Q)), block(KF_WAVES * 64);
-    const size_t lds = knn_fused_lds_bytes(npl);
-    switch (npl) {
-    case 2: hipLaunchKernelGGL(knn_fused_kernel<2>, grid, block, lds, st, a); break;
-    case 4: hipLaunchKernelGGL(knn_fused_kernel<4>, grid, block, lds, st, a); break;
-    case 6: hipLaunchKernelGGL(knn_fused_kernel<6>, grid, block, lds, st, a); break;
-    default: hipLaunchKernelGGL(knn_fused_kernel<10>, grid, block, lds, st, a); break;
-    }
+    hipLaunchKernelGGL(knn_fused_kernel, grid, block, knn_fused_lds_bytes(), st, a);
     PSG_LAUNCH_CHECK();
     return PSG_OK;
 }
@@ -878,11 +872,9 @@ extern "C" int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n
     {
         const char *kv = getenv("PSG_GCN_KNN");
         ws->knn_fused = !(kv && std::string(kv) == "matrix");
-        // the largest class of the fused kNN kernel needs 80 KB of dynamic LDS (set once, outside any stream capture)
-        PSG_CHECK_HIP(hipFuncSetAttribute((const void *)knn_fused_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)knn_fused_lds_bytes(6)));
-        PSG_CHECK_HIP(hipFuncSetAttribute((const void *)knn_fused_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)knn_fused_lds_bytes(10)));
+        // the fused kNN kernel needs 128 KB of dynamic LDS (set once, outside any stream capture)
+        PSG_CHECK_HIP(hipFuncSetAttribute((const void *)knn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)knn_fused_lds_bytes()));
     }
     // widest conv input (dense: all earlier outputs) and the total arg-max bytes per vertex of the mr layers
     const int c_max = block == PSG_GCN_BLOCK_DENSE ? std::max(GC, GC * (n_blocks - 1)) : GC;
@@ -982,6 +974,18 @@ extern "C" int psg_gcn_set_graphs(psg_gcn_ws *ws, const int32_t *nbr, psg_stream
 }
 
 extern "C" const float *psg_gcn_feats_ptr(const psg_gcn_ws *ws) { return ws ? ws->feats : nullptr; }
+
+#ifdef PSG_KF_STAMP
+// diagnostic build only: read and clear the fused kNN kernel's phase stamps (tools/knn_stamp.py)
+extern "C" int psg_dbg_knn_stamps(unsigned long long *host_out)
+{
+    PSG_CHECK_HIP(hipDeviceSynchronize());
+    PSG_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_kf_stamps), 8 * sizeof(unsigned long long)));
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    PSG_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_kf_stamps), zero, sizeof(zero)));
+    return PSG_OK;
+}
+#endif
 
 // unit op: dilated dense kNN graph of point-major features x [B][N][C] (torch_edge.py:45-79)
 extern "C" int psg_gcn_knn(psg_gcn_ws *ws, const float *x, int C, int dilation, int32_t *out_idx, psg_stream stream)

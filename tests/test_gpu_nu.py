@@ -256,9 +256,12 @@ def test_tar_nu_b4_api_costs(weights_sd, golden_tarnu_b4):
 
 def test_tar_nu_b32_invariants(weights_sd):
     """configs[2] at its full batch (32 rooms; the reference needs ~1 min per optimiser step on this size, so there is
-    no recorded run): properties that hold for any correct run - only the masked colours of every row move, they stay
-    inside tanh space's (0,1), xyz never moves without a restart, the cost falls over the first steps, and the batch
-    result equals the same rooms attacked as ... the SAME batch again (bit-reproducible apart from float-atomic sums)."""
+    no recorded run).  (1) With target = 6 (NU_target_test_semseg.py:181) the reference's early exit fires as soon as
+    `target_acc > 0.9`, and its numerator counts the masked points of ALL 32 rows while the denominator is one row's mask
+    count (target.py:105-110): the run stops at the first step whose batch-inflated ratio passes 0.9 - checked against
+    the predictions of that very step.  (2) With target = None (the `non_f` branch) the run goes on: only the masked
+    colours of every row move, they stay inside tanh space's (0,1), xyz never moves, the cost falls, and a second run
+    reproduces the first (bit-reproducible apart from the float-atomic loss sums)."""
     from pointsecguard_amd.attacks import torchattacks
     from pointsecguard_amd.attacks.torchattacks.attacks import nu as nu_mod
     from pointsecguard_amd.models.pointnet2_sem_seg import get_model
@@ -270,17 +273,30 @@ def test_tar_nu_b32_invariants(weights_sd):
     labels = rule_labels(rooms)
     mask = labels[0] == 11
     images = dev(rooms.transpose(0, 2, 1))
+    src = rooms.transpose(0, 2, 1)
+    # (1) targeted: stop rule on the inflated ratio
+    ratios = []
+    atk = torchattacks.tar_NU_attack(net, c=1, kappa=0, steps=12, lr=0.01, target=6, mask=mask)
+    torch.manual_seed(3)
+    adv = nu_mod.nu_attack(atk, images, labels.astype(np.float64), mask, 6, 5, targeted_variant=True,
+                           trace=lambda **kw: ratios.append(float((kw["pred"].cpu().numpy()[:, mask] == 6).sum()) / mask.sum()))
+    torch.cuda.synchronize()
+    assert 1 <= len(ratios) <= 12
+    assert all(r <= 0.9 for r in ratios[:-1]) and (ratios[-1] > 0.9 or len(ratios) == 12), ratios
+    out = adv.cpu().numpy()
+    assert np.array_equal(out[:, :3], src[:, :3]) and np.array_equal(out[:, 6:], src[:, 6:])
+    assert np.array_equal(out[:, 3:6][:, :, ~mask], src[:, 3:6][:, :, ~mask])
+    # (2) the non_f branch runs on
     runs = []
     for _ in range(2):
-        atk = torchattacks.tar_NU_attack(net, c=1, kappa=0, steps=8, lr=0.01, target=6, mask=mask)
-        costs, accs = [], []
+        atk = torchattacks.tar_NU_attack(net, c=1, kappa=0, steps=8, lr=0.01, target=None, mask=mask)
+        costs = []
         torch.manual_seed(3)
-        adv = nu_mod.nu_attack(atk, images, labels.astype(np.float64), mask, 6, 5, targeted_variant=True,
+        adv = nu_mod.nu_attack(atk, images, labels.astype(np.float64), mask, None, 5, targeted_variant=True,
                                trace=lambda **kw: costs.append(kw["cost"]))
         torch.cuda.synchronize()
         runs.append((adv.cpu().numpy(), costs))
     out, costs = runs[0]
-    src = rooms.transpose(0, 2, 1)
     assert len(costs) == 8 and costs[-1] < costs[0]
     assert np.array_equal(out[:, :3], src[:, :3]) and np.array_equal(out[:, 6:], src[:, 6:])
     assert np.array_equal(out[:, 3:6][:, :, ~mask], src[:, 3:6][:, :, ~mask])

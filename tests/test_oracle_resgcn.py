@@ -83,3 +83,18 @@ def test_gcn_nu_attack_step(golden_gcn_nu, gcn_oracle, t):
 def test_gcn_tar_nu_attack_step(golden_gcn_tarnu, gcn_oracle, t):
     """tcolper.tar_NU_attack: masked tar_f on row 0 + 1e-4*Smooth + c*L2."""
     _gcn_nu_check(gcn_oracle, golden_gcn_tarnu, t, 5, True)
+
+
+def test_oracle_knn_at_baseline_size_vs_reference_tables():
+    """configs[3] size (4096 points, dilations up to 27): the oracle's kNN on the reference's own block outputs equals the
+    reference's neighbour tables (tests/golden/gcn28_room.npz) except at exact distance ties."""
+    import os
+    from conftest import GOLDEN
+    from oracle import resgcn
+    g = np.load(os.path.join(GOLDEN, "gcn28_room.npz"))
+    for e in (0, 1, 14):
+        got = resgcn.knn_dilated(g["feat%d" % e], e + 1)
+        ref = g["graphs"][e + 1].astype(np.int32)
+        assert (got == ref).mean() >= 0.999, (e, (got == ref).mean())
+    xyz = np.ascontiguousarray(g["room"][:, :3])
+    assert (resgcn.knn_dilated(xyz, 1) == g["graphs"][0]).mean() >= 0.999
