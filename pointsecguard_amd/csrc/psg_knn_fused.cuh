@@ -39,7 +39,14 @@
 // back to the bitonic sort.
 #pragma once
 
-constexpr int KF_WAVES = 16;
+#ifndef KF_WAVES_CFG
+#define KF_WAVES_CFG 16
+#endif
+#ifndef KF_PREFETCH_CFG
+#define KF_PREFETCH_CFG 0
+#endif
+constexpr int KF_WAVES = KF_WAVES_CFG;
+constexpr bool KF_PREFETCH = KF_PREFETCH_CFG != 0;   // next step's operands loaded under this step's key / append work
 constexpr int KF_Q = 16;        // query rows per workgroup (one 16-column MFMA tile)
 constexpr int KF_STEP = 32;     // candidates per wave and step: two 16-row MFMA tiles (two independent accumulators)
 constexpr int KF_CAP = 1024;    // composite keys per row buffer
@@ -52,7 +59,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // workgroup, written to a buffer no other code reads.  Phases: 0 stream (operands + MFMA + keys + slot allocation),
 // 1 wait at the step barrier, 2 appends, 3 prune events, 4 final ranks, 5 number of prune events, 6 roll-backs.
 #ifdef PSG_KF_STAMP
-__device__ unsigned long long g_kf_stamps[8];
+__device__ unsigned long long g_kf_stamps[16];
 #define KF_T(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
 #define KF_ACC(i, t1, t0) kf_sum[i] += (t1) - (t0)
 #else
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
     unsigned *tau_i = tau_k + KF_Q;                                          // [KF_Q] .. and index (ties)
     unsigned *cnt = tau_i + KF_Q;                                            // [KF_Q]
     unsigned *flag = cnt + KF_Q;                                             // [3][2]: overflow, prune (by step % 3)
-    unsigned *fcnt = flag + 8;                                               // [KF_WAVES] finalists per row
+    unsigned *fcnt = flag + 8;                                               // [KF_Q] finalists per row
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 15, g = lane >> 4;
@@ -296,12 +303,7 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
     if (tid < KF_Q) { tau_k[tid] = 0xFFFFFFFFu; tau_i[tid] = 0xFFFu; cnt[tid] = 0u; }      // everything is admitted
     // the four waves of a SIMD get different priorities: the matrix pipe serves them one after the other instead of
     // interleaving them, so one wave's key / append work overlaps the next wave's MFMAs
-    switch (wave >> 2) {
-    case 0: __builtin_amdgcn_s_setprio(3); break;
-    case 1: __builtin_amdgcn_s_setprio(2); break;
-    case 2: __builtin_amdgcn_s_setprio(1); break;
-    default: break;
-    }
+    if (wave < 4) __builtin_amdgcn_s_setprio(1);
     if (tid < 6) flag[tid] = 0u;
 
     const float4 *xp4 = (const float4 *)a.xp;
@@ -317,22 +319,38 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
     __syncthreads();
 
 #ifdef PSG_KF_STAMP
-    unsigned long long kf_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long kf_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    for (int step = 0; step < n_steps; ++step) {
-        KF_T(t_a);
-        // (a register prefetch of the next step's operands was tried: 128 VGPRs + 22 spilled, 25 % slower; four waves per
-        // SIMD cover the L2 latency of these loads instead)
-        const int pair = step * KF_WAVES + wave;
-        const int t0 = min(2 * pair, last_tile), t1 = min(2 * pair + 1, last_tile);   // clamped: masked out below
-        float4 a0[4], a1[4];
+    float4 p0[4], p1[4], ps0, ps1;       // KF_PREFETCH: operands of the NEXT step
+    auto load_operands = [&](int step, float4 (&x0)[4], float4 (&x1)[4], float4 &y0, float4 &y1) {
+        const int pr = step * KF_WAVES + wave;
+        const int t0 = min(2 * pr, last_tile), t1 = min(2 * pr + 1, last_tile);   // clamped: masked out below
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            a0[i] = xp4[((tile0 + t0) * 4 + i) * 64 + lane];
-            a1[i] = xp4[((tile0 + t1) * 4 + i) * 64 + lane];
+            x0[i] = xp4[((tile0 + t0) * 4 + i) * 64 + lane];
+            x1[i] = xp4[((tile0 + t1) * 4 + i) * 64 + lane];
         }
-        const float4 s0 = sq4[t0 * 4 + g], s1 = sq4[t1 * 4 + g];
+        y0 = sq4[t0 * 4 + g];
+        y1 = sq4[t1 * 4 + g];
+    };
+    if (KF_PREFETCH) load_operands(0, p0, p1, ps0, ps1);
+    for (int step = 0; step < n_steps; ++step) {
+        KF_T(t_a);
+        const int pair = step * KF_WAVES + wave;
+        float4 a0[4], a1[4], s0, s1;
+        if (KF_PREFETCH) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a0[i] = p0[i]; a1[i] = p1[i]; }
+            s0 = ps0; s1 = ps1;
+        } else {
+            load_operands(step, a0, a1, s0, s1);
+        }
 
+#ifdef PSG_KF_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KF_T(t_a1);
+        KF_ACC(8, t_a1, t_a);          // operands landed
+#endif
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -346,6 +364,13 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i].w, bq[i].w, acc1, 0, 0, 0);
         }
         const float sj[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        // the registers of this step's operands are free now: the next step's loads fly under the key / append work
+        if (KF_PREFETCH && step + 1 < n_steps) load_operands(step + 1, p0, p1, ps0, ps1);
+#ifdef PSG_KF_STAMP
+        asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1" : "+v"(acc0[3]), "+v"(acc1[3]));   // waits for the MFMA chains
+        KF_T(t_a2);
+        KF_ACC(9, t_a2, t_a1);         // MFMA chains done
+#endif
 
         // ---- distance keys of the lane's 8 (query, candidate) pairs; admitted iff (key, index) <= tau
         const int c0 = pair * KF_STEP + 4 * g;              // candidates c0 + r (tile 0) and c0 + 16 + r (tile 1)
@@ -366,6 +391,11 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
                 if (c0 + (r < 4 ? r : 12 + r) >= a.N) mask &= ~(1u << r);
         }
         const unsigned n = (unsigned)__popc(mask);
+#ifdef PSG_KF_STAMP
+        asm volatile("" :: "v"(n));
+        KF_T(t_a3);
+        KF_ACC(10, t_a3, t_a2);        // keys + filter
+#endif
         unsigned base = 0;
         if (n) base = atomicAdd(&cnt[q], n);
         // room the NEXT step may need: about PER_STEP * KK / (candidates seen) keys per row, doubled, at most PER_STEP
@@ -393,12 +423,12 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
             KF_ACC(2, t_d, t_c);
             if (f_prune && step + 1 < n_steps) {
                 __syncthreads();
-                {
-                    const unsigned T = cnt[wave];            // one wave per row
+                for (int qq = wave; qq < KF_Q; qq += KF_WAVES) {
+                    const unsigned T = cnt[qq];
                     if (T > (unsigned)a.LOW) {
                         unsigned long long thr;
-                        const unsigned c = prune_row<KF_NPL>(ent + wave * CAP, T, KK, (unsigned)a.TOL, lane, thr);
-                        if (lane == 0) { cnt[wave] = c; tau_k[wave] = (unsigned)(thr >> 12); tau_i[wave] = (unsigned)thr & 0xFFFu; }
+                        const unsigned c = prune_row<KF_NPL>(ent + qq * CAP, T, KK, (unsigned)a.TOL, lane, thr);
+                        if (lane == 0) { cnt[qq] = c; tau_k[qq] = (unsigned)(thr >> 12); tau_i[qq] = (unsigned)thr & 0xFFFu; }
                     }
                 }
                 __syncthreads();
@@ -416,12 +446,12 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
             // at a time (<= 64 appends per row between checks)
             if (n) atomicSub(&cnt[q], n);
             __syncthreads();
-            {
-                const unsigned T = cnt[wave];
+            for (int qq = wave; qq < KF_Q; qq += KF_WAVES) {
+                const unsigned T = cnt[qq];
                 if (T > KK) {
                     unsigned long long thr;
-                    const unsigned c = prune_row<KF_NPL>(ent + wave * CAP, T, KK, 0u, lane, thr);
-                    if (lane == 0) { cnt[wave] = c; tau_k[wave] = (unsigned)(thr >> 12); tau_i[wave] = (unsigned)thr & 0xFFFu; }
+                    const unsigned c = prune_row<KF_NPL>(ent + qq * CAP, T, KK, 0u, lane, thr);
+                    if (lane == 0) { cnt[qq] = c; tau_k[qq] = (unsigned)(thr >> 12); tau_i[qq] = (unsigned)thr & 0xFFFu; }
                 }
             }
             __syncthreads();
@@ -431,12 +461,12 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
                 const bool pass = (int)c < a.N && (key[r] < tau_k[q] || (key[r] == tau_k[q] && c <= tau_i[q]));
                 if (pass) ent[q * CAP + atomicAdd(&cnt[q], 1u)] = ((unsigned long long)key[r] << 12) | c;
                 __syncthreads();
-                {
-                    const unsigned T = cnt[wave];
+                for (int qq = wave; qq < KF_Q; qq += KF_WAVES) {
+                    const unsigned T = cnt[qq];
                     if (T + 64u > (unsigned)CAP) {
                         unsigned long long thr;
-                        const unsigned c = prune_row<KF_NPL>(ent + wave * CAP, T, KK, 0u, lane, thr);
-                        if (lane == 0) { cnt[wave] = c; tau_k[wave] = (unsigned)(thr >> 12); tau_i[wave] = (unsigned)thr & 0xFFFu; }
+                        const unsigned c = prune_row<KF_NPL>(ent + qq * CAP, T, KK, 0u, lane, thr);
+                        if (lane == 0) { cnt[qq] = c; tau_k[qq] = (unsigned)(thr >> 12); tau_i[qq] = (unsigned)thr & 0xFFFu; }
                     }
                 }
                 __syncthreads();
@@ -445,13 +475,14 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
     }
     __syncthreads();
     KF_T(t_f);
-    final_ranks(ent + wave * CAP, cnt[wave], a, fcnt + wave, a.out + ((size_t)blockIdx.x * KF_Q + wave) * a.k, lane);
+    for (int qq = wave; qq < KF_Q; qq += KF_WAVES)
+        final_ranks(ent + qq * CAP, cnt[qq], a, fcnt + qq, a.out + ((size_t)blockIdx.x * KF_Q + qq) * a.k, lane);
 #ifdef PSG_KF_STAMP
     KF_T(t_g);
     KF_ACC(4, t_g, t_f);
     if (tid == 0)
-        for (int i = 0; i < 7; ++i) atomicAdd(&g_kf_stamps[i], kf_sum[i]);
+        for (int i = 0; i < 11; ++i) atomicAdd(&g_kf_stamps[i], kf_sum[i]);
 #endif
 }
 
-inline size_t knn_fused_lds_bytes() { return (size_t)KF_Q * KF_CAP * 8 + KF_Q * 8 + KF_Q * 4 + (8 + KF_WAVES) * 4; }
+inline size_t knn_fused_lds_bytes() { return (size_t)KF_Q * KF_CAP * 8 + KF_Q * 8 + KF_Q * 4 + (8 + KF_Q) * 4; }

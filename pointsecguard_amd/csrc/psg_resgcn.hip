@@ -677,7 +677,6 @@ bool knn_fused_ok(const psg_gcn_ws *ws, int C, int d)
 
 int knn_fused_launch(psg_gcn_ws *ws, int d, int32_t *out, hipStream_t st)
 {
-    static_assert(KF_WAVES == KF_Q, "one wave per query row in the prune / final phases");
     KnnFusedArgs a;
     a.xp = ws->xp; a.sq = ws->sq; a.out = out; a.N = ws->N; a.k = KNB; a.d = d;
     a.KK = (KNB - 1) * d + 1;
@@ -980,8 +979,8 @@ extern "C" const float *psg_gcn_feats_ptr(const psg_gcn_ws *ws) { return ws ? ws
 extern "C" int psg_dbg_knn_stamps(unsigned long long *host_out)
 {
     PSG_CHECK_HIP(hipDeviceSynchronize());
-    PSG_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_kf_stamps), 8 * sizeof(unsigned long long)));
-    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    PSG_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_kf_stamps), 16 * sizeof(unsigned long long)));
+    unsigned long long zero[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     PSG_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_kf_stamps), zero, sizeof(zero)));
     return PSG_OK;
 }

@@ -9,7 +9,7 @@ lib = _lib.load()
 rng = np.random.default_rng(1)
 f = torch.from_numpy(rng.standard_normal((1, 4096, 64)).astype(np.float32)).cuda()
 ws = runtime.GCNWorkspace(1, 4096, 28)
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 16)()
 names = ("stream", "barrier wait", "appends", "prune", "final", "prune events", "roll-backs")
 for d in (1, 4, 9, 17, 27):
     ws.knn(f, d); lib.psg_dbg_knn_stamps(buf)
@@ -21,4 +21,6 @@ for d in (1, 4, 9, 17, 27):
     lib.psg_dbg_knn_stamps(buf)
     v = [buf[i] / 2560.0 for i in range(7)]     # per workgroup (256 workgroups x 10 launches)
     print("d=%2d  %.1f us/launch (incl. prep) | cycles per workgroup: " % (d, t0.elapsed_time(t1) * 100) +
-          ", ".join("%s %.0f" % (n, x) for n, x in zip(names[:5], v[:5])) + " | events %.2f roll-backs %.2f" % (v[5], v[6]), flush=True)
+          ", ".join("%s %.0f" % (n, x) for n, x in zip(names[:5], v[:5])) + " | events %.2f roll-backs %.2f" % (v[5], v[6]) +
+          " | stream split: operands %.0f, mfma %.0f, keys %.0f, alloc %.0f" % (buf[8] / 2560.0, buf[9] / 2560.0, buf[10] / 2560.0,
+                                                                               v[0] - (buf[8] + buf[9] + buf[10]) / 2560.0), flush=True)
