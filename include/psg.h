@@ -280,6 +280,12 @@ int psg_gcn_ws_create(psg_ctx *ctx, int batch, int n_point, int n_blocks, psg_gc
 int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n_blocks, int block, int conv, psg_gcn_ws **out);
 int psg_gcn_ws_destroy(psg_gcn_ws *ws);
 size_t psg_gcn_ws_bytes(const psg_gcn_ws *ws);
+/* Measurement only (bench.py `roofline`): per-launch HIP-event timing on the launch stream, like psg_pn2_prof_*.  Tags:
+ * 0 fused feature-space kNN kernel (torch_edge.py:32-59), 1 other kNN launches, 2 per-vertex EdgeConv GEMM, 3 edge max,
+ * 4 fusion + prediction, 5 backward; flops = algorithmic FLOPs of the tagged launches.  While enabled the attack loop does
+ * not use its hipGraph. */
+int psg_gcn_prof_enable(psg_gcn_ws *ws, int on);
+int psg_gcn_prof_read(psg_gcn_ws *ws, int n_tags, double *total_ms, int *counts, double *flops);
 
 /* DenseDilatedKnnGraph (torch_edge.py:45-79) on point-major features x [batch][n_point][C]: neighbours at
  * ranks 0, d, 2d, ... of the ascending pairwise_distance row, k = 16; out_idx [batch][n_point][16].
@@ -339,6 +345,10 @@ int psg_rla_model_destroy(psg_rla_model *model);
 int psg_rla_ws_create(psg_ctx *ctx, int n_points, psg_rla_ws **out);
 int psg_rla_ws_destroy(psg_rla_ws *ws);
 size_t psg_rla_ws_bytes(const psg_rla_ws *ws);
+/* Measurement only: HIP-event timing of every GEMM launch (tag 0: the 1x1 convolutions and attention scores of
+ * RandLANet.py:323-410) with its algorithmic FLOPs; while enabled the BIM loop does not use its hipGraph. */
+int psg_rla_prof_enable(psg_rla_ws *ws, int on);
+int psg_rla_prof_read(psg_rla_ws *ws, int n_tags, double *total_ms, int *counts, double *flops);
 /* xyz [n_points][3] device: builds the index pyramid of main_S3DIS.py:198-207 (psg_knn_points) and the relative
  * position encodings.  Sub-sampling is the reference's: the first n / ratio points of each level. */
 int psg_rla_set_cloud(psg_rla_ws *ws, const float *xyz, psg_stream stream);

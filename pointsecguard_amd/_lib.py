@@ -62,6 +62,8 @@ SIGNATURES = {
     "psg_gcn_ws_create_cfg": (ci, [vp, ci, ci, ci, ci, ci, ctypes.POINTER(vp)]),
     "psg_gcn_ws_destroy": (ci, [vp]),
     "psg_gcn_ws_bytes": (ctypes.c_size_t, [vp]),
+    "psg_gcn_prof_enable": (ci, [vp, ci]),
+    "psg_gcn_prof_read": (ci, [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
     "psg_gcn_knn": (ci, [vp, vp, ci, ci, vp, vp]),
     "psg_gcn_forward": (ci, [vp, vp, vp, vp, vp]),
     "psg_gcn_backward": (ci, [vp, vp, vp, vp, vp]),
@@ -75,6 +77,8 @@ SIGNATURES = {
     "psg_rla_ws_create": (ci, [vp, ci, ctypes.POINTER(vp)]),
     "psg_rla_ws_destroy": (ci, [vp]),
     "psg_rla_ws_bytes": (ctypes.c_size_t, [vp]),
+    "psg_rla_prof_enable": (ci, [vp, ci]),
+    "psg_rla_prof_read": (ci, [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
     "psg_rla_set_cloud": (ci, [vp, vp, vp]),
     "psg_rla_index_ptr": (vp, [vp, ci, ci]),
     "psg_rla_forward": (ci, [vp, vp, vp, vp, vp]),

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "../../include/psg.h"
 
@@ -29,6 +30,50 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 #define PSG_LAUNCH_CHECK() PSG_CHECK_HIP(hipGetLastError())
+
+// Optional per-launch HIP-event timing of a workspace (psg_*_prof_enable / psg_*_prof_read): pairs of events recorded on
+// the LAUNCH stream around a launch (or a group of launches) with a tag and the algorithmic FLOPs of that launch; off in
+// normal operation (one branch per launch).  bench.py's `roofline` objects are computed from these.
+struct EvLog {
+    bool on = false;
+    std::vector<hipEvent_t> ev;      // pairs
+    std::vector<int> tag;
+    std::vector<double> flop;
+    size_t used = 0;
+    void reset(bool enable) { on = enable; used = 0; tag.clear(); flop.clear(); }
+    void destroy() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); ev.clear(); }
+    // sums per tag; blocks until the events have completed
+    int read(int n_tags, double *total_ms, int *counts, double *flops)
+    {
+        for (int i = 0; i < n_tags; ++i) { total_ms[i] = 0.0; counts[i] = 0; if (flops) flops[i] = 0.0; }
+        for (size_t i = 0; i < tag.size(); ++i) {
+            float ms = 0.f;
+            if (hipEventSynchronize(ev[2 * i + 1]) != hipSuccess) return -1;
+            if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) return -1;
+            if (tag[i] < n_tags) { total_ms[tag[i]] += ms; counts[tag[i]] += 1; if (flops) flops[tag[i]] += flop[i]; }
+        }
+        return 0;
+    }
+};
+struct EvScope {
+    EvLog *log; hipStream_t st; hipEvent_t stop = nullptr;
+    EvScope(EvLog *l, int tag, double flop, hipStream_t s) : log(l), st(s)
+    {
+        if (!log || !log->on) { log = nullptr; return; }
+        while (log->used + 2 > log->ev.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) { log = nullptr; return; }
+            log->ev.push_back(e);
+        }
+        hipEvent_t start = log->ev[log->used];
+        stop = log->ev[log->used + 1];
+        log->used += 2;
+        log->tag.push_back(tag);
+        log->flop.push_back(flop);
+        (void)hipEventRecord(start, st);
+    }
+    ~EvScope() { if (log) (void)hipEventRecord(stop, st); }
+};
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

@@ -101,9 +101,14 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(GemmArgs a)
     if (EPI == EPI_LRELU && a.mask_out) a.mask_out[row] = bits;
 }
 
+// profile of the GEMM launches of the call in progress on this thread (psg_rla_prof_enable): tag 0 = every 1x1
+// convolution / attention-score GEMM, with its algorithmic FLOPs
+thread_local EvLog *tl_prof = nullptr;
+
 template <int EPI>
 int rl_gemm(const GemmArgs &a, hipStream_t st)
 {
+    EvScope prof(tl_prof, 0, 2.0 * a.rows * (double)a.K * a.M, st);
     if (a.M <= 32 && a.K <= 32 && a.rows >= 4096 && !a.addend && !a.gbias && !a.mask_in) {
         hipLaunchKernelGGL(skinny_gemm_kernel<EPI>, dim3(ceil_div(a.rows, 256)), dim3(256), 0, st, a);
         PSG_LAUNCH_CHECK();
@@ -466,6 +471,7 @@ struct psg_rla_ws {
     float *feat, *dfeat, *ori, *delta, *norms;   // attack state: [N][6], [N][6], [N][3], [N][3], [4]
     int32_t *labels;
     bool cloud_set = false, have_fwd = false;
+    EvLog prof;                   // psg_rla_prof_enable
     const void *xyz_branch_model = nullptr;   // the model whose xyz-branch features (fxyz1 / fxyz2) are resident
     // hipGraph of one BIM iteration (forward, loss gradient, backward, update: ~150 short launches), valid for the
     // (model, eps, alpha, metric) below; every captured kernel works on workspace buffers, so it is cloud-independent
@@ -661,6 +667,29 @@ extern "C" int psg_rla_ws_destroy(psg_rla_ws *ws)
 
 extern "C" size_t psg_rla_ws_bytes(const psg_rla_ws *ws) { return ws ? ws->bytes : 0; }
 
+// per-launch HIP-event profile of the GEMM launches (tag 0); while enabled the BIM loop stays eager (no hipGraph)
+extern "C" int psg_rla_prof_enable(psg_rla_ws *ws, int on)
+{
+    PSG_REQUIRE(ws, "psg_rla_prof_enable: null workspace");
+    ws->prof.reset(on != 0);
+    return PSG_OK;
+}
+
+extern "C" int psg_rla_prof_read(psg_rla_ws *ws, int n_tags, double *total_ms, int *counts, double *flops)
+{
+    PSG_REQUIRE(ws && total_ms && counts && n_tags >= 1, "psg_rla_prof_read: need room for 1 tag");
+    if (ws->prof.read(n_tags, total_ms, counts, flops)) { set_error("psg_rla_prof_read: event query failed"); return PSG_ERR_HIP; }
+    return PSG_OK;
+}
+
+namespace {
+struct ProfBind {   // routes rl_gemm's scopes to the workspace of the call in progress
+    EvLog *prev;
+    explicit ProfBind(psg_rla_ws *ws) : prev(tl_prof) { tl_prof = (ws && ws->prof.on) ? &ws->prof : nullptr; }
+    ~ProfBind() { tl_prof = prev; }
+};
+}  // namespace
+
 // The index pyramid of the reference's tf_map (main_S3DIS.py:198-207) and the relative position encodings, from the
 // cloud in ws->xyz_all.
 static int build_pyramid(psg_rla_ws *ws, psg_stream stream)
@@ -696,6 +725,7 @@ extern "C" const int32_t *psg_rla_index_ptr(const psg_rla_ws *ws, int what, int 
 
 extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *features, float *logits_out, psg_stream stream)
 {
+    ProfBind bind(ws);
     PSG_REQUIRE(m && ws && features && logits_out, "psg_rla_forward: null argument");
     if (!ws->cloud_set) { set_error("psg_rla_forward: psg_rla_set_cloud has not been called"); return PSG_ERR_STATE; }
     hipStream_t st = (hipStream_t)stream;
@@ -763,6 +793,7 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
 
 extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *dlogits, float *dfeatures_out, psg_stream stream)
 {
+    ProfBind bind(ws);
     PSG_REQUIRE(m && ws && dlogits && dfeatures_out, "psg_rla_backward: null argument");
     if (!ws->have_fwd) { set_error("psg_rla_backward: no forward is resident in the workspace"); return PSG_ERR_STATE; }
     hipStream_t st = (hipStream_t)stream;
@@ -849,6 +880,7 @@ extern "C" int psg_rla_bim_attack(psg_rla_model *m, psg_rla_ws *ws, const float 
                                   float alpha, int iters, int l2_metric, float *adv_features_out, psg_stream stream)
 {
     PSG_REQUIRE(m && ws && features && labels && adv_features_out && iters > 0, "psg_rla_bim_attack: bad argument");
+    ProfBind bind(ws);
     hipStream_t st = (hipStream_t)stream;
     const size_t N = ws->N;
     int rc;
@@ -890,7 +922,7 @@ extern "C" int psg_rla_bim_attack(psg_rla_model *m, psg_rla_ws *ws, const float 
     if ((rc = iteration())) return rc;
     int it = 1;
     static const bool use_graph = !(getenv("PSG_RLA_NO_GRAPH") && atoi(getenv("PSG_RLA_NO_GRAPH")));
-    if (use_graph && iters - it >= 2) {
+    if (use_graph && !ws->prof.on && iters - it >= 2) {
         if (ws->bim_exec && (ws->bim_model != (const void *)m || ws->bim_eps != eps || ws->bim_alpha != alpha || ws->bim_metric != l2_metric)) {
             PSG_CHECK_HIP(hipStreamSynchronize(st));
             (void)hipGraphExecDestroy(ws->bim_exec);

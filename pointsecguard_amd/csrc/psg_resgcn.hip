@@ -634,6 +634,7 @@ struct psg_gcn_ws {
     const void *nb_model = nullptr;
     float nb_eps = 0.f, nb_alpha = 0.f;
     bool nb_fixed = false;
+    EvLog prof;              // psg_gcn_prof_enable
 };
 
 namespace {
@@ -670,6 +671,8 @@ __global__ void extract_color3_kernel(const float *__restrict__ x0, float *__res
     if (t < rows * 3) ori[t] = x0[(t / 3) * 9 + 3 + (t % 3)];
 }
 
+enum GcnTag { GT_KNN = 0, GT_KNN_OTHER, GT_VERTEX_GEMM, GT_EDGE_MAX, GT_HEAD, GT_BACKWARD, GT_COUNT };
+
 bool knn_fused_ok(const psg_gcn_ws *ws, int C, int d)
 {
     return ws->knn_fused && C == 64 && (ws->N % 16) == 0 && ws->N <= 4096 && (KNB - 1) * d + 1 <= 448;
@@ -685,7 +688,10 @@ int knn_fused_launch(psg_gcn_ws *ws, int d, int32_t *out, hipStream_t st)
     a.TOL = slack / 16;
     a.LOW = a.KK + slack / 4;
     const dim3 grid((unsigned)((size_t)ws->B * ws->N / KF_Q)), block(KF_WAVES * 64);
-    hipLaunchKernelGGL(knn_fused_kernel, grid, block, knn_fused_lds_bytes(), st, a);
+    {
+        EvScope prof(&ws->prof, GT_KNN, 2.0 * ws->B * (double)ws->N * ws->N * 64.0, st);
+        hipLaunchKernelGGL(knn_fused_kernel, grid, block, knn_fused_lds_bytes(), st, a);
+    }
     PSG_LAUNCH_CHECK();
     return PSG_OK;
 }
@@ -703,6 +709,7 @@ int knn_graph(psg_gcn_ws *ws, const float *x, int ld, int C, int d, int32_t *out
         }
         return knn_fused_launch(ws, d, out, st);
     }
+    EvScope prof(&ws->prof, GT_KNN_OTHER, 2.0 * ws->B * (double)ws->N * ws->N * C, st);   // round-1 path, xyz graph
     if (!have_sq) {
         hipLaunchKernelGGL(sumsq_rows_kernel, dim3(ceil_div((int)rows, 256)), dim3(256), 0, st, x, ld, C, rows, ws->sq);
         PSG_LAUNCH_CHECK();
@@ -956,6 +963,22 @@ extern "C" int psg_gcn_ws_destroy(psg_gcn_ws *ws)
 
 extern "C" size_t psg_gcn_ws_bytes(const psg_gcn_ws *ws) { return ws ? ws->bytes : 0; }
 
+// per-launch HIP-event profile (tags: 0 fused kNN kernel, 1 other kNN launches (xyz graph / round-1 path), 2 per-vertex
+// [P|Q] GEMM, 3 edge max, 4 fusion + prediction, 5 backward); while enabled the attack loop stays eager (no hipGraph)
+extern "C" int psg_gcn_prof_enable(psg_gcn_ws *ws, int on)
+{
+    PSG_REQUIRE(ws, "psg_gcn_prof_enable: null workspace");
+    ws->prof.reset(on != 0);
+    return PSG_OK;
+}
+
+extern "C" int psg_gcn_prof_read(psg_gcn_ws *ws, int n_tags, double *total_ms, int *counts, double *flops)
+{
+    PSG_REQUIRE(ws && total_ms && counts && n_tags >= GT_COUNT, "psg_gcn_prof_read: need room for %d tags", GT_COUNT);
+    if (ws->prof.read(n_tags, total_ms, counts, flops)) { set_error("psg_gcn_prof_read: event query failed"); return PSG_ERR_HIP; }
+    return PSG_OK;
+}
+
 extern "C" const int32_t *psg_gcn_edge_ptr(const psg_gcn_ws *ws, int block)
 {
     if (!ws || block < 0 || block >= ws->n_blocks) return nullptr;
@@ -1027,7 +1050,11 @@ extern "C" int psg_gcn_forward(psg_gcn_model *m, psg_gcn_ws *ws, const float *x0
             // [P | Q] = x . [W1 - W2 ; W2]^T + [b, 0]
             GemmArgs a = gemm_args(xin, ld, L.wcat, L.C, ws->pq, 2 * GC, (int)R, L.C, 2 * GC);
             a.bias = L.bcat;
-            if ((rc = launch_gemm<2, 2, EPI_LINEAR, false>(a, st))) return rc;
+            {
+                EvScope prof(&ws->prof, GT_VERTEX_GEMM, 2.0 * R * L.C * 2.0 * GC, st);
+                if ((rc = launch_gemm<2, 2, EPI_LINEAR, false>(a, st))) return rc;
+            }
+            EvScope prof(&ws->prof, GT_EDGE_MAX, 0.0, st);
             hipLaunchKernelGGL(edge_max_fwd_kernel, dim3(g256), dim3(256), 0, st, ws->pq, nbr, L.scale, L.shift,
                                (e == 0 || !res) ? nullptr : xin, F, yout, F, ws->arg + (size_t)e * R * GC, N,
                                R * GC, (ws->fixed_graphs || dense) ? nullptr : ws->sq,
@@ -1046,6 +1073,7 @@ extern "C" int psg_gcn_forward(psg_gcn_model *m, psg_gcn_ws *ws, const float *x0
             if ((rc = launch_gemm<2, 2, EPI_RELU_AFFINE, false>(a, st))) return rc;
         }
     }
+    EvScope prof_head(&ws->prof, GT_HEAD, 2.0 * R * ((double)F * 1024 + (double)F * 512 + 512.0 * 256 + 256.0 * NCLS), st);
     // fusion: Conv(F -> 1024) + ReLU + BN, global max over the room
     {
         GemmArgs a = gemm_args(ws->feats, F, m->wf, F, ws->fused, 1024, (int)R, F, 1024);
@@ -1144,6 +1172,7 @@ extern "C" int psg_gcn_backward(psg_gcn_model *m, psg_gcn_ws *ws, const float *d
     const size_t R = (size_t)B * N;
     const int g256 = ceil_div((int)(R * GC), 256);
     int rc;
+    EvScope prof(&ws->prof, GT_BACKWARD, 0.0, st);
     // prediction.3^T, then through ReLU/BN of prediction.1 (mask2; its scale s2 is folded into wp2_st)
     {
         GemmArgs a = gemm_args(dlogits, NCLS, m->wp3_t, NCLS, ws->g2, 256, (int)R, NCLS, 256);
@@ -1235,7 +1264,7 @@ extern "C" int psg_gcn_nb_attack(psg_gcn_model *m, psg_gcn_ws *ws, const float *
     struct Unfreeze { psg_gcn_ws *w; ~Unfreeze() { w->head_graph_frozen = false; } } unfreeze{ws};
     ws->head_graph_frozen = true;
     static const bool use_graph = !(getenv("PSG_GCN_NO_GRAPH") && atoi(getenv("PSG_GCN_NO_GRAPH")));
-    if (use_graph && iters - 1 - it >= 2) {
+    if (use_graph && !ws->prof.on && iters - 1 - it >= 2) {
         if (ws->nb_exec && (ws->nb_model != (const void *)m || ws->nb_eps != eps || ws->nb_alpha != alpha ||
                             ws->nb_fixed != ws->fixed_graphs)) {
             PSG_CHECK_HIP(hipStreamSynchronize(st));

@@ -63,6 +63,15 @@ class RandLAWorkspace:
         except Exception:
             pass
 
+    def prof_enable(self, on=True):
+        _lib.call("psg_rla_prof_enable", self.handle, 1 if on else 0)
+
+    def prof_read(self):
+        """(total ms, launches, algorithmic FLOPs) of the GEMM launches since prof_enable (HIP events on the launch stream)."""
+        ms, cnt, fl = (ctypes.c_double * 1)(), (ctypes.c_int * 1)(), (ctypes.c_double * 1)()
+        _lib.call("psg_rla_prof_read", self.handle, 1, ms, cnt, fl)
+        return ms[0], cnt[0], fl[0]
+
     @property
     def nbytes(self):
         return _lib.load().psg_rla_ws_bytes(self.handle)

@@ -363,6 +363,18 @@ class GCNWorkspace:
         _lib.call("psg_gcn_knn", self.handle, ptr(x), C, int(dilation), ptr(out), stream())
         return out
 
+    PROF_TAGS = ("knn_fused", "knn_other", "vertex_gemm", "edge_max", "fusion_prediction", "backward")
+
+    def prof_enable(self, on=True):
+        _lib.call("psg_gcn_prof_enable", self.handle, 1 if on else 0)
+
+    def prof_read(self):
+        """{tag: (total ms, launches, algorithmic FLOPs)} measured with HIP events on the launch stream."""
+        n = len(self.PROF_TAGS)
+        ms, cnt, fl = (ctypes.c_double * n)(), (ctypes.c_int * n)(), (ctypes.c_double * n)()
+        _lib.call("psg_gcn_prof_read", self.handle, n, ms, cnt, fl)
+        return {t: (ms[i], cnt[i], fl[i]) for i, t in enumerate(self.PROF_TAGS) if cnt[i]}
+
     def set_graphs(self, nbr):
         if nbr is not None:
             require_cuda(nbr, "nbr", torch.int32)

@@ -105,7 +105,21 @@ def _one_step(ws, model, x0, ori, labels, slot, alpha, eps, last, mask=None, tar
     _lib.call("psg_pgd_step", runtime.ptr(x0), runtime.ptr(dx0), runtime.ptr(ori), runtime.ptr(mask), B, N,
               float(alpha), float(eps), -1.0 if target is not None else 1.0, 1 if last else 0, runtime.stream())
     torch.cuda.synchronize()
+    _one_step.last_grad = dx0[:, :, 3:6].cpu().numpy().transpose(0, 2, 1)      # [B,3,N], for check_flips
     return x0[:, :, 3:6].cpu().numpy().transpose(0, 2, 1)
+
+
+def check_flips(got, nxt, grad, bar=0.999):
+    """Colours after one teacher-forced step: bit-equal on >= `bar` of the entries, and every entry that differs is a
+    gradient whose sign is not determined at fp32: |g| below 3e-3 of the largest gradient magnitude (measured: the
+    largest flipped |g| over the tested iterations is 1.6e-3 max|g|, i.e. 1.1e-5 against 6.8e-3; an entry moved by
+    +-alpha where the reference moved it by -+alpha or not at all)."""
+    diff = np.ascontiguousarray(got).view(np.uint32) != np.ascontiguousarray(nxt).view(np.uint32)
+    same = 1.0 - diff.mean()
+    assert same >= bar, same
+    if diff.any():
+        assert np.abs(grad[diff]).max() <= 3e-3 * np.abs(grad).max(), (np.abs(grad[diff]).max(), np.abs(grad).max())
+    return same
 
 
 def test_nb_attack_steps_vs_reference(gpu_model, golden_nb):
@@ -128,8 +142,7 @@ def test_nb_attack_steps_vs_reference(gpu_model, golden_nb):
         nxt = g["adv_color_final"] if t == iters - 1 else g["state_it%d" % (t + 1)]
         _set_color(x0, g["state_it%d" % t])
         got = _one_step(ws, gpu_model, x0, ori, labels, t, g["alpha"], g["eps"], last=(t == iters - 1))
-        same = (np.ascontiguousarray(got).view(np.uint32) == nxt.view(np.uint32)).mean()
-        assert same >= 0.999, (t, same)
+        check_flips(got, nxt, _one_step.last_grad)
         checked += 1
     assert checked == 7
 
@@ -152,7 +165,13 @@ def test_nb_attack_free_run_vs_reference(gpu_model, golden_nb):
     assert np.abs(out[:, 3:6] - images_np[:, 3:6]).max() <= float(g["eps"]) + float(g["alpha"]) + 1e-6
     ref = g["adv_color_final"]
     same = (out[:, 3:6].view(np.uint32) == ref.view(np.uint32)).mean()
-    assert same >= 0.5, same  # chaotic amplification of tie / rounding sign flips; see docstring above
+    # Free-running bit equality after 40 iterations is a chaotic quantity, calibrated by the reference against ITSELF
+    # (tests/golden/pn2_nb_threads.json: the same attack with 2 or 8 intra-op threads instead of 1 stays bit-identical
+    # for the first 20+ iterations and ends at 0.968): this implementation's backward sums in another order than MKL's,
+    # flips a handful of |g| < 1e-3 max|g| signs in EVERY iteration (test above), each one a 2 alpha colour change
+    # that doubles per iteration, and ends lower: 0.78 measured.  Not a parity bar (that is the teacher-forced test and
+    # the statistics below), a tripwire against gross divergence.
+    assert same >= 0.65, same
     # adversarial accuracy / mIoU parity on the same RNG slot as the reference's adversarial forward
     ev = runtime.PN2Workspace(B, 4096, 1)
     x0 = adv.transpose(1, 2).contiguous()
@@ -258,3 +277,86 @@ def test_forward_backward_vs_oracle_batch(gpu_model, oracle_net):
         assert np.abs(logp[b].cpu().numpy() - o_logp).max() <= LOGP_TOL
         o_dlogp, _ = pn2.nll_logp_grad(o_logp, labels[b], 1.0 / 4096)
         check_grad(dx0[b, :, 3:6].cpu().numpy(), oracle_net.backward_color(cache, o_dlogp))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE configs[1] at its own batch: tests/golden/pn2_nb_b8.npz = the reference's NB_attack on B = 8 rooms (two
+# batches, 16 rooms, make_golden_big.py: gen_nb_b8)
+
+@pytest.fixture(scope="module")
+def golden_nb_b8():
+    import os
+    from conftest import GOLDEN
+    return dict(np.load(os.path.join(GOLDEN, "pn2_nb_b8.npz")))
+
+
+def _b8_batch(g, bi):
+    from pointsecguard_amd.synthetic import make_rooms, rule_labels
+    rooms = make_rooms(8, int(g["seed_rooms"][bi]))
+    return rooms, rule_labels(rooms)
+
+
+def test_nb_b8_steps_vs_reference(gpu_model, golden_nb_b8):
+    from pointsecguard_amd import runtime
+    g = golden_nb_b8
+    iters = int(g["iters"])
+    rooms, lab = _b8_batch(g, 0)
+    labels = dev(lab.astype(np.int32))
+    x0 = dev(rooms)
+    ori = x0[:, :, 3:6].contiguous()
+    ws = runtime.PN2Workspace(8, 4096, iters)
+    ws.plan_build(x0, dev(g["b0_starts"][1:1 + iters], torch.int32), iters)
+    assert np.array_equal(g["state_it0"], rooms.transpose(0, 2, 1)[:, 3:6])
+    for t, nxt in ((0, g["state_it1"]), (39, g["adv_color_final"])):
+        _set_color(x0, g["state_it%d" % t])
+        got = _one_step(ws, gpu_model, x0, ori, labels, t, g["alpha"], g["eps"], last=(t == iters - 1))
+        check_flips(got, nxt, _one_step.last_grad)
+
+
+def test_nb_b8_statistical_parity_16_rooms(gpu_model, golden_nb_b8):
+    """Fused 40-iteration attack on the reference's two batches of 8 rooms with the reference's FPS draws: clean counters
+    equal (up to the handful of arg-max ties), adversarial accuracy / mIoU of each batch and of the 16 rooms together
+    within 0.01 of the reference's, per-room adversarial accuracy within 0.03, L2 distance within 1 %."""
+    from pointsecguard_amd import runtime
+    g = golden_nb_b8
+    iters, eps, alpha = int(g["iters"]), float(g["eps"]), float(g["alpha"])
+    tot_ref, tot_got = np.zeros((3, 13)), np.zeros((3, 13))
+    for bi in range(2):
+        rooms, lab = _b8_batch(g, bi)
+        p = "b%d_" % bi
+        starts = g[p + "starts"]
+        images_np = np.ascontiguousarray(rooms.transpose(0, 2, 1))
+        images, labels = dev(images_np), dev(lab.astype(np.int32))
+        ws = runtime.PN2Workspace(8, 4096, iters)
+        adv = ws.nb_attack(gpu_model, images, labels, dev(starts[1:1 + iters], torch.int32), eps, alpha, iters)
+        torch.cuda.synchronize()
+        out = adv.cpu().numpy()
+        assert np.array_equal(out[:, :3], images_np[:, :3]) and np.array_equal(out[:, 6:], images_np[:, 6:])
+        assert np.abs(out[:, 3:6] - images_np[:, 3:6]).max() <= eps + alpha + 1e-6
+        l2 = float(np.sqrt(((out - images_np).astype(np.float64) ** 2).sum()))
+        assert abs(l2 - float(g[p + "l2_dis"])) <= 0.01 * float(g[p + "l2_dis"])
+        ev = runtime.PN2Workspace(8, 4096, 1)
+        # clean forward on the reference's clean RNG slot
+        x0c = dev(rooms)
+        ev.plan_build(x0c, dev(starts[0:1], torch.int32), 1)
+        logp = ev.forward(gpu_model, 0, x0c)
+        pred = logp.argmax(2).cpu().numpy()
+        assert (pred != g[p + "clean_pred"]).mean() <= 2e-4
+        # adversarial forward on the reference's slot
+        x0a = adv.transpose(1, 2).contiguous()
+        ev.plan_build(x0a, dev(starts[iters + 1:iters + 2], torch.int32), 1)
+        counters, _ = runtime.seg_stats(ev.forward(gpu_model, 0, x0a), labels)
+        apred = ev.forward(gpu_model, 0, x0a).argmax(2).cpu().numpy()
+        torch.cuda.synchronize()
+        c = counters.cpu().numpy().astype(np.float64)
+        r = g[p + "adv_counters"].astype(np.float64)
+        tot_ref += r
+        tot_got += c
+        acc, racc = c[1].sum() / c[0].sum(), r[1].sum() / r[0].sum()
+        miou = np.mean((c[1] / (c[2] + 1e-6))[c[0] != 0])
+        rmiou = np.mean((r[1] / (r[2] + 1e-6))[r[0] != 0])
+        assert abs(acc - racc) <= 0.01 and abs(miou - rmiou) <= 0.01, (bi, acc, racc, miou, rmiou)
+        room_acc = (apred == lab).mean(1)
+        assert np.abs(room_acc - g[p + "room_adv_acc"]).max() <= 0.03, np.abs(room_acc - g[p + "room_adv_acc"]).max()
+    acc, racc = tot_got[1].sum() / tot_got[0].sum(), tot_ref[1].sum() / tot_ref[0].sum()
+    assert abs(acc - racc) <= 0.005, (acc, racc)
