@@ -156,6 +156,63 @@ int psg_pn2_activation_channels(const psg_pn2_ws *ws, int which);   /* channels 
  * Attack-loop arithmetic (PointNet/attacks/torchattacks/attacks/nontarget.py, target.py).
  * ------------------------------------------------------------------------------------------ */
 
+/* ------------------------------------------------------------------------------------------
+ * Per-operator entry points: what the STAND-ALONE forwards of the reference's public modules run on
+ * (inside get_model / DenseDeepGCN the same arithmetic is one fused kernel per module).  Point-major rows, device
+ * pointers, stream-ordered, no allocation; BatchNorm (eval) is folded into w / bias by the caller.  Input gradients only.
+ * ------------------------------------------------------------------------------------------ */
+/* sample_and_group's row assembly, pointnet_util.py:126-140: rows[(b,s,k)] = [xyz[g] - new_xyz[s], feat[g]] with
+ * g = gidx[b][s][k] (feat_first = 1: [feat, rel_xyz], the MSG order :251-254).  rows_out [B*S*K][3+D]. */
+int psg_group_rows(const float *xyz, const float *feat, const float *new_xyz, const int32_t *gidx, int B, int N, int S,
+                   int K, int D, int feat_first, float *rows_out, psg_stream stream);
+/* its transpose w.r.t. the features (index_points backward, :136): dfeat [B][N][D], zeroed here. */
+int psg_group_rows_bwd(const float *drows, const int32_t *gidx, int B, int N, int S, int K, int D, int feat_first,
+                       float *dfeat, psg_stream stream);
+/* one shared 1x1 convolution over rows (Conv -> BN(eval) -> ReLU, pointnet_util.py:200-203, 317-319):
+ * out = [relu](in . w^T + bias) [* scale + shift], w [M][K]; scale / shift (or NULL): BatchNorm AFTER the ReLU, ResGCN's
+ * BasicConv order (torch_nn.py:55-75); mask_out: ReLU bits [rows][ceil(M/32)] words or NULL. */
+int psg_pw_mlp_fwd(const float *in, int ld_in, int rows, int K, const float *w, const float *bias, int relu, int M,
+                   float *out, int ld_out, uint32_t *mask_out, const float *scale, const float *shift, psg_stream stream);
+/* its input gradient: din = (dout . w) * [ReLU bits of the layer below, or NULL]; wT [K][M] = w transposed. */
+int psg_pw_mlp_bwd(const float *dout, int ld_dout, int rows, int M, const float *wT, const uint32_t *mask_below, int K,
+                   float *din, int ld_din, psg_stream stream);
+/* backward through a layer's own ReLU (and the BatchNorm scale after it, or NULL): g[row][c] = bit ? g * scale[c] : 0. */
+int psg_apply_relu_bits(float *g, int ld, const uint32_t *bits, const float *scale, int rows, int M, psg_stream stream);
+/* PointNetSetAbstraction.forward after grouping, pointnet_util.py:200-205: n_layers shared layers over the grouped rows
+ * [n_groups*K][cin], max over the K samples.  scratch_a/b: [rows][max width]; masks[l]: ReLU bits of layer l (or NULL array);
+ * out [n_groups][widths[n-1]], arg: winning sample (first on ties, like torch.max). */
+int psg_sa_mlp_max_fwd(const float *rows_in, int n_groups, int K, int cin, int n_layers, const int *widths,
+                       const float *const *w, const float *const *bias, float *scratch_a, float *scratch_b,
+                       uint32_t *const *masks, float *out, uint8_t *arg, psg_stream stream);
+int psg_sa_mlp_max_bwd(const float *dout, const uint8_t *arg, int n_groups, int K, int cin, int n_layers,
+                       const int *widths, const float *const *wT, const uint32_t *const *masks, float *scratch_a,
+                       float *scratch_b, float *drows_in, psg_stream stream);
+/* PointNetFeaturePropagation's interpolation + concat, pointnet_util.py:301-314: out [B][N][D1+D2] =
+ * [feat1 (NULL when D1 = 0), sum_j w_j feat2[idx_j]]; idx / w from psg_three_nn. */
+int psg_three_interp_fwd(const float *feat2, const int32_t *idx, const float *w, const float *feat1, int B, int N, int S,
+                         int D1, int D2, float *out, psg_stream stream);
+/* transpose: dfeat2 [B][S][D2] (zeroed here) += w_j * dout[b][n][col0 + c], dout rows of ld floats. */
+int psg_three_interp_bwd(const float *dout, int ld, int col0, const int32_t *idx, const float *w, int B, int N, int S,
+                         int D2, float *dfeat2, psg_stream stream);
+/* pairwise_distance, ResGCN/gcn_lib/dense/torch_edge.py:32-42: x [B][N][C] -> out [B][N][N], the reference's fp32 order;
+ * sq: scratch [B*N]. */
+int psg_gcn_pairwise_distance(const float *x, int B, int N, int C, float *sq, float *out, psg_stream stream);
+/* EdgeConv2d.forward, torch_vertex.py:31-35 (BasicConv = Conv -> ReLU -> BatchNorm, torch_nn.py:55-75), 16 neighbours,
+ * 64 output channels: y_i = max_k(scale * relu(W.[x_i, x_j - x_i] + b) + shift).  x [R][ld_x], nbr [R][16] room-local,
+ * R = rooms * N; wcat [128][C] = [W1 - W2 ; W2], bcat [128] = [b, 0]; pq scratch [R][128]; arg [R][64]. */
+int psg_edgeconv_fwd(const float *x, int ld_x, int R, int N, int C, const int32_t *nbr, const float *wcat,
+                     const float *bcat, const float *scale, const float *shift, float *pq, float *out, int ld_out,
+                     uint8_t *arg, psg_stream stream);
+/* MRConv2d's gather, torch_vertex.py:16-19: cat [R][2C] = [x_i, max_k (x_j - x_i)], arg [R][C] = winning neighbour; the
+ * BasicConv after it is psg_pw_mlp_fwd with scale / shift.  _bwd: dx [R][ld_dx] = dcat_x - dcat_m, + dcat_m at the winner. */
+int psg_mrconv_gather_fwd(const float *x, int ld_x, int R, int N, int C, const int32_t *nbr, float *cat, uint8_t *arg,
+                          psg_stream stream);
+int psg_mrconv_gather_bwd(const float *dcat, int R, int N, int C, const int32_t *nbr, const uint8_t *arg, float *dx, int ld_dx,
+                          psg_stream stream);
+/* its input gradient: dx [R][ld_dx] (C columns); wcat_t [C][128]; dpq scratch [R][128]. */
+int psg_edgeconv_bwd(const float *dy, int ld_dy, int R, int N, int C, const int32_t *nbr, const uint8_t *arg,
+                     const float *scale, const float *wcat_t, float *dpq, float *dx, int ld_dx, psg_stream stream);
+
 /* [B][C][N] channel-major (reference layout) <-> [B][N][C] point-major. */
 int psg_to_point_major(const float *src_cn, int B, int C, int N, float *dst_nc, psg_stream stream);
 int psg_to_channel_major(const float *src_nc, int B, int C, int N, float *dst_cn, psg_stream stream);

@@ -28,6 +28,21 @@ SIGNATURES = {
     "psg_gather_points": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, vp, vp]),
     "psg_ball_query": (ci, [vp, vp, ci, vp, ci, ci, ci, cf, ci, vp, vp]),
     "psg_three_nn": (ci, [vp, vp, ci, vp, ci, ci, ci, vp, vp, vp]),
+    "psg_group_rows": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "psg_group_rows_bwd": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "psg_pw_mlp_fwd": (ci, [vp, ci, ci, ci, vp, vp, ci, ci, vp, ci, vp, vp, vp, vp]),
+    "psg_pw_mlp_bwd": (ci, [vp, ci, ci, ci, vp, vp, ci, vp, ci, vp]),
+    "psg_apply_relu_bits": (ci, [vp, ci, vp, vp, ci, ci, vp]),
+    "psg_mrconv_gather_fwd": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp]),
+    "psg_mrconv_gather_bwd": (ci, [vp, ci, ci, ci, vp, vp, vp, ci, vp]),
+    "psg_sa_mlp_max_fwd": (ci, [vp, ci, ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp,
+                                ctypes.POINTER(vp), vp, vp, vp]),
+    "psg_sa_mlp_max_bwd": (ci, [vp, vp, ci, ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp, vp, vp]),
+    "psg_three_interp_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]),
+    "psg_three_interp_bwd": (ci, [vp, ci, ci, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "psg_gcn_pairwise_distance": (ci, [vp, ci, ci, ci, vp, vp, vp]),
+    "psg_edgeconv_fwd": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp]),
+    "psg_edgeconv_bwd": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]),
     "psg_pn2_model_create": (ci, [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]),
     "psg_pn2_model_create_arch": (ci, [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(vp), ci, ctypes.POINTER(vp)]),
     "psg_pn2_model_destroy": (ci, [vp]),

@@ -1018,6 +1018,91 @@ extern "C" int psg_gcn_knn(psg_gcn_ws *ws, const float *x, int C, int dilation, 
     return knn_graph(ws, x, C, C, dilation, out_idx, (hipStream_t)stream);
 }
 
+// ---- per-operator entry points behind the stand-alone forwards of the reference's public modules (the whole-network
+// entry points below fuse them): thin launches of the same kernels on the caller's tensors.
+
+// pairwise_distance, torch_edge.py:32-42: x [B][N][C] -> out [B][N][N] = (|x_i|^2 + (-2 x_i.x_j)) + |x_j|^2 with the
+// reference's fp32 order (norms in torch.sum's order, dot products as the ascending-k fmaf chain); sq: scratch [B*N]
+extern "C" int psg_gcn_pairwise_distance(const float *x, int B, int N, int C, float *sq, float *out, psg_stream stream)
+{
+    PSG_REQUIRE(x && sq && out && B > 0 && N > 0 && C > 0, "psg_gcn_pairwise_distance: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t rows = (size_t)B * N;
+    hipLaunchKernelGGL(sumsq_rows_kernel, dim3(ceil_div((int)rows, 256)), dim3(256), 0, st, x, C, C, rows, sq);
+    PSG_LAUNCH_CHECK();
+    for (int b = 0; b < B; ++b) {
+        GemmArgs a = gemm_args(x + (size_t)b * N * C, C, x + (size_t)b * N * C, C, out + (size_t)b * N * N, N, N, C, N);
+        a.sq = sq + (size_t)b * N;
+        int rc = launch_gemm<2, 2, EPI_KNN_DIST, true>(a, st);
+        if (rc) return rc;
+    }
+    return PSG_OK;
+}
+
+// EdgeConv2d.forward, torch_vertex.py:31-35 with BasicConv's Conv -> ReLU -> BatchNorm(eval) (torch_nn.py:55-75):
+// y[i] = max_k ( scale * relu(W . [x_i, x_j - x_i] + b) + shift ),  j = nbr[i][k], 16 neighbours, 64 output channels.
+// x [R][ld_x] (C used columns), R = rooms * N, nbr room-local; wcat [128][C] = [W1 - W2 ; W2], bcat [128] = [b, 0]
+// (the split identity, built by the caller); pq: scratch [R][128]; arg [R][64] for the backward.
+extern "C" int psg_edgeconv_fwd(const float *x, int ld_x, int R, int N, int C, const int32_t *nbr, const float *wcat,
+                                const float *bcat, const float *scale, const float *shift, float *pq, float *out, int ld_out,
+                                uint8_t *arg, psg_stream stream)
+{
+    PSG_REQUIRE(x && nbr && wcat && bcat && scale && shift && pq && out && arg && R > 0 && N > 0 && C > 0 && R % N == 0,
+                "psg_edgeconv_fwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs a = gemm_args(x, ld_x, wcat, C, pq, 2 * GC, R, C, 2 * GC);
+    a.bias = bcat;
+    int rc;
+    if ((rc = launch_gemm<2, 2, EPI_LINEAR, false>(a, st))) return rc;
+    hipLaunchKernelGGL(edge_max_fwd_kernel, dim3(ceil_div((int)((size_t)R * GC), 256)), dim3(256), 0, st, pq, nbr, scale, shift,
+                       (const float *)nullptr, 0, out, ld_out, arg, N, (size_t)R * GC, (float *)nullptr, (float *)nullptr);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+// its input gradient: dy [R][ld_dy] -> dx [R][C]; wcat_t [C][128] = wcat transposed; dpq: scratch [R][128]
+extern "C" int psg_edgeconv_bwd(const float *dy, int ld_dy, int R, int N, int C, const int32_t *nbr, const uint8_t *arg,
+                                const float *scale, const float *wcat_t, float *dpq, float *dx, int ld_dx, psg_stream stream)
+{
+    PSG_REQUIRE(dy && nbr && arg && scale && wcat_t && dpq && dx && R > 0 && N > 0 && C > 0 && R % N == 0,
+                "psg_edgeconv_bwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    PSG_CHECK_HIP(hipMemsetAsync(dpq, 0, (size_t)R * 2 * GC * 4, st));
+    hipLaunchKernelGGL(edge_max_bwd_kernel, dim3(ceil_div((int)((size_t)R * GC), 256)), dim3(256), 0, st, dy, ld_dy, nbr, arg, scale,
+                       dpq, N, (size_t)R * GC);
+    PSG_LAUNCH_CHECK();
+    GemmArgs a = gemm_args(dpq, 2 * GC, wcat_t, 2 * GC, dx, ld_dx, R, 2 * GC, C);
+    return launch_gemm<4, 1, EPI_LINEAR, false>(a, st);
+}
+
+// MRConv2d's gather, torch_vertex.py:16-19: cat [R][2C] = [x_i, max_k (x_j - x_i)], arg [R][C] = winning neighbour (first
+// on ties); the BasicConv that follows is psg_pw_mlp_fwd (Conv -> ReLU -> BatchNorm through its scale / shift).
+extern "C" int psg_mrconv_gather_fwd(const float *x, int ld_x, int R, int N, int C, const int32_t *nbr, float *cat, uint8_t *arg,
+                                     psg_stream stream)
+{
+    PSG_REQUIRE(x && nbr && cat && arg && R > 0 && N > 0 && C > 0 && R % N == 0, "psg_mrconv_gather_fwd: bad argument");
+    const size_t tot = (size_t)R * C;
+    hipLaunchKernelGGL(mr_gather_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld_x, C, nbr,
+                       cat, arg, N, tot);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+// its transpose: dx[i] = dcat_x[i] - dcat_m[i], then dx[nbr(i, k*)] += dcat_m[i]   (dx [R][ld_dx], fully written)
+extern "C" int psg_mrconv_gather_bwd(const float *dcat, int R, int N, int C, const int32_t *nbr, const uint8_t *arg, float *dx,
+                                     int ld_dx, psg_stream stream)
+{
+    PSG_REQUIRE(dcat && nbr && arg && dx && R > 0 && N > 0 && C > 0 && R % N == 0, "psg_mrconv_gather_bwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t tot = (size_t)R * C;
+    const unsigned grid = (unsigned)((tot + 255) / 256);
+    hipLaunchKernelGGL(mr_bwd_self_kernel, dim3(grid), dim3(256), 0, st, dcat, C, dx, ld_dx, (const float *)nullptr, 0, 1, tot);
+    PSG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mr_bwd_scatter_kernel, dim3(grid), dim3(256), 0, st, dcat, C, nbr, arg, dx, ld_dx, N, tot);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
 // ==================================================================================== forward / backward
 extern "C" int psg_gcn_forward(psg_gcn_model *m, psg_gcn_ws *ws, const float *x0, float *logits_out, psg_stream stream)
 {

@@ -6,14 +6,30 @@ sample_and_group :110, PointNetSetAbstraction :166, PointNetSetAbstractionMsg :2
 Every function takes CUDA tensors and runs a hand-written gfx950 kernel through libpsg.so; there is
 no PyTorch-op or CPU fallback.  Index results are int64 like the reference's.
 
-The two nn.Module classes keep the reference's parameter layout (`mlp_convs.N`, `mlp_bns.N`) so that
-state_dicts are interchangeable; inside get_model their arithmetic is executed by the whole-network
-kernels (pointnet2_sem_seg.py), which is the only way the attack path uses them.
+The three nn.Module classes keep the reference's parameter layout (`mlp_convs.N`, `mlp_bns.N`, `conv_blocks.S.N`) so
+that state_dicts are interchangeable.  Inside get_model their arithmetic is ONE fused kernel per module
+(pointnet2_sem_seg.py), which is how the attack path uses them; called on their own (`module(xyz, points)`, the
+reference's signatures and channel-major layouts) they run on the per-operator entry points of libpsg
+(pointsecguard_amd/ops.py): eval mode only, gradients for the input features only.
 """
 import torch
 import torch.nn as nn
 
-from pointsecguard_amd import runtime
+from pointsecguard_amd import ops, runtime
+
+
+def _eval_only(module):
+    if module.training:
+        raise NotImplementedError("pointsecguard_amd implements the eval-mode attack path only; call .eval() "
+                                  "(training-mode BatchNorm statistics are out of scope)")
+
+
+def _point_major(t):
+    """[B,C,N] (the reference's layout) -> contiguous float32 [B,N,C]; None stays None."""
+    if t is None:
+        return None
+    runtime.require_cuda(t.contiguous(), "input", None)
+    return t.permute(0, 2, 1).contiguous().float()
 
 
 def square_distance(src, dst):
@@ -74,8 +90,16 @@ class PointNetSetAbstraction(nn.Module):
         self.group_all = group_all
 
     def forward(self, xyz, points):
-        raise NotImplementedError("stand-alone PointNetSetAbstraction.forward is executed by the fused whole-network "
-                                  "kernels of get_model; call the parent get_model instead")
+        """xyz [B,3,N], points [B,D,N] or None -> new_xyz [B,3,S], new_points [B,C_last,S] (pointnet_util.py:181-207)."""
+        _eval_only(self)
+        xyz_pm, pts_pm = _point_major(xyz), _point_major(points)
+        B, N, _ = xyz_pm.shape
+        fps_idx = farthest_point_sample(xyz_pm, self.npoint)              # draws its start like the reference (:75)
+        new_xyz = index_points(xyz_pm, fps_idx)
+        gidx = query_ball_point(self.radius, self.nsample, xyz_pm, new_xyz).to(torch.int32).contiguous()
+        ws, bs = zip(*[ops.fold_conv_bn(c, b) for c, b in zip(self.mlp_convs, self.mlp_bns)])
+        out = ops.SetAbstractionMLP.apply(pts_pm, xyz_pm, new_xyz.contiguous(), gidx, list(ws), list(bs), False)
+        return new_xyz.permute(0, 2, 1), out.permute(0, 2, 1)
 
 
 class PointNetSetAbstractionMsg(nn.Module):
@@ -98,8 +122,18 @@ class PointNetSetAbstractionMsg(nn.Module):
             self.bn_blocks.append(bns)
 
     def forward(self, xyz, points):
-        raise NotImplementedError("stand-alone PointNetSetAbstractionMsg.forward is executed by the fused whole-network "
-                                  "kernels of get_model; call the parent get_model instead")
+        """xyz [B,3,N], points [B,D,N] -> new_xyz [B,3,S], concatenated scale outputs [B,sum C,S] (pointnet_util.py:229-267;
+        one FPS sample for all radii, grouped rows [features, rel_xyz])."""
+        _eval_only(self)
+        xyz_pm, pts_pm = _point_major(xyz), _point_major(points)
+        fps_idx = farthest_point_sample(xyz_pm, self.npoint)
+        new_xyz = index_points(xyz_pm, fps_idx).contiguous()
+        outs = []
+        for i, radius in enumerate(self.radius_list):
+            gidx = query_ball_point(radius, self.nsample_list[i], xyz_pm, new_xyz).to(torch.int32).contiguous()
+            ws, bs = zip(*[ops.fold_conv_bn(c, b) for c, b in zip(self.conv_blocks[i], self.bn_blocks[i])])
+            outs.append(ops.SetAbstractionMLP.apply(pts_pm, xyz_pm, new_xyz, gidx, list(ws), list(bs), True))
+        return new_xyz.permute(0, 2, 1), torch.cat(outs, dim=2).permute(0, 2, 1)
 
 
 class PointNetFeaturePropagation(nn.Module):
@@ -114,5 +148,14 @@ class PointNetFeaturePropagation(nn.Module):
             last_channel = out_channel
 
     def forward(self, xyz1, xyz2, points1, points2):
-        raise NotImplementedError("stand-alone PointNetFeaturePropagation.forward is executed by the fused "
-                                  "whole-network kernels of get_model; call the parent get_model instead")
+        """xyz1 [B,3,N] (fine), xyz2 [B,3,S] (coarse), points1 [B,D1,N] or None, points2 [B,D2,S] -> [B,C_last,N]
+        (pointnet_util.py:281-320)."""
+        _eval_only(self)
+        x1, x2 = _point_major(xyz1), _point_major(xyz2)
+        if x2.shape[1] < 3:
+            raise NotImplementedError("fewer than 3 coarse points (the S == 1 branch, pointnet_util.py:298-299) is not reachable "
+                                      "from pointnet2_sem_seg and not implemented")
+        idx, w = runtime.three_nn(x1, x2)
+        ws, bs = zip(*[ops.fold_conv_bn(c, b) for c, b in zip(self.mlp_convs, self.mlp_bns)])
+        out = ops.FeaturePropagationMLP.apply(_point_major(points1), _point_major(points2), idx, w, list(ws), list(bs))
+        return out.permute(0, 2, 1)

@@ -32,8 +32,8 @@ class DenseDilated(nn.Module):
 
 def pairwise_distance(x):
     """x [B,N,C] -> [B,N,N] = (|x_i|^2 + (-2 x_i.x_j)) + |x_j|^2 with the reference's fp32 order."""
-    raise NotImplementedError("pairwise_distance is fused into the kNN kernel (psg_gcn_knn); the [B,N,N] matrix is not "
-                              "part of the public path")
+    from pointsecguard_amd import ops
+    return ops.pairwise_distance(x)
 
 
 def dense_knn_matrix(x, k=16):
