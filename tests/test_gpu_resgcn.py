@@ -195,14 +195,30 @@ def test_resgcn_python_api(gcn_weights_sd, golden_gcn_room, golden_gcn_nb):
     g = golden_gcn_room
     inputs = dev(g["room"].T[None, :, :, None])                          # [1,9,N,1]
     inputs.requires_grad_(True)
+    y = dev(g["labels"].astype(np.int64)[None])
+    # (1) the reference's graphs teacher-forced THROUGH THE PUBLIC API (the module's workspace takes the tables): tight bars
+    ws = net._workspace(1, 1024)
+    ws.set_graphs(dev(np.stack([g["nbr%d" % e].astype(np.int32)[None] for e in range(NB)])))
     out = net(inputs)
     assert out.shape == (1, 13, 1024)
-    # free-running graphs: a differently broken near-tie moves a vertex feature, and through the global max of the
-    # fusion block every point's logits a little; predictions must still agree
+    lg = out.detach()[0].T.cpu().numpy()
+    assert np.abs(lg - g["logits"]).max() <= 1e-4
+    assert (lg.argmax(1) == g["logits"].argmax(1)).mean() >= 0.9999
+    cost = torch.nn.CrossEntropyLoss()(out, y)
+    cost.backward()
+    assert abs(cost.item() - float(g["cost"])) <= 1e-4
+    gx, rx = inputs.grad[0, :, :, 0].T.cpu().numpy(), g["dx"]
+    assert (np.sign(gx[:, 3:6]) == np.sign(rx[:, 3:6])).mean() >= 0.999
+    assert np.abs(gx - rx).max() <= 1e-3 * np.abs(rx).max() + 1e-6
+    ws.set_graphs(None)
+    # (2) free-running graphs: a differently broken near-tie re-ranks a neighbourhood (every d-th of a sorted list), moves
+    # that vertex's feature and, through the global max of the fusion block, every point's logits a little: the dynamic-
+    # graph network is chaotic (28 blocks lose all edge overlap by block 6).  Five blocks stay close:
+    inputs.grad = None
+    out = net(inputs)
     lg = out.detach()[0].T.cpu().numpy()
     assert np.abs(lg - g["logits"]).max() <= 1.0
     assert (lg.argmax(1) == g["logits"].argmax(1)).mean() >= 0.97
-    y = dev(g["labels"].astype(np.int64)[None])
     cost = torch.nn.CrossEntropyLoss()(out, y)
     cost.backward()
     assert abs(cost.item() - float(g["cost"])) <= 2e-2
