@@ -334,7 +334,8 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
         y1 = sq4[t1 * 4 + g];
     };
     if (KF_PREFETCH) load_operands(0, p0, p1, ps0, ps1);
-    for (int step = 0; step < n_steps; ++step) {
+    // operands, 32 MFMAs, the 8 distance keys of the lane and the admission mask of one step
+    auto step_compute = [&](int step, unsigned (&key)[8], unsigned &mask, int &c0) {
         KF_T(t_a);
         const int pair = step * KF_WAVES + wave;
         float4 a0[4], a1[4], s0, s1;
@@ -373,10 +374,9 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
 #endif
 
         // ---- distance keys of the lane's 8 (query, candidate) pairs; admitted iff (key, index) <= tau
-        const int c0 = pair * KF_STEP + 4 * g;              // candidates c0 + r (tile 0) and c0 + 16 + r (tile 1)
-        unsigned key[8];
+        c0 = pair * KF_STEP + 4 * g;                        // candidates c0 + r (tile 0) and c0 + 16 + r (tile 1)
         const unsigned tk = tau_k[q], ti = tau_i[q];
-        unsigned mask = 0;
+        mask = 0;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const float z = r < 4 ? acc0[r] : acc1[r - 4];
@@ -390,12 +390,82 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
             for (int r = 0; r < 8; ++r)
                 if (c0 + (r < 4 ? r : 12 + r) >= a.N) mask &= ~(1u << r);
         }
-        const unsigned n = (unsigned)__popc(mask);
 #ifdef PSG_KF_STAMP
-        asm volatile("" :: "v"(n));
+        asm volatile("" :: "v"(mask));
         KF_T(t_a3);
         KF_ACC(10, t_a3, t_a2);        // keys + filter
+        KF_ACC(0, t_a3, t_a);
 #endif
+    };
+
+    // ---- FAST PATH: no barrier per step.  Slots are taken with the same atomic; an allocation that does not fit is simply
+    // not written (the row's counter then exceeds CAP, which is detected at the next synchronisation point and sends the
+    // whole workgroup through the exact per-step path below: adversarial candidate orders only).  Rows are pruned at a
+    // data-independent schedule (below); between those points the 16 waves run free, so the four waves of a SIMD overlap
+    // operand loads, MFMAs and key / append work by themselves.
+    bool need_safe = false;
+    {
+        // prune schedule, in candidates seen: first when the buffer is full (CAP, everything was admitted); a row cut to
+        // c <= KK + TOL keys at n_i admits about c / n_i of what follows (tau is fixed until the next prune), so the next
+        // prune comes when c * n / n_i reaches 0.9 CAP: n_{i+1} = 0.9 CAP / (KK + TOL) * n_i, in whole steps
+        const float grow = 0.9f * (float)CAP / (float)(KK + (unsigned)a.TOL);
+        unsigned next_prune = (unsigned)CAP;
+        for (int step = 0; step < n_steps; ++step) {
+            unsigned key[8], mask;
+            int c0;
+            step_compute(step, key, mask, c0);
+            const unsigned n = (unsigned)__popc(mask);
+            if (n) {
+                const unsigned base = atomicAdd(&cnt[q], n);
+                if (base + n <= (unsigned)CAP) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        if ((mask >> r) & 1u)
+                            ent[q * CAP + base + __popc(mask & ((1u << r) - 1u))] =
+                                ((unsigned long long)key[r] << 12) | (unsigned)(c0 + (r < 4 ? r : 12 + r));
+                }
+            }
+            const unsigned seen = (unsigned)(step + 1) * (unsigned)PER_STEP;
+            const bool prune_now = seen >= next_prune && step + 1 < n_steps;
+            if (prune_now) {
+                const unsigned nn = (unsigned)(grow * (float)seen) / (unsigned)PER_STEP * (unsigned)PER_STEP;
+                next_prune = nn > seen ? nn : seen + (unsigned)PER_STEP;
+                __syncthreads();
+                const unsigned over = __ballot(lane < KF_Q && cnt[lane & (KF_Q - 1)] > (unsigned)CAP) != 0ull;
+                if (over) { need_safe = true; break; }                 // (every wave reads the same counters: uniform)
+                for (int qq = wave; qq < KF_Q; qq += KF_WAVES) {
+                    const unsigned T = cnt[qq];
+                    if (T > (unsigned)a.LOW) {
+                        unsigned long long thr;
+                        const unsigned c = prune_row<KF_NPL>(ent + qq * CAP, T, KK, (unsigned)a.TOL, lane, thr);
+                        if (lane == 0) { cnt[qq] = c; tau_k[qq] = (unsigned)(thr >> 12); tau_i[qq] = (unsigned)thr & 0xFFFu; }
+                    }
+                }
+                __syncthreads();
+#ifdef PSG_KF_STAMP
+                kf_sum[5] += 1;
+#endif
+            }
+        }
+        __syncthreads();
+        if (!need_safe) need_safe = __ballot(lane < KF_Q && cnt[lane & (KF_Q - 1)] > (unsigned)CAP) != 0ull;
+    }
+    if (need_safe) {
+        // ---- EXACT PER-STEP PATH (rare): start over with a barrier per step, roll-back on overflow
+        __syncthreads();
+        if (tid < KF_Q) { tau_k[tid] = 0xFFFFFFFFu; tau_i[tid] = 0xFFFu; cnt[tid] = 0u; }
+        if (tid < 6) flag[tid] = 0u;
+        __syncthreads();
+#ifdef PSG_KF_STAMP
+        kf_sum[6] += 1;
+#endif
+    for (int step = 0; step < n_steps; ++step) {
+        unsigned key[8], mask;
+        int c0;
+        step_compute(step, key, mask, c0);
+        const int pair = step * KF_WAVES + wave;
+        (void)pair;
+        const unsigned n = (unsigned)__popc(mask);
         unsigned base = 0;
         if (n) base = atomicAdd(&cnt[q], n);
         // room the NEXT step may need: about PER_STEP * KK / (candidates seen) keys per row, doubled, at most PER_STEP
@@ -408,7 +478,6 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
         // (not __syncthreads(): that would also wait for the operand loads in flight; only LDS traffic must have landed)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         KF_T(t_c);
-        KF_ACC(0, t_b, t_a);
         KF_ACC(1, t_c, t_b);
         const unsigned f_ovf = flag[2 * ph], f_prune = flag[2 * ph + 1];
         if (tid == 0) { flag[2 * ((step + 2) % 3)] = 0u; flag[2 * ((step + 2) % 3) + 1] = 0u; }
@@ -439,9 +508,6 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
 #endif
             }
         } else {
-#ifdef PSG_KF_STAMP
-            kf_sum[6] += 1;
-#endif
             // ---- overflow (adversarial orders): roll the step back, cut every row to exactly KK, commit one register
             // at a time (<= 64 appends per row between checks)
             if (n) atomicSub(&cnt[q], n);
@@ -473,6 +539,7 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
             }
         }
     }
+    }   // need_safe
     __syncthreads();
     KF_T(t_f);
     for (int qq = wave; qq < KF_Q; qq += KF_WAVES)

@@ -1,21 +1,48 @@
 #!/bin/bash
-# rocprofv3 passes behind profiles/: kernel-trace stats of the bench command, then FETCH_SIZE / WRITE_SIZE
-# in separate PMC passes (usage: tools/profile_round.sh TAG)
+# rocprofv3 passes behind profiles/<TAG>_*: kernel-trace stats of every bench workload, then FETCH_SIZE / WRITE_SIZE and the
+# matrix-busy counters in SEPARATE PMC passes (program directly after `--`, no trace domains with --pmc).
+# usage (on the GPU box, from the repo root): tools/profile_round.sh TAG   ->  gpurun_out/prof_TAG/, copy what is to be kept
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
+WHAT=${2:-all}     # all | stats | pmc_pn2 | pmc_gcn
 export TMPDIR=/tmp
 O=gpurun_out/prof_$TAG
 mkdir -p $O
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pn2 -o pn2 -- python3 bench.py --steps 16 --warmup 8 --concurrency 1 --no-cpu-baseline --no-reference > $O/pn2.log 2>&1 || exit 1
-grep '^{' $O/pn2.log > $O/pn2_bench.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/gcn -o gcn -- python3 bench.py --workload resgcn --steps 2 --warmup 1 --no-cpu-baseline > $O/gcn.log 2>&1 || exit 1
-grep '^{' $O/gcn.log > $O/gcn_bench.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/msg -o msg -- python3 bench.py --workload pointnet2_msg --steps 16 --warmup 8 --concurrency 1 > $O/msg.log 2>&1 || exit 1
-grep '^{' $O/msg.log > $O/msg_bench.json
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 bench.py --steps 8 --warmup 8 --coalesce 8 --concurrency 1 --no-cpu-baseline --no-reference > $O/fetch.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 bench.py --steps 8 --warmup 8 --coalesce 8 --concurrency 1 --no-cpu-baseline --no-reference > $O/write.log 2>&1 || exit 1
+stats() {   # name, bench args...
+    local name=$1; shift
+    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -o $name -- python3 bench.py "$@" > $O/$name.log 2>&1 || return 1
+    grep '^{' $O/$name.log > $O/${name}_bench.json
+    cp $(find $O/$name -name '*kernel_stats.csv' | head -1) $O/${name}_kernel_stats.csv
+    rm -rf $O/$name
+}
+if [ $WHAT = all ] || [ $WHAT = stats ]; then
+stats pn2 --steps 16 --warmup 8 --concurrency 1 --no-cpu-baseline --no-reference --no-secondary || exit 1
+stats gcn --workload resgcn --steps 4 --warmup 4 --gcn-concurrency 1 --no-cpu-baseline --no-reference || exit 1
+stats msg --workload pointnet2_msg --steps 16 --warmup 8 --concurrency 1 --no-cpu-baseline || exit 1
+stats tarnu --workload tarnu --steps 3 --warmup 1 --nu-concurrency 1 --no-cpu-baseline || exit 1
+stats randla --workload randla --steps 2 --warmup 1 --concurrency 1 --no-cpu-baseline || exit 1
+fi
+pmc() {     # name, counters (quoted), bench args...
+    local name=$1 ctr=$2; shift 2
+    # (hipGraph replays under counter collection never returned on this pool: the attack loops stay eager in PMC passes)
+    PSG_GCN_NO_GRAPH=1 PSG_RLA_NO_GRAPH=1 timeout -k 10 240 rocprofv3 --pmc $ctr --output-format csv -d $O/$name -o p -- python3 bench.py "$@" > $O/$name.log 2>&1 || return 1
+}
+PN2="--steps 8 --warmup 8 --coalesce 8 --concurrency 1 --no-cpu-baseline --no-reference --no-secondary"
+# (a counter pass serialises every dispatch: one 4-room launch of the ResGCN attack = 15k dispatches is plenty)
+GCN="--workload resgcn --steps 4 --warmup 0 --gcn-concurrency 1 --no-cpu-baseline --no-reference"
+if [ $WHAT = all ] || [ $WHAT = pmc_pn2 ]; then
+pmc fetch FETCH_SIZE $PN2 || exit 1
+pmc write WRITE_SIZE $PN2 || exit 1
 python3 tools/pmc_traffic.py $O/fetch $O/write $O/pmc_traffic.json 64 > $O/pmc_traffic.txt
-rm -rf $O/fetch $O/write   # raw per-dispatch rows are large; the summary is what is kept
-find $O -name '*kernel_trace.csv' -delete
-find $O -name '*agent_info.csv' -delete
-ls -R $O | head -30
+pmc mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" $PN2 || exit 1
+python3 tools/pmc_mfma.py $O/mfma $O/pmc_mfma.json > $O/pmc_mfma.txt
+fi
+if [ $WHAT = all ] || [ $WHAT = pmc_gcn ]; then
+pmc gfetch FETCH_SIZE $GCN || exit 1
+pmc gwrite WRITE_SIZE $GCN || exit 1
+python3 tools/pmc_traffic.py $O/gfetch $O/gwrite $O/pmc_traffic_gcn.json 4 > $O/pmc_traffic_gcn.txt
+pmc gmfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" $GCN || exit 1
+python3 tools/pmc_mfma.py $O/gmfma $O/pmc_mfma_gcn.json > $O/pmc_mfma_gcn.txt
+fi
+rm -rf $O/fetch $O/write $O/gfetch $O/gwrite $O/mfma $O/gmfma   # raw per-dispatch rows are large; the summaries are what is kept
+ls $O
