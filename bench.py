@@ -372,23 +372,25 @@ def run_pointnet2(args, R):
         # ---- for reference: the same attack launched one 8-room step at a time (no coalescing), 2 in flight
         ref8 = None
         if G > 1 and not args.no_reference:
-            ws8 = [runtime.PN2Workspace(BATCH, NPOINT, ITERS) for _ in range(2)]
-            x8 = [d_images[n_warm][i * BATCH:(i + 1) * BATCH].contiguous() for i in range(min(4, G))]
-            l8 = [d_labels[n_warm][i * BATCH:(i + 1) * BATCH].contiguous() for i in range(min(4, G))]
-            s8 = [d_starts[n_warm][:, :, i * BATCH:(i + 1) * BATCH].contiguous() for i in range(min(4, G))]
+            n8 = int(os.environ.get("PSG_BENCH_STRICT_INFLIGHT", "4"))
+            st8 = [torch.cuda.Stream() for _ in range(n8)]
+            ws8 = [runtime.PN2Workspace(BATCH, NPOINT, ITERS) for _ in range(n8)]
+            x8 = [d_images[n_warm][i * BATCH:(i + 1) * BATCH].contiguous() for i in range(G)]
+            l8 = [d_labels[n_warm][i * BATCH:(i + 1) * BATCH].contiguous() for i in range(G)]
+            s8 = [d_starts[n_warm][:, :, i * BATCH:(i + 1) * BATCH].contiguous() for i in range(G)]
             o8 = [torch.empty_like(x) for x in x8]
 
             def run8():
                 for i in range(len(x8)):
-                    with torch.cuda.stream(streams[i % len(streams)]):
-                        ws8[i % 2].nb_attack(model, x8[i], l8[i], s8[i], EPS, ALPHA, ITERS, out=o8[i])
+                    with torch.cuda.stream(st8[i % n8]):
+                        ws8[i % n8].nb_attack(model, x8[i], l8[i], s8[i], EPS, ALPHA, ITERS, out=o8[i])
                 torch.cuda.synchronize()
 
             run8()
             t8 = time.perf_counter()
             run8()
             ref8 = {"value": BATCH * len(x8) / (time.perf_counter() - t8), "unit": "rooms/s",
-                    "note": "one launch per 8-room step, no coalescing, up to 2 in flight (this GPU only)"}
+                    "note": "one launch per 8-room step, no coalescing, %d steps in flight (this GPU only)" % n8}
             del ws8
         # ---- roofline of the dominant kernel: one extra attack with HIP-event timing of every launch
         ws.prof_enable(True)

@@ -25,7 +25,7 @@ fi
 pmc() {     # name, counters (quoted), bench args...
     local name=$1 ctr=$2; shift 2
     # (hipGraph replays under counter collection never returned on this pool: the attack loops stay eager in PMC passes)
-    PSG_GCN_NO_GRAPH=1 PSG_RLA_NO_GRAPH=1 timeout -k 10 240 rocprofv3 --pmc $ctr --output-format csv -d $O/$name -o p -- python3 bench.py "$@" > $O/$name.log 2>&1 || return 1
+    PSG_GCN_NO_GRAPH=1 PSG_RLA_NO_GRAPH=1 timeout -k 10 150 rocprofv3 --pmc $ctr --output-format csv -d $O/$name -o p -- python3 bench.py "$@" > $O/$name.log 2>&1 || return 1
 }
 PN2="--steps 8 --warmup 8 --coalesce 8 --concurrency 1 --no-cpu-baseline --no-reference --no-secondary"
 # (a counter pass serialises every dispatch: one 4-room launch of the ResGCN attack = 15k dispatches is plenty)
