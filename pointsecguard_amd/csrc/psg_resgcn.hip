@@ -37,8 +37,11 @@ int launch_gemm(const GemmArgs &a, hipStream_t st)
 {
     constexpr int BR = 64 * WM, BN = 64 * WN;
     dim3 grid(ceil_div(a.rows, BR), ceil_div(a.M, BN));
-    if (!ASC && (size_t)grid.x * grid.y < 128) {
-        // too few 128-wide tiles to fill the GPU (per-vertex GEMMs of one room): 64 x 64 tiles, one MFMA tile per wave
+    static const size_t small_below = getenv("PSG_GEMM_SMALL_BELOW") ? (size_t)atoi(getenv("PSG_GEMM_SMALL_BELOW")) : 384;
+    if (!ASC && (size_t)grid.x * grid.y < small_below) {
+        // too few 128-wide tiles to fill 256 CUs with more than one workgroup each (the per-vertex GEMMs of up to ~8 rooms:
+        // K = 64, so a tile is two short k-steps and the launch is latency-bound): 64 x 64 tiles, one MFMA tile per wave,
+        // four times as many workgroups (4 rooms: 31.6 -> 11 us per launch)
         dim3 small(ceil_div(a.rows, 64), ceil_div(a.M, 64));
         hipLaunchKernelGGL((gemm_rows_kernel<2, 2, EPI, ASC, 1, 1>), small, dim3(256), 0, st, a);
         PSG_LAUNCH_CHECK();
