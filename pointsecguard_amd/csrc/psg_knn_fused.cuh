@@ -42,16 +42,18 @@
 #ifndef KF_WAVES_CFG
 #define KF_WAVES_CFG 16
 #endif
-#ifndef KF_PREFETCH_CFG
-#define KF_PREFETCH_CFG 0
-#endif
 constexpr int KF_WAVES = KF_WAVES_CFG;
-constexpr bool KF_PREFETCH = KF_PREFETCH_CFG != 0;   // next step's operands loaded under this step's key / append work
 constexpr int KF_Q = 16;        // query rows per workgroup (one 16-column MFMA tile)
 constexpr int KF_STEP = 32;     // candidates per wave and step: two 16-row MFMA tiles (two independent accumulators)
-constexpr int KF_CAP = 1024;    // composite keys per row buffer
+#ifndef KF_CAP_CFG
+#define KF_CAP_CFG 1024
+#endif
+constexpr int KF_CAP = KF_CAP_CFG;    // composite keys per row buffer
 constexpr int KF_NPL = KF_CAP / 64;
-constexpr int KF_FIN = 512;     // the final ranking works on <= 512 survivors; the row's upper half is its scratch
+// Row buffers are KF_ROW keys apart, not KF_CAP: with a stride of 8 KiB the 16 rows start in the same LDS bank, and while
+// everything is admitted (all rows at the same fill) every append instruction was a 16-way bank conflict: the first two
+// steps took 12k cycles each instead of 7.6k.  16 bytes of skew per row spread the rows over all banks.
+constexpr int KF_ROW = KF_CAP + 2;
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -65,6 +67,16 @@ __device__ unsigned long long g_kf_stamps[16];
 #else
 #define KF_T(var)
 #define KF_ACC(i, t1, t0)
+#endif
+
+// Second diagnostic build (EXTRA=-DPSG_KF_TL, tools/knn_timeline.py): no waits inside the steps; thread 0 adds the time
+// since kernel start at every workgroup barrier exit, so differences are the real lengths of the workgroup-wide phases.
+#ifdef PSG_KF_TL
+__device__ unsigned long long g_kf_tl[32];
+#define KF_TL(idx) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    atomicAdd(&g_kf_tl[(idx)], t_ - tl0); atomicAdd(&g_kf_tl[16 + (idx)], 1ull); } } while (0)
+#else
+#define KF_TL(idx)
 #endif
 
 struct KnnFusedArgs {
@@ -117,6 +129,7 @@ __device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v)
 
 // Cut row `ent` (T composite keys, T <= 64 * NPL) to the C smallest with KK <= C <= KK + tol (tol = 0: exactly KK),
 // compacted in place; returns C and the threshold (every kept key <= thr, every dropped key > thr).  One wave.
+// Regula falsi on the distance value: 4 to 6 counting rounds.
 template <int NPL>
 __device__ __forceinline__ unsigned prune_row(unsigned long long *ent, unsigned T, unsigned KK, unsigned tol, int lane,
                                               unsigned long long &thr_out)
@@ -177,24 +190,20 @@ __device__ __forceinline__ unsigned kf_bin(unsigned long long comp, float dmin, 
     return (unsigned)fminf(fmaxf(t, 0.0f), 1023.0f);      // (NaN -> 0: fmaxf returns the other operand)
 }
 
-// Ranks 0, d, .., (k-1) d of a row's T >= KK composite keys (see the header).  One wave; `row` has KF_CAP slots.
-__device__ __forceinline__ void final_ranks(unsigned long long *row, unsigned T, const KnnFusedArgs &a, unsigned *scratch_cnt,
-                                            int32_t *out, int lane)
+// Exact ranks of a few of a row's keys without sorting it.  The row's keys are in registers (v, NV per lane, ~0 = none),
+// so the row's own LDS memory is scratch: `hist` = 512 words (1024 16-bit bins), `fin` = 256 finalists.  Keys are binned
+// by distance (1024 linear bins between the row's extremes: a monotone map, so bin order = key order), an exclusive scan
+// gives every bin its first rank, wanted(first_rank, size) flags the bins that hold a rank the caller wants, the members of
+// flagged bins ("finalists") are collected and each counts the finalists of its own bin below it: first rank of the
+// bin + that count is its exact rank, handed to emit(rank, key).  Returns false (nothing emitted) when there are more
+// than 256 finalists (hundreds of equal or crowded distances): the caller falls back to a slower exact method.  One wave.
+template <int NV, class Wanted, class Emit>
+__device__ __forceinline__ bool hist_ranks(const unsigned long long (&v)[NV], unsigned *hist, unsigned long long *fin,
+                                           unsigned *scratch_cnt, int lane, Wanted wanted, Emit emit)
 {
-    const unsigned KK = (unsigned)a.KK;
-    if (T > (unsigned)KF_FIN) {
-        unsigned long long thr;
-        const unsigned room = (unsigned)KF_FIN - KK;
-        T = prune_row<KF_NPL>(row, T, KK, room < 64u ? room : 64u, lane, thr);
-    }
-    wave_lds_fence();
-    constexpr int NV = KF_FIN / 64;
-    unsigned long long v[NV];
     unsigned kmn = 0xFFFFFFFFu, kmx = 0u;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const unsigned e = (unsigned)(i * 64 + lane);
-        v[i] = e < T ? row[e] : ~0ull;
         const unsigned kq = (unsigned)(v[i] >> 12);
         kmn = kq < kmn ? kq : kmn;
         kmx = (v[i] != ~0ull && kq > kmx) ? kq : kmx;
@@ -203,17 +212,14 @@ __device__ __forceinline__ void final_ranks(unsigned long long *row, unsigned T,
     kmx = wave_max_u32(kmx);
     const float dmin = dist_of(kmn), dmax = dist_of(kmx);
     const float scale = dmax > dmin ? 1023.0f / (dmax - dmin) : 0.0f;
-    unsigned *hist = (unsigned *)(row + KF_FIN);          // 512 words = 1024 16-bit bins
-    unsigned long long *fin = row + KF_FIN + 256;         // 256 finalists
     ((uint4 *)hist)[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
     ((uint4 *)hist)[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
     if (lane == 0) *scratch_cnt = 0u;
     wave_lds_fence();
-    unsigned bin[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        bin[i] = kf_bin(v[i], dmin, scale);
-        if (v[i] != ~0ull) atomicAdd(&hist[bin[i] >> 1], 1u << (16 * (bin[i] & 1u)));
+        const unsigned b = kf_bin(v[i], dmin, scale);
+        if (v[i] != ~0ull) atomicAdd(&hist[b >> 1], 1u << (16 * (b & 1u)));
     }
     wave_lds_fence();
     // lane owns bins 16 lane .. 16 lane + 15 (words 8 lane .. 8 lane + 7)
@@ -223,7 +229,6 @@ __device__ __forceinline__ void final_ranks(unsigned long long *row, unsigned T,
 #pragma unroll
     for (int j = 0; j < 8; ++j) tot += (w[j] & 0xFFFFu) + (w[j] >> 16);
     unsigned start = wave_incl_scan_u32(tot) - tot;      // first rank of the lane's first bin
-    const unsigned d = (unsigned)a.d, last = (unsigned)(a.k - 1) * d;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         unsigned nw = 0;
@@ -231,10 +236,7 @@ __device__ __forceinline__ void final_ranks(unsigned long long *row, unsigned T,
         for (int hlf = 0; hlf < 2; ++hlf) {
             const unsigned h = hlf ? (w[j] >> 16) : (w[j] & 0xFFFFu);
             unsigned hw = h;
-            if (h) {
-                const unsigned m = (((start + d - 1u) * a.magic) >> 18) * d;      // first multiple of d >= start
-                if (m < start + h && m <= last) hw = 0x8000u | start;             // flagged: holds the bin's first rank
-            }
+            if (h && wanted(start, h)) hw = 0x8000u | start;                      // flagged: holds the bin's first rank
             nw |= hw << (16 * hlf);
             start += h;
         }
@@ -246,7 +248,8 @@ __device__ __forceinline__ void final_ranks(unsigned long long *row, unsigned T,
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         if (v[i] != ~0ull) {
-            const unsigned hw = (hist[bin[i] >> 1] >> (16 * (bin[i] & 1u))) & 0xFFFFu;
+            const unsigned b = kf_bin(v[i], dmin, scale);            // (recomputed: 16 registers less than keeping it)
+            const unsigned hw = (hist[b >> 1] >> (16 * (b & 1u))) & 0xFFFFu;
             if (hw & 0x8000u) {
                 const unsigned pos = atomicAdd(scratch_cnt, 1u);
                 if (pos < 256u) fin[pos] = ((unsigned long long)(hw & 0x7FFFu) << 44) | v[i];
@@ -255,15 +258,7 @@ __device__ __forceinline__ void final_ranks(unsigned long long *row, unsigned T,
     }
     wave_lds_fence();
     const unsigned F = *scratch_cnt;
-    if (F > 256u) {
-        // hundreds of equal distances: sort the survivors (padding sorts last)
-        for (unsigned t = T + lane; t < (unsigned)KF_FIN; t += 64) row[t] = ~0ull;
-        wave_lds_fence();
-        wave_sort_keys<KF_FIN / 64>(row, lane);
-        wave_lds_fence();
-        if (lane < a.k) out[lane] = (int32_t)(row[(size_t)lane * d] & 0xFFFull);
-        return;
-    }
+    if (F > 256u) return false;
     const unsigned long long m44 = (1ull << 44) - 1ull;
     for (unsigned f = lane; f < F; f += 64) {
         const unsigned long long x = fin[f];
@@ -274,18 +269,60 @@ __device__ __forceinline__ void final_ranks(unsigned long long *row, unsigned T,
             const unsigned long long y = fin[g];
             rank += ((unsigned)(y >> 44) == st && (y & m44) < xc) ? 1u : 0u;
         }
-        const unsigned t = (rank * a.magic) >> 18;
-        if (t * d == rank && t < (unsigned)a.k) out[t] = (int32_t)(xc & 0xFFFull);
+        emit(rank, xc);
     }
+    return true;
+}
+
+// Ranks 0, d, .., (k-1) d of a row's T >= KK composite keys (see the header); T <= 64 NV.  One wave; `row` has KF_CAP
+// slots.
+template <int NV>
+__device__ __forceinline__ void final_ranks(unsigned long long *row, unsigned T, const KnnFusedArgs &a, unsigned *scratch_cnt,
+                                            int32_t *out, int lane)
+{
+    const unsigned KK = (unsigned)a.KK;
+    unsigned long long v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const unsigned e = (unsigned)(i * 64 + lane);
+        v[i] = e < T ? row[e] : ~0ull;
+    }
+    wave_lds_fence();
+    const unsigned d = (unsigned)a.d, last = (unsigned)(a.k - 1) * d;
+    const bool ok = hist_ranks<NV>(v, (unsigned *)row, row + 256, scratch_cnt, lane,
+        [&](unsigned start, unsigned h) {
+            const unsigned m = (((start + d - 1u) * a.magic) >> 18) * d;              // first multiple of d >= start
+            return m < start + h && m <= last;
+        },
+        [&](unsigned rank, unsigned long long xc) {
+            const unsigned t = (rank * a.magic) >> 18;
+            if (t * d == rank && t < (unsigned)a.k) out[t] = (int32_t)(xc & 0xFFFull);
+        });
+    if (ok) return;
+    // hundreds of equal distances: sort the (at most 512 smallest) keys; padding sorts last
+#pragma unroll
+    for (int i = 0; i < NV; ++i) row[i * 64 + lane] = v[i];
+    wave_lds_fence();
+    if (NV > 8 && T > 512u) {
+        unsigned long long thr;
+        const unsigned room = 512u - KK;
+        T = prune_row<NV>(row, T, KK, room < 64u ? room : 64u, lane, thr);
+        wave_lds_fence();
+        for (unsigned t = T + lane; t < 512u; t += 64) row[t] = ~0ull;
+        wave_lds_fence();
+    }
+    wave_sort_keys<8>(row, lane);
+    wave_lds_fence();
+    if (lane < a.k) out[lane] = (int32_t)(row[(size_t)lane * d] & 0xFFFull);
 }
 
 __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a)
 {
-    constexpr int CAP = KF_CAP;
+    constexpr int CAP = KF_CAP, ROW = KF_ROW;
     constexpr int PER_STEP = KF_WAVES * KF_STEP;                             // candidates per workgroup and step
     extern __shared__ __attribute__((aligned(16))) unsigned char kf_smem[];
-    unsigned long long *ent = (unsigned long long *)kf_smem;                 // [KF_Q][CAP]
-    unsigned *tau_k = (unsigned *)(ent + KF_Q * CAP);                        // [KF_Q] threshold: distance key ..
+    unsigned long long *ent = (unsigned long long *)kf_smem;                 // [KF_Q][ROW], CAP used
+    unsigned *tau_k = (unsigned *)(ent + KF_Q * ROW);                        // [KF_Q] threshold: distance key ..
     unsigned *tau_i = tau_k + KF_Q;                                          // [KF_Q] .. and index (ties)
     unsigned *cnt = tau_i + KF_Q;                                            // [KF_Q]
     unsigned *flag = cnt + KF_Q;                                             // [3][2]: overflow, prune (by step % 3)
@@ -293,6 +330,7 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 15, g = lane >> 4;
+    KF_T(t_begin);
     const int tiles_per_room = a.N >> 4;
     const int room = blockIdx.x / tiles_per_room;
     const size_t room_row0 = (size_t)room * a.N;
@@ -301,52 +339,45 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
     const unsigned KK = (unsigned)a.KK;
 
     if (tid < KF_Q) { tau_k[tid] = 0xFFFFFFFFu; tau_i[tid] = 0xFFFu; cnt[tid] = 0u; }      // everything is admitted
-    // the four waves of a SIMD get different priorities: the matrix pipe serves them one after the other instead of
-    // interleaving them, so one wave's key / append work overlaps the next wave's MFMAs
-    if (wave < 4) __builtin_amdgcn_s_setprio(1);
     if (tid < 6) flag[tid] = 0u;
 
     const float4 *xp4 = (const float4 *)a.xp;
     const float4 *sq4 = (const float4 *)(a.sq + room_row0);
     float4 bq[4];
+    auto load_queries = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bq[i] = xp4[((size_t)blockIdx.x * 4 + i) * 64 + lane];
+        for (int i = 0; i < 4; ++i) bq[i] = xp4[((size_t)blockIdx.x * 4 + i) * 64 + lane];
+    };
+    load_queries();
     const float sqi = a.sq[qrow];
 
     const int n_pairs = (a.N + KF_STEP - 1) / KF_STEP;                       // candidate pairs-of-tiles in the room
     const int n_steps = (n_pairs + KF_WAVES - 1) / KF_WAVES;
     const int last_tile = tiles_per_room - 1;
+#ifdef PSG_KF_TL
+    unsigned long long tl0 = 0;
+    if (tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl0) :: "memory");
+#endif
     __syncthreads();
+    KF_TL(0);
 
 #ifdef PSG_KF_STAMP
     unsigned long long kf_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    float4 p0[4], p1[4], ps0, ps1;       // KF_PREFETCH: operands of the NEXT step
-    auto load_operands = [&](int step, float4 (&x0)[4], float4 (&x1)[4], float4 &y0, float4 &y1) {
-        const int pr = step * KF_WAVES + wave;
-        const int t0 = min(2 * pr, last_tile), t1 = min(2 * pr + 1, last_tile);   // clamped: masked out below
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            x0[i] = xp4[((tile0 + t0) * 4 + i) * 64 + lane];
-            x1[i] = xp4[((tile0 + t1) * 4 + i) * 64 + lane];
-        }
-        y0 = sq4[t0 * 4 + g];
-        y1 = sq4[t1 * 4 + g];
-    };
-    if (KF_PREFETCH) load_operands(0, p0, p1, ps0, ps1);
-    // operands, 32 MFMAs, the 8 distance keys of the lane and the admission mask of one step
-    auto step_compute = [&](int step, unsigned (&key)[8], unsigned &mask, int &c0) {
+    // operands (two candidate tiles in MFMA operand order and their squared norms), 32 MFMAs and the 8 distances of the
+    // lane for one step.  (Loading the next step's operands early, into the registers a chain has just consumed, was
+    // tried twice and lost 6 %: the step is bound by the sum of matrix, vector and operand-path time, not by latency.)
+    auto step_compute = [&](int step, float (&dd)[8], int &c0) {
         KF_T(t_a);
         const int pair = step * KF_WAVES + wave;
-        float4 a0[4], a1[4], s0, s1;
-        if (KF_PREFETCH) {
+        const int t0 = min(2 * pair, last_tile), t1 = min(2 * pair + 1, last_tile);   // clamped: masked out below
+        float4 a0[4], a1[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { a0[i] = p0[i]; a1[i] = p1[i]; }
-            s0 = ps0; s1 = ps1;
-        } else {
-            load_operands(step, a0, a1, s0, s1);
+        for (int i = 0; i < 4; ++i) {
+            a0[i] = xp4[((tile0 + t0) * 4 + i) * 64 + lane];
+            a1[i] = xp4[((tile0 + t1) * 4 + i) * 64 + lane];
         }
-
+        const float4 s0 = sq4[t0 * 4 + g], s1 = sq4[t1 * 4 + g];
 #ifdef PSG_KF_STAMP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         KF_T(t_a1);
@@ -365,37 +396,42 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i].w, bq[i].w, acc1, 0, 0, 0);
         }
         const float sj[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        // the registers of this step's operands are free now: the next step's loads fly under the key / append work
-        if (KF_PREFETCH && step + 1 < n_steps) load_operands(step + 1, p0, p1, ps0, ps1);
 #ifdef PSG_KF_STAMP
         asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1" : "+v"(acc0[3]), "+v"(acc1[3]));   // waits for the MFMA chains
         KF_T(t_a2);
         KF_ACC(9, t_a2, t_a1);         // MFMA chains done
 #endif
 
-        // ---- distance keys of the lane's 8 (query, candidate) pairs; admitted iff (key, index) <= tau
-        c0 = pair * KF_STEP + 4 * g;                        // candidates c0 + r (tile 0) and c0 + 16 + r (tile 1)
-        const unsigned tk = tau_k[q], ti = tau_i[q];
-        mask = 0;
+        // ---- distances of the lane's 8 (query, candidate) pairs: candidates c0 + r (tile 0) and c0 + 16 + r (tile 1)
+        c0 = pair * KF_STEP + 4 * g;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const float z = r < 4 ? acc0[r] : acc1[r - 4];
             // (|x_i|^2 + (-2 x_i.x_j)) + |x_j|^2, torch_edge.py:41-43 (-2 z is exact, so the fma rounds once like the add)
-            key[r] = key_of(__fadd_rn(__fmaf_rn(-2.0f, z, sqi), sj[r]));
+            dd[r] = __fadd_rn(__fmaf_rn(-2.0f, z, sqi), sj[r]);
+        }
+#ifdef PSG_KF_STAMP
+        asm volatile("" :: "v"(dd[7]));
+        KF_T(t_a3);
+        KF_ACC(10, t_a3, t_a2);        // distances
+        KF_ACC(0, t_a3, t_a);
+#endif
+    };
+    // exact admission: keys and the mask of the pairs with (key, index) <= tau (the per-step path)
+    auto exact_filter = [&](int step, const float (&dd)[8], int c0, unsigned (&key)[8], unsigned &mask) {
+        const unsigned tk = tau_k[q], ti = tau_i[q];
+        mask = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            key[r] = key_of(dd[r]);
             const unsigned c = (unsigned)(c0 + (r < 4 ? r : 12 + r));
             mask |= ((key[r] < tk || (key[r] == tk && c <= ti)) ? 1u : 0u) << r;
         }
-        if (pair * KF_STEP + KF_STEP > a.N) {               // ragged tail (wave-uniform): candidates beyond N never pass
+        if ((step * KF_WAVES + wave) * KF_STEP + KF_STEP > a.N) {   // ragged tail (wave-uniform): candidates beyond N never pass
 #pragma unroll
             for (int r = 0; r < 8; ++r)
                 if (c0 + (r < 4 ? r : 12 + r) >= a.N) mask &= ~(1u << r);
         }
-#ifdef PSG_KF_STAMP
-        asm volatile("" :: "v"(mask));
-        KF_T(t_a3);
-        KF_ACC(10, t_a3, t_a2);        // keys + filter
-        KF_ACC(0, t_a3, t_a);
-#endif
     };
 
     // ---- FAST PATH: no barrier per step.  Slots are taken with the same atomic; an allocation that does not fit is simply
@@ -410,34 +446,67 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
         // prune comes when c * n / n_i reaches 0.9 CAP: n_{i+1} = 0.9 CAP / (KK + TOL) * n_i, in whole steps
         const float grow = 0.9f * (float)CAP / (float)(KK + (unsigned)a.TOL);
         unsigned next_prune = (unsigned)CAP;
+#ifdef PSG_KF_TL
+        int n_tl = 0;
+#endif
         for (int step = 0; step < n_steps; ++step) {
-            unsigned key[8], mask;
+            float dd[8];
             int c0;
-            step_compute(step, key, mask, c0);
-            const unsigned n = (unsigned)__popc(mask);
-            if (n) {
-                const unsigned base = atomicAdd(&cnt[q], n);
-                if (base + n <= (unsigned)CAP) {
+            step_compute(step, dd, c0);
+            KF_T(t_s1);
+            // Admission by ONE float compare per pair: not (distance > tau's distance).  A superset of the exact rule
+            // (it lets equal distances with a higher index and NaNs in; an open row's tau reads as NaN and admits
+            // everything): extra keys rank behind the ones wanted and are dropped by the next prune or the final
+            // ranking; rows they would overflow go through the exact per-step path like any other overflow.  The key and
+            // the composite are only built for the few pairs that pass.
+            const float tf = dist_of(tau_k[q]);
+            if ((step * KF_WAVES + wave) * KF_STEP + KF_STEP <= a.N) {
+                unsigned n = 0;
 #pragma unroll
-                    for (int r = 0; r < 8; ++r)
-                        if ((mask >> r) & 1u)
-                            ent[q * CAP + base + __popc(mask & ((1u << r) - 1u))] =
-                                ((unsigned long long)key[r] << 12) | (unsigned)(c0 + (r < 4 ? r : 12 + r));
+                for (int r = 0; r < 8; ++r) n += !(dd[r] > tf) ? 1u : 0u;
+                if (n) {
+                    const unsigned base = atomicAdd(&cnt[q], n);
+                    if (base + n <= (unsigned)CAP) {
+                        unsigned long long *dst = ent + q * ROW + base;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r)
+                            if (!(dd[r] > tf))
+                                *dst++ = ((unsigned long long)key_of(dd[r]) << 12) | (unsigned)(c0 + (r < 4 ? r : 12 + r));
+                    }
+                }
+            } else {
+                // ragged tail (wave-uniform, N not a multiple of 32): the exact rule, candidates beyond N masked out
+                unsigned key[8], mask;
+                exact_filter(step, dd, c0, key, mask);
+                const unsigned n = (unsigned)__popc(mask);
+                if (n) {
+                    const unsigned base = atomicAdd(&cnt[q], n);
+                    if (base + n <= (unsigned)CAP) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r)
+                            if ((mask >> r) & 1u)
+                                ent[q * ROW + base + __popc(mask & ((1u << r) - 1u))] =
+                                    ((unsigned long long)key[r] << 12) | (unsigned)(c0 + (r < 4 ? r : 12 + r));
+                    }
                 }
             }
+            KF_T(t_s2);
+            KF_ACC(2, t_s2, t_s1);
             const unsigned seen = (unsigned)(step + 1) * (unsigned)PER_STEP;
-            const bool prune_now = seen >= next_prune && step + 1 < n_steps;
-            if (prune_now) {
+            const bool sync_now = seen >= next_prune && step + 1 < n_steps;
+            if (sync_now) {
                 const unsigned nn = (unsigned)(grow * (float)seen) / (unsigned)PER_STEP * (unsigned)PER_STEP;
                 next_prune = nn > seen ? nn : seen + (unsigned)PER_STEP;
                 __syncthreads();
-                const unsigned over = __ballot(lane < KF_Q && cnt[lane & (KF_Q - 1)] > (unsigned)CAP) != 0ull;
-                if (over) { need_safe = true; break; }                 // (every wave reads the same counters: uniform)
+                KF_TL(n_tl < 3 ? 1 + 2 * n_tl : 5);
+                // (every wave reads the same counters, and no wave rewrites one before all have passed this test: a row is
+                // only pruned by waves that saw no overflow, and an overflowing counter stays above CAP)
+                if (__ballot(lane < KF_Q && cnt[lane & (KF_Q - 1)] > (unsigned)CAP) != 0ull) { need_safe = true; break; }
                 for (int qq = wave; qq < KF_Q; qq += KF_WAVES) {
                     const unsigned T = cnt[qq];
                     if (T > (unsigned)a.LOW) {
                         unsigned long long thr;
-                        const unsigned c = prune_row<KF_NPL>(ent + qq * CAP, T, KK, (unsigned)a.TOL, lane, thr);
+                        const unsigned c = prune_row<KF_NPL>(ent + qq * ROW, T, KK, (unsigned)a.TOL, lane, thr);
                         if (lane == 0) { cnt[qq] = c; tau_k[qq] = (unsigned)(thr >> 12); tau_i[qq] = (unsigned)thr & 0xFFFu; }
                     }
                 }
@@ -445,9 +514,16 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
 #ifdef PSG_KF_STAMP
                 kf_sum[5] += 1;
 #endif
+                KF_T(t_s3);
+                KF_ACC(3, t_s3, t_s2);
+                KF_TL(n_tl < 3 ? 2 + 2 * n_tl : 6);
+#ifdef PSG_KF_TL
+                ++n_tl;
+#endif
             }
         }
         __syncthreads();
+        KF_TL(8);
         if (!need_safe) need_safe = __ballot(lane < KF_Q && cnt[lane & (KF_Q - 1)] > (unsigned)CAP) != 0ull;
     }
     if (need_safe) {
@@ -460,9 +536,11 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
         kf_sum[6] += 1;
 #endif
     for (int step = 0; step < n_steps; ++step) {
+        float dd[8];
         unsigned key[8], mask;
         int c0;
-        step_compute(step, key, mask, c0);
+        step_compute(step, dd, c0);
+        exact_filter(step, dd, c0, key, mask);
         const int pair = step * KF_WAVES + wave;
         (void)pair;
         const unsigned n = (unsigned)__popc(mask);
@@ -486,7 +564,7 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
 #pragma unroll
             for (int r = 0; r < 8; ++r)
                 if ((mask >> r) & 1u)
-                    ent[q * CAP + base + __popc(mask & ((1u << r) - 1u))] =
+                    ent[q * ROW + base + __popc(mask & ((1u << r) - 1u))] =
                         ((unsigned long long)key[r] << 12) | (unsigned)(c0 + (r < 4 ? r : 12 + r));
             KF_T(t_d);
             KF_ACC(2, t_d, t_c);
@@ -496,7 +574,7 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
                     const unsigned T = cnt[qq];
                     if (T > (unsigned)a.LOW) {
                         unsigned long long thr;
-                        const unsigned c = prune_row<KF_NPL>(ent + qq * CAP, T, KK, (unsigned)a.TOL, lane, thr);
+                        const unsigned c = prune_row<KF_NPL>(ent + qq * ROW, T, KK, (unsigned)a.TOL, lane, thr);
                         if (lane == 0) { cnt[qq] = c; tau_k[qq] = (unsigned)(thr >> 12); tau_i[qq] = (unsigned)thr & 0xFFFu; }
                     }
                 }
@@ -516,7 +594,7 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
                 const unsigned T = cnt[qq];
                 if (T > KK) {
                     unsigned long long thr;
-                    const unsigned c = prune_row<KF_NPL>(ent + qq * CAP, T, KK, 0u, lane, thr);
+                    const unsigned c = prune_row<KF_NPL>(ent + qq * ROW, T, KK, 0u, lane, thr);
                     if (lane == 0) { cnt[qq] = c; tau_k[qq] = (unsigned)(thr >> 12); tau_i[qq] = (unsigned)thr & 0xFFFu; }
                 }
             }
@@ -525,13 +603,13 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
             for (int r = 0; r < 8; ++r) {
                 const unsigned c = (unsigned)(c0 + (r < 4 ? r : 12 + r));
                 const bool pass = (int)c < a.N && (key[r] < tau_k[q] || (key[r] == tau_k[q] && c <= tau_i[q]));
-                if (pass) ent[q * CAP + atomicAdd(&cnt[q], 1u)] = ((unsigned long long)key[r] << 12) | c;
+                if (pass) ent[q * ROW + atomicAdd(&cnt[q], 1u)] = ((unsigned long long)key[r] << 12) | c;
                 __syncthreads();
                 for (int qq = wave; qq < KF_Q; qq += KF_WAVES) {
                     const unsigned T = cnt[qq];
                     if (T + 64u > (unsigned)CAP) {
                         unsigned long long thr;
-                        const unsigned c = prune_row<KF_NPL>(ent + qq * CAP, T, KK, 0u, lane, thr);
+                        const unsigned c = prune_row<KF_NPL>(ent + qq * ROW, T, KK, 0u, lane, thr);
                         if (lane == 0) { cnt[qq] = c; tau_k[qq] = (unsigned)(thr >> 12); tau_i[qq] = (unsigned)thr & 0xFFFu; }
                     }
                 }
@@ -542,14 +620,25 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
     }   // need_safe
     __syncthreads();
     KF_T(t_f);
-    for (int qq = wave; qq < KF_Q; qq += KF_WAVES)
-        final_ranks(ent + qq * CAP, cnt[qq], a, fcnt + qq, a.out + ((size_t)blockIdx.x * KF_Q + qq) * a.k, lane);
+    for (int qq = wave; qq < KF_Q; qq += KF_WAVES) {
+        unsigned long long *row = ent + qq * ROW;
+        int32_t *o = a.out + ((size_t)blockIdx.x * KF_Q + qq) * a.k;
+        const unsigned T = cnt[qq];
+        if (T <= 512u) final_ranks<8>(row, T, a, fcnt + qq, o, lane);
+        else final_ranks<KF_NPL>(row, T, a, fcnt + qq, o, lane);
+    }
+    KF_TL(9);
+#ifdef PSG_KF_TL
+    __syncthreads();
+    KF_TL(10);
+#endif
 #ifdef PSG_KF_STAMP
     KF_T(t_g);
     KF_ACC(4, t_g, t_f);
+    KF_ACC(13, t_g, t_begin);
     if (tid == 0)
-        for (int i = 0; i < 11; ++i) atomicAdd(&g_kf_stamps[i], kf_sum[i]);
+        for (int i = 0; i < 14; ++i) atomicAdd(&g_kf_stamps[i], kf_sum[i]);
 #endif
 }
 
-inline size_t knn_fused_lds_bytes() { return (size_t)KF_Q * KF_CAP * 8 + KF_Q * 8 + KF_Q * 4 + (8 + KF_Q) * 4; }
+inline size_t knn_fused_lds_bytes() { return (size_t)KF_Q * KF_ROW * 8 + KF_Q * 8 + KF_Q * 4 + (8 + KF_Q) * 4; }

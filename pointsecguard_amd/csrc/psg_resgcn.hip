@@ -1011,6 +1011,16 @@ extern "C" int psg_dbg_knn_stamps(unsigned long long *host_out)
     return PSG_OK;
 }
 #endif
+#ifdef PSG_KF_TL
+extern "C" int psg_dbg_knn_tl(unsigned long long *host_out)      // [32], see g_kf_tl
+{
+    PSG_CHECK_HIP(hipDeviceSynchronize());
+    PSG_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_kf_tl), 32 * sizeof(unsigned long long)));
+    static unsigned long long zero[32];
+    PSG_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_kf_tl), zero, sizeof(zero)));
+    return PSG_OK;
+}
+#endif
 
 // unit op: dilated dense kNN graph of point-major features x [B][N][C] (torch_edge.py:45-79)
 extern "C" int psg_gcn_knn(psg_gcn_ws *ws, const float *x, int C, int dilation, int32_t *out_idx, psg_stream stream)

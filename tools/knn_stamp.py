@@ -23,4 +23,4 @@ for d in (1, 4, 9, 17, 27):
     print("d=%2d  %.1f us/launch (incl. prep) | cycles per workgroup: " % (d, t0.elapsed_time(t1) * 100) +
           ", ".join("%s %.0f" % (n, x) for n, x in zip(names[:5], v[:5])) + " | events %.2f roll-backs %.2f" % (v[5], v[6]) +
           " | stream split: operands %.0f, mfma %.0f, keys %.0f, alloc %.0f" % (buf[8] / 2560.0, buf[9] / 2560.0, buf[10] / 2560.0,
-                                                                               v[0] - (buf[8] + buf[9] + buf[10]) / 2560.0), flush=True)
+                                                                               v[0] - (buf[8] + buf[9] + buf[10]) / 2560.0) + " | whole kernel %.0f" % (buf[13] / 2560.0), flush=True)
