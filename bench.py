@@ -236,6 +236,9 @@ def main():
     ap.add_argument("--gcn-coalesce", type=int, default=4,
                     help="resgcn workload: steps fused into one device batch per launch (rooms are independent; the CE "
                          "mean's scale changes by an exact power of two, which sign() ignores)")
+    ap.add_argument("--rla-coalesce", type=int, default=4,
+                    help="randla workload: steps (clouds) fused into one device batch per launch; the clouds stay "
+                         "independent (every index stays inside its cloud), one launch of each kernel serves all of them")
     ap.add_argument("--concurrency", type=int, default=3,
                     help="device batches in flight per GPU (one HIP stream + workspace each)")
     args = ap.parse_args()
@@ -633,27 +636,29 @@ def run_randla(args, R):
     n_pts, iters = 40960, args.randla_iters
     params = randla_params(3)
     model = network.RandLAModel(params)
-    conc = max(1, min(args.concurrency, args.steps))
-    wss = [network.RandLAWorkspace(n_pts) for _ in range(conc)]
+    G = max(1, min(args.rla_coalesce, args.steps))                 # clouds per launch
+    n_launch, n_warm = -(-args.steps // G), (-(-args.warmup // G) if args.warmup > 0 else 0)
+    conc = max(1, min(args.concurrency, n_launch))
+    wss = [network.RandLAWorkspace(n_pts, batch=G) for _ in range(conc)]
     streams = [torch.cuda.Stream() for _ in range(conc)]
-    n_steps = args.steps + args.warmup
     rng = np.random.default_rng(4 + R.rank)
     clouds, host = [], []
-    for _ in range(min(n_steps, 8)):
-        xyz = (rng.random((n_pts, 3), dtype=np.float32) * np.array([8, 6, 3], np.float32)).astype(np.float32)
-        rgb = rng.random((n_pts, 3), dtype=np.float32)
-        lab = rng.integers(0, 13, n_pts)
+    for _ in range(min(n_launch + n_warm, 4)):
+        xyz = (rng.random((G * n_pts, 3), dtype=np.float32) * np.array([8, 6, 3], np.float32)).astype(np.float32)
+        rgb = rng.random((G * n_pts, 3), dtype=np.float32)
+        lab = rng.integers(0, 13, G * n_pts)
         clouds.append((torch.from_numpy(np.concatenate([xyz, rgb], 1)).cuda(), torch.from_numpy(lab.astype(np.int32)).cuda()))
-        host.append((xyz, rgb, lab))
+        host.append((xyz[:n_pts], rgb[:n_pts], lab[:n_pts]))
 
-    def step(i, n_it=iters):
-        f, y = clouds[i % len(clouds)]
+    def step(i, n_it=iters, ws_list=wss, data=clouds):
+        f, y = data[i % len(data)]
         with torch.cuda.stream(streams[i % conc]):
-            wss[i % conc].bim_attack(model, f, y, 0.05, 0.01, n_it)
+            ws_list[i % conc].bim_attack(model, f, y, 0.05, 0.01, n_it)
 
-    for i in range(args.warmup):
+    for i in range(n_warm):
         step(i)
-    elapsed = R.timed(lambda: [step(i) for i in range(args.warmup, n_steps)])
+    elapsed = R.timed(lambda: [step(i) for i in range(n_warm, n_warm + n_launch)])
+    clouds_done = G * n_launch * R.world
     # algorithmic MACs of one forward (the input-gradient pass has about the same count minus the xyz branch)
     mac = 0
     for name, cin, cout, _ in randla_layer_specs():
@@ -668,14 +673,31 @@ def run_randla(args, R):
         else:
             r = n_pts
         mac += r * cin * cout
-    result = base_line("attacked clouds/sec (RandLA-Net, 40960 pts, %d BIM iters)" % iters, "clouds/s", args.steps * R.world / elapsed,
+    result = base_line("attacked clouds/sec (RandLA-Net, 40960 pts, %d BIM iters)" % iters, "clouds/s", clouds_done / elapsed,
                        R, args, elapsed, "BIM l_inf colour attack (eps=0.05, alpha=0.01, %d iters) on RandLA-Net, 1 cloud x 40960 "
-                       "pts per call (BASELINE configs[4]); random-init weights; network parity UNPINNED (TF1 reference)" % iters,
-                       {"attacks_in_flight": conc})
-    result["ms_per_iteration"] = elapsed / args.steps / iters * 1e3
+                       "pts per step (BASELINE configs[4]); random-init weights; network parity UNPINNED (TF1 reference)" % iters,
+                       {"steps_coalesced_per_launch": G, "launches_in_flight_per_gpu": conc})
+    result["ms_per_step"] = elapsed / (G * n_launch) * 1e3
+    result["ms_per_iteration"] = elapsed / (G * n_launch) / iters * 1e3
     result["gmac_per_cloud_forward"] = mac / 1e9
-    result["tflops_effective"] = 2.0 * 2.0 * mac * iters * args.steps * R.world / elapsed / 1e12
+    result["tflops_effective"] = 2.0 * 2.0 * mac * iters * clouds_done / elapsed / 1e12
     if R.rank == 0:
+        if G > 1 and not args.no_reference:
+            # ---- the same attacks one cloud per launch (the reference's val_batch_size = 1)
+            ws1 = [network.RandLAWorkspace(n_pts) for _ in range(conc)]
+            one = [(f[i * n_pts:(i + 1) * n_pts].contiguous(), y[i * n_pts:(i + 1) * n_pts].contiguous())
+                   for f, y in clouds[:1] for i in range(G)]
+            dt1 = None
+            for rep_ in range(2):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(len(one)):
+                    step(i, iters, ws1, one)
+                torch.cuda.synchronize()
+                dt1 = time.perf_counter() - t1
+            result["uncoalesced_reference"] = {"value": len(one) / dt1, "unit": "clouds/s",
+                                               "note": "one launch per cloud, %d in flight (this GPU only)" % conc}
+            del ws1
         n_prof = 4
         wss[0].prof_enable(True)
         step(0, n_prof)
@@ -684,7 +706,7 @@ def run_randla(args, R):
         wss[0].prof_enable(False)
         achieved = fl / (ms * 1e-3) / 1e12
         result["roofline"] = {"bound": "mfma", "kernel": "gemm_rows_kernel (every 1x1 convolution / attention-score GEMM of an "
-                                                         "iteration, all shapes)", "achieved": achieved,
+                                                         "iteration, all shapes; %d cloud(s) per launch)" % G, "achieved": achieved,
                               "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS,
                               "traffic": None, "avg_launch_us": ms / cnt * 1e3, "launches": cnt, "flop_per_launch": fl / cnt,
                               "gemm_ms_per_iteration": ms / n_prof}

@@ -400,6 +400,11 @@ typedef struct psg_rla_ws psg_rla_ws;
 int psg_rla_model_create(psg_ctx *ctx, const float *const *tensors, int n_tensors, psg_rla_model **out);
 int psg_rla_model_destroy(psg_rla_model *model);
 int psg_rla_ws_create(psg_ctx *ctx, int n_points, psg_rla_ws **out);
+/* A workspace for `batch` clouds of n_points each that are attacked together (the reference's val_batch_size is 1,
+ * helper_tool.py:52, so this is a launch-coalescing device: the clouds stay independent, every neighbour / pooling /
+ * interpolation index stays inside its cloud, and one launch of each kernel serves all of them).  Every [n_points][..]
+ * argument of the calls below becomes [batch][n_points][..].  l_inf metric only (the l_2 step normalises per cloud). */
+int psg_rla_ws_create_batch(psg_ctx *ctx, int n_points, int batch, psg_rla_ws **out);
 int psg_rla_ws_destroy(psg_rla_ws *ws);
 size_t psg_rla_ws_bytes(const psg_rla_ws *ws);
 /* Measurement only: HIP-event timing of every GEMM launch (tag 0: the 1x1 convolutions and attention scores of

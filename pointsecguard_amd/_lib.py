@@ -90,6 +90,7 @@ SIGNATURES = {
     "psg_rla_model_create": (ci, [vp, ctypes.POINTER(vp), ci, ctypes.POINTER(vp)]),
     "psg_rla_model_destroy": (ci, [vp]),
     "psg_rla_ws_create": (ci, [vp, ci, ctypes.POINTER(vp)]),
+    "psg_rla_ws_create_batch": (ci, [vp, ci, ci, ctypes.POINTER(vp)]),
     "psg_rla_ws_destroy": (ci, [vp]),
     "psg_rla_ws_bytes": (ctypes.c_size_t, [vp]),
     "psg_rla_prof_enable": (ci, [vp, ci]),

@@ -286,13 +286,31 @@ __global__ void add_lrelu_kernel(const float *__restrict__ a, const float *__res
 }
 
 // random_sample (RandLANet.py:356-371): out[n'][c] = max_k f[pool[n'][k]][c], arg = first winning k
-__global__ void pool_max_fwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ pool, int C, size_t total,
-                                    float *__restrict__ out, uint8_t *__restrict__ arg)
+// out[b][p][.] = xyz[b][p][.] for p < nc_sub (3 floats per point)
+__global__ void take_prefix_kernel(const float *__restrict__ xyz, int nc, int nc_sub, size_t total, float *__restrict__ out)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
-    const size_t n = t / C;
-    const int c = (int)(t - n * C);
+    const size_t per = (size_t)nc_sub * 3;
+    out[t] = xyz[(t / per) * nc * 3 + t % per];
+}
+
+// idx[t] += (t / per_cloud) * stride: per-cloud indices -> row numbers of the cloud-major buffers
+__global__ void offset_idx_kernel(int32_t *__restrict__ idx, size_t per_cloud, int stride, size_t total)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < total) idx[t] += (int32_t)((t / per_cloud) * stride);
+}
+
+// (sampled row r = cloud b, point p < nc_sub pools over the neighbours of the SAME point in the finer level: row b * nc + p)
+__global__ void pool_max_fwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ pool, int C, size_t total,
+                                    int nc_sub, int nc, float *__restrict__ out, uint8_t *__restrict__ arg)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const size_t r = t / C;
+    const int c = (int)(t - r * C);
+    const size_t n = (r / nc_sub) * nc + r % nc_sub;
     float best = -INFINITY;
     int bk = 0;
 #pragma unroll 4
@@ -305,12 +323,13 @@ __global__ void pool_max_fwd_kernel(const float *__restrict__ f, const int32_t *
 }
 
 __global__ void pool_max_bwd_kernel(const float *__restrict__ dout, const int32_t *__restrict__ pool, const uint8_t *__restrict__ arg,
-                                    int C, size_t total, float *__restrict__ df)
+                                    int C, size_t total, int nc_sub, int nc, float *__restrict__ df)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
-    const size_t n = t / C;
-    const int c = (int)(t - n * C);
+    const size_t r = t / C;
+    const int c = (int)(t - r * C);
+    const size_t n = (r / nc_sub) * nc + r % nc_sub;
     const float g = dout[t];
     if (g != 0.0f) atomicAdd(df + (size_t)pool[n * RK + arg[t]] * C + c, g);
 }
@@ -442,9 +461,10 @@ struct psg_rla_model {
 };
 
 struct LevelBuf {
-    int n = 0, n_sub = 0, d = 0, h = 0, d_in = 0;
-    const float *xyz = nullptr;
-    int32_t *neigh = nullptr, *up = nullptr;   // [n][16], [n][1]; pool = the first n_sub rows of neigh
+    int n = 0, n_sub = 0, d = 0, h = 0, d_in = 0;   // n, n_sub: rows of ALL clouds of the workspace (B * per-cloud counts)
+    int nc = 0, nc_sub = 0;                         // per cloud
+    float *xyz = nullptr;                           // [B][nc][3]: the level's points, cloud by cloud
+    int32_t *neigh = nullptr, *up = nullptr;   // [n][16], [n][1] (row numbers of this level / of the next); pool = a cloud's first nc_sub rows
     float *relpos, *fxyz1, *fxyz2;             // [n*16][10], [n*16][h] x2
     float *fpc, *cat1, *a1, *agg1, *fagg1, *cat2, *a2, *agg2, *fagg2, *m2, *sc, *enc, *samp;
     uint32_t *m_fpc, *m_fagg1, *m_fagg2, *m_enc;
@@ -455,10 +475,12 @@ struct LevelBuf {
 
 struct psg_rla_ws {
     psg_ctx *ctx;
-    int N = 0;
+    int N = 0;                      // rows of all clouds: B * Nc
+    int B = 1, Nc = 0;              // clouds per workspace (independent: every index stays inside its cloud), points per cloud
     void *arena = nullptr;
     size_t bytes = 0;
-    float *xyz_all;                 // the five levels' points are prefixes of the cloud (first N / ratio points)
+    float *xyz_all;                 // [B][Nc][3]; a level's points are the first Nc / ratio points of each cloud
+    float *xyz_last;                // [B][nc5][3]: the sub-sampled points of the last level
     LevelBuf lv[RL];
     float *f0; uint32_t *m_f0;      // fc0 output [N][8]
     float *dec0; uint32_t *m_dec0;  // decoder_0 output [n5][1024]
@@ -564,14 +586,21 @@ extern "C" int psg_rla_model_destroy(psg_rla_model *m)
     return PSG_OK;
 }
 
-extern "C" int psg_rla_ws_create(psg_ctx *ctx, int n_points, psg_rla_ws **out)
+extern "C" int psg_rla_ws_create(psg_ctx *ctx, int n_points, psg_rla_ws **out) { return psg_rla_ws_create_batch(ctx, n_points, 1, out); }
+
+// A workspace for `batch` clouds of n_points each, attacked together: rows of every buffer are cloud-major, every index
+// (neighbours, pooling, interpolation) stays inside its cloud, so the clouds are as independent as in `batch` workspaces;
+// one launch of every kernel serves them all (the per-cloud network is ~300 launches of 5-35 us per iteration).
+extern "C" int psg_rla_ws_create_batch(psg_ctx *ctx, int n_points, int batch, psg_rla_ws **out)
 {
     PSG_REQUIRE(ctx && out, "psg_rla_ws_create: null argument");
     PSG_REQUIRE(n_points >= 8192 && n_points <= 65536 && n_points % 512 == 0,
                 "psg_rla_ws_create: n_points=%d must be a multiple of 512 in [8192, 65536] (five sub-samplings, >= 16 points left)", n_points);
+    PSG_REQUIRE(batch >= 1 && (size_t)batch * n_points <= (size_t)1 << 20, "psg_rla_ws_create: batch=%d x n_points=%d exceeds 2^20 rows",
+                batch, n_points);
     PSG_CHECK_HIP(hipSetDevice(ctx->device));
     auto *ws = new psg_rla_ws();
-    ws->ctx = ctx; ws->N = n_points;
+    ws->ctx = ctx; ws->B = batch; ws->Nc = n_points; ws->N = batch * n_points;
     for (int pass = 0; pass < 2; ++pass) {
         size_t off = 0;
         auto take = [&](size_t bytes) {
@@ -580,14 +609,15 @@ extern "C" int psg_rla_ws_create(psg_ctx *ctx, int n_points, psg_rla_ws **out)
             off += bytes;
             return (void *)p;
         };
-        const size_t N = n_points;
+        const size_t N = (size_t)ws->N;
         ws->xyz_all = (float *)take(N * 3 * 4);
-        int n = n_points, d_in = 8;
+        int n = ws->N, nc = n_points, d_in = 8;
         size_t max_edge = 0;
         for (int i = 0; i < RL; ++i) {
             LevelBuf &L = ws->lv[i];
             L.n = n; L.n_sub = n / kRatio[i]; L.d = kDout[i]; L.h = L.d / 2; L.d_in = d_in;
-            L.xyz = ws->xyz_all;
+            L.nc = nc; L.nc_sub = nc / kRatio[i];
+            L.xyz = i == 0 ? ws->xyz_all : (float *)take((size_t)n * 3 * 4);
             const size_t E = (size_t)n * RK, d = L.d, h = L.h;
             max_edge = std::max(max_edge, E * d);
             L.neigh = (int32_t *)take(E * 4); L.up = (int32_t *)take((size_t)n * 4);
@@ -601,9 +631,10 @@ extern "C" int psg_rla_ws_create(psg_ctx *ctx, int n_points, psg_rla_ws **out)
             L.m_fpc = (uint32_t *)take((size_t)n * ceil_div((int)h, 32) * 4); L.m_fagg1 = (uint32_t *)take((size_t)n * ceil_div((int)h, 32) * 4);
             L.m_fagg2 = (uint32_t *)take((size_t)n * ceil_div((int)d, 32) * 4); L.m_enc = (uint32_t *)take((size_t)n * (2 * d / 32) * 4);
             L.arg = (uint8_t *)take((size_t)L.n_sub * 2 * d);
-            n = L.n_sub; d_in = 2 * L.d;
+            n = L.n_sub; nc = L.nc_sub; d_in = 2 * L.d;
         }
         const int n5 = ws->lv[RL - 1].n_sub;
+        ws->xyz_last = (float *)take((size_t)n5 * 3 * 4);
         ws->f0 = (float *)take(N * 8 * 4); ws->m_f0 = (uint32_t *)take(N * 4);
         ws->dec0 = (float *)take((size_t)n5 * 1024 * 4); ws->m_dec0 = (uint32_t *)take((size_t)n5 * 32 * 4);
         int feat = 1024;
@@ -698,8 +729,20 @@ static int build_pyramid(psg_rla_ws *ws, psg_stream stream)
     int rc;
     for (int i = 0; i < RL; ++i) {
         LevelBuf &L = ws->lv[i];
-        if ((rc = psg_knn_points(ws->ctx, L.xyz, L.xyz, 1, L.n, L.n, RK, L.neigh, stream))) return rc;
-        if ((rc = psg_knn_points(ws->ctx, L.xyz, L.xyz, 1, L.n_sub, L.n, 1, L.up, stream))) return rc;   // sub_points = first n_sub points
+        // sub_points = the first nc_sub points of every cloud, compacted into the next level's [B][nc_sub][3]
+        float *sub = i + 1 < RL ? ws->lv[i + 1].xyz : ws->xyz_last;
+        hipLaunchKernelGGL(take_prefix_kernel, dim3(blocks_for((size_t)L.n_sub * 3)), dim3(256), 0, st, L.xyz, L.nc, L.nc_sub,
+                           (size_t)L.n_sub * 3, sub);
+        PSG_LAUNCH_CHECK();
+        if ((rc = psg_knn_points(ws->ctx, L.xyz, L.xyz, ws->B, L.nc, L.nc, RK, L.neigh, stream))) return rc;
+        if ((rc = psg_knn_points(ws->ctx, sub, L.xyz, ws->B, L.nc_sub, L.nc, 1, L.up, stream))) return rc;
+        if (ws->B > 1) {    // per-cloud indices -> row numbers
+            hipLaunchKernelGGL(offset_idx_kernel, dim3(blocks_for((size_t)L.n * RK)), dim3(256), 0, st, L.neigh, (size_t)L.nc * RK, L.nc,
+                               (size_t)L.n * RK);
+            PSG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(offset_idx_kernel, dim3(blocks_for((size_t)L.n)), dim3(256), 0, st, L.up, (size_t)L.nc, L.nc_sub, (size_t)L.n);
+            PSG_LAUNCH_CHECK();
+        }
         const size_t E = (size_t)L.n * RK;
         hipLaunchKernelGGL(relpos_kernel, dim3(blocks_for(E)), dim3(256), 0, st, L.xyz, L.neigh, E, L.relpos);
         PSG_LAUNCH_CHECK();
@@ -762,7 +805,7 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
                            L.enc, L.m_enc);
         PSG_LAUNCH_CHECK();
         hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(blocks_for((size_t)L.n_sub * 2 * d)), dim3(256), 0, st, L.enc, L.neigh, 2 * d,
-                           (size_t)L.n_sub * 2 * d, L.samp, L.arg);
+                           (size_t)L.n_sub * 2 * d, L.nc_sub, L.nc, L.samp, L.arg);
         PSG_LAUNCH_CHECK();
         fin = L.samp;
     }
@@ -832,7 +875,7 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         const size_t ne = (size_t)n * RK;
         float *din = i == 0 ? ws->d_f0 : ws->lv[i - 1].d_samp;    // gradient of this level's input features
         hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(blocks_for((size_t)L.n_sub * 2 * d)), dim3(256), 0, st, L.d_samp, L.neigh, L.arg,
-                           2 * d, (size_t)L.n_sub * 2 * d, L.d_enc);
+                           2 * d, (size_t)L.n_sub * 2 * d, L.nc_sub, L.nc, L.d_enc);
         PSG_LAUNCH_CHECK();
         if ((rc = lrelu_bwd(L.d_enc, 2 * d, L.m_enc, n, 2 * d, st))) return rc;
         if ((rc = conv_bwd(E.shortcut, L.d_enc, 2 * d, din, L.d_in, n, i == 0 ? 0 : 1, st))) return rc;
@@ -880,6 +923,7 @@ extern "C" int psg_rla_bim_attack(psg_rla_model *m, psg_rla_ws *ws, const float 
                                   float alpha, int iters, int l2_metric, float *adv_features_out, psg_stream stream)
 {
     PSG_REQUIRE(m && ws && features && labels && adv_features_out && iters > 0, "psg_rla_bim_attack: bad argument");
+    PSG_REQUIRE(ws->B == 1 || !l2_metric, "psg_rla_bim_attack: the l_2 metric normalises per cloud; use one cloud per workspace (batch=%d)", ws->B);
     ProfBind bind(ws);
     hipStream_t st = (hipStream_t)stream;
     const size_t N = ws->N;

@@ -48,11 +48,16 @@ class RandLAModel:
 
 
 class RandLAWorkspace:
-    def __init__(self, n_points, device=None):
+    """Activations, index pyramid and attack state of `batch` clouds of n_points each (batch > 1: the clouds are
+    attacked together, one kernel launch serving all of them; tensors are then [batch * n_points, ..], cloud-major)."""
+
+    def __init__(self, n_points, device=None, batch=1):
         self.ctx = runtime.context(device)
-        self.n_points = n_points
+        self.points_per_cloud, self.batch = n_points, batch
+        self.n_points = n_points * batch            # rows of every per-point tensor
         self.handle = ctypes.c_void_p()
-        _lib.check(_lib.load().psg_rla_ws_create(self.ctx, n_points, ctypes.byref(self.handle)), "psg_rla_ws_create")
+        _lib.check(_lib.load().psg_rla_ws_create_batch(self.ctx, n_points, batch, ctypes.byref(self.handle)),
+                   "psg_rla_ws_create_batch")
         self.device = torch.device("cuda", torch.cuda.current_device())
 
     def __del__(self):
@@ -82,7 +87,7 @@ class RandLAWorkspace:
         _lib.call("psg_rla_set_cloud", self.handle, runtime.ptr(xyz), runtime.stream())
 
     def index(self, what, level):
-        n = self.n_points
+        n = self.n_points                          # (row numbers of the cloud-major buffers of that level)
         for r in (4, 4, 4, 4, 2)[:level]:
             n //= r
         shape = (n, 16) if what == 0 else (n,)

@@ -161,3 +161,57 @@ def test_gpu_full_size_cloud_and_bim_class():
     ws2.set_cloud(dev(xyz[0]))
     loss1, _ = network.colper_grad(ws2.forward(model, torch.cat([dev(xyz[0]), adv], 1)), dev(labels.astype(np.int32)))
     assert loss1.item() > loss0.item()
+
+
+@pytest.mark.gpu
+def test_gpu_cloud_batch_equals_single_clouds(cloud):
+    """A workspace of 3 clouds (psg_rla_ws_create_batch: one launch of every kernel serves all of them) against three
+    one-cloud workspaces: the index pyramids are the per-cloud ones shifted by the cloud's row offset, logits agree to
+    fp32 rounding (row-wise kernels, no cross-row arithmetic; the GEMM tile shape, hence the summation order, is chosen
+    by the row count), colour gradients to float-atomic order, and the l_inf attack (sign steps) ends within the same
+    eps ball with >= 98 % of the entries identical."""
+    import torch
+    from pointsecguard_amd.randla import network
+    xyz, rgb, labels, _ = cloud
+    rng = np.random.default_rng(9)
+    B = 3
+    xyzs = [xyz] + [np.ascontiguousarray(xyz[rng.permutation(N)] * s).astype(np.float32) for s in (0.7, 1.3)]
+    rgbs = [rgb] + [rng.random((N, 3), dtype=np.float32) for _ in range(B - 1)]
+    labs = [labels] + [rng.integers(0, 13, N) for _ in range(B - 1)]
+    model = network.RandLAModel(randla_params(3))
+    wsb, ws1 = network.RandLAWorkspace(N, batch=B), network.RandLAWorkspace(N)
+    wsb.set_cloud(dev(np.concatenate(xyzs, 0)))
+    feats_b = dev(np.concatenate([np.concatenate([x, c], 1) for x, c in zip(xyzs, rgbs)], 0))
+    lab_b = dev(np.concatenate(labs).astype(np.int32))
+    logits_b = wsb.forward(model, feats_b)
+    _, dl_b = network.colper_grad(logits_b, lab_b)
+    g_b = wsb.backward(model, dl_b).cpu().numpy()
+    adv_b = wsb.bim_attack(model, feats_b, lab_b, 0.08, 0.02, 3).cpu().numpy()
+    idx_b = [[wsb.index(w, l).cpu().numpy() for l in range(5)] for w in (0, 1)]
+    # no cross-talk: new colours in the LAST cloud leave the other clouds' logits bit-identical (same launch shapes)
+    feats_c = feats_b.clone()
+    feats_c[(B - 1) * N:, 3:] = dev(rng.random((N, 3), dtype=np.float32))
+    logits_c = wsb.forward(model, feats_c)
+    assert torch.equal(logits_c[:(B - 1) * N], logits_b[:(B - 1) * N]) and not torch.equal(logits_c[(B - 1) * N:], logits_b[(B - 1) * N:])
+    torch.cuda.synchronize()
+    ratios = (1, 4, 16, 64, 256)
+    for b in range(B):
+        ws1.set_cloud(dev(xyzs[b]))
+        for l in range(5):
+            n_l, n_s = N // ratios[l], N // ratios[l] // (4 if l < 4 else 2)
+            assert np.array_equal(idx_b[0][l][b * n_l:(b + 1) * n_l], ws1.index(0, l).cpu().numpy() + b * n_l)
+            assert np.array_equal(idx_b[1][l][b * n_l:(b + 1) * n_l], ws1.index(1, l).cpu().numpy() + b * n_s)
+        f1 = dev(np.concatenate([xyzs[b], rgbs[b]], 1))
+        y1 = dev(labs[b].astype(np.int32))
+        logits1 = ws1.forward(model, f1)
+        assert float((logits1 - logits_b[b * N:(b + 1) * N]).abs().max()) <= 1e-5 * max(1.0, float(logits1.abs().max()))
+        _, dl1 = network.colper_grad(logits1, y1)          # (a sum over points, not a mean: no factor between the two)
+        g1 = ws1.backward(model, dl1).cpu().numpy()
+        scale = np.abs(g1).max()
+        # (a 1e-6 difference in an activation can flip a max-pool argmax or a leaky-relu side: few entries, bounded)
+        diff = np.abs(g_b[b * N:(b + 1) * N] - g1)
+        assert (diff <= 2e-4 * scale).mean() >= 0.995 and diff.max() <= 0.05 * scale
+        adv1 = ws1.bim_attack(model, f1, y1, 0.08, 0.02, 3).cpu().numpy()
+        part = adv_b[b * N:(b + 1) * N]
+        assert np.array_equal(part[:, :3], xyzs[b]) and np.abs(part[:, 3:] - rgbs[b]).max() <= 0.08 + 1e-6
+        assert (part == adv1).mean() >= 0.98           # (sign flips of near-zero gradient entries, compounding over 3 steps)
