@@ -328,7 +328,8 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
     unsigned *flag = cnt + KF_Q;                                             // [3][2]: overflow, prune (by step % 3)
     unsigned *fcnt = flag + 8;                                               // [KF_Q] finalists per row
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (readfirstlane: the wave number is uniform, so tile numbers and operand addresses are scalar work)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane & 15, g = lane >> 4;
     KF_T(t_begin);
     const int tiles_per_room = a.N >> 4;
