@@ -4,7 +4,7 @@
 # usage (on the GPU box, from the repo root): tools/profile_round.sh TAG   ->  gpurun_out/prof_TAG/, copy what is to be kept
 set -o pipefail
 TAG=${1:-r02}
-WHAT=${2:-all}     # all | stats | pmc_pn2 | pmc_gcn
+WHAT=${2:-all}     # all | stats | pmc_pn2 | pmc_gcn | pmc_knn
 export TMPDIR=/tmp
 O=gpurun_out/prof_$TAG
 mkdir -p $O
@@ -41,8 +41,15 @@ if [ $WHAT = all ] || [ $WHAT = pmc_gcn ]; then
 pmc gfetch FETCH_SIZE $GCN || exit 1
 pmc gwrite WRITE_SIZE $GCN || exit 1
 python3 tools/pmc_traffic.py $O/gfetch $O/gwrite $O/pmc_traffic_gcn.json 4 > $O/pmc_traffic_gcn.txt
-pmc gmfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" $GCN || exit 1
+if pmc gmfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" $GCN; then
 python3 tools/pmc_mfma.py $O/gmfma $O/pmc_mfma_gcn.json > $O/pmc_mfma_gcn.txt
+else echo "gmfma: the SQ counter pass over the whole ResGCN attack did not finish (see pmc_knn)"; fi
 fi
-rm -rf $O/fetch $O/write $O/gfetch $O/gwrite $O/mfma $O/gmfma   # raw per-dispatch rows are large; the summaries are what is kept
+if [ $WHAT = all ] || [ $WHAT = pmc_knn ]; then
+# the matrix-busy counters of the fused kNN kernel on its stand-alone launches (4 rooms per launch, d = 1, 4, 9, 17, 27): the
+# same pass over the whole ResGCN attack (gmfma above) has hung on this pool more often than not
+timeout -k 10 150 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/kmfma -o p -- python3 tools/knn_time.py 4 > $O/kmfma.log 2>&1 || exit 1
+python3 tools/pmc_mfma.py $O/kmfma $O/pmc_mfma_knn.json > $O/pmc_mfma_knn.txt
+fi
+rm -rf $O/fetch $O/write $O/gfetch $O/gwrite $O/mfma $O/gmfma $O/kmfma   # raw per-dispatch rows are large; the summaries are what is kept
 ls $O
