@@ -151,14 +151,23 @@ int conv_fwd(const RLayer &L, const float *in, int ld_in, float *out, int ld_out
 }
 
 // g[row][c] *= (bit ? 1 : slope): gradient through leaky_relu, in place
-__global__ void lrelu_bwd_kernel(float *__restrict__ g, int ld, const uint32_t *__restrict__ mask, int M, size_t total)
+// (the memory-bound kernels of this file move 16 bytes per thread: channel counts and leading dimensions are multiples of 4)
+__global__ void lrelu_bwd_kernel(float *__restrict__ g, int ld, const uint32_t *__restrict__ mask, int M, size_t total4)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const size_t row = t / M;
-    const int c = (int)(t - row * M);
-    const bool pos = (mask[row * ((M + 31) >> 5) + (c >> 5)] >> (c & 31)) & 1u;
-    if (!pos) g[row * ld + c] *= kSlope;
+    if (t >= total4) return;
+    const int m4 = M >> 2;
+    const size_t row = t / m4;
+    const int c = (int)(t - row * m4) * 4;
+    const unsigned bits = (mask[row * ((M + 31) >> 5) + (c >> 5)] >> (c & 31)) & 15u;
+    if (bits == 15u) return;
+    float4 *p = (float4 *)(g + row * ld + c);
+    float4 v = *p;
+    if (!(bits & 1u)) v.x *= kSlope;
+    if (!(bits & 2u)) v.y *= kSlope;
+    if (!(bits & 4u)) v.z *= kSlope;
+    if (!(bits & 8u)) v.w *= kSlope;
+    *p = v;
 }
 
 // din (+)= dz . W   (dz already multiplied by the activation's derivative)
@@ -171,7 +180,8 @@ int conv_bwd(const RLayer &L, const float *dz, int ld_dz, float *din, int ld_din
 
 int lrelu_bwd(float *g, int ld, const uint32_t *mask, int rows, int M, hipStream_t st)
 {
-    const size_t total = (size_t)rows * M;
+    if ((M & 3) || (ld & 3)) { set_error("lrelu_bwd: M=%d, ld=%d must be multiples of 4", M, ld); return PSG_ERR_ARG; }
+    const size_t total = (size_t)rows * (M >> 2);
     hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g, ld, mask, M, total);
     PSG_LAUNCH_CHECK();
     return PSG_OK;
@@ -194,63 +204,75 @@ __global__ void relpos_kernel(const float *__restrict__ xyz, const int32_t *__re
 
 // cat[e][0:h] = f[neigh[e]][0:h]; cat[e][h:2h] = fxyz[e][0:h]     (gather_neighbour + concat, RandLANet.py:337-339)
 __global__ void gather_concat_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh, const float *__restrict__ fxyz,
-                                     int h, size_t total, float *__restrict__ cat)
+                                     int h, size_t total4, float *__restrict__ cat)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const int d = 2 * h;
-    const size_t e = t / d;
-    const int c = (int)(t - e * d);
-    cat[t] = c < h ? f[(size_t)neigh[e] * h + c] : fxyz[e * h + (c - h)];
+    if (t >= total4) return;
+    const int d4 = h >> 1;                       // float4 per row of cat (d = 2 h channels)
+    const size_t e = t / d4;
+    const int c = (int)(t - e * d4) * 4;
+    ((float4 *)cat)[t] = c < h ? *(const float4 *)(f + (size_t)neigh[e] * h + c) : *(const float4 *)(fxyz + e * h + (c - h));
 }
 
 // att_pooling core (RandLANet.py:403-405): scores -> softmax over the 16 neighbours (kept in place of the scores),
 // agg[n][c] = sum_k cat[n][k][c] * a[n][k][c].  One thread per (point, channel).
-__global__ void att_pool_fwd_kernel(const float *__restrict__ cat, float *__restrict__ s, int d, size_t total, float *__restrict__ agg)
+// One thread per (point, 4 channels); every channel's arithmetic is the scalar sequence (max, exp, sum in k order).
+__global__ void att_pool_fwd_kernel(const float *__restrict__ cat, float *__restrict__ s, int d, size_t total4, float *__restrict__ agg)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const size_t n = t / d;
-    const int c = (int)(t - n * d);
-    float v[RK];
-    float m = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < RK; ++k) { v[k] = s[(n * RK + k) * d + c]; m = fmaxf(m, v[k]); }
-    float sum = 0.0f;
-#pragma unroll
-    for (int k = 0; k < RK; ++k) { v[k] = expf(v[k] - m); sum += v[k]; }
-    const float inv = 1.0f / sum;
-    float acc = 0.0f;
+    if (t >= total4) return;
+    const int d4 = d >> 2;
+    const size_t n = t / d4;
+    const int c = (int)(t - n * d4) * 4;
+    float4 v[RK];
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
-        const float a = v[k] * inv;
-        s[(n * RK + k) * d + c] = a;
-        acc += cat[(n * RK + k) * d + c] * a;
+        v[k] = *(const float4 *)(s + (n * RK + k) * d + c);
+        m.x = fmaxf(m.x, v[k].x); m.y = fmaxf(m.y, v[k].y); m.z = fmaxf(m.z, v[k].z); m.w = fmaxf(m.w, v[k].w);
     }
-    agg[t] = acc;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        v[k].x = expf(v[k].x - m.x); v[k].y = expf(v[k].y - m.y); v[k].z = expf(v[k].z - m.z); v[k].w = expf(v[k].w - m.w);
+        sum.x += v[k].x; sum.y += v[k].y; sum.z += v[k].z; sum.w += v[k].w;
+    }
+    const float4 inv = make_float4(1.0f / sum.x, 1.0f / sum.y, 1.0f / sum.z, 1.0f / sum.w);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        const float4 a = make_float4(v[k].x * inv.x, v[k].y * inv.y, v[k].z * inv.z, v[k].w * inv.w);
+        *(float4 *)(s + (n * RK + k) * d + c) = a;
+        const float4 x = *(const float4 *)(cat + (n * RK + k) * d + c);
+        acc.x += x.x * a.x; acc.y += x.y * a.y; acc.z += x.z * a.z; acc.w += x.w * a.w;
+    }
+    ((float4 *)agg)[t] = acc;
 }
 
 // gradient of the pooling: dcat = a * dagg (direct path); ds = a * (g - sum_j a_j g_j), g = cat * dagg (softmax path)
 __global__ void att_pool_bwd_kernel(const float *__restrict__ cat, const float *__restrict__ a, const float *__restrict__ dagg, int d,
-                                    size_t total, float *__restrict__ dcat, float *__restrict__ ds)
+                                    size_t total2, float *__restrict__ dcat, float *__restrict__ ds)
 {
+    // one thread per (point, 2 channels): 8-byte accesses, the 16 attention weights and products of both channels in registers
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const size_t n = t / d;
-    const int c = (int)(t - n * d);
-    const float g0 = dagg[t];
-    float av[RK], gv[RK];
-    float dot = 0.0f;
+    if (t >= total2) return;
+    const int d2 = d >> 1;
+    const size_t n = t / d2;
+    const int c = (int)(t - n * d2) * 2;
+    const float2 g0 = ((const float2 *)dagg)[t];
+    float2 av[RK], gv[RK];
+    float2 dot = make_float2(0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
-        av[k] = a[(n * RK + k) * d + c];
-        gv[k] = cat[(n * RK + k) * d + c] * g0;
-        dot += av[k] * gv[k];
+        av[k] = *(const float2 *)(a + (n * RK + k) * d + c);
+        const float2 x = *(const float2 *)(cat + (n * RK + k) * d + c);
+        gv[k] = make_float2(x.x * g0.x, x.y * g0.y);
+        dot.x += av[k].x * gv[k].x; dot.y += av[k].y * gv[k].y;
     }
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
-        dcat[(n * RK + k) * d + c] = av[k] * g0;
-        ds[(n * RK + k) * d + c] = av[k] * (gv[k] - dot);
+        *(float2 *)(dcat + (n * RK + k) * d + c) = make_float2(av[k].x * g0.x, av[k].y * g0.y);
+        *(float2 *)(ds + (n * RK + k) * d + c) = make_float2(av[k].x * (gv[k].x - dot.x), av[k].y * (gv[k].y - dot.y));
     }
 }
 
@@ -258,6 +280,8 @@ __global__ void att_pool_bwd_kernel(const float *__restrict__ cat, const float *
 __global__ void gather_bwd_kernel(const float *__restrict__ dcat, const int32_t *__restrict__ neigh, int h, size_t total,
                                   float *__restrict__ df)
 {
+    // (one element per thread on purpose: the lanes of an atomic instruction then hit consecutive addresses; four
+    // atomics per thread, 16 bytes apart across lanes, took 3.7x as long)
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const size_t e = t / h;
@@ -306,26 +330,30 @@ __global__ void offset_idx_kernel(int32_t *__restrict__ idx, size_t per_cloud, i
 __global__ void pool_max_fwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ pool, int C, size_t total,
                                     int nc_sub, int nc, float *__restrict__ out, uint8_t *__restrict__ arg)
 {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // total = sampled rows * C / 4
     if (t >= total) return;
-    const size_t r = t / C;
-    const int c = (int)(t - r * C);
+    const int c4 = C >> 2;
+    const size_t r = t / c4;
+    const int c = (int)(t - r * c4) * 4;
     const size_t n = (r / nc_sub) * nc + r % nc_sub;
-    float best = -INFINITY;
-    int bk = 0;
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    uchar4 bk = make_uchar4(0, 0, 0, 0);
 #pragma unroll 4
     for (int k = 0; k < RK; ++k) {
-        const float v = f[(size_t)pool[n * RK + k] * C + c];
-        if (v > best) { best = v; bk = k; }
+        const float4 v = *(const float4 *)(f + (size_t)pool[n * RK + k] * C + c);
+        if (v.x > best.x) { best.x = v.x; bk.x = (unsigned char)k; }
+        if (v.y > best.y) { best.y = v.y; bk.y = (unsigned char)k; }
+        if (v.z > best.z) { best.z = v.z; bk.z = (unsigned char)k; }
+        if (v.w > best.w) { best.w = v.w; bk.w = (unsigned char)k; }
     }
-    out[t] = best;
-    arg[t] = (uint8_t)bk;
+    ((float4 *)out)[t] = best;
+    ((uchar4 *)arg)[t] = bk;
 }
 
 __global__ void pool_max_bwd_kernel(const float *__restrict__ dout, const int32_t *__restrict__ pool, const uint8_t *__restrict__ arg,
                                     int C, size_t total, int nc_sub, int nc, float *__restrict__ df)
 {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // (one element per thread: see gather_bwd_kernel)
     if (t >= total) return;
     const size_t r = t / C;
     const int c = (int)(t - r * C);
@@ -338,19 +366,19 @@ __global__ void pool_max_bwd_kernel(const float *__restrict__ dout, const int32_
 __global__ void interp_concat_kernel(const float *__restrict__ skip, int cs, const float *__restrict__ coarse, int cc,
                                      const int32_t *__restrict__ up, size_t total, float *__restrict__ cat)
 {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // total = rows * (cs + cc) / 4
     if (t >= total) return;
-    const int w = cs + cc;
-    const size_t n = t / w;
-    const int c = (int)(t - n * w);
-    cat[t] = c < cs ? skip[n * cs + c] : coarse[(size_t)up[n] * cc + (c - cs)];
+    const int w4 = (cs + cc) >> 2;
+    const size_t n = t / w4;
+    const int c = (int)(t - n * w4) * 4;
+    ((float4 *)cat)[t] = c < cs ? *(const float4 *)(skip + n * cs + c) : *(const float4 *)(coarse + (size_t)up[n] * cc + (c - cs));
 }
 
 // its transpose: dskip[n] += dcat[n][:cs] (one writer per element), dcoarse[up[n]] += dcat[n][cs:] (atomics)
 __global__ void interp_concat_bwd_kernel(const float *__restrict__ dcat, int cs, int cc, const int32_t *__restrict__ up, size_t total,
                                          float *__restrict__ dskip, float *__restrict__ dcoarse)
 {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // (one element per thread: see gather_bwd_kernel)
     if (t >= total) return;
     const int w = cs + cc;
     const size_t n = t / w;
@@ -787,16 +815,16 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
             if ((rc = conv_fwd(E.lfa_mlp1, L.relpos, 10, L.fxyz1, h, (int)ne, true, nullptr, st))) return rc;
             if ((rc = conv_fwd(E.lfa_mlp2, L.fxyz1, h, L.fxyz2, h, (int)ne, true, nullptr, st))) return rc;
         }
-        hipLaunchKernelGGL(gather_concat_kernel, dim3(blocks_for(ne * d)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, h, ne * d, L.cat1);
+        hipLaunchKernelGGL(gather_concat_kernel, dim3(blocks_for(ne * d / 4)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, h, ne * d / 4, L.cat1);
         PSG_LAUNCH_CHECK();
         if ((rc = conv_fwd(E.att1_fc, L.cat1, d, L.a1, d, (int)ne, false, nullptr, st))) return rc;
-        hipLaunchKernelGGL(att_pool_fwd_kernel, dim3(blocks_for((size_t)n * d)), dim3(256), 0, st, L.cat1, L.a1, d, (size_t)n * d, L.agg1);
+        hipLaunchKernelGGL(att_pool_fwd_kernel, dim3(blocks_for((size_t)n * d / 4)), dim3(256), 0, st, L.cat1, L.a1, d, (size_t)n * d / 4, L.agg1);
         PSG_LAUNCH_CHECK();
         if ((rc = conv_fwd(E.att1_mlp, L.agg1, d, L.fagg1, h, n, true, L.m_fagg1, st))) return rc;
-        hipLaunchKernelGGL(gather_concat_kernel, dim3(blocks_for(ne * d)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, h, ne * d, L.cat2);
+        hipLaunchKernelGGL(gather_concat_kernel, dim3(blocks_for(ne * d / 4)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, h, ne * d / 4, L.cat2);
         PSG_LAUNCH_CHECK();
         if ((rc = conv_fwd(E.att2_fc, L.cat2, d, L.a2, d, (int)ne, false, nullptr, st))) return rc;
-        hipLaunchKernelGGL(att_pool_fwd_kernel, dim3(blocks_for((size_t)n * d)), dim3(256), 0, st, L.cat2, L.a2, d, (size_t)n * d, L.agg2);
+        hipLaunchKernelGGL(att_pool_fwd_kernel, dim3(blocks_for((size_t)n * d / 4)), dim3(256), 0, st, L.cat2, L.a2, d, (size_t)n * d / 4, L.agg2);
         PSG_LAUNCH_CHECK();
         if ((rc = conv_fwd(E.att2_mlp, L.agg2, d, L.fagg2, d, n, true, L.m_fagg2, st))) return rc;
         if ((rc = conv_fwd(E.mlp2, L.fagg2, d, L.m2, 2 * d, n, false, nullptr, st))) return rc;
@@ -804,8 +832,8 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
         hipLaunchKernelGGL(add_lrelu_kernel, dim3(blocks_for((size_t)n * 2 * d)), dim3(256), 0, st, L.m2, L.sc, 2 * d, (size_t)n * 2 * d,
                            L.enc, L.m_enc);
         PSG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(blocks_for((size_t)L.n_sub * 2 * d)), dim3(256), 0, st, L.enc, L.neigh, 2 * d,
-                           (size_t)L.n_sub * 2 * d, L.nc_sub, L.nc, L.samp, L.arg);
+        hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(blocks_for((size_t)L.n_sub * 2 * d / 4)), dim3(256), 0, st, L.enc, L.neigh, 2 * d,
+                           (size_t)L.n_sub * 2 * d / 4, L.nc_sub, L.nc, L.samp, L.arg);
         PSG_LAUNCH_CHECK();
         fin = L.samp;
     }
@@ -817,8 +845,8 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
         const LevelBuf &L = ws->lv[RL - 1 - j];
         const float *skip = j == RL - 1 ? ws->lv[0].enc : ws->lv[RL - 2 - j].samp;
         const int cs = m->dec[j].cout;
-        hipLaunchKernelGGL(interp_concat_kernel, dim3(blocks_for((size_t)L.n * (cs + cfeat))), dim3(256), 0, st, skip, cs, feat, cfeat,
-                           L.up, (size_t)L.n * (cs + cfeat), ws->dec_cat[j]);
+        hipLaunchKernelGGL(interp_concat_kernel, dim3(blocks_for((size_t)L.n * (cs + cfeat) / 4)), dim3(256), 0, st, skip, cs, feat, cfeat,
+                           L.up, (size_t)L.n * (cs + cfeat) / 4, ws->dec_cat[j]);
         PSG_LAUNCH_CHECK();
         if ((rc = conv_fwd(m->dec[j], ws->dec_cat[j], cs + cfeat, ws->dec_out[j], cs, L.n, true, ws->m_dec[j], st))) return rc;
         feat = ws->dec_out[j];
@@ -884,7 +912,7 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         if ((rc = lrelu_bwd(g_fagg2, d, L.m_fagg2, n, d, st))) return rc;
         float *g_agg2 = L.fagg2;
         if ((rc = conv_bwd(E.att2_mlp, g_fagg2, d, g_agg2, d, n, 0, st))) return rc;
-        hipLaunchKernelGGL(att_pool_bwd_kernel, dim3(blocks_for((size_t)n * d)), dim3(256), 0, st, L.cat2, L.a2, g_agg2, d, (size_t)n * d,
+        hipLaunchKernelGGL(att_pool_bwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, L.cat2, L.a2, g_agg2, d, (size_t)n * d / 2,
                            ws->scratch_a, ws->scratch_b);
         PSG_LAUNCH_CHECK();
         if ((rc = conv_bwd(E.att2_fc, ws->scratch_b, d, ws->scratch_a, d, (int)ne, 1, st))) return rc;
@@ -893,7 +921,7 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         if ((rc = lrelu_bwd(L.d_fagg1, h, L.m_fagg1, n, h, st))) return rc;
         float *g_agg1 = L.agg1;
         if ((rc = conv_bwd(E.att1_mlp, L.d_fagg1, h, g_agg1, d, n, 0, st))) return rc;
-        hipLaunchKernelGGL(att_pool_bwd_kernel, dim3(blocks_for((size_t)n * d)), dim3(256), 0, st, L.cat1, L.a1, g_agg1, d, (size_t)n * d,
+        hipLaunchKernelGGL(att_pool_bwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, L.cat1, L.a1, g_agg1, d, (size_t)n * d / 2,
                            ws->scratch_a, ws->scratch_b);
         PSG_LAUNCH_CHECK();
         if ((rc = conv_bwd(E.att1_fc, ws->scratch_b, d, ws->scratch_a, d, (int)ne, 1, st))) return rc;
