@@ -393,7 +393,7 @@ __global__ void edge_max_fwd_kernel(const float *__restrict__ pq, const int32_t 
 // dQ[nbr(i,k*)][c] += g.  dpq must be zeroed (Q half) before the launch.
 __global__ void edge_max_bwd_kernel(const float *__restrict__ dy, int ld_dy, const int32_t *__restrict__ nbr,
                                     const uint8_t *__restrict__ arg, const float *__restrict__ scale,
-                                    float *__restrict__ dpq, int N, size_t total)
+                                    float *__restrict__ dpq, int N, size_t total, float *__restrict__ zero_q = nullptr)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -403,6 +403,7 @@ __global__ void edge_max_bwd_kernel(const float *__restrict__ dy, int ld_dy, con
     float g = 0.0f;
     if (a & 0x80) g = dy[v * ld_dy + c] * scale[c];
     dpq[v * 2 * GC + c] = g;
+    if (zero_q) zero_q[v * 2 * GC + GC + c] = 0.0f;     // the Q half of the NEXT launch's buffer (ping-pong: no memset per block)
     if (g != 0.0f) {
         const size_t j = (v / N) * N + nbr[v * KNB + (a & 0x7F)];
         atomicAdd(dpq + j * 2 * GC + GC + c, g);
@@ -613,6 +614,7 @@ struct psg_gcn_ws {
     float *xp;                 // [B*N][64] the current block's features in MFMA operand order (fused kNN)
     bool knn_fused = true;     // PSG_GCN_KNN=matrix: the round-1 path (distance matrix in HBM + selection kernel)
     float *pq, *dpq;           // [B*N][128]
+    float *dpq2;               // second [B*N][128] gradient buffer of the default (res / edge) backward's ping-pong
     int32_t *nbr;              // [n_blocks][B*N][16]
     uint8_t *arg;              // [n_blocks][B*N][64]
     float *fused;              // [B*N][1024]
@@ -908,6 +910,7 @@ extern "C" int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n
         ws->xp = (float *)take(R * 64 * 4);
         ws->pq = (float *)take(R * ws->pq_w * 4);
         ws->dpq = (float *)take(R * ws->pq_w * 4);
+        ws->dpq2 = (float *)take(R * 2 * GC * 4);
         if (conv == PSG_GCN_CONV_MR) {
             ws->arg_mr = (uint8_t *)take(R * arg_total);
             ws->mask_mr = (uint32_t *)take((size_t)n_blocks * R * 2 * 4);
@@ -1302,22 +1305,26 @@ extern "C" int psg_gcn_backward(psg_gcn_model *m, psg_gcn_ws *ws, const float *d
     // backbone in reverse: G_e = d/d x_e
     PSG_CHECK_HIP(hipMemcpy2DAsync(ws->gcur, GC * 4, ws->dfeats + (size_t)(m->n_blocks - 1) * GC, (size_t)F * 4, GC * 4, R,
                                    hipMemcpyDeviceToDevice, st));
+    // [dP | dQ] buffers alternate between two blocks: the scatter kernel of block e also zeroes the Q half that block
+    // e - 1 will add into (its own buffer is still read by block e's GEMM), so one memset per backward instead of 28
+    float *pp[2] = {ws->dpq, ws->dpq2};
+    PSG_CHECK_HIP(hipMemsetAsync(pp[(m->n_blocks - 1) & 1], 0, R * 2 * GC * 4, st));
     for (int e = m->n_blocks - 1; e >= 0; --e) {
         const EdgeLayer &L = m->edge[e];
-        PSG_CHECK_HIP(hipMemsetAsync(ws->dpq, 0, R * 2 * GC * 4, st));
+        float *dpq = pp[e & 1];
         hipLaunchKernelGGL(edge_max_bwd_kernel, dim3(g256), dim3(256), 0, st, ws->gcur, GC, ws->nbr + (size_t)e * R * KNB,
-                           ws->arg + (size_t)e * R * GC, L.scale, ws->dpq, N, R * GC);
+                           ws->arg + (size_t)e * R * GC, L.scale, dpq, N, R * GC, e > 0 ? pp[(e - 1) & 1] : (float *)nullptr);
         PSG_LAUNCH_CHECK();
         if (e > 0) {
             // x_e = EdgeConv_e(x_{e-1}) + x_{e-1}:  G_{e-1} = dfeats[e-1] + G_e + [dP | dQ] . [W1-W2 ; W2]
             // (the residual's gradient slice dfeats[e-1] is added inside the GEMM's accumulate epilogue)
-            GemmArgs a = gemm_args(ws->dpq, 2 * GC, L.wcat_t, 2 * GC, ws->gcur, GC, (int)R, 2 * GC, GC);
+            GemmArgs a = gemm_args(dpq, 2 * GC, L.wcat_t, 2 * GC, ws->gcur, GC, (int)R, 2 * GC, GC);
             a.accumulate = 1;
             a.addend = ws->dfeats + (size_t)(e - 1) * GC;
             a.ld_add = F;
             if ((rc = launch_gemm<4, 1, EPI_LINEAR, false>(a, st))) return rc;
         } else {
-            GemmArgs a = gemm_args(ws->dpq, 2 * GC, L.wcat_t, 2 * GC, dx0_out, 9, (int)R, 2 * GC, 9);
+            GemmArgs a = gemm_args(dpq, 2 * GC, L.wcat_t, 2 * GC, dx0_out, 9, (int)R, 2 * GC, 9);
             if ((rc = launch_gemm<4, 1, EPI_LINEAR, false>(a, st))) return rc;
         }
     }
