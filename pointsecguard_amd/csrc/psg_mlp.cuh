@@ -252,6 +252,34 @@ __device__ __forceinline__ f32x16 tile_mac4(const float4 *__restrict__ w, int k8
     return acc;
 }
 
+// ReLU of an accumulator tile in place + its 16 "was positive" bits (bit r = register r).  Three vector instructions
+// per register (compare, select, add-with-carry shifts the bit in: registers 15 .. 0 so bit r lands at position r); the
+// compiler's version of `pos ? c : 0; m |= pos << r` took five to six, and on this chip a vector instruction of an
+// epilogue costs the matrix pipe its issue slot one for one (tools/mfma_valu_overlap.hip).
+__device__ __forceinline__ unsigned relu_bits(f32x16 &c)
+{
+    unsigned m = 0;
+#define PSG_RB(r)                                                                                                          \
+    {                                                                                                                      \
+        float x = c[r];                                                                                                    \
+        asm("v_cmp_lt_f32 vcc, 0, %0\n\tv_cndmask_b32 %0, 0, %0, vcc\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"              \
+            : "+v"(x), "+v"(m) : : "vcc");                                                                                 \
+        c[r] = x;                                                                                                          \
+    }
+    PSG_RB(15) PSG_RB(14) PSG_RB(13) PSG_RB(12) PSG_RB(11) PSG_RB(10) PSG_RB(9) PSG_RB(8)
+    PSG_RB(7) PSG_RB(6) PSG_RB(5) PSG_RB(4) PSG_RB(3) PSG_RB(2) PSG_RB(1) PSG_RB(0)
+#undef PSG_RB
+    return m;
+}
+
+// Gradient mask: c[r] = bit r of m ? c[r] : 0, as an AND with the sign-extended bit (two instructions per register).
+__device__ __forceinline__ void apply_bits(f32x16 &c, unsigned m)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        c[r] = __uint_as_float(__float_as_uint(c[r]) & (unsigned)__builtin_amdgcn_sbfe((int)m, r, 1));
+}
+
 // One 32x32 output tile over k8n chunks of 8 input channels: the multiple-of-4 part runs in the pipelined assembly
 // loop above, a tail of 1..3 chunks (first layers whose K is not a multiple of 32: 12+4, 67+5, 131+5, 259+5 channels,
 // and the 13-class head's transpose) as plain MFMAs, instead of padding K to 32 with zero work.
@@ -307,7 +335,8 @@ __device__ __forceinline__ void layer_fwd(const FwdLayer &L, float *__restrict__
         if (task < ntask) {
             const int mb = task / PB, pb = task - mb * PB;
             // bias: 4 x float4 issued before the k-loop and consumed after it, so the load latency hides behind the
-            // MFMAs (initialising the accumulators from it would put that latency in front of the first MFMA)
+            // MFMAs (initialising the accumulators from it - no zeroing moves, no adds - was measured: no faster, and the
+            // changed summation order moved one MSG oracle comparison past its tolerance)
             const float4 *bp = (const float4 *)(L.bias + mb * 32 + 4 * h);
             const float4 bq0 = bp[0], bq1 = bp[2], bq2 = bp[4], bq3 = bp[6];
             f32x16 c;
@@ -319,13 +348,7 @@ __device__ __forceinline__ void layer_fwd(const FwdLayer &L, float *__restrict__
             c[8] += bq2.x; c[9] += bq2.y; c[10] += bq2.z; c[11] += bq2.w;
             c[12] += bq3.x; c[13] += bq3.y; c[14] += bq3.z; c[15] += bq3.w;
             if (L.relu) {
-                unsigned m = 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const bool pos = c[r] > 0.0f;
-                    c[r] = pos ? c[r] : 0.0f;
-                    m |= (unsigned)pos << r;
-                }
+                const unsigned m = relu_bits(c);
                 if (L.mask) L.mask[(wg_linear * ntask + task) * 64 + lane] = (uint16_t)m;
             }
             acc[i] = c;
@@ -400,8 +423,7 @@ __device__ __forceinline__ void layer_bwd(const BwdLayer &L, float *__restrict__
             for (int r = 0; r < 16; ++r) c[r] = 0.0f;
             c = tile_mac<BLK, false>(L.w + ((size_t)mb * L.k8 + k8_lo) * 64 + lane, k8_n,
                                      buf + (size_t)k8_lo * BLK + (pb * 32 + j) * 8 + 4 * h, c);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) c[r] = ((m >> r) & 1u) ? c[r] : 0.0f;   // mask . (a + b) = mask . a + mask . b
+            apply_bits(c, m);                                                    // mask . (a + b) = mask . a + mask . b
             acc[i] = c;
         }
     }

@@ -411,14 +411,9 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
         }
         if (first < ntask) {   // bias, ReLU, mask bits and write-back exactly like layer_fwd
             const float *bp = L0.bias + first * 32 + 4 * h;
-            unsigned m = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                c[r] += bp[8 * (r >> 2) + (r & 3)];
-                const bool pos = c[r] > 0.0f;
-                c[r] = pos ? c[r] : 0.0f;
-                m |= (unsigned)pos << r;
-            }
+            for (int r = 0; r < 16; ++r) c[r] += bp[8 * (r >> 2) + (r & 3)];
+            const unsigned m = relu_bits(c);
             if (L0.mask) L0.mask[(wg * ntask + first) * 64 + lane] = (uint16_t)m;
             store_tile<P>(buf0, first, jj, h, c);
         }
