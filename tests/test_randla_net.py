@@ -215,3 +215,11 @@ def test_gpu_cloud_batch_equals_single_clouds(cloud):
         part = adv_b[b * N:(b + 1) * N]
         assert np.array_equal(part[:, :3], xyzs[b]) and np.abs(part[:, 3:] - rgbs[b]).max() <= 0.08 + 1e-6
         assert (part == adv1).mean() >= 0.98           # (sign flips of near-zero gradient entries, compounding over 3 steps)
+    # the BIM class with the reference's batch_size argument drives the same cloud-batch workspace
+    from pointsecguard_amd.randla import attack
+    atk = attack.BIM(model, B, "colper", "ut", "l_inf")
+    atk.config(magnitude=0.08, alpha=0.02, iteration=3)
+    rgb_b = atk.batch_attack(feats_b.reshape(B, N, 6), lab_b.reshape(B, N))
+    assert tuple(rgb_b.shape) == (B, N, 3) and (rgb_b.reshape(-1, 3).cpu().numpy() == adv_b[:, 3:]).mean() >= 0.98
+    with pytest.raises(NotImplementedError):
+        attack.BIM(model, B, "colper", "ut", "l_2")
