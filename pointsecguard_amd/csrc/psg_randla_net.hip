@@ -276,6 +276,156 @@ __global__ void att_pool_bwd_kernel(const float *__restrict__ cat, const float *
     }
 }
 
+
+// ---- Level 0 (d = 16 channels, h = 8): one attentive pooling in ONE kernel, nothing per-edge written.
+// The unfused chain moves the [N*16, 16] edge tensor seven times forward (gather + concat out, score GEMM in / out,
+// softmax pooling in / in / out) and about eight times backward; at 16 channels the score "GEMM" is 256 FMAs per edge, which
+// a thread does in registers.  Forward: thread (point, channel pair) holds the 2 rows of the score weights it needs,
+// walks the 16 neighbours (gathered feature row + position-encoding row = the 16 inputs), keeps its 16 x 2 scores, then
+// softmax over the neighbours and the weighted sum, in the arithmetic order of skinny_gemm_kernel / att_pool_fwd_kernel.
+// Backward recomputes scores and attention weights instead of reading them back (RandLANet.py:398-410).
+__device__ __forceinline__ void lfa16_load_x(const float *__restrict__ f, const float *__restrict__ fxyz, int j, size_t e, float (&x)[16])
+{
+    const float4 a0 = *(const float4 *)(f + (size_t)j * 8), a1 = *(const float4 *)(f + (size_t)j * 8 + 4);
+    const float4 b0 = *(const float4 *)(fxyz + e * 8), b1 = *(const float4 *)(fxyz + e * 8 + 4);
+    x[0] = a0.x; x[1] = a0.y; x[2] = a0.z; x[3] = a0.w; x[4] = a1.x; x[5] = a1.y; x[6] = a1.z; x[7] = a1.w;
+    x[8] = b0.x; x[9] = b0.y; x[10] = b0.z; x[11] = b0.w; x[12] = b1.x; x[13] = b1.y; x[14] = b1.z; x[15] = b1.w;
+}
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// the thread's own 2 channels of cat[e]: features for q < 4, position encoding for q >= 4
+__device__ __forceinline__ float2 lfa16_load_own(const float *__restrict__ f, const float *__restrict__ fxyz, int j, size_t e, int q)
+{
+    return q < 4 ? *(const float2 *)(f + (size_t)j * 8 + 2 * q) : *(const float2 *)(fxyz + e * 8 + 2 * (q - 4));
+}
+// scores of the 16 neighbours for the thread's 2 channels, and their softmax over the neighbours (in place)
+__device__ __forceinline__ void lfa16_attention(const float *__restrict__ f, const int32_t *__restrict__ nb, const float *__restrict__ fxyz,
+                                                size_t p, const float (&wr)[2][16], const float (&bias)[2], float (&a)[RK][2])
+{
+    float m[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        float x[16];
+        lfa16_load_x(f, fxyz, nb[k], p * RK + k, x);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc += x[i] * wr[c][i];
+            acc += bias[c];
+            a[k][c] = acc;
+            m[c] = fmaxf(m[c], acc);
+        }
+    }
+    float sum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < RK; ++k)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { a[k][c] = expf(a[k][c] - m[c]); sum[c] += a[k][c]; }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float inv = 1.0f / sum[c];
+#pragma unroll
+        for (int k = 0; k < RK; ++k) a[k][c] *= inv;
+    }
+}
+
+// thread = (point, channel pair): 8 threads per point (4 channels per thread took 216 - 256 registers: 1 - 2 waves per SIMD)
+__global__ __launch_bounds__(256, 4) void lfa16_fwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh,
+                                                        const float *__restrict__ fxyz, const float *__restrict__ w,
+                                                        const float *__restrict__ b, size_t n, float *__restrict__ agg)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t p = t >> 3;
+    const int q = (int)(t & 7);
+    if (p >= n) return;
+    float wr[2][16], bias[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        bias[c] = b ? b[2 * q + c] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wr[c][i] = w[(2 * q + c) * 16 + i];
+    }
+    int nb[RK];
+#pragma unroll
+    for (int k = 0; k < RK; ++k) nb[k] = neigh[p * RK + k];
+    float a[RK][2];
+    lfa16_attention(f, nb, fxyz, p, wr, bias, a);
+    float2 out = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        const float2 x = lfa16_load_own(f, fxyz, nb[k], p * RK + k, q);
+        out.x += x.x * a[k][0]; out.y += x.y * a[k][1];
+    }
+    *(float2 *)(agg + p * 16 + 2 * q) = out;
+}
+
+// gradient w.r.t. the gathered features: df[neigh[e]][i] += a[e][i] * dagg[i] + sum_c ds[e][c] * W[c][i] for i < 8, with
+// ds = a * (g - sum_k a g), g = cat * dagg (the position-encoding half carries no colour gradient).  The sum over the 16
+// channels c is split over the 8 threads of the point (each owns 2 rows of W) and closed with three shuffles; lane q then
+// adds column q: the 8 lanes of a point hit 32 consecutive bytes of the neighbour's row.
+__global__ __launch_bounds__(256, 4) void lfa16_bwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh,
+                                                        const float *__restrict__ fxyz, const float *__restrict__ w,
+                                                        const float *__restrict__ b, const float *__restrict__ dagg, size_t n,
+                                                        float *__restrict__ df)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = (t >> 3) < n;                 // (all lanes stay for the shuffles)
+    const size_t p = live ? (t >> 3) : n - 1;
+    const int q = (int)(t & 7);
+    float wr[2][16], bias[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        bias[c] = b ? b[2 * q + c] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wr[c][i] = w[(2 * q + c) * 16 + i];
+    }
+    int nb[RK];
+#pragma unroll
+    for (int k = 0; k < RK; ++k) nb[k] = neigh[p * RK + k];
+    float a[RK][2];
+    lfa16_attention(f, nb, fxyz, p, wr, bias, a);
+    const float2 dg2 = *(const float2 *)(dagg + p * 16 + 2 * q);
+    const float dg[2] = {dg2.x, dg2.y};
+    float dot[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        const float2 x = lfa16_load_own(f, fxyz, nb[k], p * RK + k, q);
+        dot[0] += a[k][0] * (x.x * dg[0]); dot[1] += a[k][1] * (x.y * dg[1]);
+    }
+#pragma unroll 4
+    for (int k = 0; k < RK; ++k) {
+        const float2 x = lfa16_load_own(f, fxyz, nb[k], p * RK + k, q);
+        const float xs[2] = {x.x, x.y};
+        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float ds = a[k][c] * (xs[c] * dg[c] - dot[c]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) part[i] += ds * wr[c][i];
+        }
+        // the direct path a * dagg belongs to the channel's owner: threads 0 .. 3 own the feature half (columns 2 q, 2 q + 1)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (q < 4 && (i >> 1) == q) part[i] += a[k][i & 1] * dg[i & 1];
+        // sum over the point's 8 lanes, result in all of them: two quad permutes and the mirror of the half row (lane i
+        // <-> 7 - i, whose quad is already summed), as DPP operands of the adds (a ds_bpermute shuffle per step made this
+        // kernel LDS-crossbar bound: 384 per thread)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            part[i] += dpp_f<0xB1>(part[i]);    // quad_perm [1,0,3,2]
+            part[i] += dpp_f<0x4E>(part[i]);    // quad_perm [2,3,0,1]
+            part[i] += dpp_f<0x141>(part[i]);   // row_half_mirror
+        }
+        float v = part[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v = q == i ? part[i] : v;
+        if (live && v != 0.0f) atomicAdd(df + (size_t)nb[k] * 8 + q, v);
+    }
+}
+
 // transpose of the neighbour gather: df[neigh[e]][c] += dcat[e][c] for c < h (the xyz half carries no colour gradient)
 __global__ void gather_bwd_kernel(const float *__restrict__ dcat, const int32_t *__restrict__ neigh, int h, size_t total,
                                   float *__restrict__ df)
@@ -521,6 +671,7 @@ struct psg_rla_ws {
     float *feat, *dfeat, *ori, *delta, *norms;   // attack state: [N][6], [N][6], [N][3], [N][3], [4]
     int32_t *labels;
     bool cloud_set = false, have_fwd = false;
+    bool fuse16 = true;           // PSG_RLA_NO_FUSE16=1: the unfused chain at level 0 too (A/B runs, tests)
     EvLog prof;                   // psg_rla_prof_enable
     const void *xyz_branch_model = nullptr;   // the model whose xyz-branch features (fxyz1 / fxyz2) are resident
     // hipGraph of one BIM iteration (forward, loss gradient, backward, update: ~150 short launches), valid for the
@@ -629,6 +780,7 @@ extern "C" int psg_rla_ws_create_batch(psg_ctx *ctx, int n_points, int batch, ps
     PSG_CHECK_HIP(hipSetDevice(ctx->device));
     auto *ws = new psg_rla_ws();
     ws->ctx = ctx; ws->B = batch; ws->Nc = n_points; ws->N = batch * n_points;
+    { const char *nf = getenv("PSG_RLA_NO_FUSE16"); ws->fuse16 = !(nf && atoi(nf)); }
     for (int pass = 0; pass < 2; ++pass) {
         size_t off = 0;
         auto take = [&](size_t bytes) {
@@ -815,17 +967,30 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
             if ((rc = conv_fwd(E.lfa_mlp1, L.relpos, 10, L.fxyz1, h, (int)ne, true, nullptr, st))) return rc;
             if ((rc = conv_fwd(E.lfa_mlp2, L.fxyz1, h, L.fxyz2, h, (int)ne, true, nullptr, st))) return rc;
         }
-        hipLaunchKernelGGL(gather_concat_kernel, dim3(blocks_for(ne * d / 4)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, h, ne * d / 4, L.cat1);
-        PSG_LAUNCH_CHECK();
-        if ((rc = conv_fwd(E.att1_fc, L.cat1, d, L.a1, d, (int)ne, false, nullptr, st))) return rc;
-        hipLaunchKernelGGL(att_pool_fwd_kernel, dim3(blocks_for((size_t)n * d / 4)), dim3(256), 0, st, L.cat1, L.a1, d, (size_t)n * d / 4, L.agg1);
-        PSG_LAUNCH_CHECK();
+        const bool fused16 = d == 16 && ws->fuse16;     // level 0: one kernel per attentive pooling (lfa16_*_kernel)
+        if (fused16) {
+            hipLaunchKernelGGL(lfa16_fwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, E.att1_fc.w,
+                               E.att1_fc.b, (size_t)n, L.agg1);
+            PSG_LAUNCH_CHECK();
+        } else {
+            hipLaunchKernelGGL(gather_concat_kernel, dim3(blocks_for(ne * d / 4)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, h, ne * d / 4, L.cat1);
+            PSG_LAUNCH_CHECK();
+            if ((rc = conv_fwd(E.att1_fc, L.cat1, d, L.a1, d, (int)ne, false, nullptr, st))) return rc;
+            hipLaunchKernelGGL(att_pool_fwd_kernel, dim3(blocks_for((size_t)n * d / 4)), dim3(256), 0, st, L.cat1, L.a1, d, (size_t)n * d / 4, L.agg1);
+            PSG_LAUNCH_CHECK();
+        }
         if ((rc = conv_fwd(E.att1_mlp, L.agg1, d, L.fagg1, h, n, true, L.m_fagg1, st))) return rc;
-        hipLaunchKernelGGL(gather_concat_kernel, dim3(blocks_for(ne * d / 4)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, h, ne * d / 4, L.cat2);
-        PSG_LAUNCH_CHECK();
-        if ((rc = conv_fwd(E.att2_fc, L.cat2, d, L.a2, d, (int)ne, false, nullptr, st))) return rc;
-        hipLaunchKernelGGL(att_pool_fwd_kernel, dim3(blocks_for((size_t)n * d / 4)), dim3(256), 0, st, L.cat2, L.a2, d, (size_t)n * d / 4, L.agg2);
-        PSG_LAUNCH_CHECK();
+        if (fused16) {
+            hipLaunchKernelGGL(lfa16_fwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, E.att2_fc.w,
+                               E.att2_fc.b, (size_t)n, L.agg2);
+            PSG_LAUNCH_CHECK();
+        } else {
+            hipLaunchKernelGGL(gather_concat_kernel, dim3(blocks_for(ne * d / 4)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, h, ne * d / 4, L.cat2);
+            PSG_LAUNCH_CHECK();
+            if ((rc = conv_fwd(E.att2_fc, L.cat2, d, L.a2, d, (int)ne, false, nullptr, st))) return rc;
+            hipLaunchKernelGGL(att_pool_fwd_kernel, dim3(blocks_for((size_t)n * d / 4)), dim3(256), 0, st, L.cat2, L.a2, d, (size_t)n * d / 4, L.agg2);
+            PSG_LAUNCH_CHECK();
+        }
         if ((rc = conv_fwd(E.att2_mlp, L.agg2, d, L.fagg2, d, n, true, L.m_fagg2, st))) return rc;
         if ((rc = conv_fwd(E.mlp2, L.fagg2, d, L.m2, 2 * d, n, false, nullptr, st))) return rc;
         if ((rc = conv_fwd(E.shortcut, fin, L.d_in, L.sc, 2 * d, n, false, nullptr, st))) return rc;
@@ -912,21 +1077,34 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         if ((rc = lrelu_bwd(g_fagg2, d, L.m_fagg2, n, d, st))) return rc;
         float *g_agg2 = L.fagg2;
         if ((rc = conv_bwd(E.att2_mlp, g_fagg2, d, g_agg2, d, n, 0, st))) return rc;
-        hipLaunchKernelGGL(att_pool_bwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, L.cat2, L.a2, g_agg2, d, (size_t)n * d / 2,
-                           ws->scratch_a, ws->scratch_b);
-        PSG_LAUNCH_CHECK();
-        if ((rc = conv_bwd(E.att2_fc, ws->scratch_b, d, ws->scratch_a, d, (int)ne, 1, st))) return rc;
-        hipLaunchKernelGGL(gather_bwd_kernel, dim3(blocks_for(ne * h)), dim3(256), 0, st, ws->scratch_a, L.neigh, h, ne * h, L.d_fagg1);
-        PSG_LAUNCH_CHECK();
+        const bool fused16 = d == 16 && ws->fuse16;
+        if (fused16) {
+            hipLaunchKernelGGL(lfa16_bwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, E.att2_fc.w,
+                               E.att2_fc.b, g_agg2, (size_t)n, L.d_fagg1);
+            PSG_LAUNCH_CHECK();
+        } else {
+            hipLaunchKernelGGL(att_pool_bwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, L.cat2, L.a2, g_agg2, d, (size_t)n * d / 2,
+                               ws->scratch_a, ws->scratch_b);
+            PSG_LAUNCH_CHECK();
+            if ((rc = conv_bwd(E.att2_fc, ws->scratch_b, d, ws->scratch_a, d, (int)ne, 1, st))) return rc;
+            hipLaunchKernelGGL(gather_bwd_kernel, dim3(blocks_for(ne * h)), dim3(256), 0, st, ws->scratch_a, L.neigh, h, ne * h, L.d_fagg1);
+            PSG_LAUNCH_CHECK();
+        }
         if ((rc = lrelu_bwd(L.d_fagg1, h, L.m_fagg1, n, h, st))) return rc;
         float *g_agg1 = L.agg1;
         if ((rc = conv_bwd(E.att1_mlp, L.d_fagg1, h, g_agg1, d, n, 0, st))) return rc;
-        hipLaunchKernelGGL(att_pool_bwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, L.cat1, L.a1, g_agg1, d, (size_t)n * d / 2,
-                           ws->scratch_a, ws->scratch_b);
-        PSG_LAUNCH_CHECK();
-        if ((rc = conv_bwd(E.att1_fc, ws->scratch_b, d, ws->scratch_a, d, (int)ne, 1, st))) return rc;
-        hipLaunchKernelGGL(gather_bwd_kernel, dim3(blocks_for(ne * h)), dim3(256), 0, st, ws->scratch_a, L.neigh, h, ne * h, L.d_fpc);
-        PSG_LAUNCH_CHECK();
+        if (fused16) {
+            hipLaunchKernelGGL(lfa16_bwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, E.att1_fc.w,
+                               E.att1_fc.b, g_agg1, (size_t)n, L.d_fpc);
+            PSG_LAUNCH_CHECK();
+        } else {
+            hipLaunchKernelGGL(att_pool_bwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, L.cat1, L.a1, g_agg1, d, (size_t)n * d / 2,
+                               ws->scratch_a, ws->scratch_b);
+            PSG_LAUNCH_CHECK();
+            if ((rc = conv_bwd(E.att1_fc, ws->scratch_b, d, ws->scratch_a, d, (int)ne, 1, st))) return rc;
+            hipLaunchKernelGGL(gather_bwd_kernel, dim3(blocks_for(ne * h)), dim3(256), 0, st, ws->scratch_a, L.neigh, h, ne * h, L.d_fpc);
+            PSG_LAUNCH_CHECK();
+        }
         if ((rc = lrelu_bwd(L.d_fpc, h, L.m_fpc, n, h, st))) return rc;
         if ((rc = conv_bwd(E.mlp1, L.d_fpc, h, din, L.d_in, n, 1, st))) return rc;
     }
