@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "psg_common.h"
 #include "psg_gemm.cuh"
 
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(256, 4) void lfa16_fwd_kernel(const float *__restri
 __global__ __launch_bounds__(256, 4) void lfa16_bwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh,
                                                         const float *__restrict__ fxyz, const float *__restrict__ w,
                                                         const float *__restrict__ b, const float *__restrict__ dagg, size_t n,
-                                                        float *__restrict__ df)
+                                                        float *__restrict__ df, float *__restrict__ dcat8)
 {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = (t >> 3) < n;                 // (all lanes stay for the shuffles)
@@ -422,8 +424,113 @@ __global__ __launch_bounds__(256, 4) void lfa16_bwd_kernel(const float *__restri
         float v = part[0];
 #pragma unroll
         for (int i = 1; i < 8; ++i) v = q == i ? part[i] : v;
-        if (live && v != 0.0f) atomicAdd(df + (size_t)nb[k] * 8 + q, v);
+        if (live) {
+            if (dcat8) dcat8[(p * RK + k) * 8 + q] = v;          // per-edge rows, gathered through the inverse list afterwards
+            else if (v != 0.0f) atomicAdd(df + (size_t)nb[k] * 8 + q, v);
+        }
     }
+}
+
+// ---- inverse lists (transposes of neigh / up) and the gathers that replace the scatter kernels below
+__global__ void iota_kernel(int32_t *__restrict__ v, size_t n)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) v[t] = (int32_t)t;
+}
+// keys[i] = neigh[(b * nc + p) * 16 + k] for the sampled edge i = (b * nc_sub + p) * 16 + k
+__global__ void sampled_keys_kernel(const int32_t *__restrict__ neigh, int nc_sub, int nc, size_t total, int32_t *__restrict__ keys)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t r = i >> 4;
+    keys[i] = neigh[((r / nc_sub) * nc + r % nc_sub) * RK + (i & 15)];
+}
+// off[t] = first position of a key >= t in the ascending array keys[0 .. m), t = 0 .. n_targets
+__global__ void lower_bound_kernel(const int32_t *__restrict__ keys, int m, int n_targets, int32_t *__restrict__ off)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_targets) return;
+    int lo = 0, hi = m;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    off[t] = lo;
+}
+// df[j][c] += sum over the edges e that point at row j (ascending e) of src[e][c], c < h   (transpose of gather_neighbour)
+__global__ void gather_inv_kernel(const float *__restrict__ src, int ld, int h, const int32_t *__restrict__ off,
+                                  const int32_t *__restrict__ ent, size_t total, float *__restrict__ df)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const size_t j = t / h;
+    const int c = (int)(t - j * h);
+    float acc = 0.0f;
+    const int e1 = off[j + 1];
+    int i = off[j];
+    for (; i + 4 <= e1; i += 4) {   // four independent row loads in flight, added in list order
+        const int e0 = ent[i], ea = ent[i + 1], eb = ent[i + 2], ec = ent[i + 3];
+        const float v0 = src[(size_t)e0 * ld + c], v1 = src[(size_t)ea * ld + c], v2 = src[(size_t)eb * ld + c], v3 = src[(size_t)ec * ld + c];
+        acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; i < e1; ++i) acc += src[(size_t)ent[i] * ld + c];
+    df[t] += acc;
+}
+// transpose of random_sample's max over neighbours: row j of the level collects, over the sampled edges i = r * 16 + k that
+// point at it (ascending), dout[r][c] where arg[r][c] == k
+__global__ void pool_max_inv_kernel(const float *__restrict__ dout, const uint8_t *__restrict__ arg, int C, const int32_t *__restrict__ off,
+                                    const int32_t *__restrict__ ent, size_t total, float *__restrict__ df)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const size_t j = t / C;
+    const int c = (int)(t - j * C);
+    float acc = 0.0f;
+    const int e1 = off[j + 1];
+    int i = off[j];
+    for (; i + 4 <= e1; i += 4) {   // four independent (arg, gradient) pairs in flight, added in list order
+        const int e0 = ent[i], ea = ent[i + 1], eb = ent[i + 2], ec = ent[i + 3];
+        const size_t r0 = (size_t)(e0 >> 4) * C + c, r1 = (size_t)(ea >> 4) * C + c, r2 = (size_t)(eb >> 4) * C + c, r3 = (size_t)(ec >> 4) * C + c;
+        const int a0 = arg[r0], a1 = arg[r1], a2 = arg[r2], a3 = arg[r3];
+        const float g0 = dout[r0], g1 = dout[r1], g2 = dout[r2], g3 = dout[r3];
+        if (a0 == (e0 & 15)) acc += g0;
+        if (a1 == (ea & 15)) acc += g1;
+        if (a2 == (eb & 15)) acc += g2;
+        if (a3 == (ec & 15)) acc += g3;
+    }
+    for (; i < e1; ++i) {
+        const int e = ent[i];
+        const size_t r = (size_t)(e >> 4);
+        if (arg[r * C + c] == (e & 15)) acc += dout[r * C + c];
+    }
+    df[t] += acc;
+}
+// transpose of nearest interpolation: dcoarse[t][c] += sum over the rows n with up[n] == t (ascending) of dcat[n][cs + c];
+// dskip[n][c] += dcat[n][c] is done by interp_skip_bwd_kernel
+__global__ void interp_inv_kernel(const float *__restrict__ dcat, int cs, int cc, const int32_t *__restrict__ off,
+                                  const int32_t *__restrict__ ent, size_t total, float *__restrict__ dcoarse)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const size_t j = t / cc;
+    const int c = (int)(t - j * cc);
+    float acc = 0.0f;
+    const int e1 = off[j + 1];
+    for (int i = off[j]; i < e1; ++i) acc += dcat[(size_t)ent[i] * (cs + cc) + cs + c];
+    dcoarse[t] += acc;
+}
+__global__ void interp_skip_bwd_kernel(const float *__restrict__ dcat, int cs, int cc, size_t total4, float *__restrict__ dskip)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // total4 = rows * cs / 4
+    if (t >= total4) return;
+    const int s4 = cs >> 2;
+    const size_t n = t / s4;
+    const int c = (int)(t - n * s4) * 4;
+    const float4 g = *(const float4 *)(dcat + n * (cs + cc) + c);
+    float4 *o = (float4 *)(dskip + n * cs + c);
+    float4 v = *o;
+    v.x += g.x; v.y += g.y; v.z += g.z; v.w += g.w;
+    *o = v;
 }
 
 // transpose of the neighbour gather: df[neigh[e]][c] += dcat[e][c] for c < h (the xyz half carries no colour gradient)
@@ -643,6 +750,13 @@ struct LevelBuf {
     int nc = 0, nc_sub = 0;                         // per cloud
     float *xyz = nullptr;                           // [B][nc][3]: the level's points, cloud by cloud
     int32_t *neigh = nullptr, *up = nullptr;   // [n][16], [n][1] (row numbers of this level / of the next); pool = a cloud's first nc_sub rows
+    // transposes of the two index arrays (the geometry is fixed for a whole attack, so they are built once per cloud): for every
+    // row j of this level the edges e = p * 16 + k with neigh[e] == j, ascending (inv_off [n + 1], inv_ent [n * 16]); for every row
+    // t of the next level the rows n with up[n] == t, ascending (invu_off [n_sub + 1], invu_ent [n]).  The backward pass GATHERS
+    // through them in that fixed order instead of scattering with float atomics: bit-reproducible, and faster.
+    int32_t *inv_off = nullptr, *inv_ent = nullptr, *invu_off = nullptr, *invu_ent = nullptr;
+    // the same for the edges of the SAMPLED points only (the max-pool reads just those): entries i = r * 16 + k, r a sampled row
+    int32_t *invp_off = nullptr, *invp_ent = nullptr;
     float *relpos, *fxyz1, *fxyz2;             // [n*16][10], [n*16][h] x2
     float *fpc, *cat1, *a1, *agg1, *fagg1, *cat2, *a2, *agg2, *fagg2, *m2, *sc, *enc, *samp;
     uint32_t *m_fpc, *m_fagg1, *m_fagg2, *m_enc;
@@ -672,6 +786,8 @@ struct psg_rla_ws {
     int32_t *labels;
     bool cloud_set = false, have_fwd = false;
     bool fuse16 = true;           // PSG_RLA_NO_FUSE16=1: the unfused chain at level 0 too (A/B runs, tests)
+    bool use_inv = true;          // PSG_RLA_ATOMICS=1: the scatter kernels with float atomics instead of the inverse-list gathers
+    size_t scratch_bytes = 0;     // of scratch_a and of scratch_b
     EvLog prof;                   // psg_rla_prof_enable
     const void *xyz_branch_model = nullptr;   // the model whose xyz-branch features (fxyz1 / fxyz2) are resident
     // hipGraph of one BIM iteration (forward, loss gradient, backward, update: ~150 short launches), valid for the
@@ -781,6 +897,7 @@ extern "C" int psg_rla_ws_create_batch(psg_ctx *ctx, int n_points, int batch, ps
     auto *ws = new psg_rla_ws();
     ws->ctx = ctx; ws->B = batch; ws->Nc = n_points; ws->N = batch * n_points;
     { const char *nf = getenv("PSG_RLA_NO_FUSE16"); ws->fuse16 = !(nf && atoi(nf)); }
+    { const char *at = getenv("PSG_RLA_ATOMICS"); ws->use_inv = !(at && atoi(at)); }
     for (int pass = 0; pass < 2; ++pass) {
         size_t off = 0;
         auto take = [&](size_t bytes) {
@@ -801,6 +918,9 @@ extern "C" int psg_rla_ws_create_batch(psg_ctx *ctx, int n_points, int batch, ps
             const size_t E = (size_t)n * RK, d = L.d, h = L.h;
             max_edge = std::max(max_edge, E * d);
             L.neigh = (int32_t *)take(E * 4); L.up = (int32_t *)take((size_t)n * 4);
+            L.inv_off = (int32_t *)take(((size_t)n + 1) * 4); L.inv_ent = (int32_t *)take(E * 4);
+            L.invu_off = (int32_t *)take(((size_t)L.n_sub + 1) * 4); L.invu_ent = (int32_t *)take((size_t)n * 4);
+            L.invp_off = (int32_t *)take(((size_t)n + 1) * 4); L.invp_ent = (int32_t *)take((size_t)L.n_sub * RK * 4);
             L.relpos = (float *)take(E * 10 * 4); L.fxyz1 = (float *)take(E * h * 4); L.fxyz2 = (float *)take(E * h * 4);
             L.fpc = (float *)take((size_t)n * h * 4); L.cat1 = (float *)take(E * d * 4); L.a1 = (float *)take(E * d * 4);
             L.agg1 = (float *)take((size_t)n * d * 4); L.fagg1 = (float *)take((size_t)n * h * 4);
@@ -831,6 +951,7 @@ extern "C" int psg_rla_ws_create_batch(psg_ctx *ctx, int n_points, int batch, ps
         ws->m_fc1 = (uint32_t *)take(N * 2 * 4); ws->m_fc2 = (uint32_t *)take(N * 4);
         ws->logits = (float *)take(N * RNCLS * 4); ws->dlogits = (float *)take(N * RNCLS * 4);
         ws->scratch_a = (float *)take(max_edge * 4); ws->scratch_b = (float *)take(max_edge * 4);
+        ws->scratch_bytes = max_edge * 4;
         ws->d_f0 = (float *)take(N * 8 * 4);
         // gradient accumulators (targets of atomics / of several consumers): one contiguous block, zeroed by ONE memset
         // at the start of a backward pass instead of ~25 small ones spread over it
@@ -901,6 +1022,25 @@ struct ProfBind {   // routes rl_gemm's scopes to the workspace of the call in p
 };
 }  // namespace
 
+// ent = the positions 0 .. m-1 of keys[], stably sorted by key (hipcub radix sort: ties keep their ascending position),
+// off[t] = where target t's run begins.  Temporaries in the workspace's two scratch buffers (idle while the pyramid is built).
+static int build_inverse(psg_rla_ws *ws, const int32_t *keys, size_t m, int n_targets, int32_t *off, int32_t *ent, hipStream_t st)
+{
+    int32_t *iota = (int32_t *)ws->scratch_a, *keys_sorted = iota + m;
+    if (2 * m * sizeof(int32_t) > ws->scratch_bytes) { set_error("build_inverse: %zu keys do not fit the scratch buffer", m); return PSG_ERR_STATE; }
+    hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(m)), dim3(256), 0, st, iota, m);
+    PSG_LAUNCH_CHECK();
+    int bits = 1;
+    while ((1 << bits) < n_targets) ++bits;
+    size_t tmp_bytes = 0;
+    PSG_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys_sorted, iota, ent, (int)m, 0, bits, st));
+    if (tmp_bytes > ws->scratch_bytes) { set_error("build_inverse: radix sort needs %zu bytes of scratch", tmp_bytes); return PSG_ERR_STATE; }
+    PSG_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs((void *)ws->scratch_b, tmp_bytes, keys, keys_sorted, iota, ent, (int)m, 0, bits, st));
+    hipLaunchKernelGGL(lower_bound_kernel, dim3(blocks_for((size_t)n_targets + 1)), dim3(256), 0, st, keys_sorted, (int)m, n_targets, off);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
 // The index pyramid of the reference's tf_map (main_S3DIS.py:198-207) and the relative position encodings, from the
 // cloud in ws->xyz_all.
 static int build_pyramid(psg_rla_ws *ws, psg_stream stream)
@@ -926,6 +1066,17 @@ static int build_pyramid(psg_rla_ws *ws, psg_stream stream)
         const size_t E = (size_t)L.n * RK;
         hipLaunchKernelGGL(relpos_kernel, dim3(blocks_for(E)), dim3(256), 0, st, L.xyz, L.neigh, E, L.relpos);
         PSG_LAUNCH_CHECK();
+        if (ws->use_inv) {
+            if ((rc = build_inverse(ws, L.neigh, E, L.n, L.inv_off, L.inv_ent, st))) return rc;
+            if ((rc = build_inverse(ws, L.up, (size_t)L.n, L.n_sub, L.invu_off, L.invu_ent, st))) return rc;
+            // (keys of the sampled edges: behind the builder's own two arrays in scratch_a)
+            const size_t ms = (size_t)L.n_sub * RK;
+            int32_t *keys_p = (int32_t *)ws->scratch_a + 2 * E;
+            if ((2 * E + ms) * sizeof(int32_t) > ws->scratch_bytes) { set_error("build_pyramid: scratch too small for the sampled-edge keys"); return PSG_ERR_STATE; }
+            hipLaunchKernelGGL(sampled_keys_kernel, dim3(blocks_for(ms)), dim3(256), 0, st, L.neigh, L.nc_sub, L.nc, ms, keys_p);
+            PSG_LAUNCH_CHECK();
+            if ((rc = build_inverse(ws, keys_p, ms, L.n, L.invp_off, L.invp_ent, st))) return rc;
+        }
     }
     ws->cloud_set = true;
     ws->have_fwd = false;
@@ -1054,8 +1205,16 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         if ((rc = conv_bwd(m->dec[j], dout, cs, ws->scratch_a, cs + cfeat, L.n, 0, st))) return rc;
         float *dskip = j == RL - 1 ? ws->lv[0].d_enc : ws->lv[RL - 2 - j].d_samp;
         float *dcoarse = j == 0 ? ws->d_dec0 : ws->d_dec_out[j - 1];
-        hipLaunchKernelGGL(interp_concat_bwd_kernel, dim3(blocks_for((size_t)L.n * (cs + cfeat))), dim3(256), 0, st, ws->scratch_a, cs,
-                           cfeat, L.up, (size_t)L.n * (cs + cfeat), dskip, dcoarse);
+        if (ws->use_inv) {
+            hipLaunchKernelGGL(interp_skip_bwd_kernel, dim3(blocks_for((size_t)L.n * cs / 4)), dim3(256), 0, st, ws->scratch_a, cs, cfeat,
+                               (size_t)L.n * cs / 4, dskip);
+            PSG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(interp_inv_kernel, dim3(blocks_for((size_t)L.n_sub * cfeat)), dim3(256), 0, st, ws->scratch_a, cs, cfeat,
+                               L.invu_off, L.invu_ent, (size_t)L.n_sub * cfeat, dcoarse);
+        } else {
+            hipLaunchKernelGGL(interp_concat_bwd_kernel, dim3(blocks_for((size_t)L.n * (cs + cfeat))), dim3(256), 0, st, ws->scratch_a, cs,
+                               cfeat, L.up, (size_t)L.n * (cs + cfeat), dskip, dcoarse);
+        }
         PSG_LAUNCH_CHECK();
     }
     if ((rc = lrelu_bwd(ws->d_dec0, 1024, ws->m_dec0, n5, 1024, st))) return rc;
@@ -1067,8 +1226,12 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         const int n = L.n, d = L.d, h = L.h;
         const size_t ne = (size_t)n * RK;
         float *din = i == 0 ? ws->d_f0 : ws->lv[i - 1].d_samp;    // gradient of this level's input features
-        hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(blocks_for((size_t)L.n_sub * 2 * d)), dim3(256), 0, st, L.d_samp, L.neigh, L.arg,
-                           2 * d, (size_t)L.n_sub * 2 * d, L.nc_sub, L.nc, L.d_enc);
+        if (ws->use_inv)
+            hipLaunchKernelGGL(pool_max_inv_kernel, dim3(blocks_for((size_t)n * 2 * d)), dim3(256), 0, st, L.d_samp, L.arg, 2 * d, L.invp_off,
+                               L.invp_ent, (size_t)n * 2 * d, L.d_enc);
+        else
+            hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(blocks_for((size_t)L.n_sub * 2 * d)), dim3(256), 0, st, L.d_samp, L.neigh, L.arg,
+                               2 * d, (size_t)L.n_sub * 2 * d, L.nc_sub, L.nc, L.d_enc);
         PSG_LAUNCH_CHECK();
         if ((rc = lrelu_bwd(L.d_enc, 2 * d, L.m_enc, n, 2 * d, st))) return rc;
         if ((rc = conv_bwd(E.shortcut, L.d_enc, 2 * d, din, L.d_in, n, i == 0 ? 0 : 1, st))) return rc;
@@ -1080,14 +1243,23 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         const bool fused16 = d == 16 && ws->fuse16;
         if (fused16) {
             hipLaunchKernelGGL(lfa16_bwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, E.att2_fc.w,
-                               E.att2_fc.b, g_agg2, (size_t)n, L.d_fagg1);
+                               E.att2_fc.b, g_agg2, (size_t)n, L.d_fagg1, ws->use_inv ? ws->scratch_a : (float *)nullptr);
             PSG_LAUNCH_CHECK();
+            if (ws->use_inv) {
+                hipLaunchKernelGGL(gather_inv_kernel, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 8, h, L.inv_off, L.inv_ent,
+                                   (size_t)n * h, L.d_fagg1);
+                PSG_LAUNCH_CHECK();
+            }
         } else {
             hipLaunchKernelGGL(att_pool_bwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, L.cat2, L.a2, g_agg2, d, (size_t)n * d / 2,
                                ws->scratch_a, ws->scratch_b);
             PSG_LAUNCH_CHECK();
             if ((rc = conv_bwd(E.att2_fc, ws->scratch_b, d, ws->scratch_a, d, (int)ne, 1, st))) return rc;
-            hipLaunchKernelGGL(gather_bwd_kernel, dim3(blocks_for(ne * h)), dim3(256), 0, st, ws->scratch_a, L.neigh, h, ne * h, L.d_fagg1);
+            if (ws->use_inv)
+                hipLaunchKernelGGL(gather_inv_kernel, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 2 * h, h, L.inv_off,
+                                   L.inv_ent, (size_t)n * h, L.d_fagg1);
+            else
+                hipLaunchKernelGGL(gather_bwd_kernel, dim3(blocks_for(ne * h)), dim3(256), 0, st, ws->scratch_a, L.neigh, h, ne * h, L.d_fagg1);
             PSG_LAUNCH_CHECK();
         }
         if ((rc = lrelu_bwd(L.d_fagg1, h, L.m_fagg1, n, h, st))) return rc;
@@ -1095,14 +1267,23 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         if ((rc = conv_bwd(E.att1_mlp, L.d_fagg1, h, g_agg1, d, n, 0, st))) return rc;
         if (fused16) {
             hipLaunchKernelGGL(lfa16_bwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, E.att1_fc.w,
-                               E.att1_fc.b, g_agg1, (size_t)n, L.d_fpc);
+                               E.att1_fc.b, g_agg1, (size_t)n, L.d_fpc, ws->use_inv ? ws->scratch_a : (float *)nullptr);
             PSG_LAUNCH_CHECK();
+            if (ws->use_inv) {
+                hipLaunchKernelGGL(gather_inv_kernel, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 8, h, L.inv_off, L.inv_ent,
+                                   (size_t)n * h, L.d_fpc);
+                PSG_LAUNCH_CHECK();
+            }
         } else {
             hipLaunchKernelGGL(att_pool_bwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, L.cat1, L.a1, g_agg1, d, (size_t)n * d / 2,
                                ws->scratch_a, ws->scratch_b);
             PSG_LAUNCH_CHECK();
             if ((rc = conv_bwd(E.att1_fc, ws->scratch_b, d, ws->scratch_a, d, (int)ne, 1, st))) return rc;
-            hipLaunchKernelGGL(gather_bwd_kernel, dim3(blocks_for(ne * h)), dim3(256), 0, st, ws->scratch_a, L.neigh, h, ne * h, L.d_fpc);
+            if (ws->use_inv)
+                hipLaunchKernelGGL(gather_inv_kernel, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 2 * h, h, L.inv_off,
+                                   L.inv_ent, (size_t)n * h, L.d_fpc);
+            else
+                hipLaunchKernelGGL(gather_bwd_kernel, dim3(blocks_for(ne * h)), dim3(256), 0, st, ws->scratch_a, L.neigh, h, ne * h, L.d_fpc);
             PSG_LAUNCH_CHECK();
         }
         if ((rc = lrelu_bwd(L.d_fpc, h, L.m_fpc, n, h, st))) return rc;

@@ -223,3 +223,22 @@ def test_gpu_cloud_batch_equals_single_clouds(cloud):
     assert tuple(rgb_b.shape) == (B, N, 3) and (rgb_b.reshape(-1, 3).cpu().numpy() == adv_b[:, 3:]).mean() >= 0.98
     with pytest.raises(NotImplementedError):
         attack.BIM(model, B, "colper", "ut", "l_2")
+
+
+@pytest.mark.gpu
+def test_gpu_gradient_is_bit_reproducible(cloud, gpu):
+    """The backward pass gathers through inverse lists built once per cloud (no float atomics): two runs give the same
+    bits, and so do two 3-step attacks."""
+    import torch
+    from pointsecguard_amd.randla import network
+    xyz, rgb, labels, _ = cloud
+    model, ws, _ = gpu
+    ws.set_cloud(dev(xyz))
+    feats, lab = dev(np.concatenate([xyz, rgb], 1)), dev(labels.astype(np.int32))
+    grads = []
+    for _ in range(2):
+        _, dl = network.colper_grad(ws.forward(model, feats), lab)
+        grads.append(ws.backward(model, dl).clone())
+    assert torch.equal(grads[0], grads[1])
+    advs = [ws.bim_attack(model, feats, lab, 0.08, 0.02, 3).clone() for _ in range(2)]
+    assert torch.equal(advs[0], advs[1])
