@@ -431,6 +431,82 @@ __global__ __launch_bounds__(256, 4) void lfa16_bwd_kernel(const float *__restri
     }
 }
 
+// ---- Levels 1-4: attention scores without a per-edge GEMM.  The score layer is linear in cat = [f[neigh] | fxyz], so
+//     s[e] = W . cat[e] = (W1 . f)[neigh[e]] + W2 . fxyz[e] = T[neigh[e]] + S2[e]
+// with T = f . W1^T an [n, d] GEMM on POINTS (16x fewer rows than edges) and S2 = fxyz . W2^T a per-edge tensor that depends on
+// geometry and weights only: computed once per (cloud, model) with the position encodings and kept where the concatenation used
+// to be.  (The same identity as EdgeConv's split in psg_resgcn.hip.)  Forward: one kernel reads T through the neighbour
+// index, S2, and the two halves of cat on the fly; nothing but the attention weights (for the backward) and the pooled
+// [n, d] is written: the gather + concat pass and the [N*16, d] x [d, d] GEMM are gone.  Backward: ds is summed over the
+// in-edges of every point (inverse list) into dT [n, d], and the feature gradient is dT . W1 - again a GEMM on points.
+__global__ void att_pool_split_fwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh, const float *__restrict__ fxyz,
+                                          const float *__restrict__ T, const float *__restrict__ S2, int h, size_t total4,
+                                          float *__restrict__ a_out, float *__restrict__ agg)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total4) return;
+    const int d = 2 * h, d4 = d >> 2;
+    const size_t n = t / d4;
+    const int c = (int)(t - n * d4) * 4;
+    float4 v[RK];
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        const size_t e = n * RK + k;
+        const float4 tt = *(const float4 *)(T + (size_t)neigh[e] * d + c);
+        const float4 s2 = *(const float4 *)(S2 + e * d + c);
+        v[k] = make_float4(tt.x + s2.x, tt.y + s2.y, tt.z + s2.z, tt.w + s2.w);
+        m.x = fmaxf(m.x, v[k].x); m.y = fmaxf(m.y, v[k].y); m.z = fmaxf(m.z, v[k].z); m.w = fmaxf(m.w, v[k].w);
+    }
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        v[k].x = expf(v[k].x - m.x); v[k].y = expf(v[k].y - m.y); v[k].z = expf(v[k].z - m.z); v[k].w = expf(v[k].w - m.w);
+        sum.x += v[k].x; sum.y += v[k].y; sum.z += v[k].z; sum.w += v[k].w;
+    }
+    const float4 inv = make_float4(1.0f / sum.x, 1.0f / sum.y, 1.0f / sum.z, 1.0f / sum.w);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        const size_t e = n * RK + k;
+        const float4 a = make_float4(v[k].x * inv.x, v[k].y * inv.y, v[k].z * inv.z, v[k].w * inv.w);
+        *(float4 *)(a_out + e * d + c) = a;
+        const float4 x = c < h ? *(const float4 *)(f + (size_t)neigh[e] * h + c) : *(const float4 *)(fxyz + e * h + (c - h));
+        acc.x += x.x * a.x; acc.y += x.y * a.y; acc.z += x.z * a.z; acc.w += x.w * a.w;
+    }
+    ((float4 *)agg)[t] = acc;
+}
+
+// ds[e] = a * (g - sum_k a g), g = cat * dagg, for all d channels; ddir[e] = a * dagg for the feature half (c < h)
+__global__ void att_pool_split_bwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh, const float *__restrict__ fxyz,
+                                          const float *__restrict__ a, const float *__restrict__ dagg, int h, size_t total4,
+                                          float *__restrict__ ds, float *__restrict__ ddir)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total4) return;
+    const int d = 2 * h, d4 = d >> 2;
+    const size_t n = t / d4;
+    const int c = (int)(t - n * d4) * 4;
+    const float4 g0 = ((const float4 *)dagg)[t];
+    float4 av[RK];
+    float4 dot = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        const size_t e = n * RK + k;
+        av[k] = *(const float4 *)(a + e * d + c);
+        const float4 x = c < h ? *(const float4 *)(f + (size_t)neigh[e] * h + c) : *(const float4 *)(fxyz + e * h + (c - h));
+        dot.x += av[k].x * (x.x * g0.x); dot.y += av[k].y * (x.y * g0.y); dot.z += av[k].z * (x.z * g0.z); dot.w += av[k].w * (x.w * g0.w);
+    }
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        const size_t e = n * RK + k;
+        const float4 x = c < h ? *(const float4 *)(f + (size_t)neigh[e] * h + c) : *(const float4 *)(fxyz + e * h + (c - h));
+        *(float4 *)(ds + e * d + c) = make_float4(av[k].x * (x.x * g0.x - dot.x), av[k].y * (x.y * g0.y - dot.y),
+                                                  av[k].z * (x.z * g0.z - dot.z), av[k].w * (x.w * g0.w - dot.w));
+        if (c < h) *(float4 *)(ddir + e * h + c) = make_float4(av[k].x * g0.x, av[k].y * g0.y, av[k].z * g0.z, av[k].w * g0.w);
+    }
+}
+
 // ---- inverse lists (transposes of neigh / up) and the gathers that replace the scatter kernels below
 __global__ void iota_kernel(int32_t *__restrict__ v, size_t n)
 {
@@ -458,6 +534,7 @@ __global__ void lower_bound_kernel(const int32_t *__restrict__ keys, int m, int 
     off[t] = lo;
 }
 // df[j][c] += sum over the edges e that point at row j (ascending e) of src[e][c], c < h   (transpose of gather_neighbour)
+template <bool ASSIGN = false>
 __global__ void gather_inv_kernel(const float *__restrict__ src, int ld, int h, const int32_t *__restrict__ off,
                                   const int32_t *__restrict__ ent, size_t total, float *__restrict__ df)
 {
@@ -474,7 +551,7 @@ __global__ void gather_inv_kernel(const float *__restrict__ src, int ld, int h, 
         acc += v0; acc += v1; acc += v2; acc += v3;
     }
     for (; i < e1; ++i) acc += src[(size_t)ent[i] * ld + c];
-    df[t] += acc;
+    if (ASSIGN) df[t] = acc; else df[t] += acc;
 }
 // transpose of random_sample's max over neighbours: row j of the level collects, over the sampled edges i = r * 16 + k that
 // point at it (ascending), dout[r][c] where arg[r][c] == k
@@ -786,6 +863,7 @@ struct psg_rla_ws {
     int32_t *labels;
     bool cloud_set = false, have_fwd = false;
     bool fuse16 = true;           // PSG_RLA_NO_FUSE16=1: the unfused chain at level 0 too (A/B runs, tests)
+    bool split = true;            // PSG_RLA_NO_SPLIT=1: levels 1-4 through the gather + per-edge score GEMM chain (A/B runs)
     bool use_inv = true;          // PSG_RLA_ATOMICS=1: the scatter kernels with float atomics instead of the inverse-list gathers
     size_t scratch_bytes = 0;     // of scratch_a and of scratch_b
     EvLog prof;                   // psg_rla_prof_enable
@@ -898,6 +976,7 @@ extern "C" int psg_rla_ws_create_batch(psg_ctx *ctx, int n_points, int batch, ps
     ws->ctx = ctx; ws->B = batch; ws->Nc = n_points; ws->N = batch * n_points;
     { const char *nf = getenv("PSG_RLA_NO_FUSE16"); ws->fuse16 = !(nf && atoi(nf)); }
     { const char *at = getenv("PSG_RLA_ATOMICS"); ws->use_inv = !(at && atoi(at)); }
+    { const char *ns = getenv("PSG_RLA_NO_SPLIT"); ws->split = !(ns && atoi(ns)) && ws->use_inv; }
     for (int pass = 0; pass < 2; ++pass) {
         size_t off = 0;
         auto take = [&](size_t bytes) {
@@ -1117,9 +1196,24 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
         if (!xyz_ready) {   // the xyz branch depends on the cloud and the weights only: once per (cloud, model)
             if ((rc = conv_fwd(E.lfa_mlp1, L.relpos, 10, L.fxyz1, h, (int)ne, true, nullptr, st))) return rc;
             if ((rc = conv_fwd(E.lfa_mlp2, L.fxyz1, h, L.fxyz2, h, (int)ne, true, nullptr, st))) return rc;
+            if (ws->split && d > 16) {   // S2 = fxyz . W2^T (the position-encoding half of the score layer), kept in the cat buffers
+                GemmArgs g1 = rl_args(L.fxyz1, h, E.att1_fc.w + h, d, L.cat1, d, (int)ne, h, d);
+                if ((rc = rl_gemm<EPI_LINEAR>(g1, st))) return rc;
+                GemmArgs g2 = rl_args(L.fxyz2, h, E.att2_fc.w + h, d, L.cat2, d, (int)ne, h, d);
+                if ((rc = rl_gemm<EPI_LINEAR>(g2, st))) return rc;
+            }
         }
         const bool fused16 = d == 16 && ws->fuse16;     // level 0: one kernel per attentive pooling (lfa16_*_kernel)
-        if (fused16) {
+        const bool split = d > 16 && ws->split;         // levels 1-4: scores = T[neigh] + S2 (att_pool_split_*_kernel)
+        if (split) {
+            float *T1 = L.agg2;                          // [n][d] scratch: written by the second pooling only later
+            GemmArgs g = rl_args(L.fpc, h, E.att1_fc.w, d, T1, d, n, h, d);
+            g.bias = E.att1_fc.b;
+            if ((rc = rl_gemm<EPI_LINEAR>(g, st))) return rc;
+            hipLaunchKernelGGL(att_pool_split_fwd_kernel, dim3(blocks_for((size_t)n * d / 4)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, T1,
+                               L.cat1, h, (size_t)n * d / 4, L.a1, L.agg1);
+            PSG_LAUNCH_CHECK();
+        } else if (fused16) {
             hipLaunchKernelGGL(lfa16_fwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, E.att1_fc.w,
                                E.att1_fc.b, (size_t)n, L.agg1);
             PSG_LAUNCH_CHECK();
@@ -1131,7 +1225,15 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
             PSG_LAUNCH_CHECK();
         }
         if ((rc = conv_fwd(E.att1_mlp, L.agg1, d, L.fagg1, h, n, true, L.m_fagg1, st))) return rc;
-        if (fused16) {
+        if (split) {
+            float *T2 = L.m2;                            // [n][d] scratch inside the [n][2d] buffer mlp2 writes afterwards
+            GemmArgs g = rl_args(L.fagg1, h, E.att2_fc.w, d, T2, d, n, h, d);
+            g.bias = E.att2_fc.b;
+            if ((rc = rl_gemm<EPI_LINEAR>(g, st))) return rc;
+            hipLaunchKernelGGL(att_pool_split_fwd_kernel, dim3(blocks_for((size_t)n * d / 4)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, T2,
+                               L.cat2, h, (size_t)n * d / 4, L.a2, L.agg2);
+            PSG_LAUNCH_CHECK();
+        } else if (fused16) {
             hipLaunchKernelGGL(lfa16_fwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, E.att2_fc.w,
                                E.att2_fc.b, (size_t)n, L.agg2);
             PSG_LAUNCH_CHECK();
@@ -1241,12 +1343,32 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         float *g_agg2 = L.fagg2;
         if ((rc = conv_bwd(E.att2_mlp, g_fagg2, d, g_agg2, d, n, 0, st))) return rc;
         const bool fused16 = d == 16 && ws->fuse16;
-        if (fused16) {
+        const bool split = d > 16 && ws->split;
+        // split levels: ds [E][d] and the direct term [E][h] per edge, summed over every point's in-edges (dT [n][d], and
+        // straight into the feature gradient), then the score layer's feature half transposed on POINTS: df += dT . W1
+        auto split_bwd = [&](const float *fin_, const float *fxyz_, const float *a_, const float *dagg_, const RLayer &fc, float *df_) -> int {
+            float *ds = ws->scratch_b, *ddir = ws->scratch_a, *dT = L.m2;
+            hipLaunchKernelGGL(att_pool_split_bwd_kernel, dim3(blocks_for((size_t)n * d / 4)), dim3(256), 0, st, fin_, L.neigh, fxyz_, a_, dagg_,
+                               h, (size_t)n * d / 4, ds, ddir);
+            PSG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(gather_inv_kernel<true>, dim3(blocks_for((size_t)n * d)), dim3(256), 0, st, ds, d, d, L.inv_off, L.inv_ent,
+                               (size_t)n * d, dT);
+            PSG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(gather_inv_kernel<false>, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ddir, h, h, L.inv_off, L.inv_ent,
+                               (size_t)n * h, df_);
+            PSG_LAUNCH_CHECK();
+            GemmArgs g = rl_args(dT, d, fc.wt, d, df_, h, n, d, h);     // rows i < h of W^T: df[.][i] += sum_c dT[.][c] W[c][i]
+            g.accumulate = 1;
+            return rl_gemm<EPI_LINEAR>(g, st);
+        };
+        if (split) {
+            if ((rc = split_bwd(L.fagg1, L.fxyz2, L.a2, g_agg2, E.att2_fc, L.d_fagg1))) return rc;
+        } else if (fused16) {
             hipLaunchKernelGGL(lfa16_bwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, E.att2_fc.w,
                                E.att2_fc.b, g_agg2, (size_t)n, L.d_fagg1, ws->use_inv ? ws->scratch_a : (float *)nullptr);
             PSG_LAUNCH_CHECK();
             if (ws->use_inv) {
-                hipLaunchKernelGGL(gather_inv_kernel, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 8, h, L.inv_off, L.inv_ent,
+                hipLaunchKernelGGL(gather_inv_kernel<false>, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 8, h, L.inv_off, L.inv_ent,
                                    (size_t)n * h, L.d_fagg1);
                 PSG_LAUNCH_CHECK();
             }
@@ -1256,7 +1378,7 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
             PSG_LAUNCH_CHECK();
             if ((rc = conv_bwd(E.att2_fc, ws->scratch_b, d, ws->scratch_a, d, (int)ne, 1, st))) return rc;
             if (ws->use_inv)
-                hipLaunchKernelGGL(gather_inv_kernel, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 2 * h, h, L.inv_off,
+                hipLaunchKernelGGL(gather_inv_kernel<false>, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 2 * h, h, L.inv_off,
                                    L.inv_ent, (size_t)n * h, L.d_fagg1);
             else
                 hipLaunchKernelGGL(gather_bwd_kernel, dim3(blocks_for(ne * h)), dim3(256), 0, st, ws->scratch_a, L.neigh, h, ne * h, L.d_fagg1);
@@ -1265,12 +1387,14 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         if ((rc = lrelu_bwd(L.d_fagg1, h, L.m_fagg1, n, h, st))) return rc;
         float *g_agg1 = L.agg1;
         if ((rc = conv_bwd(E.att1_mlp, L.d_fagg1, h, g_agg1, d, n, 0, st))) return rc;
-        if (fused16) {
+        if (split) {
+            if ((rc = split_bwd(L.fpc, L.fxyz1, L.a1, g_agg1, E.att1_fc, L.d_fpc))) return rc;
+        } else if (fused16) {
             hipLaunchKernelGGL(lfa16_bwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, E.att1_fc.w,
                                E.att1_fc.b, g_agg1, (size_t)n, L.d_fpc, ws->use_inv ? ws->scratch_a : (float *)nullptr);
             PSG_LAUNCH_CHECK();
             if (ws->use_inv) {
-                hipLaunchKernelGGL(gather_inv_kernel, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 8, h, L.inv_off, L.inv_ent,
+                hipLaunchKernelGGL(gather_inv_kernel<false>, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 8, h, L.inv_off, L.inv_ent,
                                    (size_t)n * h, L.d_fpc);
                 PSG_LAUNCH_CHECK();
             }
@@ -1280,7 +1404,7 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
             PSG_LAUNCH_CHECK();
             if ((rc = conv_bwd(E.att1_fc, ws->scratch_b, d, ws->scratch_a, d, (int)ne, 1, st))) return rc;
             if (ws->use_inv)
-                hipLaunchKernelGGL(gather_inv_kernel, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 2 * h, h, L.inv_off,
+                hipLaunchKernelGGL(gather_inv_kernel<false>, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 2 * h, h, L.inv_off,
                                    L.inv_ent, (size_t)n * h, L.d_fpc);
             else
                 hipLaunchKernelGGL(gather_bwd_kernel, dim3(blocks_for(ne * h)), dim3(256), 0, st, ws->scratch_a, L.neigh, h, ne * h, L.d_fpc);
