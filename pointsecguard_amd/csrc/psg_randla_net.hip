@@ -477,33 +477,34 @@ __global__ void att_pool_split_fwd_kernel(const float *__restrict__ f, const int
     ((float4 *)agg)[t] = acc;
 }
 
-// ds[e] = a * (g - sum_k a g), g = cat * dagg, for all d channels; ddir[e] = a * dagg for the feature half (c < h)
+// ds[e] = a * (g - sum_k a g), g = cat * dagg, for all d channels; ddir[e] = a * dagg for the feature half (c < h).
+// One thread per (point, 2 channels): the 16 attention weights and the 16 products stay in registers, every input is read once
+// (4 channels per thread had to read cat twice or drop to one wave per SIMD).
 __global__ void att_pool_split_bwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh, const float *__restrict__ fxyz,
-                                          const float *__restrict__ a, const float *__restrict__ dagg, int h, size_t total4,
+                                          const float *__restrict__ a, const float *__restrict__ dagg, int h, size_t total2,
                                           float *__restrict__ ds, float *__restrict__ ddir)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total4) return;
-    const int d = 2 * h, d4 = d >> 2;
-    const size_t n = t / d4;
-    const int c = (int)(t - n * d4) * 4;
-    const float4 g0 = ((const float4 *)dagg)[t];
-    float4 av[RK];
-    float4 dot = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= total2) return;
+    const int d = 2 * h, d2 = d >> 1;
+    const size_t n = t / d2;
+    const int c = (int)(t - n * d2) * 2;
+    const float2 g0 = ((const float2 *)dagg)[t];
+    float2 av[RK], gv[RK];
+    float2 dot = make_float2(0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
         const size_t e = n * RK + k;
-        av[k] = *(const float4 *)(a + e * d + c);
-        const float4 x = c < h ? *(const float4 *)(f + (size_t)neigh[e] * h + c) : *(const float4 *)(fxyz + e * h + (c - h));
-        dot.x += av[k].x * (x.x * g0.x); dot.y += av[k].y * (x.y * g0.y); dot.z += av[k].z * (x.z * g0.z); dot.w += av[k].w * (x.w * g0.w);
+        av[k] = *(const float2 *)(a + e * d + c);
+        const float2 x = c < h ? *(const float2 *)(f + (size_t)neigh[e] * h + c) : *(const float2 *)(fxyz + e * h + (c - h));
+        gv[k] = make_float2(x.x * g0.x, x.y * g0.y);
+        dot.x += av[k].x * gv[k].x; dot.y += av[k].y * gv[k].y;
     }
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
         const size_t e = n * RK + k;
-        const float4 x = c < h ? *(const float4 *)(f + (size_t)neigh[e] * h + c) : *(const float4 *)(fxyz + e * h + (c - h));
-        *(float4 *)(ds + e * d + c) = make_float4(av[k].x * (x.x * g0.x - dot.x), av[k].y * (x.y * g0.y - dot.y),
-                                                  av[k].z * (x.z * g0.z - dot.z), av[k].w * (x.w * g0.w - dot.w));
-        if (c < h) *(float4 *)(ddir + e * h + c) = make_float4(av[k].x * g0.x, av[k].y * g0.y, av[k].z * g0.z, av[k].w * g0.w);
+        *(float2 *)(ds + e * d + c) = make_float2(av[k].x * (gv[k].x - dot.x), av[k].y * (gv[k].y - dot.y));
+        if (c < h) *(float2 *)(ddir + e * h + c) = make_float2(av[k].x * g0.x, av[k].y * g0.y);
     }
 }
 
@@ -1348,8 +1349,8 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         // straight into the feature gradient), then the score layer's feature half transposed on POINTS: df += dT . W1
         auto split_bwd = [&](const float *fin_, const float *fxyz_, const float *a_, const float *dagg_, const RLayer &fc, float *df_) -> int {
             float *ds = ws->scratch_b, *ddir = ws->scratch_a, *dT = L.m2;
-            hipLaunchKernelGGL(att_pool_split_bwd_kernel, dim3(blocks_for((size_t)n * d / 4)), dim3(256), 0, st, fin_, L.neigh, fxyz_, a_, dagg_,
-                               h, (size_t)n * d / 4, ds, ddir);
+            hipLaunchKernelGGL(att_pool_split_bwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, fin_, L.neigh, fxyz_, a_, dagg_,
+                               h, (size_t)n * d / 2, ds, ddir);
             PSG_LAUNCH_CHECK();
             hipLaunchKernelGGL(gather_inv_kernel<true>, dim3(blocks_for((size_t)n * d)), dim3(256), 0, st, ds, d, d, L.inv_off, L.inv_ent,
                                (size_t)n * d, dT);
