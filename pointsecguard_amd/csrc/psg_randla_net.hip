@@ -440,41 +440,44 @@ __global__ __launch_bounds__(256, 4) void lfa16_bwd_kernel(const float *__restri
 // [n, d] is written: the gather + concat pass and the [N*16, d] x [d, d] GEMM are gone.  Backward: ds is summed over the
 // in-edges of every point (inverse list) into dT [n, d], and the feature gradient is dT . W1 - again a GEMM on points.
 __global__ void att_pool_split_fwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh, const float *__restrict__ fxyz,
-                                          const float *__restrict__ T, const float *__restrict__ S2, int h, size_t total4,
+                                          const float *__restrict__ T, const float *__restrict__ S2, int h, size_t total2,
                                           float *__restrict__ a_out, float *__restrict__ agg)
 {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total4) return;
-    const int d = 2 * h, d4 = d >> 2;
-    const size_t n = t / d4;
-    const int c = (int)(t - n * d4) * 4;
-    float4 v[RK];
-    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread per (point, 2 channels)
+    if (t >= total2) return;
+    const int d = 2 * h, d2 = d >> 1;
+    const size_t n = t / d2;
+    const int c = (int)(t - n * d2) * 2;
+    int nb[RK];
+#pragma unroll
+    for (int k = 0; k < RK; ++k) nb[k] = neigh[n * RK + k];
+    float2 v[RK];
+    float2 m = make_float2(-INFINITY, -INFINITY);
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
         const size_t e = n * RK + k;
-        const float4 tt = *(const float4 *)(T + (size_t)neigh[e] * d + c);
-        const float4 s2 = *(const float4 *)(S2 + e * d + c);
-        v[k] = make_float4(tt.x + s2.x, tt.y + s2.y, tt.z + s2.z, tt.w + s2.w);
-        m.x = fmaxf(m.x, v[k].x); m.y = fmaxf(m.y, v[k].y); m.z = fmaxf(m.z, v[k].z); m.w = fmaxf(m.w, v[k].w);
+        const float2 tt = *(const float2 *)(T + (size_t)nb[k] * d + c);
+        const float2 s2 = *(const float2 *)(S2 + e * d + c);
+        v[k] = make_float2(tt.x + s2.x, tt.y + s2.y);
+        m.x = fmaxf(m.x, v[k].x); m.y = fmaxf(m.y, v[k].y);
     }
-    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 sum = make_float2(0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
-        v[k].x = expf(v[k].x - m.x); v[k].y = expf(v[k].y - m.y); v[k].z = expf(v[k].z - m.z); v[k].w = expf(v[k].w - m.w);
-        sum.x += v[k].x; sum.y += v[k].y; sum.z += v[k].z; sum.w += v[k].w;
+        v[k].x = expf(v[k].x - m.x); v[k].y = expf(v[k].y - m.y);
+        sum.x += v[k].x; sum.y += v[k].y;
     }
-    const float4 inv = make_float4(1.0f / sum.x, 1.0f / sum.y, 1.0f / sum.z, 1.0f / sum.w);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float2 inv = make_float2(1.0f / sum.x, 1.0f / sum.y);
+    float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
         const size_t e = n * RK + k;
-        const float4 a = make_float4(v[k].x * inv.x, v[k].y * inv.y, v[k].z * inv.z, v[k].w * inv.w);
-        *(float4 *)(a_out + e * d + c) = a;
-        const float4 x = c < h ? *(const float4 *)(f + (size_t)neigh[e] * h + c) : *(const float4 *)(fxyz + e * h + (c - h));
-        acc.x += x.x * a.x; acc.y += x.y * a.y; acc.z += x.z * a.z; acc.w += x.w * a.w;
+        const float2 a = make_float2(v[k].x * inv.x, v[k].y * inv.y);
+        *(float2 *)(a_out + e * d + c) = a;
+        const float2 x = c < h ? *(const float2 *)(f + (size_t)nb[k] * h + c) : *(const float2 *)(fxyz + e * h + (c - h));
+        acc.x += x.x * a.x; acc.y += x.y * a.y;
     }
-    ((float4 *)agg)[t] = acc;
+    ((float2 *)agg)[t] = acc;
 }
 
 // ds[e] = a * (g - sum_k a g), g = cat * dagg, for all d channels; ddir[e] = a * dagg for the feature half (c < h).
@@ -1211,8 +1214,8 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
             GemmArgs g = rl_args(L.fpc, h, E.att1_fc.w, d, T1, d, n, h, d);
             g.bias = E.att1_fc.b;
             if ((rc = rl_gemm<EPI_LINEAR>(g, st))) return rc;
-            hipLaunchKernelGGL(att_pool_split_fwd_kernel, dim3(blocks_for((size_t)n * d / 4)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, T1,
-                               L.cat1, h, (size_t)n * d / 4, L.a1, L.agg1);
+            hipLaunchKernelGGL(att_pool_split_fwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, T1,
+                               L.cat1, h, (size_t)n * d / 2, L.a1, L.agg1);
             PSG_LAUNCH_CHECK();
         } else if (fused16) {
             hipLaunchKernelGGL(lfa16_fwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, E.att1_fc.w,
@@ -1231,8 +1234,8 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
             GemmArgs g = rl_args(L.fagg1, h, E.att2_fc.w, d, T2, d, n, h, d);
             g.bias = E.att2_fc.b;
             if ((rc = rl_gemm<EPI_LINEAR>(g, st))) return rc;
-            hipLaunchKernelGGL(att_pool_split_fwd_kernel, dim3(blocks_for((size_t)n * d / 4)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, T2,
-                               L.cat2, h, (size_t)n * d / 4, L.a2, L.agg2);
+            hipLaunchKernelGGL(att_pool_split_fwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, T2,
+                               L.cat2, h, (size_t)n * d / 2, L.a2, L.agg2);
             PSG_LAUNCH_CHECK();
         } else if (fused16) {
             hipLaunchKernelGGL(lfa16_fwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, E.att2_fc.w,
