@@ -236,7 +236,7 @@ def main():
     ap.add_argument("--gcn-coalesce", type=int, default=4,
                     help="resgcn workload: steps fused into one device batch per launch (rooms are independent; the CE "
                          "mean's scale changes by an exact power of two, which sign() ignores)")
-    ap.add_argument("--rla-coalesce", type=int, default=4,
+    ap.add_argument("--rla-coalesce", type=int, default=8,
                     help="randla workload: steps (clouds) fused into one device batch per launch; the clouds stay "
                          "independent (every index stays inside its cloud), one launch of each kernel serves all of them")
     ap.add_argument("--concurrency", type=int, default=3,
@@ -256,7 +256,7 @@ def main():
         # line of its own (value, roofline, cpu_baseline) under "secondary"; `python bench.py --workload NAME` runs one alone
         import copy
         sec = {}
-        for name, steps, warm in (("tarnu", 3, 1), ("resgcn", 24, 8), ("pointnet2_msg", 16, 8), ("randla", 24, 8)):
+        for name, steps, warm in (("tarnu", 3, 1), ("resgcn", 24, 8), ("pointnet2_msg", 16, 8), ("randla", 48, 8)):
             a2 = copy.copy(args)
             a2.workload, a2.steps, a2.warmup, a2.cpu_seconds = name, steps, warm, min(args.cpu_seconds, 6.0)
             t0 = time.time()
