@@ -335,7 +335,7 @@ __device__ __forceinline__ void lfa16_attention(const float *__restrict__ f, con
 }
 
 // thread = (point, channel pair): 8 threads per point (4 channels per thread took 216 - 256 registers: 1 - 2 waves per SIMD)
-__global__ __launch_bounds__(256, 4) void lfa16_fwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh,
+__global__ __launch_bounds__(256, 3) void lfa16_fwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh,
                                                         const float *__restrict__ fxyz, const float *__restrict__ w,
                                                         const float *__restrict__ b, size_t n, float *__restrict__ agg)
 {
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, 4) void lfa16_fwd_kernel(const float *__restri
 // ds = a * (g - sum_k a g), g = cat * dagg (the position-encoding half carries no colour gradient).  The sum over the 16
 // channels c is split over the 8 threads of the point (each owns 2 rows of W) and closed with three shuffles; lane q then
 // adds column q: the 8 lanes of a point hit 32 consecutive bytes of the neighbour's row.
-__global__ __launch_bounds__(256, 4) void lfa16_bwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh,
+__global__ __launch_bounds__(256, 2) void lfa16_bwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh,
                                                         const float *__restrict__ fxyz, const float *__restrict__ w,
                                                         const float *__restrict__ b, const float *__restrict__ dagg, size_t n,
                                                         float *__restrict__ df, float *__restrict__ dcat8)
