@@ -424,30 +424,38 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
         constexpr int RG = NT / 32, JI = P / RG;
         static_assert(P % RG == 0, "row groups must tile the points");
         const int ql = tid & 31, rg = tid >> 5;
+        // address arithmetic: the room's bases are wave-uniform (scalar 64-bit), the per-row offsets are 24-bit products
+        // (row < 2^12 .. 2^16, channels < 2^11: v_mul_u32_u24 runs at full rate, a 32-bit v_mul_lo at a quarter of it, and
+        // the 64-bit per-thread versions of these cost ~10 % of this kernel's matrix time: vector work is not hidden)
+        const int32_t *nn_i = a.nn_idx + ((size_t)b * a.N + n0) * 3;
+        const float *nn_wp = a.nn_w + ((size_t)b * a.N + n0) * 3;
+        const float *f1b = a.feat1 ? a.feat1 + ((size_t)b * a.N + n0) * a.C1 : nullptr;
+        const float *f2b = a.feat2 + (size_t)b * a.S * a.C2;
         int i0[JI], i1[JI], i2[JI];
         float w0[JI], w1[JI], w2[JI];
 #pragma unroll
         for (int u = 0; u < JI; ++u) {
-            const size_t n = (size_t)b * a.N + n0 + rg + u * RG;
-            i0[u] = a.nn_idx[n * 3]; i1[u] = a.nn_idx[n * 3 + 1]; i2[u] = a.nn_idx[n * 3 + 2];
-            w0[u] = a.nn_w[n * 3]; w1[u] = a.nn_w[n * 3 + 1]; w2[u] = a.nn_w[n * 3 + 2];
+            const int n3 = (rg + u * RG) * 3;
+            i0[u] = nn_i[n3]; i1[u] = nn_i[n3 + 1]; i2[u] = nn_i[n3 + 2];
+            w0[u] = nn_wp[n3]; w1[u] = nn_wp[n3 + 1]; w2[u] = nn_wp[n3 + 2];
         }
         if (a.feat1) {
 #pragma unroll
             for (int u = 0; u < JI; ++u) {
                 const int j = rg + u * RG;
-                const float4 *f4 = (const float4 *)(a.feat1 + ((size_t)b * a.N + n0 + j) * a.C1);
-                for (int q = ql; q < (a.C1 >> 2); q += 32) *(float4 *)(buf0 + L::off(4 * q, j)) = f4[q];
+                const unsigned o1 = __umul24((unsigned)j, (unsigned)a.C1);
+                for (int q = ql; q < (a.C1 >> 2); q += 32) *(float4 *)(buf0 + L::off(4 * q, j)) = *(const float4 *)(f1b + (o1 + 4u * q));
             }
         }
 #pragma unroll
         for (int u = 0; u < JI; ++u) {
             const int j = rg + u * RG;
-            const float4 *g0 = (const float4 *)(a.feat2 + ((size_t)b * a.S + i0[u]) * a.C2);
-            const float4 *g1 = (const float4 *)(a.feat2 + ((size_t)b * a.S + i1[u]) * a.C2);
-            const float4 *g2 = (const float4 *)(a.feat2 + ((size_t)b * a.S + i2[u]) * a.C2);
+            // (uniform base + 32-bit offset: the loads take the SGPR-base form, no 64-bit vector adds per address)
+            const unsigned o0 = __umul24((unsigned)i0[u], (unsigned)a.C2), oa = __umul24((unsigned)i1[u], (unsigned)a.C2),
+                           ob = __umul24((unsigned)i2[u], (unsigned)a.C2);
             for (int q = ql; q < (a.C2 >> 2); q += 32) {
-                const float4 u0 = g0[q], u1 = g1[q], u2 = g2[q];
+                const float4 u0 = *(const float4 *)(f2b + (o0 + 4u * q)), u1 = *(const float4 *)(f2b + (oa + 4u * q)),
+                             u2 = *(const float4 *)(f2b + (ob + 4u * q));
                 float4 r;
                 r.x = u0.x * w0[u] + u1.x * w1[u] + u2.x * w2[u];
                 r.y = u0.y * w0[u] + u1.y * w1[u] + u2.y * w2[u];
@@ -621,19 +629,25 @@ __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
         }
         return;
     }
-    // `in` = gradient of the concat input [C1 skip rows | C2 interpolated rows][point]
-    if (a.dfeat1) {
-        for (int t = tid; t < P * a.C1; t += NT) {
-            const int j = t / a.C1, c = t - j * a.C1;
-            const float v = in[L::off(c, j)];
-            a.dfeat1[((size_t)b * a.N + n0 + j) * a.C1 + c] = v;   // sole writer of the skip-link gradient: plain store
+    // `in` = gradient of the concat input [C1 skip rows | C2 interpolated rows][point], written out as plain rows, 16 bytes per
+    // thread: 32 consecutive lanes cover 512 contiguous bytes of one row (no division by a run-time channel count, one
+    // ds_read_b128 and one global store per 4 channels; the element-wise loops this replaces cost a quarter-rate integer
+    // division and a 4-byte LDS read + store per element: ~600 vector instructions per thread in fp2 backward).
+    // The coarser module gathers the interpolated part through the inverse 3-NN lists (pointnet_util.py:308: the transpose
+    // of index_points + weighted sum, without atomics).
+    {
+        constexpr int RG = NT / 32;
+        const int ql = tid & 31, rg = tid >> 5;
+        float *d1 = a.dfeat1 ? a.dfeat1 + ((size_t)b * a.N + n0) * a.C1 : nullptr;     // sole writer of the skip-link gradient
+        float *d2 = a.dint_out + ((size_t)b * a.N + n0) * a.C2;
+        for (int j = rg; j < P; j += RG) {
+            if (d1) {
+                const unsigned o = __umul24((unsigned)j, (unsigned)a.C1);
+                for (int q = ql; q < (a.C1 >> 2); q += 32) *(float4 *)(d1 + (o + 4u * q)) = *(const float4 *)(in + L::off(4 * q, j));
+            }
+            const unsigned o = __umul24((unsigned)j, (unsigned)a.C2);
+            for (int q = ql; q < (a.C2 >> 2); q += 32) *(float4 *)(d2 + (o + 4u * q)) = *(const float4 *)(in + L::off(a.C1 + 4 * q, j));
         }
-    }
-    // interpolated-part gradient as plain rows; the coarser module gathers them through the inverse 3-NN lists
-    // (pointnet_util.py:308: the transpose of index_points + weighted sum, without atomics)
-    for (int t = tid; t < P * a.C2; t += NT) {
-        const int j = t / a.C2, c = t - j * a.C2;
-        a.dint_out[((size_t)b * a.N + n0 + j) * a.C2 + c] = in[L::off(a.C1 + c, j)];
     }
 }
 
