@@ -253,9 +253,19 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
         if (a.nninv_off) {
             const int32_t *off = a.nninv_off + (size_t)b * (a.S + 1) + s0 + g;
             const int2 *ent = a.nninv_ent + (size_t)b * 3 * a.n_fine;
-            for (int e = off[0]; e < off[1]; ++e) {
+            const float *drows = a.dint + (size_t)b * a.n_fine * a.ld + cc;
+            const int e1 = off[1];
+            int e = off[0];
+            for (; e + 4 <= e1; e += 4) {   // four entries and their rows in flight; added in list order
+                const int2 p0 = ent[e], p1 = ent[e + 1], p2 = ent[e + 2], p3 = ent[e + 3];
+                const float v0 = drows[(size_t)p0.x * a.ld], v1 = drows[(size_t)p1.x * a.ld], v2 = drows[(size_t)p2.x * a.ld],
+                            v3 = drows[(size_t)p3.x * a.ld];
+                acc += __int_as_float(p0.y) * v0; acc += __int_as_float(p1.y) * v1;
+                acc += __int_as_float(p2.y) * v2; acc += __int_as_float(p3.y) * v3;
+            }
+            for (; e < e1; ++e) {
                 const int2 pe = ent[e];
-                acc += __int_as_float(pe.y) * a.dint[((size_t)b * a.n_fine + pe.x) * a.ld + cc];
+                acc += __int_as_float(pe.y) * drows[(size_t)pe.x * a.ld];
             }
         }
         if (a.ginv_off) {
@@ -489,9 +499,19 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
     }
     // `in` now holds the last layer's output
     if (a.out) {
-        for (int t = tid; t < P * a.Cout; t += NT) {
-            const int j = t / a.Cout, c = t - j * a.Cout;
-            a.out[((size_t)b * a.N + n0 + j) * a.Cout + c] = in[L::off(c, j)];
+        if ((a.Cout & 3) == 0) {   // 16 bytes per thread, 32 lanes per row (see fp_bwd_kernel's output rows)
+            constexpr int RG = NT / 32;
+            const int ql = tid & 31, rg = tid >> 5;
+            float *ob = a.out + ((size_t)b * a.N + n0) * a.Cout;
+            for (int j = rg; j < P; j += RG) {
+                const unsigned o = __umul24((unsigned)j, (unsigned)a.Cout);
+                for (int q = ql; q < (a.Cout >> 2); q += 32) *(float4 *)(ob + (o + 4u * q)) = *(const float4 *)(in + L::off(4 * q, j));
+            }
+        } else {
+            for (int t = tid; t < P * a.Cout; t += NT) {
+                const int j = t / a.Cout, c = t - j * a.Cout;
+                a.out[((size_t)b * a.N + n0 + j) * a.Cout + c] = in[L::off(c, j)];
+            }
         }
     }
     if (a.logp && !(a.diag & 4)) {
