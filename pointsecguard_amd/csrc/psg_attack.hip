@@ -30,31 +30,48 @@ __global__ void to_channel_major_kernel(const float *__restrict__ src, float *__
 
 constexpr int MAXC = 32;
 
-__global__ void ce_logp_grad_kernel(const float *__restrict__ logp, const int32_t *__restrict__ labels, int target,
-                                    int rows, int rows_active, int n_cls, float scale, float *__restrict__ dlogp,
-                                    float *__restrict__ cost)
+// 256 rows per workgroup staged through LDS: the rows of a block are one contiguous piece of logp / dlogp, so global
+// accesses are whole cache lines (a thread per row reading its n_cls floats directly strides the lanes 52 bytes apart);
+// the per-row arithmetic is unchanged.
+__global__ __launch_bounds__(256) void ce_logp_grad_kernel(const float *__restrict__ logp, const int32_t *__restrict__ labels, int target,
+                                                            int rows, int rows_active, int n_cls, float scale, float *__restrict__ dlogp,
+                                                            float *__restrict__ cost)
 {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    float *g = dlogp + (size_t)r * n_cls;
-    if (r >= rows_active) {
-        for (int c = 0; c < n_cls; ++c) g[c] = 0.0f;
-        return;
+    __shared__ float s_z[256 * MAXC];
+    const int r0 = blockIdx.x * 256, nr = min(256, rows - r0);
+    const float *src = logp + (size_t)r0 * n_cls;
+    for (int i = threadIdx.x; i < nr * n_cls; i += 256) s_z[i] = src[i];
+    __syncthreads();
+    const int r = r0 + (int)threadIdx.x;
+    float g[MAXC];
+    if ((int)threadIdx.x < nr) {
+        if (r >= rows_active) {
+            for (int c = 0; c < n_cls; ++c) g[c] = 0.0f;
+        } else {
+            const float *lp = s_z + threadIdx.x * n_cls;        // (n_cls = 13: an odd stride, conflict-free)
+            float z[MAXC];
+            float m = -INFINITY;
+            for (int c = 0; c < n_cls; ++c) { z[c] = lp[c]; m = fmaxf(m, z[c]); }
+            float s = 0.0f;
+            for (int c = 0; c < n_cls; ++c) s += expf(z[c] - m);
+            const float lse = logf(s);
+            const int y = labels ? labels[r] : target;
+            for (int c = 0; c < n_cls; ++c) {
+                float lp2 = (z[c] - m) - lse;  // second log_softmax (CrossEntropyLoss applied to log-probs)
+                float p = expf(lp2);
+                g[c] = (p - (c == y ? 1.0f : 0.0f)) * scale;
+                if (cost && c == y) atomicAdd(cost, -lp2 * scale);
+            }
+        }
     }
-    const float *lp = logp + (size_t)r * n_cls;
-    float z[MAXC];
-    float m = -INFINITY;
-    for (int c = 0; c < n_cls; ++c) { z[c] = lp[c]; m = fmaxf(m, z[c]); }
-    float s = 0.0f;
-    for (int c = 0; c < n_cls; ++c) s += expf(z[c] - m);
-    const float lse = logf(s);
-    const int y = labels ? labels[r] : target;
-    for (int c = 0; c < n_cls; ++c) {
-        float lp2 = (z[c] - m) - lse;  // second log_softmax (CrossEntropyLoss applied to log-probs)
-        float p = expf(lp2);
-        g[c] = (p - (c == y ? 1.0f : 0.0f)) * scale;
-        if (cost && c == y) atomicAdd(cost, -lp2 * scale);
+    __syncthreads();
+    if ((int)threadIdx.x < nr) {
+        float *o = s_z + threadIdx.x * n_cls;
+        for (int c = 0; c < n_cls; ++c) o[c] = g[c];
     }
+    __syncthreads();
+    float *dst = dlogp + (size_t)r0 * n_cls;
+    for (int i = threadIdx.x; i < nr * n_cls; i += 256) dst[i] = s_z[i];
 }
 
 __global__ void pgd_step_kernel(float *__restrict__ x, const float *__restrict__ grad, const float *__restrict__ ori,
