@@ -20,23 +20,27 @@
 // producer of the features (edge_max_fwd_kernel) writes that copy, knn_prep_kernel does it for the stand-alone entry.
 //
 // Selection.  Per query row a buffer of CAP = 1024 composite keys (distance key << 12 | candidate index: ascending
-// distance, lowest index first, a strict total order) lives in LDS (128 KB per workgroup, one workgroup per CU) with a
-// threshold tau.  A candidate is appended iff its key <= tau; slots come from one LDS atomic per lane and step.  When
-// a row gets close to full the workgroup PRUNES: one wave per row finds (regula falsi on the distance value, counting
+// distance, lowest index first, a strict total order) lives in LDS (rows 1026 keys apart - see KF_ROW -, 128 KB per
+// workgroup, one workgroup per CU) with a threshold tau.  In the stream a pair is admitted by one float compare, not
+// (distance > tau's distance): a superset of "key <= tau" (equal distances with a higher index and NaNs get in too; they rank
+// behind the keys wanted and are dropped by the next cut); slots come from one LDS atomic per lane and step.  On a
+// data-independent schedule the workgroup PRUNES: one wave per row finds (regula falsi on the distance value, counting
 // with DPP wave sums) a new tau with KK <= #(keys <= tau) <= KK + TOL and compacts the row in place.  tau is never below
 // the KK-th smallest key seen so far, so the buffer always contains the true top-KK of what has been seen: exact for any
 // input order.  Everything is admitted until the first prune (after 1024 candidates); after it a row receives
-// ~KK ln(N / 1024) more keys, so typical rows are pruned once or twice.  If an append would overflow CAP (adversarial
-// orders) the step is rolled back, every row is cut to exactly KK and the step's candidates are committed one
-// accumulator register at a time (<= 64 appends per row between checks, KK + 64 <= CAP): slow, but it terminates and is
-// exact; ties are ordered by index, so an exact cut always reaches KK.
+// ~KK ln(N / 1024) more keys, so typical rows are pruned once or twice.  An allocation that does not fit is not written;
+// the counter then exceeds CAP, the next synchronisation point sees it and the workgroup redoes its stream on the exact
+// per-step path: exact composite admission, a barrier per step, and on overflow the step is rolled back, every row is cut
+// to exactly KK and the step's candidates are committed one accumulator register at a time (<= 64 appends per row
+// between checks, KK + 64 <= CAP): slow, but it terminates and is exact; ties are ordered by index, so an exact cut
+// always reaches KK.
 //
 // Final ranks.  Only ranks 0, d, .., 15 d are wanted, so the row is not sorted (a 512-key bitonic sort through
-// ds_bpermute cost 34k cycles per row): the <= 512 survivors are binned by distance (1024 linear bins, a monotone map, so
-// bin order = key order), an exclusive scan gives every bin its first rank, the bins that contain a wanted rank are
-// flagged, their few members ("finalists") are collected and each finalist counts the finalists of its own bin below it:
-// first rank of the bin + that count is its exact rank.  More than 256 finalists (hundreds of equal distances) fall
-// back to the bitonic sort.
+// ds_bpermute cost 34k cycles per row): the row's keys (up to 1024, in registers: the row's LDS is scratch by then) are
+// binned by distance (1024 linear bins, a monotone map, so bin order = key order), an exclusive scan gives every bin its
+// first rank, the bins that contain a wanted rank are flagged, their few members ("finalists") are collected and each
+// finalist counts the finalists of its own bin below it: first rank of the bin + that count is its exact rank.  More
+// than 256 finalists (hundreds of equal distances) fall back to a cut to 512 keys + the bitonic sort.
 #pragma once
 
 #ifndef KF_WAVES_CFG
