@@ -38,6 +38,10 @@ struct GemmArgs {
     int accumulate;       // 1: out += result;  2: out = addend + result (out is not read)
     const float *addend;  // with accumulate: out = (out + addend[row][c]) + result  (rows of ld_add floats), or null
     int ld_add;
+    // derivative of a leaky ReLU applied to what is STORED (after accumulate / addend): out *= (bit ? 1 : post_slope).  The
+    // last contributor of a gradient buffer applies the activation's derivative itself instead of a separate pass.
+    const uint32_t *post_mask = nullptr;   // [rows][ceil(M/32)] words, or null
+    float post_slope = 0.0f;
 };
 
 // TQ x TI = 32-row x 32-channel MFMA tiles per wave (2 x 2 by default; 1 x 1 gives 64 x 64 workgroup tiles, i.e. four
@@ -219,6 +223,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
             unsigned mbits = 0;
             unsigned min_bits = 0xFFFFFFFFu;
             if (a.mask_in && row < a.rows && cbase < a.M) min_bits = a.mask_in[(size_t)row * ((a.M + 31) >> 5) + (cbase >> 5)];
+            unsigned post_bits = 0xFFFFFFFFu;
+            if (a.post_mask && row < a.rows && cbase < a.M) post_bits = a.post_mask[(size_t)row * ((a.M + 31) >> 5) + (cbase >> 5)];
             float vals[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -267,6 +273,13 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
                             }
                             v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
                         }
+                        if (a.post_mask) {
+                            const unsigned pb = post_bits >> (8 * g + 4 * h);
+                            if (!(pb & 1u)) v.x *= a.post_slope;
+                            if (!(pb & 2u)) v.y *= a.post_slope;
+                            if (!(pb & 4u)) v.z *= a.post_slope;
+                            if (!(pb & 8u)) v.w *= a.post_slope;
+                        }
                         *dst = v;
                     } else {
 #pragma unroll
@@ -275,7 +288,9 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
                                 float *dst = o + 8 * g + u;
                                 float base = a.accumulate == 1 ? *dst : 0.0f;
                                 if (a.accumulate && a.addend) base += a.addend[(size_t)row * a.ld_add + c + u];
-                                *dst = a.accumulate ? vals[4 * g + u] + base : vals[4 * g + u];
+                                float vv = a.accumulate ? vals[4 * g + u] + base : vals[4 * g + u];
+                                if (a.post_mask && !((post_bits >> (8 * g + 4 * h + u)) & 1u)) vv *= a.post_slope;
+                                *dst = vv;
                             }
                     }
                 }

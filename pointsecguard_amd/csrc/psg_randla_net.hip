@@ -89,15 +89,24 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(GemmArgs a)
             }
             z[u] = acc;
         }
+        const unsigned pb = a.post_mask ? a.post_mask[row] >> m0 : 0xFu;       // (M <= 32: one mask word per row)
         if (vec_out) {
             float4 *o4 = (float4 *)(out + m0);
             float4 v = make_float4(z[0], z[1], z[2], z[3]);
             if (a.accumulate == 1) { const float4 o = *o4; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            if (!(pb & 1u)) v.x *= a.post_slope;
+            if (!(pb & 2u)) v.y *= a.post_slope;
+            if (!(pb & 4u)) v.z *= a.post_slope;
+            if (!(pb & 8u)) v.w *= a.post_slope;
             *o4 = v;
         } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (m0 + u < a.M) out[m0 + u] = a.accumulate == 1 ? out[m0 + u] + z[u] : z[u];
+                if (m0 + u < a.M) {
+                    float vv = a.accumulate == 1 ? out[m0 + u] + z[u] : z[u];
+                    if (!((pb >> u) & 1u)) vv *= a.post_slope;
+                    out[m0 + u] = vv;
+                }
         }
     }
     if (EPI == EPI_LRELU && a.mask_out) a.mask_out[row] = bits;
@@ -173,10 +182,15 @@ __global__ void lrelu_bwd_kernel(float *__restrict__ g, int ld, const uint32_t *
 }
 
 // din (+)= dz . W   (dz already multiplied by the activation's derivative)
-int conv_bwd(const RLayer &L, const float *dz, int ld_dz, float *din, int ld_din, int rows, int accumulate, hipStream_t st)
+// `lrelu_mask`: when this GEMM is the LAST contributor to din and din is the gradient of a leaky-ReLU output, the sign
+// bits of that activation: its derivative is applied to what is stored (after the accumulate), no separate pass
+int conv_bwd(const RLayer &L, const float *dz, int ld_dz, float *din, int ld_din, int rows, int accumulate, hipStream_t st,
+             const uint32_t *lrelu_mask = nullptr)
 {
     GemmArgs a = rl_args(dz, ld_dz, L.wt, L.cout, din, ld_din, rows, L.cout, L.cin);
     a.accumulate = accumulate;
+    a.post_mask = lrelu_mask;
+    a.post_slope = kSlope;
     return rl_gemm<EPI_LINEAR>(a, st);
 }
 
@@ -538,9 +552,12 @@ __global__ void lower_bound_kernel(const int32_t *__restrict__ keys, int m, int 
     off[t] = lo;
 }
 // df[j][c] += sum over the edges e that point at row j (ascending e) of src[e][c], c < h   (transpose of gather_neighbour)
+// `mask` (or null): sign bits [rows][ceil(h/32)] of the leaky ReLU whose output gradient df is; this kernel is then the last
+// contributor to df and applies the activation's derivative to what it stores
 template <bool ASSIGN = false>
 __global__ void gather_inv_kernel(const float *__restrict__ src, int ld, int h, const int32_t *__restrict__ off,
-                                  const int32_t *__restrict__ ent, size_t total, float *__restrict__ df)
+                                  const int32_t *__restrict__ ent, size_t total, float *__restrict__ df,
+                                  const uint32_t *__restrict__ mask = nullptr)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -555,12 +572,15 @@ __global__ void gather_inv_kernel(const float *__restrict__ src, int ld, int h, 
         acc += v0; acc += v1; acc += v2; acc += v3;
     }
     for (; i < e1; ++i) acc += src[(size_t)ent[i] * ld + c];
-    if (ASSIGN) df[t] = acc; else df[t] += acc;
+    float v = ASSIGN ? acc : df[t] + acc;
+    if (mask && !((mask[j * ((h + 31) >> 5) + (c >> 5)] >> (c & 31)) & 1u)) v *= kSlope;
+    df[t] = v;
 }
 // transpose of random_sample's max over neighbours: row j of the level collects, over the sampled edges i = r * 16 + k that
 // point at it (ascending), dout[r][c] where arg[r][c] == k
 __global__ void pool_max_inv_kernel(const float *__restrict__ dout, const uint8_t *__restrict__ arg, int C, const int32_t *__restrict__ off,
-                                    const int32_t *__restrict__ ent, size_t total, float *__restrict__ df)
+                                    const int32_t *__restrict__ ent, size_t total, float *__restrict__ df,
+                                    const uint32_t *__restrict__ mask = nullptr)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -584,12 +604,15 @@ __global__ void pool_max_inv_kernel(const float *__restrict__ dout, const uint8_
         const size_t r = (size_t)(e >> 4);
         if (arg[r * C + c] == (e & 15)) acc += dout[r * C + c];
     }
-    df[t] += acc;
+    float v = df[t] + acc;
+    if (mask && !((mask[j * ((C + 31) >> 5) + (c >> 5)] >> (c & 31)) & 1u)) v *= kSlope;     // (last contributor: see gather_inv_kernel)
+    df[t] = v;
 }
 // transpose of nearest interpolation: dcoarse[t][c] += sum over the rows n with up[n] == t (ascending) of dcat[n][cs + c];
 // dskip[n][c] += dcat[n][c] is done by interp_skip_bwd_kernel
 __global__ void interp_inv_kernel(const float *__restrict__ dcat, int cs, int cc, const int32_t *__restrict__ off,
-                                  const int32_t *__restrict__ ent, size_t total, float *__restrict__ dcoarse)
+                                  const int32_t *__restrict__ ent, size_t total, float *__restrict__ dcoarse,
+                                  const uint32_t *__restrict__ mask = nullptr)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -598,7 +621,9 @@ __global__ void interp_inv_kernel(const float *__restrict__ dcat, int cs, int cc
     float acc = 0.0f;
     const int e1 = off[j + 1];
     for (int i = off[j]; i < e1; ++i) acc += dcat[(size_t)ent[i] * (cs + cc) + cs + c];
-    dcoarse[t] += acc;
+    float v = dcoarse[t] + acc;
+    if (mask && !((mask[j * ((cc + 31) >> 5) + (c >> 5)] >> (c & 31)) & 1u)) v *= kSlope;    // (last contributor: see gather_inv_kernel)
+    dcoarse[t] = v;
 }
 __global__ void interp_skip_bwd_kernel(const float *__restrict__ dcat, int cs, int cc, size_t total4, float *__restrict__ dskip)
 {
@@ -1293,21 +1318,23 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
     const int N = ws->N;
     int rc;
     // head
-    if ((rc = conv_bwd(m->fc, dlogits, RNCLS, ws->d_fc2o, 32, N, 0, st))) return rc;
-    if ((rc = lrelu_bwd(ws->d_fc2o, 32, ws->m_fc2, N, 32, st))) return rc;
-    if ((rc = conv_bwd(m->fc2, ws->d_fc2o, 32, ws->d_fc1o, 64, N, 0, st))) return rc;
-    if ((rc = lrelu_bwd(ws->d_fc1o, 64, ws->m_fc1, N, 64, st))) return rc;
+    // (leaky-ReLU derivatives: applied by the LAST contributor of each gradient buffer as it stores - a GEMM epilogue or an
+    // inverse-list gather - instead of 29 separate passes per iteration; `fuse` is off on the atomics path, whose scatter
+    // kernels cannot know when a buffer is complete)
+    const bool fuse = ws->use_inv;
+    if ((rc = conv_bwd(m->fc, dlogits, RNCLS, ws->d_fc2o, 32, N, 0, st, ws->m_fc2))) return rc;
+    if ((rc = conv_bwd(m->fc2, ws->d_fc2o, 32, ws->d_fc1o, 64, N, 0, st, ws->m_fc1))) return rc;
     // every gradient accumulator starts at zero and collects its consumers (one memset for the whole block; the last
     // decoder layer's gradient, written next by a plain GEMM store, lies in it too)
     PSG_CHECK_HIP(hipMemsetAsync(ws->acc, 0, ws->acc_bytes, st));
-    if ((rc = conv_bwd(m->fc1, ws->d_fc1o, 64, ws->d_dec_out[RL - 1], m->fc1.cin, N, 0, st))) return rc;
+    if ((rc = conv_bwd(m->fc1, ws->d_fc1o, 64, ws->d_dec_out[RL - 1], m->fc1.cin, N, 0, st, ws->m_dec[RL - 1]))) return rc;
     const int n5 = ws->lv[RL - 1].n_sub;
     // decoder, last layer first
     for (int j = RL - 1; j >= 0; --j) {
         const LevelBuf &L = ws->lv[RL - 1 - j];
         const int cs = m->dec[j].cout, cfeat = m->dec[j].cin - cs;
         float *dout = ws->d_dec_out[j];
-        if ((rc = lrelu_bwd(dout, cs, ws->m_dec[j], L.n, cs, st))) return rc;
+        if (!fuse && j < RL - 1 && (rc = lrelu_bwd(dout, cs, ws->m_dec[j], L.n, cs, st))) return rc;   // (j = RL - 1: done by fc1's GEMM)
         if ((rc = conv_bwd(m->dec[j], dout, cs, ws->scratch_a, cs + cfeat, L.n, 0, st))) return rc;
         float *dskip = j == RL - 1 ? ws->lv[0].d_enc : ws->lv[RL - 2 - j].d_samp;
         float *dcoarse = j == 0 ? ws->d_dec0 : ws->d_dec_out[j - 1];
@@ -1315,15 +1342,16 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
             hipLaunchKernelGGL(interp_skip_bwd_kernel, dim3(blocks_for((size_t)L.n * cs / 4)), dim3(256), 0, st, ws->scratch_a, cs, cfeat,
                                (size_t)L.n * cs / 4, dskip);
             PSG_LAUNCH_CHECK();
+            // (the coarser buffer is complete after this gather: it applies the derivative of the activation that produced it)
             hipLaunchKernelGGL(interp_inv_kernel, dim3(blocks_for((size_t)L.n_sub * cfeat)), dim3(256), 0, st, ws->scratch_a, cs, cfeat,
-                               L.invu_off, L.invu_ent, (size_t)L.n_sub * cfeat, dcoarse);
+                               L.invu_off, L.invu_ent, (size_t)L.n_sub * cfeat, dcoarse, j == 0 ? ws->m_dec0 : ws->m_dec[j - 1]);
         } else {
             hipLaunchKernelGGL(interp_concat_bwd_kernel, dim3(blocks_for((size_t)L.n * (cs + cfeat))), dim3(256), 0, st, ws->scratch_a, cs,
                                cfeat, L.up, (size_t)L.n * (cs + cfeat), dskip, dcoarse);
         }
         PSG_LAUNCH_CHECK();
     }
-    if ((rc = lrelu_bwd(ws->d_dec0, 1024, ws->m_dec0, n5, 1024, st))) return rc;
+    if (!fuse && (rc = lrelu_bwd(ws->d_dec0, 1024, ws->m_dec0, n5, 1024, st))) return rc;
     if ((rc = conv_bwd(m->decoder0, ws->d_dec0, 1024, ws->lv[RL - 1].d_samp, 1024, n5, 1, st))) return rc;
     // encoder, deepest level first
     for (int i = RL - 1; i >= 0; --i) {
@@ -1334,23 +1362,23 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         float *din = i == 0 ? ws->d_f0 : ws->lv[i - 1].d_samp;    // gradient of this level's input features
         if (ws->use_inv)
             hipLaunchKernelGGL(pool_max_inv_kernel, dim3(blocks_for((size_t)n * 2 * d)), dim3(256), 0, st, L.d_samp, L.arg, 2 * d, L.invp_off,
-                               L.invp_ent, (size_t)n * 2 * d, L.d_enc);
+                               L.invp_ent, (size_t)n * 2 * d, L.d_enc, L.m_enc);
         else
             hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(blocks_for((size_t)L.n_sub * 2 * d)), dim3(256), 0, st, L.d_samp, L.neigh, L.arg,
                                2 * d, (size_t)L.n_sub * 2 * d, L.nc_sub, L.nc, L.d_enc);
         PSG_LAUNCH_CHECK();
-        if ((rc = lrelu_bwd(L.d_enc, 2 * d, L.m_enc, n, 2 * d, st))) return rc;
+        if (!fuse && (rc = lrelu_bwd(L.d_enc, 2 * d, L.m_enc, n, 2 * d, st))) return rc;
         if ((rc = conv_bwd(E.shortcut, L.d_enc, 2 * d, din, L.d_in, n, i == 0 ? 0 : 1, st))) return rc;
         float *g_fagg2 = L.agg2;   // forward buffers that are dead by now serve as gradient buffers of the same shape
-        if ((rc = conv_bwd(E.mlp2, L.d_enc, 2 * d, g_fagg2, d, n, 0, st))) return rc;
-        if ((rc = lrelu_bwd(g_fagg2, d, L.m_fagg2, n, d, st))) return rc;
+        if ((rc = conv_bwd(E.mlp2, L.d_enc, 2 * d, g_fagg2, d, n, 0, st, L.m_fagg2))) return rc;
         float *g_agg2 = L.fagg2;
         if ((rc = conv_bwd(E.att2_mlp, g_fagg2, d, g_agg2, d, n, 0, st))) return rc;
         const bool fused16 = d == 16 && ws->fuse16;
         const bool split = d > 16 && ws->split;
         // split levels: ds [E][d] and the direct term [E][h] per edge, summed over every point's in-edges (dT [n][d], and
         // straight into the feature gradient), then the score layer's feature half transposed on POINTS: df += dT . W1
-        auto split_bwd = [&](const float *fin_, const float *fxyz_, const float *a_, const float *dagg_, const RLayer &fc, float *df_) -> int {
+        auto split_bwd = [&](const float *fin_, const float *fxyz_, const float *a_, const float *dagg_, const RLayer &fc, float *df_,
+                             const uint32_t *mask_) -> int {
             float *ds = ws->scratch_b, *ddir = ws->scratch_a, *dT = L.m2;
             hipLaunchKernelGGL(att_pool_split_bwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, fin_, L.neigh, fxyz_, a_, dagg_,
                                h, (size_t)n * d / 2, ds, ddir);
@@ -1363,17 +1391,19 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
             PSG_LAUNCH_CHECK();
             GemmArgs g = rl_args(dT, d, fc.wt, d, df_, h, n, d, h);     // rows i < h of W^T: df[.][i] += sum_c dT[.][c] W[c][i]
             g.accumulate = 1;
+            g.post_mask = mask_;                                        // last contributor of df_: the activation's derivative
+            g.post_slope = kSlope;
             return rl_gemm<EPI_LINEAR>(g, st);
         };
         if (split) {
-            if ((rc = split_bwd(L.fagg1, L.fxyz2, L.a2, g_agg2, E.att2_fc, L.d_fagg1))) return rc;
+            if ((rc = split_bwd(L.fagg1, L.fxyz2, L.a2, g_agg2, E.att2_fc, L.d_fagg1, L.m_fagg1))) return rc;
         } else if (fused16) {
             hipLaunchKernelGGL(lfa16_bwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, E.att2_fc.w,
                                E.att2_fc.b, g_agg2, (size_t)n, L.d_fagg1, ws->use_inv ? ws->scratch_a : (float *)nullptr);
             PSG_LAUNCH_CHECK();
             if (ws->use_inv) {
                 hipLaunchKernelGGL(gather_inv_kernel<false>, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 8, h, L.inv_off, L.inv_ent,
-                                   (size_t)n * h, L.d_fagg1);
+                                   (size_t)n * h, L.d_fagg1, L.m_fagg1);
                 PSG_LAUNCH_CHECK();
             }
         } else {
@@ -1383,23 +1413,23 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
             if ((rc = conv_bwd(E.att2_fc, ws->scratch_b, d, ws->scratch_a, d, (int)ne, 1, st))) return rc;
             if (ws->use_inv)
                 hipLaunchKernelGGL(gather_inv_kernel<false>, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 2 * h, h, L.inv_off,
-                                   L.inv_ent, (size_t)n * h, L.d_fagg1);
+                                   L.inv_ent, (size_t)n * h, L.d_fagg1, L.m_fagg1);
             else
                 hipLaunchKernelGGL(gather_bwd_kernel, dim3(blocks_for(ne * h)), dim3(256), 0, st, ws->scratch_a, L.neigh, h, ne * h, L.d_fagg1);
             PSG_LAUNCH_CHECK();
         }
-        if ((rc = lrelu_bwd(L.d_fagg1, h, L.m_fagg1, n, h, st))) return rc;
+        if (!fuse && (rc = lrelu_bwd(L.d_fagg1, h, L.m_fagg1, n, h, st))) return rc;
         float *g_agg1 = L.agg1;
         if ((rc = conv_bwd(E.att1_mlp, L.d_fagg1, h, g_agg1, d, n, 0, st))) return rc;
         if (split) {
-            if ((rc = split_bwd(L.fpc, L.fxyz1, L.a1, g_agg1, E.att1_fc, L.d_fpc))) return rc;
+            if ((rc = split_bwd(L.fpc, L.fxyz1, L.a1, g_agg1, E.att1_fc, L.d_fpc, L.m_fpc))) return rc;
         } else if (fused16) {
             hipLaunchKernelGGL(lfa16_bwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, E.att1_fc.w,
                                E.att1_fc.b, g_agg1, (size_t)n, L.d_fpc, ws->use_inv ? ws->scratch_a : (float *)nullptr);
             PSG_LAUNCH_CHECK();
             if (ws->use_inv) {
                 hipLaunchKernelGGL(gather_inv_kernel<false>, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 8, h, L.inv_off, L.inv_ent,
-                                   (size_t)n * h, L.d_fpc);
+                                   (size_t)n * h, L.d_fpc, L.m_fpc);
                 PSG_LAUNCH_CHECK();
             }
         } else {
@@ -1409,15 +1439,15 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
             if ((rc = conv_bwd(E.att1_fc, ws->scratch_b, d, ws->scratch_a, d, (int)ne, 1, st))) return rc;
             if (ws->use_inv)
                 hipLaunchKernelGGL(gather_inv_kernel<false>, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 2 * h, h, L.inv_off,
-                                   L.inv_ent, (size_t)n * h, L.d_fpc);
+                                   L.inv_ent, (size_t)n * h, L.d_fpc, L.m_fpc);
             else
                 hipLaunchKernelGGL(gather_bwd_kernel, dim3(blocks_for(ne * h)), dim3(256), 0, st, ws->scratch_a, L.neigh, h, ne * h, L.d_fpc);
             PSG_LAUNCH_CHECK();
         }
-        if ((rc = lrelu_bwd(L.d_fpc, h, L.m_fpc, n, h, st))) return rc;
-        if ((rc = conv_bwd(E.mlp1, L.d_fpc, h, din, L.d_in, n, 1, st))) return rc;
+        if (!fuse && (rc = lrelu_bwd(L.d_fpc, h, L.m_fpc, n, h, st))) return rc;
+        // (level 0: this GEMM completes d_f0, the gradient of fc0's leaky-ReLU output)
+        if ((rc = conv_bwd(E.mlp1, L.d_fpc, h, din, L.d_in, n, 1, st, i == 0 ? ws->m_f0 : (const uint32_t *)nullptr))) return rc;
     }
-    if ((rc = lrelu_bwd(ws->d_f0, 8, ws->m_f0, N, 8, st))) return rc;
     if ((rc = conv_bwd(m->fc0, ws->d_f0, 8, dfeatures_out, 6, N, 0, st))) return rc;
     ws->have_fwd = false;   // agg / fagg buffers were reused as gradient scratch
     return PSG_OK;
