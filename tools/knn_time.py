@@ -8,7 +8,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 f = torch.from_numpy(rng.standard_normal((B, 4096, 64)).astype(np.float32)).cuda()
 ws = runtime.GCNWorkspace(B, 4096, 28)
 out = []
-for d in (1, 4, 9, 17, 27):
+for d in [int(x) for x in os.environ.get("KNN_D", "1,4,9,17,27").split(",")]:
     ws.knn(f, d)
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
     t0.record()
