@@ -349,6 +349,13 @@ int psg_gcn_prof_read(psg_gcn_ws *ws, int n_tags, double *total_ms, int *counts,
  * Distances follow the reference's fp32 order (ascending-k fmaf dot, (|xi|^2 + -2 xi.xj) + |xj|^2);
  * equal distances resolve to the lowest index (torch.topk leaves that order unspecified). */
 int psg_gcn_knn(psg_gcn_ws *ws, const float *x, int C, int dilation, int32_t *out_idx, psg_stream stream);
+/* Measurement only: counters of the feature-space kNN kernel since the last reset, for workspaces created while the
+ * environment holds PSG_GCN_KNN_STATS=1 (all zero otherwise).  The kernel decides most of a distance row on a bf16 MFMA
+ * approximation with a proven error bound and evaluates the reference's fp32 distance (torch_edge.py:41-43) only for the
+ * candidates that can hold a wanted rank; tiles whose bound cannot be kept take the all-fp32 path inside the same launch.
+ * host_out8: [0] 32-query tiles, [1] tiles that took the exact path, [2] rows ranked on the fast path, [3] exact distances
+ * evaluated there, [4] row cuts, [5] entries held at the end of the stream, [6..7] 0.  Synchronises the device. */
+int psg_gcn_knn_stats(psg_gcn_ws *ws, unsigned long long *host_out8, int reset);
 
 /* DenseDeepGCN.forward (architecture.py:58-68): x0 [batch][n_point][9] point-major -> logits [batch][n_point][13]. */
 int psg_gcn_forward(psg_gcn_model *model, psg_gcn_ws *ws, const float *x0, float *logits_out, psg_stream stream);

@@ -80,6 +80,7 @@ SIGNATURES = {
     "psg_gcn_prof_enable": (ci, [vp, ci]),
     "psg_gcn_prof_read": (ci, [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
     "psg_gcn_knn": (ci, [vp, vp, ci, ci, vp, vp]),
+    "psg_gcn_knn_stats": (ci, [vp, ctypes.POINTER(ctypes.c_ulonglong), ci]),
     "psg_gcn_forward": (ci, [vp, vp, vp, vp, vp]),
     "psg_gcn_backward": (ci, [vp, vp, vp, vp, vp]),
     "psg_gcn_nb_attack": (ci, [vp, vp, vp, vp, cf, cf, ci, vp, vp]),

@@ -1,0 +1,118 @@
+// Fused feature-space kNN kernels of the ResGCN path (C = 64) in their own translation unit: compiled with the MFMA
+// accumulators in VGPRs (every accumulator is read by vector compares right after the matrix instructions: the AGPR form
+// costs one v_accvgpr_read per value) and with -ffp-contract=off (the exact distances follow the reference's fp32
+// evaluation order, SURVEY 8a').  psg_resgcn.hip calls the launchers below (psg_knn.h).
+#include "psg_knn.h"
+#include "psg_common.h"
+
+#include <cstdlib>
+#include <mutex>
+
+#include "psg_wave.cuh"
+#include "psg_knn_ops.cuh"
+
+namespace {
+#include "psg_knn_fused.cuh"
+#include "psg_knn_bf.cuh"
+
+// xp / bp / sq for the stand-alone entry point: one wave per point, lane = feature (C = 64)
+__global__ void knn_prep_kernel(const float *__restrict__ x, int ld, size_t rows, float *__restrict__ xp, float *__restrict__ sq,
+                                unsigned short *__restrict__ bp)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t v = t >> 6;
+    if (v >= rows) return;
+    const int c = (int)(t & 63);
+    const float val = x[v * ld + c];
+    knn_store_xp(xp, v, c, val);
+    if (bp) knn_store_bp(bp, v, c, val);
+    const float s = knn_wave_sumsq(val, threadIdx.x & 63);
+    if (c == 0) {
+        sq[v] = s;
+        if (bp) knn_store_aug((uint4 *)bp, v, s);
+    }
+}
+}  // namespace
+
+namespace psg {
+
+size_t knn_xp_bytes(size_t rows) { return rows * 64 * sizeof(float); }
+size_t knn_bp_bytes(size_t rows) { return (rows + 31) / 32 * 9 * 64 * 16; }
+
+hipError_t knn_setup()
+{
+    static std::once_flag once;
+    static hipError_t rc = hipSuccess;
+    std::call_once(once, [] {
+        rc = hipFuncSetAttribute((const void *)knn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_fused_lds_bytes());
+        if (rc == hipSuccess)
+            rc = hipFuncSetAttribute((const void *)knn_bf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_bf_lds_bytes());
+    });
+    return rc;
+}
+
+bool knn_shape_ok(int N, int k, int d, KnnPath path)
+{
+    if (N <= 0 || N > 4096 || (k - 1) * d + 1 > 448) return false;
+    return path == KNN_PATH_BF16 ? (N % 32) == 0 : (N % 16) == 0;
+}
+
+hipError_t knn_prep_launch(const float *x, int ld, size_t rows, const KnnBuffers &buf, bool want_bp, hipStream_t st)
+{
+    hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((rows * 64 + 255) / 256)), dim3(256), 0, st, x, ld, rows, buf.xp, buf.sq,
+                       want_bp ? (unsigned short *)buf.bp : (unsigned short *)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t knn_launch(const KnnBuffers &buf, int B, int N, int k, int d, int32_t *out, KnnPath path, hipStream_t st)
+{
+    KnnFusedArgs f;
+    f.xp = buf.xp; f.sq = buf.sq; f.out = out; f.N = N; f.k = k; f.d = d;
+    f.KK = (k - 1) * d + 1;
+    f.magic = (unsigned)(((1u << 18) + (unsigned)d - 1u) / (unsigned)d);
+    const int slack = KF_CAP - f.KK;
+    f.TOL = slack / 16;
+    f.LOW = f.KK + slack / 4;
+    if (path == KNN_PATH_F32) {
+        hipLaunchKernelGGL(knn_fused_kernel, dim3((unsigned)((size_t)B * N / KF_Q)), dim3(KF_WAVES * 64), knn_fused_lds_bytes(), st, f);
+        return hipGetLastError();
+    }
+    KnnBfArgs a;
+    a.bp = (const kb_u32x4 *)buf.bp; a.sq = buf.sq; a.out = out; a.N = N; a.k = k; a.d = d; a.KK = f.KK; a.magic = f.magic;
+    const int bslack = KB_CAP - a.KK;
+    a.LOW = a.KK + bslack / 4;
+    // cut schedule (candidates seen): first when a row holds first_cut entries (everything is admitted until then), then
+    // whenever the ~kept entries of the last cut, admitted at the rate kept / n, would fill 0.85 CAP
+    static const int first_small = getenv("PSG_KNN_FIRST_CUT_KK") ? atoi(getenv("PSG_KNN_FIRST_CUT_KK")) : 100;
+    a.first_cut = a.KK <= first_small ? 512 : 1024;
+    a.grow = 0.85f * (float)KB_CAP / (float)(a.KK + a.KK / 8 + 32);
+    a.exact = f;
+    a.stats = buf.stats;
+    hipLaunchKernelGGL(knn_bf_kernel, dim3((unsigned)((size_t)B * N / KB_Q)), dim3(KB_WAVES * 64), knn_bf_lds_bytes(), st, a);
+    return hipGetLastError();
+}
+
+}  // namespace psg
+
+#ifdef PSG_KF_STAMP
+// diagnostic build only: read and clear the fused kNN kernel's phase stamps (tools/knn_stamp.py)
+extern "C" int psg_dbg_knn_stamps(unsigned long long *host_out)
+{
+    PSG_CHECK_HIP(hipDeviceSynchronize());
+    PSG_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_kf_stamps), 16 * sizeof(unsigned long long)));
+    unsigned long long zero[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    PSG_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_kf_stamps), zero, sizeof(zero)));
+    return PSG_OK;
+}
+#endif
+#ifdef PSG_KF_TL
+extern "C" int psg_dbg_knn_tl(unsigned long long *host_out)      // [32], see g_kf_tl
+{
+    PSG_CHECK_HIP(hipDeviceSynchronize());
+    PSG_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_kf_tl), 32 * sizeof(unsigned long long)));
+    static unsigned long long zero[32];
+    PSG_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_kf_tl), zero, sizeof(zero)));
+    return PSG_OK;
+}
+#endif
+

@@ -3,8 +3,9 @@
 // it).  Reference: ResGCN/gcn_lib/dense/torch_edge.py:32-59 (pairwise_distance, dense_knn_matrix: topk(-dist, k*d)) and
 // :19-29 (DenseDilated: every d-th of the sorted neighbours).
 //
-// Included by psg_resgcn.hip inside its anonymous namespace, after the wave helpers (key_of, wave_sum_u32,
-// wave_sort_keys, ...) it shares with the round-1 selection kernel.
+// Included by psg_knn.hip inside its anonymous namespace, after the wave helpers (psg_wave.cuh: key_of, wave_sum_u32,
+// wave_sort_keys, ...) it shares with the round-1 selection kernel.  Since round 3 this kernel is the EXACT path: the
+// default is the bf16-prefilter kernel (psg_knn_bf.cuh), which calls knn_exact_block below for the tiles it cannot decide.
 //
 // Work split.  A workgroup of 16 waves owns 16 QUERY points of one room and streams all N candidates of that room past
 // them; wave w takes candidate pairs-of-tiles w, w + 16, ... (32 candidates per wave and step, 512 per workgroup and
@@ -17,7 +18,8 @@
 // the distance is (|x_i|^2 + (-2 x_i.x_j)) + |x_j|^2 with torch's rounding: equal features give bit-equal distances.
 // Operands are read straight from L2 in MFMA operand order ("xp": [point / 16][4][64 lanes] float4, element e of
 // lane l in quarter i = feature 4 (4 i + e) + (l >> 4) of point (l & 15)), one coalesced 1-KiB load per quarter; the
-// producer of the features (edge_max_fwd_kernel) writes that copy, knn_prep_kernel does it for the stand-alone entry.
+// producer of the features (edge_max_fwd_kernel) writes that copy, knn_prep_kernel does it for the stand-alone entry
+// (psg_knn_ops.cuh, psg_knn.hip).
 //
 // Selection.  Per query row a buffer of CAP = 1024 composite keys (distance key << 12 | candidate index: ascending
 // distance, lowest index first, a strict total order) lives in LDS (rows 1026 keys apart - see KF_ROW -, 128 KB per
@@ -93,31 +95,6 @@ struct KnnFusedArgs {
     unsigned magic;    // ceil(2^18 / d): x / d = (x * magic) >> 18 for x < 2^18 / d
     int LOW, TOL;      // a prune event cuts the rows above LOW to [KK, KK + TOL]
 };
-
-// xp / sq for the stand-alone entry point: one wave per point, lane = feature (C = 64)
-__global__ void knn_prep_kernel(const float *__restrict__ x, int ld, size_t rows, float *__restrict__ xp, float *__restrict__ sq)
-{
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t v = t >> 6;
-    if (v >= rows) return;
-    const int c = (int)(t & 63);
-    const float val = x[v * ld + c];
-    const int s = c >> 2, g = c & 3;
-    xp[(v >> 4) * 1024 + (size_t)((((s >> 2) * 64) + (int)(v & 15) + 16 * g) * 4 + (s & 3))] = val;
-    if (sq) {
-        // torch.sum(x * x, -1) for 64 contiguous floats (same order as sumsq_rows_kernel / edge_max_fwd_kernel)
-        const int lane = threadIdx.x & 63;
-        const float q2 = __fmul_rn(val, val);
-        const float u = __fadd_rn(q2, __shfl(q2, (lane + 32) & 63));
-        float tl = __fadd_rn(u, __shfl(u, (lane + 8) & 63));
-        tl = __fadd_rn(tl, __shfl(u, (lane + 16) & 63));
-        tl = __fadd_rn(tl, __shfl(u, (lane + 24) & 63));
-        float sacc = __shfl(tl, 0);
-#pragma unroll
-        for (int l = 1; l < 8; ++l) sacc = __fadd_rn(sacc, __shfl(tl, l));
-        if (lane == 0) sq[v] = sacc;
-    }
-}
 
 // inclusive prefix sum over the 64 lanes (row scans by DPP row_shr, then the row totals by row_bcast)
 __device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v)
@@ -320,11 +297,14 @@ __device__ __forceinline__ void final_ranks(unsigned long long *row, unsigned T,
     if (lane < a.k) out[lane] = (int32_t)(row[(size_t)lane * d] & 0xFFFull);
 }
 
-__global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a)
+// The whole exact path for the 16 queries [16 qblk, 16 qblk + 16) by one workgroup of KF_WAVES waves; kf_smem = the
+// workgroup's dynamic LDS (knn_fused_lds_bytes()).  Called by knn_fused_kernel (one block per workgroup) and, as the exact
+// fallback for a 32-query tile, by the bf16-prefilter kernel (psg_knn_bf.cuh).  Ends with every output of the block stored;
+// the caller synchronises the workgroup before it reuses the LDS.
+__device__ __forceinline__ void knn_exact_block(const KnnFusedArgs &a, const int qblk, unsigned char *kf_smem)
 {
     constexpr int CAP = KF_CAP, ROW = KF_ROW;
     constexpr int PER_STEP = KF_WAVES * KF_STEP;                             // candidates per workgroup and step
-    extern __shared__ __attribute__((aligned(16))) unsigned char kf_smem[];
     unsigned long long *ent = (unsigned long long *)kf_smem;                 // [KF_Q][ROW], CAP used
     unsigned *tau_k = (unsigned *)(ent + KF_Q * ROW);                        // [KF_Q] threshold: distance key ..
     unsigned *tau_i = tau_k + KF_Q;                                          // [KF_Q] .. and index (ties)
@@ -337,10 +317,10 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
     const int q = lane & 15, g = lane >> 4;
     KF_T(t_begin);
     const int tiles_per_room = a.N >> 4;
-    const int room = blockIdx.x / tiles_per_room;
+    const int room = qblk / tiles_per_room;
     const size_t room_row0 = (size_t)room * a.N;
     const size_t tile0 = (size_t)room * tiles_per_room;                      // first operand tile of the room
-    const size_t qrow = (size_t)blockIdx.x * KF_Q + q;
+    const size_t qrow = (size_t)qblk * KF_Q + q;
     const unsigned KK = (unsigned)a.KK;
 
     if (tid < KF_Q) { tau_k[tid] = 0xFFFFFFFFu; tau_i[tid] = 0xFFFu; cnt[tid] = 0u; }      // everything is admitted
@@ -351,7 +331,7 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
     float4 bq[4];
     auto load_queries = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bq[i] = xp4[((size_t)blockIdx.x * 4 + i) * 64 + lane];
+        for (int i = 0; i < 4; ++i) bq[i] = xp4[((size_t)qblk * 4 + i) * 64 + lane];
     };
     load_queries();
     const float sqi = a.sq[qrow];
@@ -627,7 +607,7 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
     KF_T(t_f);
     for (int qq = wave; qq < KF_Q; qq += KF_WAVES) {
         unsigned long long *row = ent + qq * ROW;
-        int32_t *o = a.out + ((size_t)blockIdx.x * KF_Q + qq) * a.k;
+        int32_t *o = a.out + ((size_t)qblk * KF_Q + qq) * a.k;
         const unsigned T = cnt[qq];
         if (T <= 512u) final_ranks<8>(row, T, a, fcnt + qq, o, lane);
         else final_ranks<KF_NPL>(row, T, a, fcnt + qq, o, lane);
@@ -644,6 +624,19 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
     if (tid == 0)
         for (int i = 0; i < 14; ++i) atomicAdd(&g_kf_stamps[i], kf_sum[i]);
 #endif
+}
+
+__global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char kf_smem[];
+    knn_exact_block(a, (int)blockIdx.x, kf_smem);
+}
+
+// the same as a call (the prefilter kernel's cold path: inlined twice it doubled that kernel and spilled its stream loop)
+__device__ __noinline__ void knn_exact_block_cold(const KnnFusedArgs a, const int qblk)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char kf_smem[];
+    knn_exact_block(a, qblk, kf_smem);
 }
 
 inline size_t knn_fused_lds_bytes() { return (size_t)KF_Q * KF_ROW * 8 + KF_Q * 8 + KF_Q * 4 + (8 + KF_Q) * 4; }

@@ -1101,6 +1101,7 @@ extern "C" int psg_rla_ws_destroy(psg_rla_ws *ws)
     if (!ws) return PSG_OK;
     if (ws->bim_exec) (void)hipGraphExecDestroy(ws->bim_exec);
     if (ws->arena) (void)hipFree(ws->arena);
+    ws->prof.destroy();
     delete ws;
     return PSG_OK;
 }

@@ -23,6 +23,9 @@
 
 #include "psg_common.h"
 #include "psg_gemm.cuh"
+#include "psg_knn.h"
+#include "psg_knn_ops.cuh"
+#include "psg_wave.cuh"
 
 using namespace psg;
 
@@ -118,92 +121,6 @@ constexpr int KS_WAVES = 4;          // rows per workgroup (independent waves)
 constexpr int KS_PER_LANE = 64;      // N <= 4096
 constexpr int KS_MAX_SEL = 512;
 
-__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned dpp_get(unsigned v)   // lanes of rows outside ROW_MASK read 0
-{
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-// sum over the 64 lanes, wave-uniform result (row butterflies, then row_bcast15 / row_bcast31 into lane 63)
-__device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
-{
-    v += dpp_get<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
-    v += dpp_get<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
-    v += dpp_get<0x141, 0xF>(v);   // row_half_mirror
-    v += dpp_get<0x140, 0xF>(v);   // row_mirror: every lane holds its row's sum
-    v += dpp_get<0x142, 0xA>(v);   // row_bcast15 -> rows 1, 3
-    v += dpp_get<0x143, 0xC>(v);   // row_bcast31 -> rows 2, 3
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
-{
-    unsigned o;
-    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false); v = o > v ? o : v;
-    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false); v = o > v ? o : v;
-    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false); v = o > v ? o : v;
-    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false); v = o > v ? o : v;
-    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false); v = o > v ? o : v;
-    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false); v = o > v ? o : v;
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-__device__ __forceinline__ unsigned key_of(float f)
-{
-    const unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float dist_of(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
-
-// Bitonic sort of M = 64 * SL composite keys held SL per lane (element e = lane * SL + slot): strides below SL
-// are compare-exchanges between a lane's own registers, strides of SL and more exchange whole registers with the
-// partner lane (two 32-bit cross-lane permutes per key); nothing goes through LDS memory and there is no fence per
-// step (the LDS version spent 23 us of the 60 us selection here).
-template <int SL, int STRIDE>
-__device__ __forceinline__ void sort_intra(unsigned long long (&v)[SL], int lane, unsigned size)
-{
-    if constexpr (STRIDE >= 1 && STRIDE < SL) {
-#pragma unroll
-        for (int s0 = 0; s0 < SL; ++s0) {
-            if ((s0 & STRIDE) == 0) {
-                const unsigned e = (unsigned)lane * SL + s0;
-                const bool up = (e & size) == 0;
-                const unsigned long long a = v[s0], b = v[s0 | STRIDE];
-                const bool sw = (a > b) == up;
-                v[s0] = sw ? b : a;
-                v[s0 | STRIDE] = sw ? a : b;
-            }
-        }
-    }
-}
-
-template <int SL>
-__device__ __forceinline__ void wave_sort_keys(unsigned long long *cand, int lane)
-{
-    unsigned long long v[SL];
-#pragma unroll
-    for (int s0 = 0; s0 < SL; ++s0) v[s0] = cand[lane * SL + s0];
-    constexpr unsigned M = 64u * SL;
-    for (unsigned size = 2; size <= M; size <<= 1) {
-        for (unsigned stride = size >> 1; stride >= (unsigned)SL; stride >>= 1) {   // partner lane = lane ^ (stride / SL)
-            const int ls = (int)(stride / SL);
-            const bool lower = (lane & ls) == 0;
-#pragma unroll
-            for (int s0 = 0; s0 < SL; ++s0) {
-                const unsigned e = (unsigned)lane * SL + s0;
-                const bool up = (e & size) == 0;
-                const unsigned long long o =
-                    ((unsigned long long)__shfl_xor((unsigned)(v[s0] >> 32), ls) << 32) | __shfl_xor((unsigned)v[s0], ls);
-                const bool keep_min = lower == up;
-                v[s0] = keep_min ? (o < v[s0] ? o : v[s0]) : (o > v[s0] ? o : v[s0]);
-            }
-        }
-        if (size > 4) sort_intra<SL, 4>(v, lane, size);
-        if (size > 2) sort_intra<SL, 2>(v, lane, size);
-        sort_intra<SL, 1>(v, lane, size);
-    }
-#pragma unroll
-    for (int s0 = 0; s0 < SL; ++s0) cand[lane * SL + s0] = v[s0];
-}
 
 __global__ __launch_bounds__(KS_WAVES * 64) void knn_select_kernel(const float *__restrict__ dist, int N, size_t rows,
                                                                   int k, int d, int32_t *__restrict__ out)
@@ -337,15 +254,13 @@ __global__ __launch_bounds__(KS_WAVES * 64) void knn_select_kernel(const float *
     if (lane < k) out[row * k + lane] = (int32_t)(cand[(size_t)lane * d] & 0xFFFull);
 }
 
-#include "psg_knn_fused.cuh"
-
 // ---- EdgeConv edge pass (forward): y[i][c] = max_k ( s_c * relu(P[i][c] + Q[nbr(i,k)][c]) + t_c ) (+ residual)
 // One thread per (vertex, channel), channel fastest: the 64 lanes of a wave read one 256-byte Q row.
 __global__ void edge_max_fwd_kernel(const float *__restrict__ pq, const int32_t *__restrict__ nbr,
                                     const float *__restrict__ scale, const float *__restrict__ shift,
                                     const float *__restrict__ resid, int ld_res, float *__restrict__ out, int ld_out,
                                     uint8_t *__restrict__ arg, int N, size_t total, float *__restrict__ sq_out,
-                                    float *__restrict__ xp_out)
+                                    float *__restrict__ xp_out, unsigned short *__restrict__ bp_out)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -368,24 +283,18 @@ __global__ void edge_max_fwd_kernel(const float *__restrict__ pq, const int32_t 
     if (resid) best += resid[v * ld_res + c];
     out[v * ld_out + c] = best;
     arg[t] = (uint8_t)(bk | (bact ? 0x80 : 0));
-    if (xp_out) {   // the next block's kNN reads the features in MFMA operand order (psg_knn_fused.cuh)
-        const int s4 = c >> 2, g4 = c & 3;
-        xp_out[(v >> 4) * 1024 + (size_t)((((s4 >> 2) * 64) + (int)(v & 15) + 16 * g4) * 4 + (s4 & 3))] = best;
+    if (xp_out) {   // the next block's kNN reads the features in MFMA operand order (psg_knn_ops.cuh)
+        knn_store_xp(xp_out, v, c, best);
+        if (bp_out) knn_store_bp(bp_out, v, c, best);
     }
     if (sq_out) {
         // squared norm of the vertex's 64 new features for the next block's kNN, in torch.sum's order for 64
-        // contiguous floats (sumsq_rows_kernel): u_c = x_c^2 + x_{c+32}^2, t_l = ((u_l + u_{8+l}) + u_{16+l}) + u_{24+l},
-        // s = t_0 + t_1 + ... + t_7 left to right.  One wave holds exactly one vertex (lane = channel).
-        const int lane = threadIdx.x & 63;
-        const float q2 = __fmul_rn(best, best);
-        const float u = __fadd_rn(q2, __shfl(q2, (lane + 32) & 63));
-        float tl = __fadd_rn(u, __shfl(u, (lane + 8) & 63));
-        tl = __fadd_rn(tl, __shfl(u, (lane + 16) & 63));
-        tl = __fadd_rn(tl, __shfl(u, (lane + 24) & 63));      // valid in lanes 0..7
-        float sacc = __shfl(tl, 0);
-#pragma unroll
-        for (int l = 1; l < 8; ++l) sacc = __fadd_rn(sacc, __shfl(tl, l));
-        if (lane == 0) sq_out[v] = sacc;
+        // contiguous floats (sumsq_rows_kernel).  One wave holds exactly one vertex (lane = channel).
+        const float sacc = knn_wave_sumsq(best, threadIdx.x & 63);
+        if (c == 0) {
+            sq_out[v] = sacc;
+            if (bp_out) knn_store_aug((uint4 *)bp_out, v, sacc);
+        }
     }
 }
 
@@ -611,8 +520,10 @@ struct psg_gcn_ws {
     float *feats, *dfeats;     // [B*N][fdim]
     float *dist;               // [B*N][N]
     float *sq;                 // [B*N]
-    float *xp;                 // [B*N][64] the current block's features in MFMA operand order (fused kNN)
-    bool knn_fused = true;     // PSG_GCN_KNN=matrix: the round-1 path (distance matrix in HBM + selection kernel)
+    float *xp;                 // [B*N][64] the current block's features in fp32 MFMA operand order (exact fused kNN)
+    void *bp;                  // [B*N/32][9][64] 16-byte bf16 hi / lo / augmented fragments (prefilter kNN, psg_knn_ops.cuh)
+    int knn_mode = 2;          // 2 = bf16 prefilter (default), 1 = exact fused kernel (PSG_GCN_KNN=f32), 0 = round-1 path (=matrix)
+    unsigned long long *knn_stats = nullptr;   // PSG_GCN_KNN_STATS=1: device counters of the prefilter kernel
     float *pq, *dpq;           // [B*N][128]
     float *dpq2;               // second [B*N][128] gradient buffer of the default (res / edge) backward's ping-pong
     int32_t *nbr;              // [n_blocks][B*N][16]
@@ -678,41 +589,35 @@ __global__ void extract_color3_kernel(const float *__restrict__ x0, float *__res
 
 enum GcnTag { GT_KNN = 0, GT_KNN_OTHER, GT_VERTEX_GEMM, GT_EDGE_MAX, GT_HEAD, GT_BACKWARD, GT_COUNT };
 
-bool knn_fused_ok(const psg_gcn_ws *ws, int C, int d)
+// which kernel builds the dilated graph of C-wide features: the bf16-prefilter kernel (default), the exact fused kernel
+// (PSG_GCN_KNN=f32, and sizes the prefilter does not take), or -1 = the round-1 path (distance matrix in HBM + selection
+// kernel: the xyz graph of the head, dense blocks, PSG_GCN_KNN=matrix)
+int knn_path(const psg_gcn_ws *ws, int C, int d)
 {
-    return ws->knn_fused && C == 64 && (ws->N % 16) == 0 && ws->N <= 4096 && (KNB - 1) * d + 1 <= 448;
+    if (ws->knn_mode == 0 || C != 64) return -1;
+    if (ws->knn_mode == 2 && knn_shape_ok(ws->N, KNB, d, KNN_PATH_BF16)) return KNN_PATH_BF16;
+    return knn_shape_ok(ws->N, KNB, d, KNN_PATH_F32) ? KNN_PATH_F32 : -1;
 }
 
-int knn_fused_launch(psg_gcn_ws *ws, int d, int32_t *out, hipStream_t st)
+KnnBuffers knn_buffers(const psg_gcn_ws *ws)
 {
-    KnnFusedArgs a;
-    a.xp = ws->xp; a.sq = ws->sq; a.out = out; a.N = ws->N; a.k = KNB; a.d = d;
-    a.KK = (KNB - 1) * d + 1;
-    a.magic = (unsigned)(((1u << 18) + (unsigned)d - 1u) / (unsigned)d);
-    const int slack = KF_CAP - a.KK;
-    a.TOL = slack / 16;
-    a.LOW = a.KK + slack / 4;
-    const dim3 grid((unsigned)((size_t)ws->B * ws->N / KF_Q)), block(KF_WAVES * 64);
-    {
-        EvScope prof(&ws->prof, GT_KNN, 2.0 * ws->B * (double)ws->N * ws->N * 64.0, st);
-        hipLaunchKernelGGL(knn_fused_kernel, grid, block, knn_fused_lds_bytes(), st, a);
-    }
-    PSG_LAUNCH_CHECK();
-    return PSG_OK;
+    KnnBuffers b;
+    b.xp = ws->xp; b.bp = ws->bp; b.sq = ws->sq; b.stats = ws->knn_stats;
+    return b;
 }
 
-// have_sq: ws->sq (and, on the fused path, ws->xp) already hold the norms / operand copy of x (the forward pass gets
-// them from the producing edge_max_fwd kernel)
+// have_sq: ws->sq (and, on the fused paths, ws->xp / ws->bp) already hold the norms / operand copies of x (the forward
+// pass gets them from the producing edge_max_fwd kernel)
 int knn_graph(psg_gcn_ws *ws, const float *x, int ld, int C, int d, int32_t *out, hipStream_t st, bool have_sq = false)
 {
     const size_t rows = (size_t)ws->B * ws->N;
-    if (knn_fused_ok(ws, C, d)) {
-        if (!have_sq) {
-            hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)ceil_div((int)(rows * 64), 256)), dim3(256), 0, st, x, ld, rows,
-                               ws->xp, ws->sq);
-            PSG_LAUNCH_CHECK();
-        }
-        return knn_fused_launch(ws, d, out, st);
+    const int path = knn_path(ws, C, d);
+    if (path >= 0) {
+        const KnnBuffers buf = knn_buffers(ws);
+        if (!have_sq) PSG_CHECK_HIP(knn_prep_launch(x, ld, rows, buf, path == KNN_PATH_BF16, st));
+        EvScope prof(&ws->prof, GT_KNN, 2.0 * ws->B * (double)ws->N * ws->N * 64.0, st);
+        PSG_CHECK_HIP(knn_launch(buf, ws->B, ws->N, KNB, d, out, (KnnPath)path, st));
+        return PSG_OK;
     }
     EvScope prof(&ws->prof, GT_KNN_OTHER, 2.0 * ws->B * (double)ws->N * ws->N * C, st);   // round-1 path, xyz graph
     if (!have_sq) {
@@ -882,10 +787,11 @@ extern "C" int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n
     ws->block = block; ws->conv = conv;
     {
         const char *kv = getenv("PSG_GCN_KNN");
-        ws->knn_fused = !(kv && std::string(kv) == "matrix");
-        // the fused kNN kernel needs 128 KB of dynamic LDS (set once, outside any stream capture)
-        PSG_CHECK_HIP(hipFuncSetAttribute((const void *)knn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)knn_fused_lds_bytes()));
+        const std::string mode = kv ? kv : "";
+        ws->knn_mode = mode == "matrix" ? 0 : (mode == "f32" ? 1 : 2);
+        // the fused kNN kernels need 129 KB of dynamic LDS (raised once, outside any stream capture); a device that does
+        // not grant it keeps the round-1 path (distance matrix in HBM + selection kernel)
+        if (ws->knn_mode && knn_setup() != hipSuccess) { (void)hipGetLastError(); ws->knn_mode = 0; }
     }
     // widest conv input (dense: all earlier outputs) and the total arg-max bytes per vertex of the mr layers
     const int c_max = block == PSG_GCN_BLOCK_DENSE ? std::max(GC, GC * (n_blocks - 1)) : GC;
@@ -907,7 +813,9 @@ extern "C" int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n
         ws->dfeats = (float *)take(R * ws->fdim * 4);
         ws->dist = (float *)take(R * n_point * 4);
         ws->sq = (float *)take(R * 4);
-        ws->xp = (float *)take(R * 64 * 4);
+        ws->xp = (float *)take(knn_xp_bytes(R));
+        ws->bp = take(knn_bp_bytes(R));
+        ws->knn_stats = getenv("PSG_GCN_KNN_STATS") ? (unsigned long long *)take(8 * sizeof(unsigned long long)) : nullptr;
         ws->pq = (float *)take(R * ws->pq_w * 4);
         ws->dpq = (float *)take(R * ws->pq_w * 4);
         ws->dpq2 = (float *)take(R * 2 * GC * 4);
@@ -949,6 +857,7 @@ extern "C" int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n
             }
         }
     }
+    if (ws->knn_stats) (void)hipMemset(ws->knn_stats, 0, 8 * sizeof(unsigned long long));
     *out = ws;
     return PSG_OK;
 }
@@ -963,7 +872,22 @@ extern "C" int psg_gcn_ws_destroy(psg_gcn_ws *ws)
     if (!ws) return PSG_OK;
     if (ws->nb_exec) (void)hipGraphExecDestroy(ws->nb_exec);
     if (ws->arena) (void)hipFree(ws->arena);
+    ws->prof.destroy();
     delete ws;
+    return PSG_OK;
+}
+
+// Diagnostic counters of the bf16-prefilter kNN kernel since the last reset (workspaces created with PSG_GCN_KNN_STATS=1;
+// otherwise all zero): [0] 32-query tiles, [1] tiles that took the exact path, [2] rows ranked on the fast path,
+// [3] finalists (exact distances evaluated), [4] row cuts, [5] entries held at the end of the stream.  Synchronises.
+extern "C" int psg_gcn_knn_stats(psg_gcn_ws *ws, unsigned long long *host_out8, int reset)
+{
+    PSG_REQUIRE(ws && host_out8, "psg_gcn_knn_stats: null argument");
+    for (int i = 0; i < 8; ++i) host_out8[i] = 0ull;
+    if (!ws->knn_stats) return PSG_OK;
+    PSG_CHECK_HIP(hipDeviceSynchronize());
+    PSG_CHECK_HIP(hipMemcpy(host_out8, ws->knn_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) PSG_CHECK_HIP(hipMemset(ws->knn_stats, 0, 8 * sizeof(unsigned long long)));
     return PSG_OK;
 }
 
@@ -1002,28 +926,6 @@ extern "C" int psg_gcn_set_graphs(psg_gcn_ws *ws, const int32_t *nbr, psg_stream
 }
 
 extern "C" const float *psg_gcn_feats_ptr(const psg_gcn_ws *ws) { return ws ? ws->feats : nullptr; }
-
-#ifdef PSG_KF_STAMP
-// diagnostic build only: read and clear the fused kNN kernel's phase stamps (tools/knn_stamp.py)
-extern "C" int psg_dbg_knn_stamps(unsigned long long *host_out)
-{
-    PSG_CHECK_HIP(hipDeviceSynchronize());
-    PSG_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_kf_stamps), 16 * sizeof(unsigned long long)));
-    unsigned long long zero[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    PSG_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_kf_stamps), zero, sizeof(zero)));
-    return PSG_OK;
-}
-#endif
-#ifdef PSG_KF_TL
-extern "C" int psg_dbg_knn_tl(unsigned long long *host_out)      // [32], see g_kf_tl
-{
-    PSG_CHECK_HIP(hipDeviceSynchronize());
-    PSG_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_kf_tl), 32 * sizeof(unsigned long long)));
-    static unsigned long long zero[32];
-    PSG_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_kf_tl), zero, sizeof(zero)));
-    return PSG_OK;
-}
-#endif
 
 // unit op: dilated dense kNN graph of point-major features x [B][N][C] (torch_edge.py:45-79)
 extern "C" int psg_gcn_knn(psg_gcn_ws *ws, const float *x, int C, int dilation, int32_t *out_idx, psg_stream stream)
@@ -1071,7 +973,8 @@ extern "C" int psg_edgeconv_fwd(const float *x, int ld_x, int R, int N, int C, c
     int rc;
     if ((rc = launch_gemm<2, 2, EPI_LINEAR, false>(a, st))) return rc;
     hipLaunchKernelGGL(edge_max_fwd_kernel, dim3(ceil_div((int)((size_t)R * GC), 256)), dim3(256), 0, st, pq, nbr, scale, shift,
-                       (const float *)nullptr, 0, out, ld_out, arg, N, (size_t)R * GC, (float *)nullptr, (float *)nullptr);
+                       (const float *)nullptr, 0, out, ld_out, arg, N, (size_t)R * GC, (float *)nullptr, (float *)nullptr,
+                       (unsigned short *)nullptr);
     PSG_LAUNCH_CHECK();
     return PSG_OK;
 }
@@ -1155,12 +1058,15 @@ extern "C" int psg_gcn_forward(psg_gcn_model *m, psg_gcn_ws *ws, const float *x0
                 EvScope prof(&ws->prof, GT_VERTEX_GEMM, 2.0 * R * L.C * 2.0 * GC, st);
                 if ((rc = launch_gemm<2, 2, EPI_LINEAR, false>(a, st))) return rc;
             }
+            // the next block's kNN kernel decides which operand copies this kernel writes beside the features
+            const int next_path = (!ws->fixed_graphs && !dense && e + 1 < m->n_blocks)
+                                      ? knn_path(ws, GC, m->block == PSG_GCN_BLOCK_PLAIN ? 1 : e + 1) : -1;
             EvScope prof(&ws->prof, GT_EDGE_MAX, 0.0, st);
             hipLaunchKernelGGL(edge_max_fwd_kernel, dim3(g256), dim3(256), 0, st, ws->pq, nbr, L.scale, L.shift,
                                (e == 0 || !res) ? nullptr : xin, F, yout, F, ws->arg + (size_t)e * R * GC, N,
                                R * GC, (ws->fixed_graphs || dense) ? nullptr : ws->sq,
-                               (!ws->fixed_graphs && !dense && e + 1 < m->n_blocks &&
-                                knn_fused_ok(ws, GC, m->block == PSG_GCN_BLOCK_PLAIN ? 1 : e + 1)) ? ws->xp : nullptr);
+                               next_path >= 0 ? ws->xp : nullptr,
+                               next_path == KNN_PATH_BF16 ? (unsigned short *)ws->bp : nullptr);
             PSG_LAUNCH_CHECK();
         } else {
             // MRConv2d: BasicConv(cat[x, max_k (x_j - x_i)]) per vertex (+ x for a residual block)

@@ -363,6 +363,13 @@ class GCNWorkspace:
         _lib.call("psg_gcn_knn", self.handle, ptr(x), C, int(dilation), ptr(out), stream())
         return out
 
+    def knn_stats(self, reset=True):
+        """Counters of the bf16-prefilter kNN kernel (workspaces created under PSG_GCN_KNN_STATS=1): dict of tiles,
+        exact_tiles, rows, finalists, cuts, entries."""
+        buf = (ctypes.c_ulonglong * 8)()
+        _lib.call("psg_gcn_knn_stats", self.handle, buf, 1 if reset else 0)
+        return dict(zip(("tiles", "exact_tiles", "rows", "finalists", "cuts", "entries"), [int(v) for v in buf[:6]]))
+
     PROF_TAGS = ("knn_fused", "knn_other", "vertex_gemm", "edge_max", "fusion_prediction", "backward")
 
     def prof_enable(self, on=True):

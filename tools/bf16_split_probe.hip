@@ -1,0 +1,120 @@
+// Probe behind the error bound of the bf16 prefilter of the feature-space kNN (psg_knn_bf.cuh): how far is
+//     D~ = sq_i - 2 * [ (hi_i.hi_j + hi_i.lo_j + lo_i.hi_j) - sq_j / 2 ]      (13 v_mfma_f32_32x32x16_bf16, fp32 accumulate)
+// from the reference's fp32 distance D = (sq_i + (-2 z_ij)) + sq_j with z the ascending-k fmaf chain
+// (ResGCN/gcn_lib/dense/torch_edge.py:41-43), as a fraction of the room's largest squared norm?
+// The kernel uses C_ERR * sqmax as the bound; this prints the measured maximum per data set (random, offset clouds, wide
+// per-channel dynamic range, near-cancelling pairs, tiny and huge magnitudes) so the constant can be checked against hardware.
+// Build + run on the GPU box:  hipcc --offload-arch=gfx950 -O2 -ffp-contract=off tools/bf16_split_probe.hip -o /tmp/probe && /tmp/probe
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ unsigned short bf16_rne(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+union Frag { bf16x8 v; unsigned short s[8]; };
+
+// one wave per (candidate tile, query tile); x row-major [n][64], sq [n]; out[i_query][j_cand] = acc
+__global__ void probe_kernel(const float *x, const float *sq, int n, float *out)
+{
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int ct = blockIdx.x, qt = blockIdx.y;
+    Frag ah[4], al[4], qh[4], ql[4], aa, qa;
+    for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * s + 8 * h + j;
+            const float c = x[(size_t)(ct * 32 + r) * 64 + k], q = x[(size_t)(qt * 32 + r) * 64 + k];
+            const unsigned short chi = bf16_rne(c), qhi = bf16_rne(q);
+            ah[s].s[j] = chi; al[s].s[j] = bf16_rne(c - bf16_f(chi));
+            qh[s].s[j] = qhi; ql[s].s[j] = bf16_rne(q - bf16_f(qhi));
+        }
+    // augmented k-step: candidate side -(sq_j / 2) in three bf16 pieces, query side 1, 1, 1
+    const float hj = -0.5f * sq[ct * 32 + r];
+    const unsigned short p1 = bf16_rne(hj);
+    const float r1 = hj - bf16_f(p1);
+    const unsigned short p2 = bf16_rne(r1);
+    const unsigned short p3 = bf16_rne(r1 - bf16_f(p2));
+    for (int j = 0; j < 8; ++j) { aa.s[j] = 0; qa.s[j] = 0; }
+    if (h == 0) { aa.s[0] = p1; aa.s[1] = p2; aa.s[2] = p3; qa.s[0] = qa.s[1] = qa.s[2] = 0x3F80; }
+    f32x16 acc = {0};
+    for (int s = 0; s < 4; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s].v, qh[s].v, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s].v, ql[s].v, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s].v, qh[s].v, acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa.v, qa.v, acc, 0, 0, 0);
+    // D: col = lane & 31 (B = query), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (A = candidate)
+    for (int g = 0; g < 16; ++g) {
+        const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
+        out[(size_t)(qt * 32 + r) * n + ct * 32 + row] = acc[g];
+    }
+}
+
+static float sumsq_torch(const float *p)   // torch.sum(x*x, -1) for 64 contiguous floats (SURVEY 8a')
+{
+    float acc[4][8] = {};
+    for (int pass = 0; pass < 2; ++pass)
+        for (int jq = 0; jq < 4; ++jq)
+            for (int l = 0; l < 8; ++l) { const float v = p[32 * pass + 8 * jq + l]; acc[jq][l] = acc[jq][l] + v * v; }
+    float s = 0;
+    for (int l = 0; l < 8; ++l) { const float t = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l]; s = l ? s + t : t; }
+    return s;
+}
+
+int main()
+{
+    const int n = 1024;
+    std::mt19937 rng(1);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    std::uniform_real_distribution<float> ud(0.f, 1.f);
+    struct Set { const char *name; std::vector<float> x; };
+    std::vector<Set> sets;
+    auto mk = [&](const char *name, auto gen) { Set s; s.name = name; s.x.resize((size_t)n * 64); for (int i = 0; i < n; ++i) for (int k = 0; k < 64; ++k) s.x[(size_t)i * 64 + k] = gen(i, k); sets.push_back(std::move(s)); };
+    mk("gaussian", [&](int, int) { return nd(rng); });
+    mk("offset+10", [&](int, int) { return 10.f + nd(rng); });
+    std::vector<float> sc(64); for (auto &v : sc) v = std::pow(10.f, 6.f * ud(rng) - 3.f);
+    mk("channel scales 1e-3..1e3", [&](int, int k) { return sc[k] * nd(rng); });
+    std::vector<float> base(64); for (auto &v : base) v = nd(rng);
+    mk("near-cancelling (x_j ~ -x_i)", [&](int i, int k) { return ((i & 1) ? -1.f : 1.f) * base[k] * (1.f + 1e-3f * nd(rng)); });
+    mk("tiny 1e-15", [&](int, int) { return 1e-15f * nd(rng); });
+    mk("huge 1e15", [&](int, int) { return 1e15f * nd(rng); });
+    mk("relu-like sparse", [&](int, int) { const float v = nd(rng); return v > 0.5f ? v : 0.f; });
+    mk("row scales 1e-2..1e2", [&](int i, int) { return std::pow(10.f, 4.f * ((i * 37) % 101) / 100.f - 2.f) * nd(rng); });
+    float *dx, *dsq, *dout;
+    hipMalloc(&dx, (size_t)n * 64 * 4); hipMalloc(&dsq, n * 4); hipMalloc(&dout, (size_t)n * n * 4);
+    std::vector<float> out((size_t)n * n), sq(n);
+    for (auto &s : sets) {
+        float sqmax = 0;
+        for (int i = 0; i < n; ++i) { sq[i] = sumsq_torch(&s.x[(size_t)i * 64]); sqmax = std::fmax(sqmax, sq[i]); }
+        hipMemcpy(dx, s.x.data(), (size_t)n * 64 * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dsq, sq.data(), n * 4, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(probe_kernel, dim3(n / 32, n / 32), dim3(64), 0, 0, dx, dsq, n, dout);
+        hipMemcpy(out.data(), dout, (size_t)n * n * 4, hipMemcpyDeviceToHost);
+        double worst_d = 0, worst_acc = 0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                const float *a = &s.x[(size_t)i * 64], *b = &s.x[(size_t)j * 64];
+                float z = 0; double ze = 0, sabs = 0;
+                for (int k = 0; k < 64; ++k) { z = std::fmaf(a[k], b[k], z); ze += (double)a[k] * b[k]; sabs += std::fabs((double)a[k] * b[k]); }
+                const float D = (sq[i] + (-2.0f * z)) + sq[j];
+                const double acc = out[(size_t)i * n + j];
+                const double Dt = (double)sq[i] - 2.0 * acc;
+                worst_d = std::fmax(worst_d, std::fabs(Dt - (double)D) / sqmax);
+                worst_acc = std::fmax(worst_acc, std::fabs(acc - (ze - 0.5 * sq[j])) / (sabs + 0.5 * sq[j] + 1e-300));
+            }
+        printf("%-32s sqmax %.3e   max |D~ - D| / sqmax = 2^%.2f   max |acc - exact| / sum|terms| = 2^%.2f\n", s.name, sqmax,
+               std::log2(worst_d + 1e-300), std::log2(worst_acc + 1e-300));
+    }
+    return 0;
+}
