@@ -106,6 +106,14 @@ extern "C" int psg_dbg_knn_stamps(unsigned long long *host_out)
 }
 #endif
 #ifdef PSG_KF_TL
+extern "C" int psg_dbg_knn_ph(unsigned long long *host_out)      // [32], see g_kb_ph
+{
+    PSG_CHECK_HIP(hipDeviceSynchronize());
+    PSG_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_kb_ph), 32 * sizeof(unsigned long long)));
+    static unsigned long long zero[32];
+    PSG_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_kb_ph), zero, sizeof(zero)));
+    return PSG_OK;
+}
 extern "C" int psg_dbg_knn_tl(unsigned long long *host_out)      // [32], see g_kf_tl
 {
     PSG_CHECK_HIP(hipDeviceSynchronize());

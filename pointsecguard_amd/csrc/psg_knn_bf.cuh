@@ -63,6 +63,16 @@ typedef unsigned kb_u32x4 __attribute__((ext_vector_type(4)));     // one 16-byt
 #define KB_TL(idx)
 #endif
 
+#ifdef PSG_KF_TL
+__device__ unsigned long long g_kb_ph[32];      // phase cycle sums of the final ranking / cuts (wave 0 of every workgroup)
+#define KB_PH_BEGIN unsigned long long ph_t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_t0_) :: "memory")
+#define KB_PH(idx) do { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    if (threadIdx.x == 0) { atomicAdd(&g_kb_ph[(idx)], t_ - ph_t0_); atomicAdd(&g_kb_ph[16 + (idx)], 1ull); } ph_t0_ = t_; } while (0)
+#else
+#define KB_PH_BEGIN
+#define KB_PH(idx)
+#endif
+
 struct KnnBfArgs {
     const kb_u32x4 *bp;   // [rows / 32][9][64] fragments (psg_knn_ops.cuh)
     const float *sq;   // [rows]
@@ -90,267 +100,341 @@ __device__ __forceinline__ unsigned kb_wave_excl_scan_max(unsigned v, int lane)
     return lane ? up : 0u;
 }
 
-// ---- a row's entries binned by key: the machinery shared by the cuts and the final ranking.  1024 bins of 16 bits (512
-// words of the row's own LDS, which is scratch once the entries are in registers).  Bin 0 takes every key within 2 EK of the
-// smallest (the query itself, far below the rest in high dimensions: a linear map from the minimum would leave most bins
-// empty), bins 1..1023 are linear between the first key above that and the largest: a monotone map.
-struct KbBins { unsigned lowmax, k2; float scale; };
-
-template <int NV>
-__device__ __forceinline__ KbBins kb_bins_of_row(const unsigned (&v)[NV], unsigned T, int lane)
-{
-    unsigned kmn = 0xFFFFFFFFu, kmx = 0u;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const bool valid = (unsigned)(i * 64 + lane) < T;
-        const unsigned kq = v[i] >> 12;
-        kmn = (valid && kq < kmn) ? kq : kmn;
-        kmx = (valid && kq > kmx) ? kq : kmx;
-    }
-    kmn = ~wave_max_u32(~kmn);
-    kmx = wave_max_u32(kmx);
-    KbBins B;
-    B.lowmax = kmn + KB_MARGIN;
-    unsigned k2 = 0xFFFFFFFFu;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const bool valid = (unsigned)(i * 64 + lane) < T;
-        const unsigned kq = v[i] >> 12;
-        k2 = (valid && kq > B.lowmax && kq < k2) ? kq : k2;
-    }
-    k2 = ~wave_max_u32(~k2);
-    B.k2 = k2 == 0xFFFFFFFFu ? B.lowmax + 1u : k2;
-    const unsigned range = kmx > B.k2 ? kmx - B.k2 : 1u;
-    B.scale = 1022.0f / (float)range;
-    return B;
-}
-__device__ __forceinline__ unsigned kb_bin(const KbBins &B, unsigned ent)
-{
-    const unsigned kq = ent >> 12;
-    const unsigned b = 1u + (unsigned)((float)(kq - B.k2) * B.scale);       // (kq < k2 only when kq <= lowmax)
-    return kq <= B.lowmax ? 0u : (b > 1023u ? 1023u : b);
-}
-
-// counts of the 1024 bins -> hist; the lane's own 16 bins (16 lane .. 16 lane + 15) come back in wd, `start` = number of
-// entries in the bins before them; bn[i] = bin of entry i
-template <int NV>
-__device__ __forceinline__ void kb_histogram(const unsigned (&v)[NV], unsigned T, const KbBins &B, unsigned *hist, int lane,
-                                             unsigned (&bn)[NV], unsigned (&wd)[8], unsigned &start)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ((uint2 *)hist)[4 * lane + j] = make_uint2(0u, 0u);
-    wave_lds_fence();
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        bn[i] = kb_bin(B, v[i]);
-        if ((unsigned)(i * 64 + lane) < T) atomicAdd(&hist[bn[i] >> 1], 1u << (16 * (bn[i] & 1u)));
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const uint2 t = ((const uint2 *)hist)[4 * lane + j]; wd[2 * j] = t.x; wd[2 * j + 1] = t.y; }
-    unsigned tot = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) tot += (wd[j] & 0xFFFFu) + (wd[j] >> 16);
-    start = wave_incl_scan_u32(tot) - tot;
-}
-
-// Cut a row of T entries: the bin in which the cumulative count reaches KK gives thr = the largest key up to that bin
-// (KK <= #(keys <= thr) <= KK + that bin's population); every entry with key <= tauk = thr + 2 EK is kept, compacted in place.
-// One wave; returns the number kept.
-// (not inlined: with the cuts, the final ranking and the exact path inlined the kernel spilled inside its stream loop.  LDS
+// ---- cuts and final ranking of a row.  Both work on the row's entries in registers (element i of lane l = entry 64 i + l,
+// slots beyond T hold the sentinel 0xFFFFFFFF: real entries are below 2^31) and use the row's own LDS as scratch.
+// (Not inlined: with the cuts, the final ranking and the exact path inlined the kernel spilled inside its stream loop.  LDS
 // locations travel as dword offsets into the workgroup's dynamic LDS, so that every access stays a ds_ instruction: a
-// pointer parameter would be a generic pointer and turn them into flat_ accesses)
-template <int NV>
-__device__ __noinline__ unsigned kb_cut_row(unsigned row_dw, unsigned T, unsigned KK, int lane, unsigned &tauk_out)
+// pointer parameter would be a generic pointer and turn them into flat_ accesses.)
+
+// Cut R rows (one wave; R = 2: the wave's two rows side by side, two independent dependency chains for the scheduler: these
+// phases are bound by DPP / LDS latency, not by issue).  Per row: the first entry value above the smallest key's 2 EK
+// neighbourhood (the query itself sits far below the rest in high dimensions) starts 256 linear bins of 32-bit counters,
+// everything below goes to bin 0; the bin in which the cumulative count reaches KK gives thr with #(entries <= thr) >= KK;
+// every entry with key <= tauk = key(thr) + 2 EK (+ 2 for the float bin edges) is kept, compacted in place.  Lane 0 stores
+// the new count and the admission threshold on acc of each row.
+struct KbCutArgs { unsigned row_dw, T[2], KK, cnt_dw, thr_dw; float ci[2], half_unit; };
+
+template <int NV, int R>
+__device__ __noinline__ void kb_cut_rows(const KbCutArgs c, int lane)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char kb_smem[];
-    unsigned *row = (unsigned *)kb_smem + row_dw;
-    unsigned v[NV], bn[NV], wd[8], start;
+    unsigned *row[R];
+    unsigned v[R][NV], mn[R], mx1[R];
+    KB_PH_BEGIN;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const unsigned e = (unsigned)(i * 64 + lane);
-        v[i] = e < T ? row[e] : 0xFFFFFFFFu;
-    }
-    wave_lds_fence();
-    const KbBins B = kb_bins_of_row<NV>(v, T, lane);
-    kb_histogram<NV>(v, T, B, row, lane, bn, wd, start);
-    unsigned s = start, tb = 0xFFFFu;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const unsigned h = (wd[t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
-        if (s < KK && KK <= s + h) tb = (unsigned)(16 * lane + t);
-        s += h;
-    }
-    const unsigned binB = ~wave_max_u32(~tb);                 // exactly one lane holds the crossing bin (KK <= T)
-    unsigned kth = 0u;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const unsigned kq = v[i] >> 12;
-        kth = ((unsigned)(i * 64 + lane) < T && bn[i] <= binB && kq > kth) ? kq : kth;
-    }
-    kth = wave_max_u32(kth);
-    unsigned tauk = kth + KB_MARGIN;
-    tauk = tauk > 0xFFFFEu ? 0xFFFFEu : tauk;
-    const unsigned keepmax = (tauk << 12) | 0xFFFu;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    unsigned base = 0;
-    wave_lds_fence();
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const bool keep = (unsigned)(i * 64 + lane) < T && v[i] <= keepmax;
-        const unsigned long long bl = __ballot(keep);
-        if (keep) row[base + __popcll(bl & lt_mask)] = v[i];
-        base += (unsigned)__popcll(bl);
-    }
-    tauk_out = tauk;
-    return base;
-}
-
-// Exact ranks 0, d, .., (k-1) d of one row from its T >= KK approximate entries (see the header).  `row` = the row's LDS
-// (entries on entry, scratch afterwards: 512 words of 16-bit bins + 256 finalists); qbuf = 64 floats of wave-private LDS.
-// Returns the number of finalists, or 0xFFFFFFFF when the row must take the exact path.  One wave.
-struct KbFinalArgs {          // by value: a reference to the kernel's argument struct would force it (and every pointer in it) through the stack
-    const float *xp, *sq;
-    unsigned k, d, magic;
-};
-
-template <int NV>
-__device__ __noinline__ unsigned kb_final_row(unsigned row_dw, unsigned T, const KbFinalArgs a, size_t room_row0, size_t qglob,
-                                              float sqi, unsigned qbuf_dw, int32_t *out, int lane)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char kb_smem[];
-    unsigned *row = (unsigned *)kb_smem + row_dw;
-    float *qbuf = (float *)kb_smem + qbuf_dw;
-    unsigned v[NV], bn[NV], wd[8], start;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const unsigned e = (unsigned)(i * 64 + lane);
-        v[i] = e < T ? row[e] : 0xFFFFFFFFu;
-    }
-    // the query's 64 features in k order for the exact chains (feature k = 16 i + 4 e + g: element e of float4 [i][g])
-    {
-        const float *xq = a.xp + ((qglob >> 4) * 256 + (qglob & 15)) * 4;
-        qbuf[lane] = xq[((lane >> 4) * 64 + 16 * (lane & 3)) * 4 + ((lane >> 2) & 3)];
-    }
-    wave_lds_fence();
-    const KbBins B = kb_bins_of_row<NV>(v, T, lane);
-    const unsigned w = (unsigned)((float)KB_MARGIN * B.scale) + 2u;          // window half width in bins
-    unsigned *hist = row;
-    unsigned long long *fin = (unsigned long long *)(row + 512);
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    unsigned F = 0;
-    if (w > 15u) {
-        // the kept keys span only a few error margins: every entry is a finalist of one run
-        if (T > (unsigned)KB_MAXFIN) return 0xFFFFFFFFu;
+    for (int rw = 0; rw < R; ++rw) {
+        row[rw] = (unsigned *)kb_smem + c.row_dw + rw * KB_WAVES * KB_ROW;
+        mn[rw] = 0xFFFFFFFFu; mx1[rw] = 0u;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const unsigned e = (unsigned)(i * 64 + lane);
-            if (e < T) fin[e] = (unsigned long long)v[i];
+            const unsigned x = row[rw][e];
+            v[rw][i] = e < c.T[rw] ? x : 0xFFFFFFFFu;
+            mn[rw] = v[rw][i] < mn[rw] ? v[rw][i] : mn[rw];
+            mx1[rw] = v[rw][i] + 1u > mx1[rw] ? v[rw][i] + 1u : mx1[rw];          // (the sentinel wraps to 0)
         }
-        F = T;
-    } else {
-        kb_histogram<NV>(v, T, B, hist, lane, bn, wd, start);
-        const unsigned d = a.d, last = (a.k - 1u) * d;
-        unsigned core = 0, s = start;
+    }
+    wave_lds_fence();
+    KB_PH(0);
+    unsigned lowE[R], mn2[R];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const unsigned h = (wd[t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
-            const unsigned m = (((s + d - 1u) * a.magic) >> 18) * d;              // first multiple of d >= s
-            if (h && m < s + h && m <= last) core |= 1u << t;
-            s += h;
-        }
-        // dilate the core bins by w (< 16: the neighbours' masks suffice), then find the runs
-        const unsigned prevc = lane ? (unsigned)__shfl_up((int)core, 1) : 0u;
-        const unsigned nextc = lane < 63 ? (unsigned)__shfl_down((int)core, 1) : 0u;
-        const unsigned long long W = (unsigned long long)prevc | ((unsigned long long)core << 16) | ((unsigned long long)nextc << 32);
-        unsigned long long D = W;
-        for (unsigned sh = 1; sh <= w; ++sh) D |= (W << sh) | (W >> sh);
-        const unsigned flg = (unsigned)(D >> 16) & 0xFFFFu;
-        const unsigned pf = lane ? (((unsigned)__shfl_up((int)flg, 1) >> 15) & 1u) : 0u;
-        const unsigned rb = flg & ~((flg << 1) | pf) & 0xFFFFu;                   // bins that begin a run
-        unsigned lastp = 0;
-        s = start;
+    for (int rw = 0; rw < R; ++rw) {
+        mn[rw] = ~wave_max_u32(~mn[rw]);
+        lowE[rw] = (((mn[rw] >> 12) + KB_MARGIN) << 12) | 0xFFFu;               // entries up to here: bin 0
+        mn2[rw] = 0xFFFFFFFFu;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            if ((rb >> t) & 1u) lastp = ((unsigned)(16 * lane + t + 1) << 16) | s;
-            s += (wd[t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
-        }
-        unsigned cur = kb_wave_excl_scan_max(lastp, lane);                        // the run begin in force at the lane's first bin
-        s = start;
-        unsigned nw[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        for (int i = 0; i < NV; ++i) mn2[rw] = (v[rw][i] > lowE[rw] && v[rw][i] < mn2[rw]) ? v[rw][i] : mn2[rw];
+    }
+    float scale[R], inv_scale[R];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            if ((rb >> t) & 1u) cur = ((unsigned)(16 * lane + t + 1) << 16) | s;
-            if ((flg >> t) & 1u) nw[t >> 1] |= (0x8000u | (cur & 0x7FFFu)) << (16 * (t & 1));   // flagged: first rank of its run
-            s += (wd[t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
-        }
+    for (int rw = 0; rw < R; ++rw) {
+        const unsigned mx = wave_max_u32(mx1[rw]) - 1u;
+        mn2[rw] = ~wave_max_u32(~mn2[rw]);                                      // 0xFFFFFFFF (sentinel or none): one bin
+        mn2[rw] = mn2[rw] > mx ? mx : mn2[rw];
+        const float span = (float)(mx - mn2[rw] + 1u);
+        scale[rw] = 254.0f / span; inv_scale[rw] = span * (1.0f / 254.0f);
+        // 256 counters; the lane owns bins 4 lane .. 4 lane + 3
+        ((uint2 *)row[rw])[2 * lane] = make_uint2(0u, 0u);
+        ((uint2 *)row[rw])[2 * lane + 1] = make_uint2(0u, 0u);
+    }
+    wave_lds_fence();
+    KB_PH(1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ((uint2 *)hist)[4 * lane + j] = make_uint2(nw[2 * j], nw[2 * j + 1]);
-        wave_lds_fence();
+    for (int rw = 0; rw < R; ++rw)
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const bool valid = (unsigned)(i * 64 + lane) < T;
-            const unsigned hw = (hist[bn[i] >> 1] >> (16 * (bn[i] & 1u))) & 0xFFFFu;
-            const bool take = valid && (hw & 0x8000u);
+            unsigned bb = 1u + (unsigned)((float)(v[rw][i] - mn2[rw]) * scale[rw]);   // (sentinels land in bin 255 and are taken out below)
+            bb = v[rw][i] <= lowE[rw] ? 0u : (bb > 255u ? 255u : bb);
+            atomicAdd(&row[rw][bb], 1u);
+        }
+    wave_lds_fence();
+    KB_PH(2);
+    unsigned keepmax[R];
+#pragma unroll
+    for (int rw = 0; rw < R; ++rw) {
+        const uint2 ca = ((const uint2 *)row[rw])[2 * lane], cb = ((const uint2 *)row[rw])[2 * lane + 1];
+        const unsigned c3 = cb.y - (lane == 63 ? (unsigned)(NV * 64) - c.T[rw] : 0u);
+        const unsigned tot = ca.x + ca.y + cb.x + c3;
+        const unsigned incl = wave_incl_scan_u32(tot), start = incl - tot;
+        const unsigned s0 = start + ca.x, s1 = s0 + ca.y, s2 = s1 + cb.x;
+        const unsigned mybin = (unsigned)(4 * lane) + (s0 < c.KK ? 1u : 0u) + (s1 < c.KK ? 1u : 0u) + (s2 < c.KK ? 1u : 0u);
+        const unsigned long long own = __ballot(start < c.KK && c.KK <= incl);          // exactly one lane (KK <= T)
+        const unsigned binB = (unsigned)__builtin_amdgcn_readlane((int)mybin, (int)__builtin_ctzll(own));
+        // an entry of a bin <= binB (>= 1) has 1 + (v - mn2) * scale < binB + 1 in float: v - mn2 < binB / scale * (1 + 2^-22),
+        // less than one key above; key(thr) + 2 covers that and the floor of the shift
+        const unsigned X = binB ? mn2[rw] + (unsigned)((float)binB * inv_scale[rw]) : lowE[rw];
+        unsigned tauk = (X >> 12) + 2u + KB_MARGIN;
+        tauk = tauk > 0xFFFFEu ? 0xFFFFEu : tauk;
+        keepmax[rw] = (tauk << 12) | 0xFFFu;
+        // admit iff key <= tauk, i.e. acc * m2 + ci < tauk + 1; two more units cover the float evaluation
+        if (lane == 0) ((float *)kb_smem)[c.thr_dw + rw * KB_WAVES] = (c.ci[rw] - (float)(tauk + 3u)) * c.half_unit;
+    }
+    KB_PH(3);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned base[R];
+#pragma unroll
+    for (int rw = 0; rw < R; ++rw) base[rw] = 0u;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int rw = 0; rw < R; ++rw) {
+            const bool keep = v[rw][i] <= keepmax[rw];                  // (sentinels are above any keepmax)
+            const unsigned long long bl = __ballot(keep);
+            if (keep) row[rw][base[rw] + __popcll(bl & lt_mask)] = v[rw][i];
+            base[rw] += (unsigned)__popcll(bl);
+        }
+    if (lane == 0) {
+#pragma unroll
+        for (int rw = 0; rw < R; ++rw) ((unsigned *)kb_smem)[c.cnt_dw + rw * KB_WAVES] = base[rw];
+    }
+    KB_PH(4);
+}
+
+// Exact ranks 0, d, .., (k-1) d of R rows (the wave's two, side by side like the cuts) from their T >= KK approximate
+// entries (see the header).  Row LDS: 1024 bins of 16 bits (counts, then first ranks) + 256 finalists; scr = 96 words of
+// wave-private LDS per row (the query's 64 features, 32 words of flagged-bin bitmap).  Bin 0 takes every key within 2 EK of
+// the smallest, bins 1.. have a power-of-two width over the keys above that: exact integer edges, so a window is
+// w = ceil(2 EK / width) bins to each side.  Returns the number of finalists, or 0xFFFFFFFF when a row must take the exact
+// path.
+struct KbFinalArgs {          // by value: a reference to the kernel's argument struct would force it (and every pointer in it) through the stack
+    const float *xp, *sq;
+    int32_t *out;             // the first row's output; the second row's is 16 k further
+    size_t room_row0, qglob;  // global row of the room's first point and of the first row's query (second: + 16)
+    unsigned row_dw, scr_dw, T[2], k, d, magic;
+    float sqi[2];
+};
+
+template <int NV, int R>
+__device__ __noinline__ unsigned kb_final_rows(const KbFinalArgs a, int lane)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char kb_smem[];
+    unsigned *row[R], *bitmap[R];
+    float *qbuf[R];
+    unsigned v[R][NV], bn[R][NV], mn[R], mx1[R];
+    KB_PH_BEGIN;
+#pragma unroll
+    for (int rw = 0; rw < R; ++rw) {
+        row[rw] = (unsigned *)kb_smem + a.row_dw + rw * KB_WAVES * KB_ROW;
+        qbuf[rw] = (float *)kb_smem + a.scr_dw + rw * 96;
+        bitmap[rw] = (unsigned *)kb_smem + a.scr_dw + rw * 96 + 64;
+        mn[rw] = 0xFFFFFFFFu; mx1[rw] = 0u;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const unsigned e = (unsigned)(i * 64 + lane);
+            const unsigned x = row[rw][e];
+            v[rw][i] = e < a.T[rw] ? x : 0xFFFFFFFFu;
+            mn[rw] = v[rw][i] < mn[rw] ? v[rw][i] : mn[rw];
+            mx1[rw] = v[rw][i] + 1u > mx1[rw] ? v[rw][i] + 1u : mx1[rw];
+        }
+        // the query's 64 features in k order for the exact chains (feature k = 16 i + 4 e + g: element e of float4 [i][g])
+        const size_t qg = a.qglob + (size_t)(rw * KB_WAVES);
+        const float *xq = a.xp + ((qg >> 4) * 256 + (qg & 15)) * 4;
+        qbuf[rw][lane] = xq[((lane >> 4) * 64 + 16 * (lane & 3)) * 4 + ((lane >> 2) & 3)];
+        if (lane < 32) bitmap[rw][lane] = 0u;
+    }
+    wave_lds_fence();
+    KB_PH(5);
+    unsigned kmx[R], lowmax[R], k2[R];
+#pragma unroll
+    for (int rw = 0; rw < R; ++rw) {
+        lowmax[rw] = ((~wave_max_u32(~mn[rw])) >> 12) + KB_MARGIN;
+        k2[rw] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const unsigned kq = v[rw][i] >> 12;
+            k2[rw] = (kq > lowmax[rw] && kq < k2[rw]) ? kq : k2[rw];          // (a sentinel's key 0xFFFFF is above every real key)
+        }
+    }
+    unsigned sh[R], w[R], c0[R], low_ent[R];
+#pragma unroll
+    for (int rw = 0; rw < R; ++rw) {
+        kmx[rw] = (wave_max_u32(mx1[rw]) - 1u) >> 12;
+        k2[rw] = ~wave_max_u32(~k2[rw]);
+        const unsigned range = (k2[rw] <= kmx[rw]) ? kmx[rw] - k2[rw] : 0u;
+        unsigned s = range > 1022u ? (unsigned)(32 - __builtin_clz(range)) - 10u : 0u;
+        if ((range >> s) > 1022u) ++s;                              // bins 1 .. 1 + (range >> s) <= 1023
+        sh[rw] = s;
+        w[rw] = (KB_MARGIN + (1u << s) - 1u) >> s;                  // window half width in bins (<= 2 EK = 20)
+        c0[rw] = ((1u << s) - k2[rw]) << 12;                        // bin = (v + c0) >> (12 + s) above lowmax
+        low_ent[rw] = (lowmax[rw] << 12) | 0xFFFu;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ((uint2 *)row[rw])[4 * lane + j] = make_uint2(0u, 0u);
+    }
+    wave_lds_fence();
+    KB_PH(6);
+#pragma unroll
+    for (int rw = 0; rw < R; ++rw)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            unsigned bb = (v[rw][i] + c0[rw]) >> (12u + sh[rw]);
+            bb = v[rw][i] <= low_ent[rw] ? 0u : (bb > 1023u ? 1023u : bb);   // (sentinels: bin 1023, taken out below)
+            bn[rw][i] = bb;
+            atomicAdd(&row[rw][bb >> 1], 1u + (bb & 1u) * 0xFFFFu);
+        }
+    wave_lds_fence();
+    KB_PH(7);
+    // the lane's own 16 bins (16 lane .. 16 lane + 15) -> the number of entries below each bin, written back in place
+#pragma unroll
+    for (int rw = 0; rw < R; ++rw) {
+        unsigned wd[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint2 t = ((const uint2 *)row[rw])[4 * lane + j]; wd[2 * j] = t.x; wd[2 * j + 1] = t.y; }
+        if (lane == 63) wd[7] -= ((unsigned)(NV * 64) - a.T[rw]) << 16;
+        unsigned tot = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tot += (wd[j] & 0xFFFFu) + (wd[j] >> 16);
+        unsigned s = wave_incl_scan_u32(tot) - tot;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned lo = wd[j] & 0xFFFFu, hi = wd[j] >> 16;
+            wd[j] = s | ((s + lo) << 16);
+            s += lo + hi;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ((uint2 *)row[rw])[4 * lane + j] = make_uint2(wd[2 * j], wd[2 * j + 1]);
+    }
+    wave_lds_fence();
+    KB_PH(8);
+    // lane j < k: the bin that holds approximate rank j d = the last bin with at most j d entries below it; flag its window
+    if (lane < (int)a.k) {
+        const unsigned m = (unsigned)lane * a.d;
+        unsigned lo[R], hi[R];
+#pragma unroll
+        for (int rw = 0; rw < R; ++rw) { lo[rw] = 0u; hi[rw] = 1023u; }
+#pragma unroll 1
+        for (int it = 0; it < 10; ++it)
+#pragma unroll
+            for (int rw = 0; rw < R; ++rw) {
+                const unsigned mid = (lo[rw] + hi[rw] + 1u) >> 1;
+                const bool le = (unsigned)((const unsigned short *)row[rw])[mid] <= m;
+                lo[rw] = le ? mid : lo[rw];
+                hi[rw] = le ? hi[rw] : mid - 1u;
+            }
+#pragma unroll
+        for (int rw = 0; rw < R; ++rw) {
+            const unsigned L = lo[rw] > w[rw] ? lo[rw] - w[rw] : 0u, H = lo[rw] + w[rw] < 1023u ? lo[rw] + w[rw] : 1023u;
+            for (unsigned wi = L >> 5; wi <= (H >> 5); ++wi) {
+                const unsigned first = wi == (L >> 5) ? (L & 31u) : 0u, lastb = wi == (H >> 5) ? (H & 31u) : 31u;
+                atomicOr(&bitmap[rw][wi], (0xFFFFFFFFu >> (31u - lastb)) & (0xFFFFFFFFu << first));
+            }
+        }
+    }
+    wave_lds_fence();
+    KB_PH(9);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned F[R];
+#pragma unroll
+    for (int rw = 0; rw < R; ++rw) F[rw] = 0u;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int rw = 0; rw < R; ++rw) {
+            unsigned long long *fin = (unsigned long long *)(row[rw] + 512);
+            const bool take = ((bitmap[rw][bn[rw][i] >> 5] >> (bn[rw][i] & 31u)) & 1u) && (int)v[rw][i] >= 0;
             const unsigned long long bl = __ballot(take);
-            const unsigned pos = F + (unsigned)__popcll(bl & lt_mask);
-            if (take && pos < (unsigned)KB_MAXFIN) fin[pos] = ((unsigned long long)(hw & 0x7FFFu) << 44) | (unsigned long long)v[i];
-            F += (unsigned)__popcll(bl);
+            const unsigned pos = F[rw] + (unsigned)__popcll(bl & lt_mask);
+            if (take && pos < (unsigned)KB_MAXFIN) fin[pos] = (unsigned long long)v[rw][i];
+            F[rw] += (unsigned)__popcll(bl);
         }
-    }
     wave_lds_fence();
-    if (F > (unsigned)KB_MAXFIN) return 0xFFFFFFFFu;
+    KB_PH(10);
+    unsigned Fmax = 0, Fsum = 0;
+#pragma unroll
+    for (int rw = 0; rw < R; ++rw) { Fmax = F[rw] > Fmax ? F[rw] : Fmax; Fsum += F[rw]; }
+    if (Fmax > (unsigned)KB_MAXFIN) return 0xFFFFFFFFu;
     const float4 *xp4 = (const float4 *)a.xp;
-    const float4 *q4 = (const float4 *)qbuf;
     const unsigned long long m44 = (1ull << 44) - 1ull;
-    for (unsigned f0 = 0; f0 < F; f0 += 64) {
+    for (unsigned f0 = 0; f0 < Fmax; f0 += 64) {
         const unsigned f = f0 + (unsigned)lane;
-        const unsigned long long x = f < F ? fin[f] : 0ull;
-        const unsigned idx = (unsigned)x & 0xFFFu;
-        const size_t vc = room_row0 + idx;
-        const float4 *pc = xp4 + (vc >> 4) * 256 + (vc & 15);
-        float4 C[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) C[j] = pc[(j >> 2) * 64 + 16 * (j & 3)];
-        const float sqj = a.sq[vc];
-        // ascending-k fmaf chain from 0 (k = 16 i + 4 e + g), the exact kernel's arithmetic
-        float z = 0.0f;
+        for (int rw = 0; rw < R; ++rw) {
+            unsigned long long *fin = (unsigned long long *)(row[rw] + 512);
+            const float4 *q4 = (const float4 *)qbuf[rw];
+            const unsigned ent = f < F[rw] ? (unsigned)fin[f] : 0u;
+            const unsigned idx = ent & 0xFFFu;
+            const size_t vc = a.room_row0 + idx;
+            const float4 *pc = xp4 + (vc >> 4) * 256 + (vc & 15);
+            float4 C[16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 qa = q4[4 * i], qb = q4[4 * i + 1], qc = q4[4 * i + 2], qd = q4[4 * i + 3];
-            z = __fmaf_rn(qa.x, C[4 * i].x, z); z = __fmaf_rn(qa.y, C[4 * i + 1].x, z); z = __fmaf_rn(qa.z, C[4 * i + 2].x, z); z = __fmaf_rn(qa.w, C[4 * i + 3].x, z);
-            z = __fmaf_rn(qb.x, C[4 * i].y, z); z = __fmaf_rn(qb.y, C[4 * i + 1].y, z); z = __fmaf_rn(qb.z, C[4 * i + 2].y, z); z = __fmaf_rn(qb.w, C[4 * i + 3].y, z);
-            z = __fmaf_rn(qc.x, C[4 * i].z, z); z = __fmaf_rn(qc.y, C[4 * i + 1].z, z); z = __fmaf_rn(qc.z, C[4 * i + 2].z, z); z = __fmaf_rn(qc.w, C[4 * i + 3].z, z);
-            z = __fmaf_rn(qd.x, C[4 * i].w, z); z = __fmaf_rn(qd.y, C[4 * i + 1].w, z); z = __fmaf_rn(qd.z, C[4 * i + 2].w, z); z = __fmaf_rn(qd.w, C[4 * i + 3].w, z);
+            for (int j = 0; j < 16; ++j) C[j] = pc[(j >> 2) * 64 + 16 * (j & 3)];
+            const float sqj = a.sq[vc];
+            // first rank of the finalist's run = entries below the first bin of the unbroken stretch of flagged bins it sits in
+            unsigned bb = (ent + c0[rw]) >> (12u + sh[rw]);
+            bb = ent <= low_ent[rw] ? 0u : (bb > 1023u ? 1023u : bb);
+            int wi = (int)(bb >> 5);
+            unsigned zeros = ~bitmap[rw][wi] & (0xFFFFFFFFu >> (31u - (bb & 31u)));      // unflagged bins at or below bb in its word
+            while (__ballot(zeros == 0u && wi > 0) != 0ull) {
+                if (zeros == 0u && wi > 0) { --wi; zeros = ~bitmap[rw][wi]; }
+            }
+            const unsigned b0 = zeros ? (unsigned)(wi * 32 + 32 - __builtin_clz(zeros)) : 0u;
+            const unsigned long long tag = (unsigned long long)((const unsigned short *)row[rw])[b0] << 44;
+            // ascending-k fmaf chain from 0 (k = 16 i + 4 e + g), the exact kernel's arithmetic
+            float z = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 qa = q4[4 * i], qb = q4[4 * i + 1], qc = q4[4 * i + 2], qd = q4[4 * i + 3];
+                z = __fmaf_rn(qa.x, C[4 * i].x, z); z = __fmaf_rn(qa.y, C[4 * i + 1].x, z); z = __fmaf_rn(qa.z, C[4 * i + 2].x, z); z = __fmaf_rn(qa.w, C[4 * i + 3].x, z);
+                z = __fmaf_rn(qb.x, C[4 * i].y, z); z = __fmaf_rn(qb.y, C[4 * i + 1].y, z); z = __fmaf_rn(qb.z, C[4 * i + 2].y, z); z = __fmaf_rn(qb.w, C[4 * i + 3].y, z);
+                z = __fmaf_rn(qc.x, C[4 * i].z, z); z = __fmaf_rn(qc.y, C[4 * i + 1].z, z); z = __fmaf_rn(qc.z, C[4 * i + 2].z, z); z = __fmaf_rn(qc.w, C[4 * i + 3].z, z);
+                z = __fmaf_rn(qd.x, C[4 * i].w, z); z = __fmaf_rn(qd.y, C[4 * i + 1].w, z); z = __fmaf_rn(qd.z, C[4 * i + 2].w, z); z = __fmaf_rn(qd.w, C[4 * i + 3].w, z);
+            }
+            // (|x_i|^2 + (-2 x_i.x_j)) + |x_j|^2, torch_edge.py:41-43, as in the exact kernel
+            const float dd = __fadd_rn(__fmaf_rn(-2.0f, z, a.sqi[rw]), sqj);
+            if (f < F[rw]) fin[f] = tag | ((unsigned long long)key_of(dd) << 12) | (unsigned long long)idx;
         }
-        // (|x_i|^2 + (-2 x_i.x_j)) + |x_j|^2, torch_edge.py:41-43, as in the exact kernel
-        const float dd = __fadd_rn(__fmaf_rn(-2.0f, z, sqi), sqj);
-        if (f < F) fin[f] = (x & ~m44) | ((unsigned long long)key_of(dd) << 12) | (unsigned long long)idx;
     }
     wave_lds_fence();
+    KB_PH(11);
     const unsigned d = a.d;
-    for (unsigned f0 = 0; f0 < F; f0 += 64) {
+    for (unsigned f0 = 0; f0 < Fmax; f0 += 64) {
         const unsigned f = f0 + (unsigned)lane;
-        const unsigned long long x = f < F ? fin[f] : ~0ull;
-        const unsigned long long xlo = x & ~m44;              // the smallest value of x's run
+        unsigned long long x[R], xlo[R];
+        unsigned below[R], below_run[R];
+#pragma unroll
+        for (int rw = 0; rw < R; ++rw) {
+            const unsigned long long *fin = (const unsigned long long *)(row[rw] + 512);
+            x[rw] = f < F[rw] ? fin[f] : ~0ull;
+            xlo[rw] = x[rw] & ~m44;                             // the smallest value of x's run
+            below[rw] = 0u; below_run[rw] = 0u;
+        }
         // rank = first rank of the run + (finalists below x) - (finalists below the run)
-        unsigned below = 0, below_run = 0;
-        unsigned g = 0;
-        for (; g + 4 <= F; g += 4) {
-            const unsigned long long y0 = fin[g], y1 = fin[g + 1], y2 = fin[g + 2], y3 = fin[g + 3];
-            below += (y0 < x ? 1u : 0u) + (y1 < x ? 1u : 0u) + (y2 < x ? 1u : 0u) + (y3 < x ? 1u : 0u);
-            below_run += (y0 < xlo ? 1u : 0u) + (y1 < xlo ? 1u : 0u) + (y2 < xlo ? 1u : 0u) + (y3 < xlo ? 1u : 0u);
+        for (unsigned g = 0; g < Fmax; g += 2)
+#pragma unroll
+            for (int rw = 0; rw < R; ++rw) {
+                const unsigned long long *fin = (const unsigned long long *)(row[rw] + 512);
+                const unsigned long long y0 = g < F[rw] ? fin[g] : ~0ull, y1 = g + 1 < F[rw] ? fin[g + 1] : ~0ull;
+                below[rw] += (y0 < x[rw] ? 1u : 0u) + (y1 < x[rw] ? 1u : 0u);
+                below_run[rw] += (y0 < xlo[rw] ? 1u : 0u) + (y1 < xlo[rw] ? 1u : 0u);
+            }
+#pragma unroll
+        for (int rw = 0; rw < R; ++rw) {
+            const unsigned rank = (unsigned)(x[rw] >> 44) + below[rw] - below_run[rw];
+            const unsigned t = (rank * a.magic) >> 18;
+            if (f < F[rw] && t * d == rank && t < a.k) a.out[(size_t)(rw * KB_WAVES) * a.k + t] = (int32_t)(x[rw] & 0xFFFull);
         }
-        for (; g < F; ++g) {
-            const unsigned long long y = fin[g];
-            below += y < x ? 1u : 0u;
-            below_run += y < xlo ? 1u : 0u;
-        }
-        const unsigned rank = (unsigned)(x >> 44) + below - below_run;
-        const unsigned t = (rank * a.magic) >> 18;
-        if (f < F && t * d == rank && t < a.k) out[t] = (int32_t)(x & 0xFFFull);
     }
-    return F;
+    KB_PH(12);
+    return Fsum;
 }
 
 __global__ __launch_bounds__(KB_WAVES * 64) void knn_bf_kernel(KnnBfArgs a)
@@ -362,8 +446,8 @@ __global__ __launch_bounds__(KB_WAVES * 64) void knn_bf_kernel(KnnBfArgs a)
     float *thr_f = (float *)(ent + KB_Q * ROW);               // [KB_Q] admission threshold on acc
     unsigned *cnt = (unsigned *)(thr_f + KB_Q);               // [KB_Q]
     float *csq = (float *)(cnt + KB_Q);                       // [KB_Q] |x_i|^2 of the tile's queries
-    float *qbuf = csq + KB_Q + 64 * (threadIdx.x >> 6);       // [KB_WAVES][64] a row's query features during its final ranking
-    unsigned *smax = (unsigned *)(csq + KB_Q + 64 * KB_WAVES);   // [KB_WAVES]
+    float *scr = csq + KB_Q + 192 * (threadIdx.x >> 6);       // [KB_WAVES][2][96] per wave and row: the query's features + flagged-bin bitmap (final ranking)
+    unsigned *smax = (unsigned *)(csq + KB_Q + 192 * KB_WAVES);  // [KB_WAVES]
     unsigned *fail = smax + KB_WAVES;                         // [4] (one used)
     unsigned *sink = fail + 4 + threadIdx.x;                  // [KB_WAVES * 64] one word per thread: entries that fail the test
 
@@ -473,19 +557,22 @@ __global__ __launch_bounds__(KB_WAVES * 64) void knn_bf_kernel(KnnBfArgs a)
                 // (every wave sees the same counters here: a row is only cut by waves that saw no overflow, and an
                 // overflowing counter stays above CAP)
                 if (__ballot(lane < KB_Q && cnt[lane & (KB_Q - 1)] > (unsigned)CAP) != 0ull) { need_exact = true; break; }
-                for (int rr = wave; rr < KB_Q; rr += KB_WAVES) {
-                    const unsigned T = cnt[rr];
-                    if (T > (unsigned)a.LOW) {
-                        unsigned tauk;
-                        const unsigned c = T <= 512u ? kb_cut_row<8>((unsigned)(rr * ROW), T, KK, lane, tauk)
-                                                     : kb_cut_row<KB_NPL>((unsigned)(rr * ROW), T, KK, lane, tauk);
-                        // admit iff key <= tauk, i.e. acc * m2 + ci < tauk + 1; two more units cover the float evaluation
-                        if (lane == 0) {
-                            cnt[rr] = c;
-                            thr_f[rr] = (__fmaf_rn(csq[rr], inv_unit, KB_OFF) - (float)(tauk + 3u)) * half_unit;
-                        }
-                        ++st_cut;
-                    }
+                {
+                    // the wave's two rows (wave, wave + 16) side by side when both are due, else the one that is
+                    const unsigned T0 = cnt[wave], T1 = cnt[wave + KB_WAVES];
+                    const bool c0 = T0 > (unsigned)a.LOW, c1 = T1 > (unsigned)a.LOW;
+                    KbCutArgs ca;
+                    ca.KK = KK; ca.half_unit = half_unit;
+                    const int first = c0 ? 0 : 1;
+                    ca.row_dw = (unsigned)((wave + first * KB_WAVES) * ROW);
+                    ca.cnt_dw = (unsigned)(cnt - (unsigned *)kb_smem) + (unsigned)(wave + first * KB_WAVES);
+                    ca.thr_dw = (unsigned)(thr_f - (float *)kb_smem) + (unsigned)(wave + first * KB_WAVES);
+                    ca.T[0] = c0 ? T0 : T1; ca.T[1] = T1;
+                    ca.ci[0] = __fmaf_rn(csq[wave + first * KB_WAVES], inv_unit, KB_OFF);
+                    ca.ci[1] = __fmaf_rn(csq[wave + KB_WAVES], inv_unit, KB_OFF);
+                    const unsigned Tm = c0 && c1 ? (T0 > T1 ? T0 : T1) : ca.T[0];
+                    if (c0 && c1) { if (Tm <= 512u) kb_cut_rows<8, 2>(ca, lane); else kb_cut_rows<KB_NPL, 2>(ca, lane); st_cut += 2; }
+                    else if (c0 || c1) { if (Tm <= 512u) kb_cut_rows<8, 1>(ca, lane); else kb_cut_rows<KB_NPL, 1>(ca, lane); st_cut += 1; }
                 }
                 __syncthreads();
 #ifdef PSG_KF_TL
@@ -499,17 +586,19 @@ __global__ __launch_bounds__(KB_WAVES * 64) void knn_bf_kernel(KnnBfArgs a)
         if (!need_exact) need_exact = __ballot(lane < KB_Q && cnt[lane & (KB_Q - 1)] > (unsigned)CAP) != 0ull;
         if (!need_exact) {
             bool ok = true;
-            KbFinalArgs fa;
-            fa.xp = a.exact.xp; fa.sq = a.sq; fa.k = (unsigned)a.k; fa.d = (unsigned)a.d; fa.magic = a.magic;
-            for (int rr = wave; rr < KB_Q; rr += KB_WAVES) {
-                const unsigned row = (unsigned)(rr * ROW), qb = (unsigned)(qbuf - (float *)kb_smem);
-                const size_t qg = (size_t)tile * KB_Q + rr;
-                int32_t *o = a.out + qg * a.k;
-                const unsigned T = cnt[rr];
-                const unsigned nf = T <= 512u ? kb_final_row<8>(row, T, fa, room_row0, qg, csq[rr], qb, o, lane)
-                                              : kb_final_row<KB_NPL>(row, T, fa, room_row0, qg, csq[rr], qb, o, lane);
-                ok = ok && nf != 0xFFFFFFFFu;
-                st_fin += nf; st_ent += T;
+            {
+                KbFinalArgs fa;
+                fa.xp = a.exact.xp; fa.sq = a.sq; fa.k = (unsigned)a.k; fa.d = (unsigned)a.d; fa.magic = a.magic;
+                fa.room_row0 = room_row0; fa.qglob = (size_t)tile * KB_Q + wave;
+                fa.out = a.out + fa.qglob * a.k;
+                fa.row_dw = (unsigned)(wave * ROW); fa.scr_dw = (unsigned)(scr - (float *)kb_smem);
+                fa.T[0] = cnt[wave]; fa.T[1] = cnt[wave + KB_WAVES];
+                fa.sqi[0] = csq[wave]; fa.sqi[1] = csq[wave + KB_WAVES];
+                const unsigned Tm = fa.T[0] > fa.T[1] ? fa.T[0] : fa.T[1];
+                const unsigned nf = Tm <= 256u ? kb_final_rows<4, 2>(fa, lane)
+                                  : (Tm <= 512u ? kb_final_rows<8, 2>(fa, lane) : kb_final_rows<KB_NPL, 2>(fa, lane));
+                ok = nf != 0xFFFFFFFFu;
+                st_fin += nf; st_ent += fa.T[0] + fa.T[1];
             }
             if (!ok && lane == 0) *fail = 1u;
             KB_TL(9);
@@ -549,6 +638,6 @@ __global__ __launch_bounds__(KB_WAVES * 64) void knn_bf_kernel(KnnBfArgs a)
 
 inline size_t knn_bf_lds_bytes()
 {
-    const size_t own = (size_t)KB_Q * KB_ROW * 4 + KB_Q * 12 + KB_WAVES * 64 * 4 + KB_WAVES * 4 + 16 + KB_WAVES * 64 * 4;
+    const size_t own = (size_t)KB_Q * KB_ROW * 4 + KB_Q * 12 + KB_WAVES * 192 * 4 + KB_WAVES * 4 + 16 + KB_WAVES * 64 * 4;
     return own > knn_fused_lds_bytes() ? own : knn_fused_lds_bytes();
 }

@@ -1,0 +1,126 @@
+"""The bf16-prefilter kNN kernel (psg_knn_bf.cuh, PSG_GCN_KNN=bf16; reference: ResGCN/gcn_lib/dense/torch_edge.py:32-59, 19-29)
+must return the SAME tables as the CPU oracle, bit for bit: approximate distances only decide which few candidates get the
+reference's fp32 distance, inside a proven error bound, and every tile whose bound cannot be kept takes the exact path in the
+same launch.  Covered: every buffer class at 4096 points, adversarial candidate orders, massive exact ties, several rooms,
+heavy-tailed norms and a large common offset (the bound scales with the room's largest squared norm: those rooms exercise the
+exact-path fallback), non-finite features, and the counters that tell which path ran."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda().contiguous()
+
+
+def oracle_rooms(f, d):
+    from oracle import resgcn
+    return np.stack([resgcn.knn_dilated(f[b], d) for b in range(f.shape[0])])
+
+
+def bf16_workspace(batch, n):
+    from pointsecguard_amd import runtime
+    old = {k: os.environ.get(k) for k in ("PSG_GCN_KNN", "PSG_GCN_KNN_STATS")}
+    os.environ["PSG_GCN_KNN"] = "bf16"
+    os.environ["PSG_GCN_KNN_STATS"] = "1"
+    try:
+        return runtime.GCNWorkspace(batch, n, 28)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("d", [1, 2, 4, 9, 10, 17, 18, 27])
+def test_every_buffer_class_4096(d):
+    rng = np.random.default_rng(200 + d)
+    f = (rng.standard_normal((1, 4096, 64)) * rng.uniform(0.2, 3.0, (1, 1, 64))).astype(np.float32)
+    ws = bf16_workspace(1, 4096)
+    ws.knn_stats()
+    got = ws.knn(dev(f), d).cpu().numpy()
+    st = ws.knn_stats()
+    assert np.array_equal(got, oracle_rooms(f, d))
+    # the prefilter path itself produced these tables (no tile fell back) and evaluated only a few exact distances per row
+    assert st["tiles"] == 128 and st["exact_tiles"] == 0 and st["rows"] == 4096
+    assert 16 <= st["finalists"] / st["rows"] <= 160
+
+
+def test_adversarial_orders_and_ties():
+    rng = np.random.default_rng(7)
+    n = 2048
+    u = rng.standard_normal(64).astype(np.float32)
+    shrink = (1.0 - np.arange(n, dtype=np.float32) / n)[:, None] * u[None] * 4 + rng.standard_normal((n, 64)).astype(np.float32) * 1e-3
+    ws = bf16_workspace(1, n)
+    for name, f in (("shrinking", shrink), ("growing", shrink[::-1].copy())):
+        for d in (1, 5, 27):
+            got = ws.knn(dev(f[None]), d).cpu().numpy()
+            assert np.array_equal(got, oracle_rooms(f[None], d)), (name, d)
+    f = rng.standard_normal((n, 64)).astype(np.float32)
+    dup = rng.permutation(n)[:1500]
+    f[dup] = f[dup[0]]
+    for d in (1, 12, 27):
+        got = ws.knn(dev(f[None]), d).cpu().numpy()
+        assert np.array_equal(got, oracle_rooms(f[None], d)), ("ties", d)
+
+
+def test_heavy_tails_offsets_and_rooms():
+    """Norms spread over three orders of magnitude, a common offset 30 x the spread (the distance scale is then a tiny
+    fraction of the largest squared norm: wide error bands, many finalists or the exact path) and three rooms per launch."""
+    rng = np.random.default_rng(11)
+    n = 1024
+    base = rng.standard_normal((3, n, 64)).astype(np.float32)
+    heavy = base * np.exp(rng.standard_normal((3, n, 1)) * 1.5).astype(np.float32)
+    offset = base + 30.0
+    relu = np.maximum(base + 0.5, 0).astype(np.float32)
+    ws = bf16_workspace(3, n)
+    for name, f in (("heavy", heavy), ("offset", offset), ("relu", relu)):
+        for d in (1, 6, 20):
+            got = ws.knn(dev(f), d).cpu().numpy()
+            assert got.max() < n
+            assert np.array_equal(got, oracle_rooms(f, d)), (name, d)
+
+
+def test_degenerate_rooms_take_the_exact_path():
+    """All-zero features (every distance ties), tiny and huge magnitudes: rooms outside the range the bound is stated for
+    are handed to the exact kernel inside the launch and still equal the oracle."""
+    from pointsecguard_amd import runtime
+    rng = np.random.default_rng(3)
+    n = 512
+    ws = bf16_workspace(1, n)
+    ex = runtime.GCNWorkspace(1, n, 28)
+    zero = np.zeros((1, n, 64), np.float32)
+    tiny = (rng.standard_normal((1, n, 64)) * 1e-12).astype(np.float32)
+    huge = (rng.standard_normal((1, n, 64)) * 1e19).astype(np.float32)       # squared norms overflow to inf
+    for name, f in (("zero", zero), ("tiny", tiny)):
+        ws.knn_stats()
+        got = ws.knn(dev(f), 3).cpu().numpy()
+        st = ws.knn_stats()
+        assert st["exact_tiles"] == st["tiles"] == n // 32, name
+        assert np.array_equal(got, oracle_rooms(f, 3)), name
+    # non-finite distances have no defined order in the reference either: only require the two kernels to agree
+    assert torch.equal(ws.knn(dev(huge), 3), ex.knn(dev(huge), 3))
+
+
+def test_default_is_the_exact_kernel_and_both_agree_on_network_like_features():
+    """Features with a few huge-norm points (what the fitted ResGCN-28 produces: largest squared norm 40 x the mean): the
+    default workspace (exact kernel) and the prefilter workspace return identical tables; the latter reports how many
+    tiles it had to hand to the exact path."""
+    from pointsecguard_amd import runtime
+    rng = np.random.default_rng(5)
+    f = np.maximum(rng.standard_normal((2, 4096, 64)) * 2 + 1, 0).astype(np.float32)
+    f[:, :40] *= 6.0
+    ws = bf16_workspace(2, 4096)
+    ex = runtime.GCNWorkspace(2, 4096, 28)
+    assert ex.knn_stats()["tiles"] == 0            # no counters without PSG_GCN_KNN_STATS / on the exact kernel
+    for d in (1, 13, 27):
+        ws.knn_stats()
+        a = ws.knn(dev(f), d)
+        st = ws.knn_stats()
+        assert st["tiles"] == 256
+        assert torch.equal(a, ex.knn(dev(f), d)), d

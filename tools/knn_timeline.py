@@ -22,4 +22,10 @@ for d in [int(x) for x in os.environ.get("KNN_D", "1,4,9,17,27").split(",")]:
         ws.knn(f, d)
     t1.record(); torch.cuda.synchronize()
     lib.psg_dbg_knn_tl(buf)
+    if hasattr(lib, "psg_dbg_knn_ph"):
+        ph = (ctypes.c_ulonglong * 32)()
+        lib.psg_dbg_knn_ph(ph)
+        pn = ("cut:load", "cut:k2", "cut:hist", "cut:scan", "cut:compact", "fin:load", "fin:k2", "fin:hist", "fin:cum", "fin:search",
+              "fin:collect", "fin:exact", "fin:rank")
+        print("      phases (cycles per call of wave 0): " + "  ".join("%s %.0f" % (pn[i], ph[i] / ph[16 + i]) for i in range(13) if ph[16 + i]), flush=True)
     print("d=%2d  %.0f us per call  " % (d, t0.elapsed_time(t1) * 100) + "  ".join("%s %.0f" % (names[i], buf[i] / buf[16 + i]) for i in range(12) if buf[16 + i]), flush=True)
