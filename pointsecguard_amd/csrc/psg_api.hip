@@ -1,5 +1,7 @@
 // Context, error reporting and version of libpsg.so.
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "psg_common.h"
 
@@ -8,6 +10,23 @@ thread_local char g_err[512] = "";
 }
 
 namespace psg {
+bool trace_sync_enabled()
+{
+    static const bool on = getenv("PSG_TRACE_SYNC") && atoi(getenv("PSG_TRACE_SYNC"));
+    return on;
+}
+
+void trace_sync_point(const char *file, int line)
+{
+    static unsigned long n = 0;
+    const char *base = strrchr(file, '/');
+    fprintf(stderr, "[psg trace] launch %lu at %s:%d issued\n", ++n, base ? base + 1 : file, line);
+    fflush(stderr);
+    hipError_t e = hipDeviceSynchronize();
+    fprintf(stderr, "[psg trace] launch %lu done (%s)\n", n, hipGetErrorString(e));
+    fflush(stderr);
+}
+
 void set_error(const char *fmt, ...)
 {
     va_list ap;

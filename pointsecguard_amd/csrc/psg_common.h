@@ -29,7 +29,17 @@ void set_error(const char *fmt, ...);
         }                                                                                        \
     } while (0)
 
-#define PSG_LAUNCH_CHECK() PSG_CHECK_HIP(hipGetLastError())
+// Diagnosis only (PSG_TRACE_SYNC=1, eager launches outside any stream capture): after every checked launch the device is
+// synchronised and the launch site is written to stderr, so that a run that stops shows the last launch that completed
+// and the one that did not (tools/profile_round.sh gmfma_trace; DESIGN.md section 4, "the counter-pass hang").
+bool trace_sync_enabled();
+void trace_sync_point(const char *file, int line);
+
+#define PSG_LAUNCH_CHECK()                                                                       \
+    do {                                                                                         \
+        PSG_CHECK_HIP(hipGetLastError());                                                        \
+        if (psg::trace_sync_enabled()) psg::trace_sync_point(__FILE__, __LINE__);                 \
+    } while (0)
 
 // Optional per-launch HIP-event timing of a workspace (psg_*_prof_enable / psg_*_prof_read): pairs of events recorded on
 // the LAUNCH stream around a launch (or a group of launches) with a tag and the algorithmic FLOPs of that launch; off in

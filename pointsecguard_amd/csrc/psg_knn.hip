@@ -73,6 +73,8 @@ hipError_t knn_launch(const KnnBuffers &buf, int B, int N, int k, int d, int32_t
     const int slack = KF_CAP - f.KK;
     f.TOL = slack / 16;
     f.LOW = f.KK + slack / 4;
+    static const int xcd_order = getenv("PSG_KNN_XCD_ORDER") ? atoi(getenv("PSG_KNN_XCD_ORDER")) : 1;
+    f.xcd_order = xcd_order;
     if (path == KNN_PATH_F32) {
         hipLaunchKernelGGL(knn_fused_kernel, dim3((unsigned)((size_t)B * N / KF_Q)), dim3(KF_WAVES * 64), knn_fused_lds_bytes(), st, f);
         return hipGetLastError();

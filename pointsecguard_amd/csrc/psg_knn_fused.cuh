@@ -94,6 +94,7 @@ struct KnnFusedArgs {
     int KK;            // (k - 1) d + 1 keys decide the output (<= 448)
     unsigned magic;    // ceil(2^18 / d): x / d = (x * magic) >> 18 for x < 2^18 / d
     int LOW, TOL;      // a prune event cuts the rows above LOW to [KK, KK + TOL]
+    int xcd_order;     // 1: XCD-aware block order (default); 0: identity (PSG_KNN_XCD_ORDER=0, A/B and diagnosis)
 };
 
 // inclusive prefix sum over the 64 lanes (row scans by DPP row_shr, then the row totals by row_bcast)
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a
     // blocks [x G / 8, (x + 1) G / 8): a room's operand copy is fetched into one or two L2s instead of all eight (speed
     // only; round 2 measured 35.5 MB of HBM traffic per 4-room launch against 5.3 MB algorithmic with the identity order)
     const unsigned G = gridDim.x, b = blockIdx.x;
-    knn_exact_block(a, (int)((G & 7u) == 0u ? (b & 7u) * (G >> 3) + (b >> 3) : b), kf_smem);
+    knn_exact_block(a, (int)((G & 7u) == 0u && a.xcd_order ? (b & 7u) * (G >> 3) + (b >> 3) : b), kf_smem);
 }
 
 // the same as a call (the prefilter kernel's cold path: inlined twice it doubled that kernel and spilled its stream loop)
