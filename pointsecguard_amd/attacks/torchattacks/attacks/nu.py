@@ -68,9 +68,13 @@ def nu_attack(atk, images, labels, mask, target, neighbour, targeted_variant=Fal
     for step in range(atk.steps):
         _lib.call("psg_nu_tanh_color", runtime.ptr(w), runtime.ptr(mask_d), B, N, runtime.ptr(x0), st())
         if step >= planned_until:
-            # first horizon covers steps 0..10, then 10 at a time: a restart (which may move xyz) can only
-            # follow a step that is a multiple of 10 greater than 10
-            n_plan = min((CHUNK + 1) if step == 0 else CHUNK, atk.steps - step)
+            # Geometry windows end after steps 10, 20, 30, ..: a restart (which draws from the RNG and may move xyz) can
+            # only follow a step that is a multiple of 10 greater than 10, so the FPS draws of a window come out of the
+            # generator in the reference's order.  The first forward is planned ALONE: the accuracy exits can end the
+            # attack right after it (at batch 32 the targeted one always does, target.py:105-121), and a plan for
+            # eleven forwards would then be ten too many; the rest of the first window follows with step 1.
+            window_end = 1 if step == 0 else ((step - 1) // CHUNK + 1) * CHUNK + 1      # [0], [1..10], [11..20], ..
+            n_plan = min(window_end - step, atk.steps - step)
             starts = draw_fps_starts(B, N, n_plan).to(dev)
             ws.plan_build(x0, starts, n_plan)
             plan_base, planned_until = step, step + n_plan

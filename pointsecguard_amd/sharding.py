@@ -33,6 +33,15 @@ def draw_fps_starts_sharded(total_batch, n_point, n_forward, lo, hi):
     return out
 
 
+def fps_start_table_sharded(seed, n_forward, total_batch, lo, hi, n_point=4096):
+    """The same for a whole attack's table of draws (bench.py: `iters` forwards planned at once): int32
+    [n_forward][4][hi - lo] = columns lo..hi of the table a single process would draw for `total_batch` rooms from
+    numpy's default_rng(seed), level by level.  Every rank passes the same seed and its own column range."""
+    rng = np.random.default_rng(seed)
+    return np.stack([rng.integers(0, n, (n_forward, total_batch))[:, lo:hi] for n in (n_point, 1024, 256, 64)],
+                    axis=1).astype(np.int32)
+
+
 def reduce_counters(counters, group=None):
     """Sum int64 counters over all ranks (no-op without an initialised process group)."""
     import torch.distributed as dist

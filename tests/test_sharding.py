@@ -36,6 +36,16 @@ def test_sharded_fps_draws_equal_single_process():
     assert torch.equal(torch.cat(parts, dim=2), full)
 
 
+def test_bench_fps_table_union_equals_single_process():
+    """bench.py's headline path: every rank takes its columns of the table one process would draw for the global batch."""
+    for world in (2, 8):
+        full = sharding.fps_start_table_sharded(77, 40, 8 * world, 0, 8 * world)
+        parts = [sharding.fps_start_table_sharded(77, 40, 8 * world, 8 * r, 8 * (r + 1)) for r in range(world)]
+        assert full.shape == (40, 4, 8 * world) and full.dtype == np.int32
+        assert np.array_equal(np.concatenate(parts, axis=2), full)
+        assert full[:, 0].max() < 4096 and full[:, 3].max() < 64
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -96,8 +106,21 @@ def test_bench_plain_gpus2_launches_its_own_ranks():
         assert len(lines) == 1, out.stdout
         line = lines[0]
         assert line["rehearsal"] is True and line["value"] is None and line["n_gpus"] == 2 and line["units_all_ranks"] == 8
+        assert line["n_ranks_seen"] == 2
         # rank 1 sleeps twice as long as rank 0: the reported time is the MAX over ranks
         assert line["ms_per_step"] >= 3.9
+
+
+def test_bench_plain_gpus8_rehearsal():
+    """The same with 8 ranks (the node the driver's scaling run uses), and --scaling strong for the configs[2] workload:
+    every rank reaches the barriers, the all-reduce counts 8 ranks, rank 0 prints one line."""
+    out, lines = _run_bench(["--gpus", "8", "--steps", "2", "--warmup", "0", "--workload", "tarnu", "--scaling", "strong"],
+                            {"PSG_BENCH_REHEARSE": "1", "OMP_NUM_THREADS": "1"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len(lines) == 1, out.stdout
+    line = lines[0]
+    assert line["n_gpus"] == 8 and line["n_ranks_seen"] == 8 and line["units_all_ranks"] == 16 and line["scaling"] == "strong"
+    assert line["ms_per_step"] >= 2 * 8 * 0.99       # rank 7 sleeps 8 x rank 0's time: MAX over ranks
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
