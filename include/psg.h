@@ -197,6 +197,11 @@ int psg_three_interp_bwd(const float *dout, int ld, int col0, const int32_t *idx
 /* pairwise_distance, ResGCN/gcn_lib/dense/torch_edge.py:32-42: x [B][N][C] -> out [B][N][N], the reference's fp32 order;
  * sq: scratch [B*N]. */
 int psg_gcn_pairwise_distance(const float *x, int B, int N, int C, float *sq, float *out, psg_stream stream);
+/* torch.max_pool2d(fusion, [N, 1]) of DenseDeepGCN.forward (ResGCN/sem_seg_dense/architecture.py:64) on point-major rows
+ * x [B][N][C] (C a multiple of 64): out_max [B][C] = maximum over the N points, out_arg [B][C] = the row that holds it
+ * (lowest row on equal values); scratch: [B*C] 8-byte words (cleared here).  SURVEY 8(b)'s `psg_global_max`. */
+int psg_global_max(const float *x, int B, int N, int C, unsigned long long *scratch, float *out_max, int32_t *out_arg,
+                   psg_stream stream);
 /* EdgeConv2d.forward, torch_vertex.py:31-35 (BasicConv = Conv -> ReLU -> BatchNorm, torch_nn.py:55-75), 16 neighbours,
  * 64 output channels: y_i = max_k(scale * relu(W.[x_i, x_j - x_i] + b) + shift).  x [R][ld_x], nbr [R][16] room-local,
  * R = rooms * N; wcat [128][C] = [W1 - W2 ; W2], bcat [128] = [b, 0]; pq scratch [R][128]; arg [R][64]. */

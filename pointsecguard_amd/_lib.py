@@ -41,6 +41,7 @@ SIGNATURES = {
     "psg_three_interp_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]),
     "psg_three_interp_bwd": (ci, [vp, ci, ci, vp, vp, ci, ci, ci, ci, vp, vp]),
     "psg_gcn_pairwise_distance": (ci, [vp, ci, ci, ci, vp, vp, vp]),
+    "psg_global_max": (ci, [vp, ci, ci, ci, vp, vp, vp, vp]),
     "psg_edgeconv_fwd": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp]),
     "psg_edgeconv_bwd": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]),
     "psg_pn2_model_create": (ci, [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]),

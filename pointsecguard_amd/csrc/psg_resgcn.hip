@@ -931,6 +931,22 @@ extern "C" int psg_gcn_set_graphs(psg_gcn_ws *ws, const int32_t *nbr, psg_stream
 
 extern "C" const float *psg_gcn_feats_ptr(const psg_gcn_ws *ws) { return ws ? ws->feats : nullptr; }
 
+// unit op: torch.max_pool2d(x, [N, 1]) of DenseDeepGCN.forward (architecture.py:64) on point-major rows: per room and
+// channel the maximum over the N points and the row that holds it (lowest row on equal values)
+extern "C" int psg_global_max(const float *x, int B, int N, int C, unsigned long long *scratch, float *out_max,
+                              int32_t *out_arg, psg_stream stream)
+{
+    PSG_REQUIRE(x && scratch && out_max && out_arg && B > 0 && N > 0 && C > 0 && C % 64 == 0,
+                "psg_global_max: bad argument (C must be a multiple of 64)");
+    hipStream_t st = (hipStream_t)stream;
+    PSG_CHECK_HIP(hipMemsetAsync(scratch, 0, (size_t)B * C * 8, st));
+    hipLaunchKernelGGL(colmax_partial_kernel, dim3(C / 64, ceil_div(N, 64), B), dim3(256), 0, st, x, N, C, 64, scratch);
+    PSG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colmax_decode_kernel, dim3(ceil_div(B * C, 256)), dim3(256), 0, st, scratch, (size_t)B * C, out_max, out_arg);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
 // unit op: dilated dense kNN graph of point-major features x [B][N][C] (torch_edge.py:45-79)
 extern "C" int psg_gcn_knn(psg_gcn_ws *ws, const float *x, int C, int dilation, int32_t *out_idx, psg_stream stream)
 {

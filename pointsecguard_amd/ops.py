@@ -236,3 +236,16 @@ def pairwise_distance(x):
     out = torch.empty(B, N, N, device=x.device)
     _lib.call("psg_gcn_pairwise_distance", runtime.ptr(x), B, N, C, runtime.ptr(sq), runtime.ptr(out), runtime.stream())
     return out
+
+
+def global_max(x):
+    """torch.max_pool2d(x, [N, 1]) of DenseDeepGCN.forward (architecture.py:64) for point-major x [B, N, C] (C a multiple
+    of 64): (max [B, C], arg-max row [B, C] int32, lowest row on equal values)."""
+    runtime.require_cuda(x, "x", torch.float32)
+    B, N, C = x.shape
+    scratch = torch.empty(B * C, dtype=torch.int64, device=x.device)
+    mx = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    arg = torch.empty(B, C, dtype=torch.int32, device=x.device)
+    _lib.call("psg_global_max", runtime.ptr(x.contiguous()), B, N, C, runtime.ptr(scratch), runtime.ptr(mx), runtime.ptr(arg),
+              runtime.stream())
+    return mx, arg

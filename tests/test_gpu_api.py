@@ -148,3 +148,18 @@ def test_gcn_lib_helpers(golden_gcn_room):
     torch.manual_seed(1)
     dd(full)
     assert torch.equal(torch.rand(1), after_ref)                          # exactly one CPU-generator draw, like torch_edge.py:21
+
+
+def test_global_max():
+    """psg_global_max = torch.max_pool2d(x, [N, 1]) of DenseDeepGCN.forward (architecture.py:64) on point-major rows: value and
+    first arg-max row per room and channel, incl. ties, negatives and N not a multiple of the row chunk."""
+    from pointsecguard_amd import ops
+    rng = np.random.default_rng(4)
+    for B, N, C in ((1, 4096, 1024), (3, 1000, 64), (2, 65, 128)):
+        x = rng.standard_normal((B, N, C)).astype(np.float32)
+        x[:, :, 0] = -np.abs(x[:, :, 0]) - 1.0                 # an all-negative channel
+        x[:, N // 3, 1] = 9.0
+        x[:, N // 2, 1] = 9.0                                  # a tie: the lower row wins
+        mx, arg = ops.global_max(torch.from_numpy(x).cuda())
+        assert np.array_equal(mx.cpu().numpy(), x.max(axis=1))
+        assert np.array_equal(arg.cpu().numpy(), x.argmax(axis=1).astype(np.int32))
