@@ -26,6 +26,23 @@ def _edge_layer(seq):
     return conv.weight.reshape(conv.weight.shape[0], -1), bias, scale, shift
 
 
+def _neighbours(edge_index, n_point):
+    """edge_index [2,B,N,k] -> int32 neighbour table [B,N,k].  The kernels take the centre of edge (b, i, k) to be vertex i
+    itself (what DenseDilatedKnnGraph produces, torch_edge.py:57-58); the reference gathers x_i through edge_index[1]
+    (torch_vertex.py:17,32), so any other centre row - and any index outside the room - is refused instead of silently
+    computing something else."""
+    if edge_index.dim() != 4 or edge_index.shape[0] != 2 or edge_index.shape[2] != n_point:
+        raise ValueError("edge_index must be [2, B, N=%d, k], got %s" % (n_point, tuple(edge_index.shape)))
+    nbr, ctr = edge_index[0], edge_index[1]
+    own = torch.arange(n_point, device=edge_index.device, dtype=ctr.dtype).view(1, n_point, 1)
+    if not bool((ctr == own).all()):
+        raise NotImplementedError("edge_index[1] must be the vertex's own index (arange over N broadcast over B and k): the "
+                                  "stand-alone graph convolutions do not gather the centre through an index")
+    if bool((nbr < 0).any()) or bool((nbr >= n_point).any()):
+        raise ValueError("edge_index[0] holds neighbour indices outside [0, %d)" % n_point)
+    return nbr.to(torch.int32).contiguous()
+
+
 def _rows(x):
     """[B,C,N,1] -> contiguous point-major [B,N,C]."""
     return x[:, :, :, 0].permute(0, 2, 1).contiguous().float()
@@ -40,7 +57,7 @@ class EdgeConv2d(nn.Module):
         """x [B,C,N,1], edge_index [2,B,N,16] (neighbour, centre; the centre row is arange) -> [B,64,N,1]:
         max_k BasicConv(cat[x_i, x_j - x_i]) (torch_vertex.py:31-35)."""
         w, b, scale, shift = _edge_layer(self.nn)
-        nbr = edge_index[0].to(torch.int32).contiguous()
+        nbr = _neighbours(edge_index, x.shape[2])
         y = ops.EdgeConv.apply(_rows(x), nbr, w, b, scale, shift)
         return y.permute(0, 2, 1).unsqueeze(-1)
 
@@ -55,7 +72,7 @@ class MRConv2d(nn.Module):
     def forward(self, x, edge_index):
         """x [B,C,N,1], edge_index [2,B,N,16] -> [B,M,N,1] (torch_vertex.py:16-20)."""
         w, b, scale, shift = _edge_layer(self.nn)
-        nbr = edge_index[0].to(torch.int32).contiguous()
+        nbr = _neighbours(edge_index, x.shape[2])
         y = ops.MRConv.apply(_rows(x), nbr, w, b, scale, shift)
         return y.permute(0, 2, 1).unsqueeze(-1)
 

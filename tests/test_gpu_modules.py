@@ -137,6 +137,16 @@ def test_graph_convolutions_standalone(g, gcn_weights_sd):
     dense.load_state_dict(sd, strict=True)
     yd = dense.cuda().eval()(x)
     assert yd.shape == (1, 128, 1024, 1) and torch.equal(yd[:, :64], x) and torch.allclose(yd[:, 64:], yp, atol=1e-5)
+    # an edge_index the kernels cannot honour is refused, not silently mis-read: a centre row that is not the vertex itself
+    # (the reference gathers x_i through edge_index[1], torch_vertex.py:17,32) and neighbours outside the room
+    bad_centre = edge.clone()
+    bad_centre[1, 0, 5, 2] = 7
+    with pytest.raises(NotImplementedError):
+        blk.body.gconv(x, bad_centre)
+    bad_nbr = edge.clone()
+    bad_nbr[0, 0, 3, 0] = x.shape[2]
+    with pytest.raises(ValueError):
+        mr(x, bad_nbr)
 
 
 def test_pairwise_distance_bits(golden_gcn_room):
