@@ -713,14 +713,42 @@ def run_randla(args, R):
         wss[0].prof_enable(True)
         step(0, n_prof)
         torch.cuda.synchronize()
-        ms, cnt, fl = wss[0].prof_read()
+        kern = wss[0].prof_read_kernels()
         wss[0].prof_enable(False)
-        achieved = fl / (ms * 1e-3) / 1e12
-        result["roofline"] = {"bound": "mfma", "kernel": "gemm_rows_kernel (every 1x1 convolution / attention-score GEMM of an "
-                                                         "iteration, all shapes; %d cloud(s) per launch)" % G, "achieved": achieved,
-                              "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS,
-                              "traffic": None, "avg_launch_us": ms / cnt * 1e3, "launches": cnt, "flop_per_launch": fl / cnt,
-                              "gemm_ms_per_iteration": ms / n_prof}
+        # roofline of the kernel with the largest total time.  Every kernel of this network at these sizes is bound by
+        # bandwidth / latency, not by the matrix pipe (the GEMM layers have K, M <= 512 on at most a few thousand to a few
+        # hundred thousand rows): achieved = algorithmic bytes of its launches / their HIP-event time against the HBM
+        # peak; the FLOP-based fraction of the same launches rides along, and `traffic` is the counted HBM volume per
+        # launch from the committed PMC passes of this command (profiles/*_pmc_traffic_randla.json) when they exist
+        dom = max(kern, key=lambda k: kern[k][0])
+        ms, cnt, fl, by = kern[dom]
+        symbol = {"gemm_rows_kernel<2,2,.,.,1,1> (64x64 tiles)": ("void psg::gemm_rows_kernel<2, 2, 0, false, 1, 1>(psg::GemmArgs)",
+                                                                 "void psg::gemm_rows_kernel<2, 2, 3, false, 1, 1>(psg::GemmArgs)"),
+                  "gemm_rows_kernel<2,2> (128x128 tiles)": ("void psg::gemm_rows_kernel<2, 2, 0, false, 2, 2>(psg::GemmArgs)",
+                                                            "void psg::gemm_rows_kernel<2, 2, 3, false, 2, 2>(psg::GemmArgs)"),
+                  "gemm_rows_kernel<4,1> (256x64 tiles)": ("void psg::gemm_rows_kernel<4, 1, 0, false, 2, 2>(psg::GemmArgs)",
+                                                           "void psg::gemm_rows_kernel<4, 1, 3, false, 2, 2>(psg::GemmArgs)"),
+                  "skinny_gemm_kernel": ("void (anonymous namespace)::skinny_gemm_kernel<0>(psg::GemmArgs)",
+                                         "void (anonymous namespace)::skinny_gemm_kernel<3>(psg::GemmArgs)")}[dom]
+        traffic, src = None, None
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_randla.json")))
+        if files:
+            with open(files[-1]) as fh:
+                table = json.load(fh)
+            rows_ = [table[s] for s in symbol if s in table]
+            if rows_ and table.get("_meta", {}).get("device_batch_rooms") == G:
+                n_l = sum(r["launches_fetch_pass"] for r in rows_)
+                traffic = sum(r["hbm_bytes_per_launch"] * r["launches_fetch_pass"] for r in rows_) / max(n_l, 1)
+                src = "profiles/" + os.path.basename(files[-1])
+        gbs = by / (ms * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "kernel": dom + " (linear and leaky-ReLU epilogues; %d cloud(s) per launch)" % G,
+                              "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                              "traffic": traffic, "traffic_source": src, "algorithmic_bytes": by / cnt,
+                              "avg_launch_us": ms / cnt * 1e3, "launches": cnt,
+                              "mfma_frac_same_launches": fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                              "share_of_gemm_time": ms / sum(v[0] for v in kern.values())}
+        result["gemm_kernels_ms_per_iteration"] = {k: round(v[0] / n_prof, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])}
         if want_cpu(args, R):
             from oracle import randla, randla_net
             xyz, rgb, lab = host[0]

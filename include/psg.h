@@ -423,6 +423,10 @@ size_t psg_rla_ws_bytes(const psg_rla_ws *ws);
  * RandLANet.py:323-410) with its algorithmic FLOPs; while enabled the BIM loop does not use its hipGraph. */
 int psg_rla_prof_enable(psg_rla_ws *ws, int on);
 int psg_rla_prof_read(psg_rla_ws *ws, int n_tags, double *total_ms, int *counts, double *flops);
+/* The same launches split by kernel (n_tags >= 4): 0 = the 64 x 64-tile row GEMM of the point-sized layers, 1 = 128 x 128
+ * tiles, 2 = 256 x 64 tiles, 3 = the row-per-thread kernel of the 8-32 channel layers; bytes = algorithmic bytes of the
+ * tagged launches (input rows, output rows, addend rows, weights, mask words): these kernels are bandwidth-bound. */
+int psg_rla_prof_read_kernels(psg_rla_ws *ws, int n_tags, double *total_ms, int *counts, double *flops, double *bytes);
 /* xyz [n_points][3] device: builds the index pyramid of main_S3DIS.py:198-207 (psg_knn_points) and the relative
  * position encodings.  Sub-sampling is the reference's: the first n / ratio points of each level. */
 int psg_rla_set_cloud(psg_rla_ws *ws, const float *xyz, psg_stream stream);

@@ -97,6 +97,7 @@ SIGNATURES = {
     "psg_rla_ws_bytes": (ctypes.c_size_t, [vp]),
     "psg_rla_prof_enable": (ci, [vp, ci]),
     "psg_rla_prof_read": (ci, [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
+    "psg_rla_prof_read_kernels": (ci, [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "psg_rla_set_cloud": (ci, [vp, vp, vp]),
     "psg_rla_index_ptr": (vp, [vp, ci, ci]),
     "psg_rla_forward": (ci, [vp, vp, vp, vp, vp]),

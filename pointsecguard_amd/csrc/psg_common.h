@@ -48,26 +48,30 @@ struct EvLog {
     bool on = false;
     std::vector<hipEvent_t> ev;      // pairs
     std::vector<int> tag;
-    std::vector<double> flop;
+    std::vector<double> flop, bytes;     // algorithmic FLOPs / bytes of the tagged launch
     size_t used = 0;
-    void reset(bool enable) { on = enable; used = 0; tag.clear(); flop.clear(); }
+    void reset(bool enable) { on = enable; used = 0; tag.clear(); flop.clear(); bytes.clear(); }
     void destroy() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); ev.clear(); }
     // sums per tag; blocks until the events have completed
-    int read(int n_tags, double *total_ms, int *counts, double *flops)
+    int read(int n_tags, double *total_ms, int *counts, double *flops, double *bytes_out = nullptr)
     {
-        for (int i = 0; i < n_tags; ++i) { total_ms[i] = 0.0; counts[i] = 0; if (flops) flops[i] = 0.0; }
+        for (int i = 0; i < n_tags; ++i) { total_ms[i] = 0.0; counts[i] = 0; if (flops) flops[i] = 0.0; if (bytes_out) bytes_out[i] = 0.0; }
         for (size_t i = 0; i < tag.size(); ++i) {
             float ms = 0.f;
             if (hipEventSynchronize(ev[2 * i + 1]) != hipSuccess) return -1;
             if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) return -1;
-            if (tag[i] < n_tags) { total_ms[tag[i]] += ms; counts[tag[i]] += 1; if (flops) flops[tag[i]] += flop[i]; }
+            if (tag[i] < n_tags) {
+                total_ms[tag[i]] += ms; counts[tag[i]] += 1;
+                if (flops) flops[tag[i]] += flop[i];
+                if (bytes_out) bytes_out[tag[i]] += bytes[i];
+            }
         }
         return 0;
     }
 };
 struct EvScope {
     EvLog *log; hipStream_t st; hipEvent_t stop = nullptr;
-    EvScope(EvLog *l, int tag, double flop, hipStream_t s) : log(l), st(s)
+    EvScope(EvLog *l, int tag, double flop, hipStream_t s, double bytes = 0.0) : log(l), st(s)
     {
         if (!log || !log->on) { log = nullptr; return; }
         while (log->used + 2 > log->ev.size()) {
@@ -80,6 +84,7 @@ struct EvScope {
         log->used += 2;
         log->tag.push_back(tag);
         log->flop.push_back(flop);
+        log->bytes.push_back(bytes);
         (void)hipEventRecord(start, st);
     }
     ~EvScope() { if (log) (void)hipEventRecord(stop, st); }

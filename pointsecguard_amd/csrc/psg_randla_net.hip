@@ -112,14 +112,22 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(GemmArgs a)
     if (EPI == EPI_LRELU && a.mask_out) a.mask_out[row] = bits;
 }
 
-// profile of the GEMM launches of the call in progress on this thread (psg_rla_prof_enable): tag 0 = every 1x1
-// convolution / attention-score GEMM, with its algorithmic FLOPs
+// profile of the GEMM launches of the call in progress on this thread (psg_rla_prof_enable), by kernel: tag 0 = 64 x 64
+// tiles (gemm_rows_kernel<2,2,.,.,1,1>: the point-sized layers), 1 = 128 x 128 tiles, 2 = 256 x 64 tiles, 3 = the
+// row-per-thread kernel of the 8-32 channel layers; each launch with its algorithmic FLOPs and bytes (input rows, output
+// rows - twice when accumulated into -, addend rows, weights, mask words)
 thread_local EvLog *tl_prof = nullptr;
 
 template <int EPI>
 int rl_gemm(const GemmArgs &a, hipStream_t st)
 {
-    EvScope prof(tl_prof, 0, 2.0 * a.rows * (double)a.K * a.M, st);
+    const bool skinny = a.M <= 32 && a.K <= 32 && a.rows >= 4096 && !a.addend && !a.gbias && !a.mask_in;
+    const bool wide = !skinny && a.M <= 64 && a.rows >= 32768;
+    const bool small_tile = !skinny && !wide && (size_t)ceil_div(a.rows, 128) * ceil_div(a.M, 128) < RL_SMALL_TILE_BELOW;
+    const double bytes = 4.0 * ((double)a.rows * a.K + (double)a.rows * a.M * (a.accumulate ? 2.0 : 1.0) +
+                                (a.addend ? (double)a.rows * a.M : 0.0) + (double)a.K * a.M +
+                                ((a.mask_out || a.post_mask) ? (double)a.rows * ((a.M + 31) / 32) : 0.0));
+    EvScope prof(tl_prof, skinny ? 3 : (wide ? 2 : (small_tile ? 0 : 1)), 2.0 * a.rows * (double)a.K * a.M, st, bytes);
     if (a.M <= 32 && a.K <= 32 && a.rows >= 4096 && !a.addend && !a.gbias && !a.mask_in) {
         hipLaunchKernelGGL(skinny_gemm_kernel<EPI>, dim3(ceil_div(a.rows, 256)), dim3(256), 0, st, a);
         PSG_LAUNCH_CHECK();
@@ -1118,8 +1126,22 @@ extern "C" int psg_rla_prof_enable(psg_rla_ws *ws, int on)
 
 extern "C" int psg_rla_prof_read(psg_rla_ws *ws, int n_tags, double *total_ms, int *counts, double *flops)
 {
+    // (one tag = every GEMM launch, as before round 3: the per-kernel split is psg_rla_prof_read_kernels)
     PSG_REQUIRE(ws && total_ms && counts && n_tags >= 1, "psg_rla_prof_read: need room for 1 tag");
-    if (ws->prof.read(n_tags, total_ms, counts, flops)) { set_error("psg_rla_prof_read: event query failed"); return PSG_ERR_HIP; }
+    double ms[4], fl[4];
+    int cnt[4];
+    if (ws->prof.read(4, ms, cnt, fl)) { set_error("psg_rla_prof_read: event query failed"); return PSG_ERR_HIP; }
+    total_ms[0] = ms[0] + ms[1] + ms[2] + ms[3];
+    counts[0] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    if (flops) flops[0] = fl[0] + fl[1] + fl[2] + fl[3];
+    for (int i = 1; i < n_tags; ++i) { total_ms[i] = 0.0; counts[i] = 0; if (flops) flops[i] = 0.0; }
+    return PSG_OK;
+}
+
+extern "C" int psg_rla_prof_read_kernels(psg_rla_ws *ws, int n_tags, double *total_ms, int *counts, double *flops, double *bytes)
+{
+    PSG_REQUIRE(ws && total_ms && counts && flops && bytes && n_tags >= 4, "psg_rla_prof_read_kernels: need room for 4 tags");
+    if (ws->prof.read(n_tags, total_ms, counts, flops, bytes)) { set_error("psg_rla_prof_read_kernels: event query failed"); return PSG_ERR_HIP; }
     return PSG_OK;
 }
 

@@ -77,6 +77,17 @@ class RandLAWorkspace:
         _lib.call("psg_rla_prof_read", self.handle, 1, ms, cnt, fl)
         return ms[0], cnt[0], fl[0]
 
+    PROF_KERNELS = ("gemm_rows_kernel<2,2,.,.,1,1> (64x64 tiles)", "gemm_rows_kernel<2,2> (128x128 tiles)",
+                    "gemm_rows_kernel<4,1> (256x64 tiles)", "skinny_gemm_kernel")
+
+    def prof_read_kernels(self):
+        """{kernel: (total ms, launches, algorithmic FLOPs, algorithmic bytes)} of the GEMM launches since prof_enable."""
+        n = len(self.PROF_KERNELS)
+        ms, cnt = (ctypes.c_double * n)(), (ctypes.c_int * n)()
+        fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)()
+        _lib.call("psg_rla_prof_read_kernels", self.handle, n, ms, cnt, fl, by)
+        return {k: (ms[i], cnt[i], fl[i], by[i]) for i, k in enumerate(self.PROF_KERNELS) if cnt[i]}
+
     @property
     def nbytes(self):
         return _lib.load().psg_rla_ws_bytes(self.handle)

@@ -3,8 +3,8 @@
 # matrix-busy counters in SEPARATE PMC passes (program directly after `--`, no trace domains with --pmc).
 # usage (on the GPU box, from the repo root): tools/profile_round.sh TAG   ->  gpurun_out/prof_TAG/, copy what is to be kept
 set -o pipefail
-TAG=${1:-r02}
-WHAT=${2:-all}     # all | stats | pmc_pn2 | pmc_gcn | pmc_knn
+TAG=${1:-r03}
+WHAT=${2:-all}     # all | stats | pmc_pn2 | pmc_gcn | pmc_knn | pmc_rla
 export TMPDIR=/tmp
 O=gpurun_out/prof_$TAG
 mkdir -p $O
@@ -19,12 +19,12 @@ if [ $WHAT = all ] || [ $WHAT = stats ]; then
 stats pn2 --steps 16 --warmup 8 --concurrency 1 --no-cpu-baseline --no-reference --no-secondary || exit 1
 stats gcn --workload resgcn --steps 4 --warmup 4 --gcn-concurrency 1 --no-cpu-baseline --no-reference || exit 1
 stats msg --workload pointnet2_msg --steps 16 --warmup 8 --concurrency 1 --no-cpu-baseline || exit 1
-stats tarnu --workload tarnu --steps 3 --warmup 1 --nu-concurrency 1 --no-cpu-baseline || exit 1
+stats tarnu --workload tarnu --steps 2 --warmup 1 --nu-concurrency 1 --no-cpu-baseline || exit 1
 stats randla --workload randla --steps 2 --warmup 1 --concurrency 1 --no-cpu-baseline || exit 1
 fi
 pmc() {     # name, counters (quoted), bench args...
     local name=$1 ctr=$2; shift 2
-    # (hipGraph replays under counter collection never returned on this pool: the attack loops stay eager in PMC passes)
+    # (the attack loops stay eager in PMC passes: per-dispatch counter rows need per-dispatch launches)
     PSG_GCN_NO_GRAPH=1 PSG_RLA_NO_GRAPH=1 timeout -k 10 150 rocprofv3 --pmc $ctr --output-format csv -d $O/$name -o p -- python3 bench.py "$@" > $O/$name.log 2>&1 || return 1
 }
 PN2="--steps 8 --warmup 8 --coalesce 8 --concurrency 1 --no-cpu-baseline --no-reference --no-secondary"
@@ -41,15 +41,21 @@ if [ $WHAT = all ] || [ $WHAT = pmc_gcn ]; then
 pmc gfetch FETCH_SIZE $GCN || exit 1
 pmc gwrite WRITE_SIZE $GCN || exit 1
 python3 tools/pmc_traffic.py $O/gfetch $O/gwrite $O/pmc_traffic_gcn.json 4 > $O/pmc_traffic_gcn.txt
-if pmc gmfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" $GCN; then
+# (round 2 saw this pass stop twice at the end of a long series of profiler sessions; on a fresh box it finishes, traced
+# launch by launch and plain, with either kNN block order: tools/gmfma_trace.sh, profiles/r03_gmfma_trace_*)
+pmc gmfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" $GCN || exit 1
 python3 tools/pmc_mfma.py $O/gmfma $O/pmc_mfma_gcn.json > $O/pmc_mfma_gcn.txt
-else echo "gmfma: the SQ counter pass over the whole ResGCN attack did not finish (see pmc_knn)"; fi
+fi
+if [ $WHAT = all ] || [ $WHAT = pmc_rla ]; then
+RLA="--workload randla --steps 8 --warmup 0 --concurrency 1 --randla-iters 6 --no-cpu-baseline --no-reference"
+pmc rfetch FETCH_SIZE $RLA || exit 1
+pmc rwrite WRITE_SIZE $RLA || exit 1
+python3 tools/pmc_traffic.py $O/rfetch $O/rwrite $O/pmc_traffic_randla.json 8 > $O/pmc_traffic_randla.txt
 fi
 if [ $WHAT = all ] || [ $WHAT = pmc_knn ]; then
-# the matrix-busy counters of the fused kNN kernel on its stand-alone launches (4 rooms per launch, d = 1, 4, 9, 17, 27): the
-# same pass over the whole ResGCN attack (gmfma above) has hung on this pool more often than not
+# the matrix-busy counters of the fused kNN kernel on its stand-alone launches (4 rooms per launch, d = 1, 4, 9, 17, 27)
 timeout -k 10 150 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/kmfma -o p -- python3 tools/knn_time.py 4 > $O/kmfma.log 2>&1 || exit 1
 python3 tools/pmc_mfma.py $O/kmfma $O/pmc_mfma_knn.json > $O/pmc_mfma_knn.txt
 fi
-rm -rf $O/fetch $O/write $O/gfetch $O/gwrite $O/mfma $O/gmfma $O/kmfma   # raw per-dispatch rows are large; the summaries are what is kept
+rm -rf $O/fetch $O/write $O/gfetch $O/gwrite $O/mfma $O/gmfma $O/kmfma $O/rfetch $O/rwrite   # raw per-dispatch rows are large; the summaries are what is kept
 ls $O
