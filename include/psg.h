@@ -439,6 +439,22 @@ int psg_rla_forward(psg_rla_model *model, psg_rla_ws *ws, const float *features,
 int psg_rla_backward(psg_rla_model *model, psg_rla_ws *ws, const float *dlogits, float *dfeatures_out, psg_stream stream);
 /* the attack's loss (bim.py:110-116) and its gradient w.r.t. the logits; loss_out (nullable) device scalar */
 int psg_rla_colper_grad(const float *logits, const int32_t *labels, int n, float *dlogits, float *loss_out, psg_stream stream);
+/* The same with the targeted attacks' mask and sign (TBIM bim.py:393-397 / :350-351, tar_NUattack.py:105-110): ys = the
+ * labels the hinge is taken against (the target class on the origin points), mask [n] bytes or NULL = which points
+ * contribute, sign = -1 for goal 't' (grad = -grad). */
+int psg_rla_colper_grad_masked(const float *logits, const int32_t *ys, const uint8_t *mask, float sign, int n, float *dlogits,
+                               float *loss_out, psg_stream stream);
+/* One BIM update (bim.py:84-98) of the colour half of feat [n][6] from dfeat [n][6]; ori [n][3] the clean colours; l_2:
+ * norms = 2 floats and delta = [n][3] floats of scratch.  psg_rla_bim_attack's step as its own entry, for the attacks whose
+ * loop reads an accuracy back every iteration (TBIM.batch_attack, bim.py:484-505). */
+int psg_rla_bim_step(float *feat, const float *dfeat, const float *ori, int n, float eps, float alpha, int l2_metric, float *norms,
+                     float *delta, psg_stream stream);
+/* NUattack / tar_NUattack (ares/ares/attack/NUattack.py:12-74, tar_NUattack.py:12-84): adversarial colours of the tanh-space
+ * variable d_ws into feat [n][6] columns 3..5 (mask: only those points move) and dist2[0] = |adv - x|_2^2; then one TF1-Adam
+ * step (t = 1, 2, ..) on d_ws of loss = |adv - x|_2 + c * score from dfeat = d score / d features. */
+int psg_rla_nu_color(const float *xs, const float *dws, const uint8_t *mask, int n, float *feat, float *dist2, psg_stream stream);
+int psg_rla_nu_adam_step(const float *xs, float *dws, float *m, float *v, const uint8_t *mask, const float *feat,
+                         const float *dfeat, const float *dist2, int n, float c, float lr, int t, psg_stream stream);
 /* `iters` BIM updates (goal 'ut') of the colour half of `features`; l2_metric 0: l_inf, 1: l_2 (bim.py:84-98);
  * builds the cloud's geometry itself.  adv_features_out [n_points][6]. */
 int psg_rla_bim_attack(psg_rla_model *model, psg_rla_ws *ws, const float *features, const int32_t *labels, float eps,

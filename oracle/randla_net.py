@@ -114,3 +114,78 @@ def bim_step(xs, xs_adv, grad, eps, alpha, metric="l_inf", x_min=0.0, x_max=1.0)
             delta = delta * np.float32(eps / nrm)
         out = xs + delta
     return np.clip(out, x_min, x_max).astype(np.float32)
+
+
+# ---- the other attacks of the reference's tester (tester_S3DIS.py:36-44): TBIM / tar_NBattack, NUattack, tar_NUattack.
+# Source-read restatements like everything above (PARITY UNPINNED).
+
+def colper_loss_masked(logits, ys, mask=None):
+    """TBIM.colperloss / tar_NUattack.NUloss (bim.py:393-397, tar_NUattack.py:105-110): the hinge of colper_loss against
+    the labels `ys` (the target class on the origin points), each point's term multiplied by mask."""
+    onehot = F.one_hot(ys, logits.shape[1]).to(logits.dtype)
+    real = (onehot * logits).sum(-1)
+    other = ((1 - onehot) * logits).max(-1)[0]
+    loss = torch.clamp(other - real, min=0)
+    if mask is not None:
+        loss = loss * mask.to(logits.dtype)
+    return loss.sum()
+
+
+def score_and_grad(orc, xyz0, rgb, ys, pyr, mask=None):
+    """-> (score, logits [N,13], d score / d rgb [N,3]) of the (masked) hinge for one cloud."""
+    t = [[torch.from_numpy(np.ascontiguousarray(a)).long() if a.dtype.kind == "i" else torch.from_numpy(np.ascontiguousarray(a))
+          for a in lst] for lst in pyr]
+    t[0] = [a.to(orc.dtype) for a in t[0]]
+    c = torch.from_numpy(np.ascontiguousarray(rgb)).to(orc.dtype).requires_grad_(True)
+    feats = torch.cat([torch.from_numpy(np.ascontiguousarray(xyz0, np.float32)).to(orc.dtype), c], -1)
+    logits = orc.forward(feats, *t)
+    m = None if mask is None else torch.from_numpy(np.asarray(mask, np.float32))
+    score = colper_loss_masked(logits, torch.from_numpy(np.asarray(ys)).long(), m)
+    score.backward()
+    return float(score.detach()), logits.detach().numpy(), c.grad.numpy()
+
+
+NU_BOUND = np.float32(1.0 - 1e-6)
+
+
+def nu_color(xs, dws, mask=None):
+    """NUattack.py:29-31 (+ tar_NUattack.py:41): ws = atanh(2 b x - b) + d_ws, adv = (tanh(ws) + 1) / 2; masked variant
+    adv = mask adv + (1 - mask) x.  float32 like the TF graph."""
+    xs, dws = np.asarray(xs, np.float32), np.asarray(dws, np.float32)
+    ws = np.arctanh(np.float32(2.0) * NU_BOUND * xs - NU_BOUND).astype(np.float32) + dws
+    adv = (np.float32(0.5) * (np.tanh(ws) + np.float32(1.0))).astype(np.float32)
+    if mask is not None:
+        adv = np.where(np.asarray(mask, bool)[:, None], adv, xs)
+    return adv, ws
+
+
+def nu_adam_step(xs, dws, m, v, t, dscore_drgb, c, lr, mask=None, b1=0.9, b2=0.999, eps=1e-8):
+    """One tf.train.AdamOptimizer step on d_ws of loss = |adv - x|_2 + c * score (NUattack.py:55-59): the gradient of the
+    distance term is (adv - x) / |adv - x|_2, the chain through tanh is (1 - tanh^2) / 2 (x mask), Adam in TF1's form
+    lr_t = lr sqrt(1 - b2^t) / (1 - b1^t), d_ws -= lr_t m / (sqrt(v) + eps).  Returns (d_ws, m, v, dist)."""
+    adv, ws = nu_color(xs, dws, mask)
+    d = (adv - np.asarray(xs, np.float32)).astype(np.float64)
+    dist = float(np.sqrt((d ** 2).sum()))
+    g = (d / dist if dist > 0 else np.zeros_like(d)) + float(c) * np.asarray(dscore_drgb, np.float64)
+    g = g * 0.5 * (1.0 - np.tanh(ws.astype(np.float64)) ** 2)
+    if mask is not None:
+        g = g * np.asarray(mask, np.float64)[:, None]
+    g = g.astype(np.float32)
+    m = (np.float32(b1) * m + np.float32(1 - b1) * g).astype(np.float32)
+    v = (np.float32(b2) * v + np.float32(1 - b2) * g * g).astype(np.float32)
+    lr_t = np.float32(lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t))
+    dws = (np.asarray(dws, np.float32) - lr_t * m / (np.sqrt(v) + np.float32(eps))).astype(np.float32)
+    return dws, m, v, dist
+
+
+def mean_iou(y_pred, y_true):
+    """compute_iou of the attack classes (bim.py:153-165): sklearn's confusion_matrix over the labels that occur, mean of
+    intersection / union."""
+    y_pred, y_true = np.asarray(y_pred).ravel(), np.asarray(y_true).ravel()
+    labs = np.unique(np.concatenate([y_pred, y_true]))
+    iou = []
+    for l in labs:
+        inter = np.sum((y_pred == l) & (y_true == l))
+        union = np.sum(y_true == l) + np.sum(y_pred == l) - inter
+        iou.append(inter / np.float32(union))
+    return float(np.mean(iou))

@@ -103,6 +103,10 @@ SIGNATURES = {
     "psg_rla_forward": (ci, [vp, vp, vp, vp, vp]),
     "psg_rla_backward": (ci, [vp, vp, vp, vp, vp]),
     "psg_rla_colper_grad": (ci, [vp, vp, ci, vp, vp, vp]),
+    "psg_rla_colper_grad_masked": (ci, [vp, vp, vp, cf, ci, vp, vp, vp]),
+    "psg_rla_bim_step": (ci, [vp, vp, vp, ci, cf, cf, ci, vp, vp, vp]),
+    "psg_rla_nu_color": (ci, [vp, vp, vp, ci, vp, vp, vp]),
+    "psg_rla_nu_adam_step": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, ci, vp]),
     "psg_rla_bim_attack": (ci, [vp, vp, vp, vp, cf, cf, ci, ci, vp, vp]),
     "psg_seg_stats": (ci, [vp, vp, ci, ci, vp, vp, vp]),
     "psg_vote_add": (ci, [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]),

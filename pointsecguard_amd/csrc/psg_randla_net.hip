@@ -759,9 +759,11 @@ __global__ void interp_concat_bwd_kernel(const float *__restrict__ dcat, int cs,
     else if (g != 0.0f) atomicAdd(dcoarse + (size_t)up[n] * cc + (c - cs), g);
 }
 
-// "colper" loss of the BIM attack (bim.py:110-116): sum_n max(0, max_k((1 - onehot) * z)_k - z_y); gradient w.r.t. z
-__global__ void colper_grad_kernel(const float *__restrict__ z, const int32_t *__restrict__ y, int n, float *__restrict__ dz,
-                                   float *__restrict__ loss)
+// "colper" loss of the BIM attack (bim.py:110-116): sum_n max(0, max_k((1 - onehot) * z)_k - z_y); gradient w.r.t. z.
+// mask (TBIM / tar_NUattack, bim.py:393-397, tar_NUattack.py:105-110): the per-point loss is multiplied by mask[n] (the
+// points of the origin class); `sign` multiplies the gradient (goal 't': grad = -grad, bim.py:350-351).
+__global__ void colper_grad_kernel(const float *__restrict__ z, const int32_t *__restrict__ y, const uint8_t *__restrict__ mask,
+                                   float sign, int n, float *__restrict__ dz, float *__restrict__ loss)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float l = 0.0f;
@@ -773,12 +775,12 @@ __global__ void colper_grad_kernel(const float *__restrict__ z, const int32_t *_
         for (int k = 0; k < RNCLS; ++k)
             if (k != yi && zi[k] > other) { other = zi[k]; oi = k; }
         const float real = zi[yi];
-        const bool on = other - real > 0.0f;
+        const bool on = other - real > 0.0f && (!mask || mask[i]);
         l = on ? other - real : 0.0f;
         for (int k = 0; k < RNCLS; ++k) dz[(size_t)i * RNCLS + k] = 0.0f;
         if (on) {
-            dz[(size_t)i * RNCLS + yi] = -1.0f;
-            if (oi != yi) dz[(size_t)i * RNCLS + oi] = 1.0f;
+            dz[(size_t)i * RNCLS + yi] = -sign;
+            if (oi != yi) dz[(size_t)i * RNCLS + oi] = sign;
         }
     }
     if (loss) {
@@ -1481,7 +1483,119 @@ extern "C" int psg_rla_colper_grad(const float *logits, const int32_t *labels, i
     PSG_REQUIRE(logits && labels && dlogits && n > 0, "psg_rla_colper_grad: bad argument");
     hipStream_t st = (hipStream_t)stream;
     if (loss_out) PSG_CHECK_HIP(hipMemsetAsync(loss_out, 0, 4, st));
-    hipLaunchKernelGGL(colper_grad_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, logits, labels, n, dlogits, loss_out);
+    hipLaunchKernelGGL(colper_grad_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, logits, labels, (const uint8_t *)nullptr, 1.0f, n,
+                       dlogits, loss_out);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+extern "C" int psg_rla_colper_grad_masked(const float *logits, const int32_t *ys, const uint8_t *mask, float sign, int n,
+                                          float *dlogits, float *loss_out, psg_stream stream)
+{
+    PSG_REQUIRE(logits && ys && dlogits && n > 0, "psg_rla_colper_grad_masked: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (loss_out) PSG_CHECK_HIP(hipMemsetAsync(loss_out, 0, 4, st));
+    hipLaunchKernelGGL(colper_grad_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, logits, ys, mask, sign, n, dlogits, loss_out);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+// One BIM update of the colour half of feat [n][6] from its gradient dfeat [n][6] (bim.py:84-98): l_inf or l_2 (norms:
+// 2 floats of scratch), then the clip to [0, 1].  The step of psg_rla_bim_attack as an entry of its own, for the attacks
+// whose loop lives on the host because the reference reads an accuracy back every iteration (TBIM's `sr > 0.9` exit).
+extern "C" int psg_rla_bim_step(float *feat, const float *dfeat, const float *ori, int n, float eps, float alpha, int l2_metric,
+                                float *norms, float *delta, psg_stream stream)
+{
+    PSG_REQUIRE(feat && dfeat && ori && n > 0 && (!l2_metric || (norms && delta)), "psg_rla_bim_step: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t N = (size_t)n;
+    if (!l2_metric) {
+        hipLaunchKernelGGL(bim_linf_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, feat, dfeat, ori, N, alpha, eps);
+        PSG_LAUNCH_CHECK();
+        return PSG_OK;
+    }
+    PSG_CHECK_HIP(hipMemsetAsync(norms, 0, 8, st));
+    hipLaunchKernelGGL(sq_norm_kernel, dim3(256), dim3(256), 0, st, dfeat, 6, 3, N, norms);
+    PSG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bim_l2_delta_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, feat, dfeat, ori, N, alpha, norms, delta);
+    PSG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sq_norm_kernel, dim3(256), dim3(256), 0, st, delta, 3, 0, N, norms + 1);
+    PSG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bim_l2_apply_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, feat, ori, delta, N, eps, norms + 1);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+// ---- NUattack / tar_NUattack (ares/ares/attack/NUattack.py:12-74, tar_NUattack.py:12-84): Adam on d_ws in tanh space.
+//   ws = atanh(2 b x - b) + d_ws (b = 1 - 1e-6), adv = (tanh(ws) + 1) / 2, masked: adv = mask adv + (1 - mask) x;
+//   loss = |adv - x|_2 + c * score;  TF1 Adam: lr_t = lr sqrt(1 - b2^t) / (1 - b1^t), d_ws -= lr_t m / (sqrt(v) + 1e-8).
+namespace {
+constexpr float kNuBound = 1.0f - 1e-6f;
+
+__global__ void nu_color_kernel(const float *__restrict__ xs, const float *__restrict__ dws, const uint8_t *__restrict__ mask,
+                                size_t n, float *__restrict__ feat, float *__restrict__ dist2)
+{
+    float s = 0.0f;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * 3; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = t / 3;
+        const int c = (int)(t % 3);
+        const float x = xs[t];
+        const float w = atanhf(2.0f * kNuBound * x - kNuBound) + dws[t];
+        float adv = 0.5f * (tanhf(w) + 1.0f);
+        if (mask && !mask[i]) adv = x;
+        feat[i * 6 + 3 + c] = adv;
+        const float d = adv - x;
+        s += d * d;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(dist2, s);
+}
+
+__global__ void nu_adam_kernel(const float *__restrict__ xs, float *__restrict__ dws, float *__restrict__ m, float *__restrict__ v,
+                               const uint8_t *__restrict__ mask, const float *__restrict__ feat, const float *__restrict__ dfeat,
+                               const float *__restrict__ dist2, size_t n, float c, float lr_t, float b1, float b2, float eps)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 3) return;
+    const size_t i = t / 3;
+    const int ch = (int)(t % 3);
+    const float x = xs[t];
+    const float w = atanhf(2.0f * kNuBound * x - kNuBound) + dws[t];
+    const float th = tanhf(w);
+    const float adv = feat[i * 6 + 3 + ch];
+    const float dist = sqrtf(dist2[0]);
+    // d loss / d adv = (adv - x) / |adv - x|_2 + c * d score / d adv;  d adv / d d_ws = mask * (1 - tanh^2) / 2
+    float g = (dist > 0.0f ? (adv - x) / dist : 0.0f) + c * dfeat[i * 6 + 3 + ch];
+    g *= (mask && !mask[i]) ? 0.0f : 0.5f * (1.0f - th * th);
+    const float mm = b1 * m[t] + (1.0f - b1) * g;
+    const float vv = b2 * v[t] + (1.0f - b2) * g * g;
+    m[t] = mm;
+    v[t] = vv;
+    dws[t] -= lr_t * mm / (sqrtf(vv) + eps);
+}
+}  // namespace
+
+// adv colours of d_ws into feat [n][6] (columns 3..5) and dist2[0] = |adv - x|_2^2 (cleared here)
+extern "C" int psg_rla_nu_color(const float *xs, const float *dws, const uint8_t *mask, int n, float *feat, float *dist2,
+                                psg_stream stream)
+{
+    PSG_REQUIRE(xs && dws && feat && dist2 && n > 0, "psg_rla_nu_color: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    PSG_CHECK_HIP(hipMemsetAsync(dist2, 0, 4, st));
+    hipLaunchKernelGGL(nu_color_kernel, dim3(256), dim3(256), 0, st, xs, dws, mask, (size_t)n, feat, dist2);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+// one Adam step (t = 1, 2, ..) on d_ws from dfeat = d score / d features [n][6] of the forward that psg_rla_nu_color fed
+extern "C" int psg_rla_nu_adam_step(const float *xs, float *dws, float *m, float *v, const uint8_t *mask, const float *feat,
+                                    const float *dfeat, const float *dist2, int n, float c, float lr, int t, psg_stream stream)
+{
+    PSG_REQUIRE(xs && dws && m && v && feat && dfeat && dist2 && n > 0 && t >= 1, "psg_rla_nu_adam_step: bad argument");
+    const double b1 = 0.9, b2 = 0.999;
+    const float lr_t = (float)((double)lr * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t)));
+    hipLaunchKernelGGL(nu_adam_kernel, dim3(blocks_for((size_t)n * 3)), dim3(256), 0, (hipStream_t)stream, xs, dws, m, v, mask, feat,
+                       dfeat, dist2, (size_t)n, c, lr_t, 0.9f, 0.999f, 1e-8f);
     PSG_LAUNCH_CHECK();
     return PSG_OK;
 }

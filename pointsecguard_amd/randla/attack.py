@@ -1,14 +1,19 @@
-"""BIM colour attack on RandLA-Net behind the call shape of the reference's ares BIM class
-(RandLA-Net/ares/ares/attack/bim.py:10-58 constructor, :118-150 config, :152-236 batch_attack).
+"""The colour attacks of the reference's RandLA-Net tester (tester_S3DIS.py:36-44) behind the call shapes of its ares
+classes: BIM / NBattack (bim.py:10-236, NBattack.py:8-48: non-targeted), TBIM / tar_NBattack (bim.py:277-505,
+NBattack.py:53-65: targeted, origin class -> target class), NUattack / tar_NUattack (NUattack.py, tar_NUattack.py: Adam in
+tanh space on distance + c * hinge).
 
-The reference builds a TensorFlow graph around a session; here the attack is one fused device loop
-(`psg_rla_bim_attack`): `iteration` gradient steps of the "colper" loss (bim.py:110-116) on the colour half of the
-features of one 40 960-point cloud (val_batch_size = 1), l_inf or l_2 update (bim.py:84-98), goal 'ut'.
+The reference builds TensorFlow graphs around a session; here BIM is one fused device loop (`psg_rla_bim_attack`) and the
+attacks whose loop reads an accuracy back every iteration (TBIM's `sr > 0.9`, NU's `acc < 1/13`, tar_NU's `sr > 0.95`)
+keep that loop on the host over the step entry points (forward, masked hinge gradient, backward, update step): exactly
+one small read-back per iteration, like the reference's session.run.  `batch_attack` takes the cloud's features [N, 6]
+(xyz, rgb) and labels [N] instead of the reference's flattened data_batch list; the returned metric tuples are the
+reference's, the adversarial colours stay available as `.last_adv`.  Network parity is UNPINNED (oracle/randla_net.py).
 """
 import numpy as np
 import torch
 
-from pointsecguard_amd import runtime
+from pointsecguard_amd import _lib, runtime
 from pointsecguard_amd.randla import network
 
 
@@ -18,7 +23,7 @@ class BIM:
         if not isinstance(model, network.RandLAModel):
             raise TypeError("model must be a pointsecguard_amd.randla.network.RandLAModel")
         if goal != "ut" or distance_metric not in ("l_inf", "l_2") or iteration_callback is not None:
-            raise NotImplementedError("implemented: goal='ut', l_inf / l_2")
+            raise NotImplementedError("BIM / NBattack: goal='ut', l_inf / l_2 (the targeted attack is TBIM / tar_NBattack)")
         if batch_size < 1 or (batch_size > 1 and distance_metric != "l_inf"):
             raise NotImplementedError("batch_size > 1 (clouds attacked together in one cloud-batch workspace) is implemented "
                                       "for l_inf; the l_2 step normalises per cloud: use batch_size=1 "
@@ -53,7 +58,246 @@ class BIM:
         n = f.shape[-2]
         if n not in self._ws:
             self._ws[n] = network.RandLAWorkspace(n, batch=self.batch_size)
-        adv = self._ws[n].bim_attack(self.model, f.reshape(-1, 6), y.reshape(-1), self.eps, self.alpha, self.iteration,
+        # bim.py:204-232: one update before the loop, then `iteration` more
+        adv = self._ws[n].bim_attack(self.model, f.reshape(-1, 6), y.reshape(-1), self.eps, self.alpha, self.iteration + 1,
                                      metric=self.distance_metric)
         rgb = adv[:, 3:6].contiguous()
         return rgb.reshape(self.batch_size, n, 3) if batched else rgb
+
+
+def _mean_iou(pred, true):
+    """compute_iou of the reference's attack classes (bim.py:153-165)."""
+    pred, true = np.asarray(pred).ravel(), np.asarray(true).ravel()
+    iou = []
+    for l in np.unique(np.concatenate([pred, true])):
+        inter = np.sum((pred == l) & (true == l))
+        iou.append(inter / np.float32(np.sum(true == l) + np.sum(pred == l) - inter))
+    return float(np.mean(iou))
+
+
+class _StepAttack:
+    """Shared plumbing of the host-loop attacks: device buffers of one cloud and the step entry points."""
+
+    def __init__(self, model, batch_size=1):
+        if not isinstance(model, network.RandLAModel):
+            raise TypeError("model must be a pointsecguard_amd.randla.network.RandLAModel")
+        if batch_size != 1:
+            raise NotImplementedError("one cloud per call (ConfigS3DIS.val_batch_size = 1): the accuracy exits are per cloud")
+        self.model, self.batch_size = model, batch_size
+        self.iteration, self.logger, self.last_adv = None, None, None
+        self._ws = {}
+
+    def _setup(self, features, labels):
+        f = features if isinstance(features, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(features, np.float32))
+        y = labels if isinstance(labels, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(labels))
+        f = f.float().cuda().contiguous()
+        if f.dim() != 2 or f.shape[1] != 6:
+            raise ValueError("features must be [N, 6] (xyz, rgb) of one cloud, got %s" % (tuple(f.shape),))
+        n = f.shape[0]
+        if n not in self._ws:
+            self._ws[n] = network.RandLAWorkspace(n)
+        ws = self._ws[n]
+        ws.set_cloud(f[:, 0:3].contiguous())
+        return ws, f.clone(), y.to(torch.int32).cuda().contiguous(), n
+
+    @staticmethod
+    def _grad(ws, model, feat, ys, mask, sign):
+        logits = ws.forward(model, feat)
+        dlogits = torch.empty_like(logits)
+        _lib.call("psg_rla_colper_grad_masked", runtime.ptr(logits), runtime.ptr(ys), None if mask is None else runtime.ptr(mask),
+                  float(sign), logits.shape[0], runtime.ptr(dlogits), None, runtime.stream())
+        return logits, ws.backward(model, dlogits)
+
+
+class TBIM(_StepAttack):
+    """Targeted BIM (bim.py:277-505): the points of class `ori` are pushed to class `target`; the hinge is taken against
+    the target labels on the masked points only, the gradient is negated (goal 't'), the update rule is BIM's; the loop
+    stops when more than 90 % of the masked points are predicted as the target (bim.py:504-505).  Note the reference's
+    `xs_adv_var = mask * xs_adv_var + (1 - mask) * xs_adv_var` (bim.py:318) is the identity: every colour may move."""
+
+    def __init__(self, model, batch_size=1, loss="colper", goal="t", distance_metric="l_2", session=None, iteration_callback=None):
+        super().__init__(model, batch_size)
+        if goal not in ("t", "tm", "ut") or distance_metric not in ("l_inf", "l_2") or iteration_callback is not None:
+            raise NotImplementedError("implemented: goal 't' / 'tm' / 'ut', l_inf / l_2")
+        self.goal, self.distance_metric = goal, distance_metric
+        self.eps = self.alpha = None
+
+    def config(self, **kwargs):
+        if "magnitude" in kwargs:
+            self.eps = float(np.asarray(kwargs["magnitude"]).reshape(-1)[0])
+        if "alpha" in kwargs:
+            self.alpha = float(np.asarray(kwargs["alpha"]).reshape(-1)[0])
+        if "iteration" in kwargs:
+            self.iteration = int(kwargs["iteration"])
+        if "logger" in kwargs:
+            self.logger = kwargs["logger"]
+
+    def batch_attack(self, features, labels, target=None, ori=2):
+        """-> (target_points, sr, other_acc, original_other_accuracy, new_dists, other_mIoU, original_other_mIoU),
+        bim.py:508."""
+        if self.eps is None or self.alpha is None or self.iteration is None:
+            raise RuntimeError("call config(magnitude=..., alpha=..., iteration=...) first")
+        ws, feat, y, n = self._setup(features, labels)
+        lab = y.cpu().numpy()
+        mask_h = lab == ori
+        target_points = float(mask_h.sum())
+        if target_points == 0:
+            raise ValueError("no point of the origin class %d in this cloud (tester_S3DIS.py:311-314 skips such clouds)" % ori)
+        ys_target = np.where(mask_h, target, lab).astype(np.int32)
+        targeted = self.goal in ("t", "tm")
+        ys = torch.from_numpy(ys_target if targeted else lab.astype(np.int32)).cuda()
+        mask = torch.from_numpy(mask_h.astype(np.uint8)).cuda()
+        ori_rgb = feat[:, 3:6].contiguous()
+        norms = torch.zeros(2, dtype=torch.float32, device=feat.device)
+        delta = torch.empty(n, 3, dtype=torch.float32, device=feat.device)
+        pred0 = ws.forward(self.model, feat).argmax(1).cpu().numpy()
+        original_other_accuracy = float(np.sum(pred0[~mask_h] == lab[~mask_h]) / (n - target_points))
+        original_other_miou = _mean_iou(pred0[~mask_h], lab[~mask_h])
+        sr = other_acc = other_miou = 0.0
+        # bim.py:470-482 runs the update once before the loop; its result is the loop's starting point
+        for it in range(self.iteration + 1):
+            logits, dfeat = self._grad(ws, self.model, feat, ys, mask, -1.0 if targeted else 1.0)
+            pred = logits.argmax(1).cpu().numpy()            # the one read-back of the iteration (the reference's session.run)
+            sr = float(np.sum(pred[mask_h] == ys_target[mask_h]) / target_points)
+            other_acc = float(np.sum(pred[~mask_h] == ys_target[~mask_h]) / (n - target_points))
+            other_miou = _mean_iou(pred[~mask_h], lab[~mask_h])
+            _lib.call("psg_rla_bim_step", runtime.ptr(feat), runtime.ptr(dfeat), runtime.ptr(ori_rgb), n, self.eps, self.alpha,
+                      1 if self.distance_metric == "l_2" else 0, runtime.ptr(norms), runtime.ptr(delta), runtime.stream())
+            if it > 0 and sr > 0.90:                         # (the update before the loop is not followed by the test)
+                break
+        self.last_adv = feat[:, 3:6].contiguous()
+        new_dists = float(torch.linalg.vector_norm(self.last_adv - ori_rgb))
+        out = (target_points, sr, other_acc, original_other_accuracy, new_dists, other_miou, original_other_miou)
+        if self.logger is not None:
+            self.logger.info("points={}, sr={},  other_acc={}, original_other_accuracy={}, new_dists={}, other_mIoU={}, "
+                             "original_other_mIoU={}".format(*out))
+        return out
+
+
+class NBattack(BIM):
+    """NBattack.py:8-48: BIM plus a `rand_init_magnitude` setting.  The reference computes the random start point but never
+    assigns it (`setup_xs` still assigns the clean colours, NBattack.py:27-29), so the attack IS BIM; the setting is
+    accepted and, like there, has no effect."""
+
+    def __init__(self, model, batch_size=1, loss="colper", goal="ut", distance_metric="l_2", session=None, iteration_callback=None):
+        super().__init__(model, batch_size, loss, goal, distance_metric, session, iteration_callback)
+        self.rand_init_eps = None
+
+    def config(self, **kwargs):
+        super().config(**kwargs)
+        if "rand_init_magnitude" in kwargs:
+            self.rand_init_eps = float(np.asarray(kwargs["rand_init_magnitude"]).reshape(-1)[0])
+
+
+class tar_NBattack(TBIM):
+    """NBattack.py:53-65: TBIM plus the same unused `rand_init_magnitude` setting."""
+
+    def __init__(self, model, batch_size=1, loss="colper", goal="t", distance_metric="l_2", session=None, iteration_callback=None):
+        super().__init__(model, batch_size, loss, goal, distance_metric, session, iteration_callback)
+        self.rand_init_eps = None
+
+    def config(self, **kwargs):
+        super().config(**kwargs)
+        if "rand_init_magnitude" in kwargs:
+            self.rand_init_eps = float(np.asarray(kwargs["rand_init_magnitude"]).reshape(-1)[0])
+
+
+class NUattack(_StepAttack):
+    """NUattack.py:12-245: Adam (lr 0.01) on d_ws with adv = (tanh(atanh(2 b x - b) + d_ws) + 1) / 2, loss =
+    |adv - x|_2 + cs * score, score = the colper hinge against the labels (goal 'ut': NUattack.py:47-48 keeps the un-negated
+    hinge).  One search step of `iteration` Adam steps (the reference returns inside its first search step), stopping early
+    when the accuracy falls below 1/13 (:213); then the random-noise baseline of the same l_2 size (:236-252)."""
+
+    def __init__(self, model, batch_size=1, goal="ut", distance_metric="l_2", cw_loss_c=99999.0, confidence=0.0, learning_rate=0.01):
+        super().__init__(model, batch_size)
+        if goal != "ut" or distance_metric != "l_2":
+            raise NotImplementedError("NUattack: goal 'ut', l_2 (tester_S3DIS.py:39)")
+        self.lr, self.cs, self.iteration = float(learning_rate), 1.0, 1000
+
+    def config(self, **kwargs):
+        if "cs" in kwargs:
+            self.cs = float(np.asarray(kwargs["cs"]).reshape(-1)[0])
+        if "iteration" in kwargs:
+            self.iteration = int(kwargs["iteration"])
+        if "logger" in kwargs:
+            self.logger = kwargs["logger"]
+
+    def _run(self, features, labels, ys_h, mask_h, stop):
+        ws, feat, y, n = self._setup(features, labels)
+        dev = feat.device
+        xs = feat[:, 3:6].contiguous()
+        ys = torch.from_numpy(ys_h.astype(np.int32)).cuda()
+        mask = None if mask_h is None else torch.from_numpy(mask_h.astype(np.uint8)).cuda()
+        dws, m, v = (torch.zeros(n, 3, dtype=torch.float32, device=dev) for _ in range(3))
+        dist2 = torch.zeros(1, dtype=torch.float32, device=dev)
+        mptr = None if mask is None else runtime.ptr(mask)
+        pred0 = ws.forward(self.model, feat).argmax(1).cpu().numpy()
+        state = {"pred0": pred0, "n": n, "xs": xs, "ws": ws, "feat": feat}
+        for t in range(1, self.iteration + 1):
+            _lib.call("psg_rla_nu_color", runtime.ptr(xs), runtime.ptr(dws), mptr, n, runtime.ptr(feat), runtime.ptr(dist2), runtime.stream())
+            _, dfeat = self._grad(ws, self.model, feat, ys, mask, 1.0)
+            _lib.call("psg_rla_nu_adam_step", runtime.ptr(xs), runtime.ptr(dws), runtime.ptr(m), runtime.ptr(v), mptr, runtime.ptr(feat),
+                      runtime.ptr(dfeat), runtime.ptr(dist2), n, self.cs, self.lr, t, runtime.stream())
+            # the reference evaluates the UPDATED variable (NUattack.py:189-198): colours and logits after the step
+            _lib.call("psg_rla_nu_color", runtime.ptr(xs), runtime.ptr(dws), mptr, n, runtime.ptr(feat), runtime.ptr(dist2), runtime.stream())
+            pred = ws.forward(self.model, feat).argmax(1)
+            stats = torch.cat([dist2, pred.eq(y).sum().float().reshape(1)]).cpu()      # the iteration's one read-back
+            state.update(pred=pred, dist=float(stats[0]) ** 0.5, correct=float(stats[1]), steps=t)
+            if stop(state):
+                break
+        self.last_adv = feat[:, 3:6].contiguous()
+        return state
+
+    def batch_attack(self, features, labels):
+        """-> (acc, original_accuracy, new_dists, mIoU, original_mIoU, rand_acc, rand_mIoU), NUattack.py:233."""
+        lab = (labels.cpu().numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels)).astype(np.int64)
+        st = self._run(features, labels, lab, None, lambda s: s["correct"] / s["n"] < 1 / 13)
+        n, pred = st["n"], st["pred"].cpu().numpy()
+        acc, miou = float(np.sum(pred == lab) / n), _mean_iou(pred, lab)
+        original_accuracy, original_miou = float(np.sum(st["pred0"] == lab) / n), _mean_iou(st["pred0"], lab)
+        # random noise of the same l_2 size (NUattack.py:236-252); numpy's global generator, like the reference
+        noise = np.random.uniform(0, 1, size=(n, 3))
+        noise = noise / np.linalg.norm(noise) * st["dist"]
+        rnd = st["feat"].clone()
+        rnd[:, 3:6] = torch.clamp(st["xs"] + torch.from_numpy(noise.astype(np.float32)).cuda(), 0, 1)
+        rpred = st["ws"].forward(self.model, rnd).argmax(1).cpu().numpy()
+        out = (acc, original_accuracy, st["dist"], miou, original_miou, float(np.sum(rpred == lab) / n), _mean_iou(rpred, lab))
+        if self.logger is not None:
+            self.logger.info("acc={}, original_acc={}, new_dists={}, mIoU={}, original_mIoU={}, rand_acc={}, rand_mIoU={}".format(*out))
+        return out
+
+
+class tar_NUattack(NUattack):
+    """tar_NUattack.py:12-244: the masked variant - only the points of class `ori` move (tar_NUattack.py:41), the hinge is
+    taken against the target labels on those points (:105-110), the loop stops when more than 95 % of them are predicted as
+    the target (:235)."""
+
+    def __init__(self, model, batch_size=1, goal="t", distance_metric="l_2", confidence=0.0, learning_rate=0.01):
+        _StepAttack.__init__(self, model, batch_size)
+        if goal != "t" or distance_metric != "l_2":
+            raise NotImplementedError("tar_NUattack: goal 't', l_2 (tester_S3DIS.py:44)")
+        self.lr, self.cs, self.iteration = float(learning_rate), 1.0, 1000
+
+    def batch_attack(self, features, labels, target=None, ori=2):
+        """-> (target_points, sr, other_acc, original_other_accuracy, new_dists, other_mIoU, original_other_mIoU)."""
+        lab = (labels.cpu().numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels)).astype(np.int64)
+        mask_h = lab == ori
+        target_points = float(mask_h.sum())
+        if target_points == 0:
+            raise ValueError("no point of the origin class %d in this cloud (tester_S3DIS.py:253-256 skips such clouds)" % ori)
+        ys_target = np.where(mask_h, target, lab)
+        mask_t = torch.from_numpy(mask_h).cuda()
+        ys_t = torch.from_numpy(ys_target).cuda()
+
+        def stop(s):
+            s["sr"] = float((s["pred"][mask_t] == ys_t[mask_t]).sum()) / target_points
+            return s["sr"] > 0.95
+        st = self._run(features, labels, ys_target, mask_h, stop)
+        n, pred, pred0 = st["n"], st["pred"].cpu().numpy(), st["pred0"]
+        out = (target_points, st["sr"], float(np.sum(pred[~mask_h] == ys_target[~mask_h]) / (n - target_points)),
+               float(np.sum(pred0[~mask_h] == lab[~mask_h]) / (n - target_points)), st["dist"],
+               _mean_iou(pred[~mask_h], lab[~mask_h]), _mean_iou(pred0[~mask_h], lab[~mask_h]))
+        if self.logger is not None:
+            self.logger.info("points={}, sr={},  other_acc={}, original_other_accuracy={}, new_dists={}, other_mIoU={}, "
+                             "original_other_mIoU={}".format(*out))
+        return out

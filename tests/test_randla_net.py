@@ -218,7 +218,7 @@ def test_gpu_cloud_batch_equals_single_clouds(cloud):
     # the BIM class with the reference's batch_size argument drives the same cloud-batch workspace
     from pointsecguard_amd.randla import attack
     atk = attack.BIM(model, B, "colper", "ut", "l_inf")
-    atk.config(magnitude=0.08, alpha=0.02, iteration=3)
+    atk.config(magnitude=0.08, alpha=0.02, iteration=2)   # bim.py:204-232: one update before the loop -> 3 updates like adv_b
     rgb_b = atk.batch_attack(feats_b.reshape(B, N, 6), lab_b.reshape(B, N))
     assert tuple(rgb_b.shape) == (B, N, 3) and (rgb_b.reshape(-1, 3).cpu().numpy() == adv_b[:, 3:]).mean() >= 0.98
     with pytest.raises(NotImplementedError):
@@ -242,3 +242,143 @@ def test_gpu_gradient_is_bit_reproducible(cloud, gpu):
     assert torch.equal(grads[0], grads[1])
     advs = [ws.bim_attack(model, feats, lab, 0.08, 0.02, 3).clone() for _ in range(2)]
     assert torch.equal(advs[0], advs[1])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The other attacks of the reference's tester (tester_S3DIS.py:36-44): TBIM / tar_NBattack, NUattack, tar_NUattack, against
+# the source-read restatements of oracle/randla_net.py (PARITY UNPINNED like the network itself).
+
+def test_masked_hinge_and_nu_rules_cpu():
+    """The restated loss / update rules on hand-made numbers (no GPU)."""
+    import torch
+    z = torch.tensor([[0.5, 2.0, -1.0], [3.0, 0.1, 0.2], [-1.0, -2.0, -3.0]])
+    ys = torch.tensor([0, 0, 2])
+    # point 0: other = max(0*, 2, -1) = 2 -> 1.5; point 1: real 3, other max(0*, .1, .2) = .2 -> 0; point 2: the masked
+    # true logit counts as 0 in the max (bim.py:113): other = max(-1, -2, 0*) = 0, real = -3 -> 3
+    assert abs(float(randla_net.colper_loss_masked(z, ys)) - 4.5) < 1e-6
+    assert abs(float(randla_net.colper_loss_masked(z, ys, torch.tensor([1.0, 1.0, 0.0]))) - 1.5) < 1e-6
+    xs = np.array([[0.2, 0.5, 0.9]], np.float32)
+    adv, _ = randla_net.nu_color(xs, np.zeros_like(xs))
+    assert np.abs(adv - (xs * (1 - 1e-6) + 0.5e-6)).max() < 1e-6        # tanh(atanh(t)) = t: the bound scaling only
+    adv_m, _ = randla_net.nu_color(np.repeat(xs, 2, 0), np.ones((2, 3), np.float32), mask=np.array([True, False]))
+    assert np.array_equal(adv_m[1], xs[0]) and (adv_m[0] > xs[0]).all()
+    dws, m, v, dist = randla_net.nu_adam_step(xs, np.zeros_like(xs), np.zeros_like(xs), np.zeros_like(xs), 1,
+                                              np.array([[1.0, -1.0, 0.0]], np.float32), 2.0, 0.01)
+    # first Adam step: |update| = lr * m_hat / (sqrt(v_hat) + eps') = lr for every entry with a gradient
+    assert np.allclose(np.abs(dws[0, :2]), 0.01, rtol=1e-3) and dws[0, 0] < 0 < dws[0, 1]
+    assert randla_net.mean_iou([0, 0, 1, 1], [0, 1, 1, 1]) == pytest.approx((1 / 2 + 2 / 3) / 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric,eps,alpha", [("l_inf", 0.08, 0.02), ("l_2", 3.0, 1.0)])
+def test_gpu_tbim_steps_vs_oracle(cloud, gpu, metric, eps, alpha):
+    """TBIM: masked hinge against the target labels, negated gradient (descent), BIM's update; teacher-forced like the BIM
+    test.  Then the class: the reference's tuple, the `sr > 0.9` stop and an honest success rate."""
+    import torch
+    from pointsecguard_amd import _lib, runtime
+    from pointsecguard_amd.randla import attack
+    xyz, rgb, labels, pyr = cloud
+    model, ws, orc = gpu
+    ws.set_cloud(dev(xyz))
+    ori, target = 2, 7
+    mask_h = labels == ori
+    ys_target = np.where(mask_h, target, labels)
+    feat = dev(np.concatenate([xyz, rgb], 1))
+    ys, mask = dev(ys_target.astype(np.int32)), dev(mask_h.astype(np.uint8))
+    ori_rgb = dev(rgb)
+    norms, delta = torch.zeros(2, device="cuda"), torch.empty(len(rgb), 3, device="cuda")
+    cur = rgb.copy()
+    for it in range(3):
+        logits = ws.forward(model, feat)
+        dl = torch.empty_like(logits)
+        loss = torch.zeros(1, device="cuda")
+        _lib.call("psg_rla_colper_grad_masked", runtime.ptr(logits), runtime.ptr(ys), runtime.ptr(mask), -1.0, len(rgb), runtime.ptr(dl),
+                  runtime.ptr(loss), runtime.stream())
+        g = ws.backward(model, dl)
+        score_ref, _, g_ref = randla_net.score_and_grad(orc, xyz, cur, ys_target, pyr, mask_h)
+        assert abs(loss.item() - score_ref) <= 1e-4 * max(1.0, abs(score_ref))
+        got = g.cpu().numpy()[:, 3:6]
+        assert (np.abs(got + g_ref) <= 1e-3 * np.abs(g_ref).max()).mean() >= 0.995         # sign -1: the negated gradient
+        _lib.call("psg_rla_bim_step", runtime.ptr(feat), runtime.ptr(g), runtime.ptr(ori_rgb), len(rgb), eps, alpha,
+                  1 if metric == "l_2" else 0, runtime.ptr(norms), runtime.ptr(delta), runtime.stream())
+        adv = feat.cpu().numpy()
+        assert np.array_equal(adv[:, :3], xyz)
+        if metric == "l_inf" or it == 0:
+            want = randla_net.bim_step(rgb, cur, -g_ref, eps, alpha, metric)
+            assert (np.abs(adv[:, 3:6] - want) <= (1e-5 if metric == "l_inf" else 1e-4)).mean() >= 0.995, it
+        cur = adv[:, 3:6].copy()
+    atk = attack.tar_NBattack(model, 1, "colper", "t", metric)
+    atk.config(magnitude=eps, alpha=alpha, iteration=4, rand_init_magnitude=0.5)
+    points, sr, other_acc, ori_other_acc, dist, other_miou, ori_other_miou = atk.batch_attack(np.concatenate([xyz, rgb], 1), labels,
+                                                                                            target=target, ori=ori)
+    assert points == mask_h.sum() and 0.0 <= sr <= 1.0 and 0.0 <= other_acc <= 1.0 and 0.0 < other_miou <= 1.0
+    adv = atk.last_adv.cpu().numpy()
+    assert adv.min() >= 0.0 and adv.max() <= 1.0
+    if metric == "l_inf":
+        assert np.abs(adv - rgb).max() <= eps + 1e-6
+    else:
+        assert dist <= eps * (1 + 1e-5)
+    # the masked score (what the attack minimises) did not grow
+    s0, _, _ = randla_net.score_and_grad(orc, xyz, rgb, ys_target, pyr, mask_h)
+    s1, _, _ = randla_net.score_and_grad(orc, xyz, adv, ys_target, pyr, mask_h)
+    assert s1 <= s0 * (1 + 1e-6)
+    with pytest.raises(ValueError):
+        atk.batch_attack(np.concatenate([xyz, rgb], 1), np.zeros_like(labels), target=target, ori=ori)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("masked", [False, True])
+def test_gpu_nu_steps_vs_oracle(cloud, gpu, masked):
+    """NUattack / tar_NUattack: three Adam steps in tanh space, the oracle teacher-forced with the GPU's optimiser state."""
+    import torch
+    from pointsecguard_amd import _lib, runtime
+    from pointsecguard_amd.randla import attack
+    xyz, rgb, labels, pyr = cloud
+    model, ws, orc = gpu
+    ws.set_cloud(dev(xyz))
+    n = len(rgb)
+    ori, target, c, lr = 3, 9, 0.5, 0.01
+    mask_h = (labels == ori) if masked else None
+    ys_h = np.where(labels == ori, target, labels) if masked else labels
+    feat = dev(np.concatenate([xyz, rgb], 1))
+    xs, ys = dev(rgb), dev(ys_h.astype(np.int32))
+    mask = dev(mask_h.astype(np.uint8)) if masked else None
+    mptr = runtime.ptr(mask) if masked else None
+    # start away from d_ws = 0: there the distance is the 1e-6 bound scaling alone and its gradient (adv - x) / |adv - x| a unit
+    # vector of tanh / atanh rounding noise (the reference's first step has that property too; nothing to compare)
+    dws0 = (0.05 * np.random.default_rng(8).standard_normal((n, 3))).astype(np.float32)
+    dws = dev(dws0)
+    m, v = (torch.zeros(n, 3, device="cuda") for _ in range(2))
+    dist2 = torch.zeros(1, device="cuda")
+    for t in range(1, 4):
+        h_dws, h_m, h_v = dws.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy()
+        _lib.call("psg_rla_nu_color", runtime.ptr(xs), runtime.ptr(dws), mptr, n, runtime.ptr(feat), runtime.ptr(dist2), runtime.stream())
+        adv_ref, _ = randla_net.nu_color(rgb, h_dws, mask_h)
+        assert np.abs(feat.cpu().numpy()[:, 3:6] - adv_ref).max() <= 2e-6
+        logits = ws.forward(model, feat)
+        dl = torch.empty_like(logits)
+        _lib.call("psg_rla_colper_grad_masked", runtime.ptr(logits), runtime.ptr(ys), mptr, 1.0, n, runtime.ptr(dl), None, runtime.stream())
+        dfeat = ws.backward(model, dl)
+        _lib.call("psg_rla_nu_adam_step", runtime.ptr(xs), runtime.ptr(dws), runtime.ptr(m), runtime.ptr(v), mptr, runtime.ptr(feat),
+                  runtime.ptr(dfeat), runtime.ptr(dist2), n, c, lr, t, runtime.stream())
+        _, _, g_ref = randla_net.score_and_grad(orc, xyz, adv_ref, ys_h, pyr, mask_h)
+        w_dws, w_m, w_v, dist = randla_net.nu_adam_step(rgb, h_dws, h_m, h_v, t, g_ref, c, lr, mask_h)
+        # (at t = 1 the distance is the 1e-6 bound scaling alone, 5e-5 in all: tanh / atanh rounding shows at the 1e-7 level)
+        assert abs(float(dist2.item()) ** 0.5 - dist) <= max(1e-4 * dist, 5e-7)
+        # Adam divides by sqrt(v): entries with a near-zero gradient amplify rounding; compare where the oracle's gradient is
+        # not negligible, and the moments everywhere
+        assert (np.abs(m.cpu().numpy() - w_m) <= 1e-3 * np.abs(w_m).max() + 1e-12).mean() >= 0.995
+        big = np.abs(w_m) > 1e-2 * np.abs(w_m).max()
+        assert (np.abs(dws.cpu().numpy() - w_dws)[big] <= 2e-4).mean() >= 0.99, t
+        if masked:
+            assert np.array_equal(dws.cpu().numpy()[~mask_h], dws0[~mask_h])            # the other points' variable never moves
+    cls = attack.tar_NUattack(model) if masked else attack.NUattack(model, 1, "ut", "l_2")
+    cls.config(cs=c, iteration=3)
+    np.random.seed(0)
+    out = cls.batch_attack(np.concatenate([xyz, rgb], 1), labels, target=target, ori=ori) if masked else \
+        cls.batch_attack(np.concatenate([xyz, rgb], 1), labels)
+    assert len(out) == 7 and all(np.isfinite(out))
+    adv = cls.last_adv.cpu().numpy()
+    assert adv.min() >= 0.0 and adv.max() <= 1.0
+    if masked:
+        assert np.abs(adv[~mask_h] - rgb[~mask_h]).max() == 0.0 and np.abs(adv[mask_h] - rgb[mask_h]).max() > 0.0
