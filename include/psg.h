@@ -407,6 +407,21 @@ int psg_knn_points(psg_ctx *ctx, const float *support, const float *query, int b
  * moving mean, moving variance or NULL (eps 1e-6, folded on the host).
  * ------------------------------------------------------------------------------------------ */
 #define PSG_RLA_NUM_LAYERS 55
+/* Possibility-based crop sampler of the RandLA-Net input pipeline (RandLA-Net/main_S3DIS.py:116-187, spatially_regular_gen):
+ * one object per cloud, points [n][3] f32 and the float64 possibility of every point resident on the device.
+ * argmin = np.argmin / np.min of the possibility (:134-137); query = the cloud's KDTree.query(pick, k)[1][0] (:151-156): the k
+ * nearest points ascending by (float64 squared distance, index); update = possibility[idx] += (1 - d / max d)^2 with the
+ * reference's float32 d (:163-166).  What the reference draws from numpy's generator stays on the host
+ * (pointsecguard_amd/randla/sampler.py). */
+typedef struct psg_rla_sampler psg_rla_sampler;
+int psg_rla_sampler_create(psg_ctx *ctx, const float *points_host, const double *possibility_host, int n_points,
+                           psg_rla_sampler **out);
+int psg_rla_sampler_destroy(psg_rla_sampler *s);
+int psg_rla_sampler_argmin(psg_rla_sampler *s, int *index_out, double *value_out, psg_stream stream);
+int psg_rla_sampler_query(psg_rla_sampler *s, const float *pick_host3, int k, int32_t *out_idx, psg_stream stream);
+int psg_rla_sampler_update(psg_rla_sampler *s, const int32_t *idx, int k, const float *pick_host3, float *scratch, psg_stream stream);
+int psg_rla_sampler_possibility(psg_rla_sampler *s, double *host_out);
+
 typedef struct psg_rla_model psg_rla_model;
 typedef struct psg_rla_ws psg_rla_ws;
 int psg_rla_model_create(psg_ctx *ctx, const float *const *tensors, int n_tensors, psg_rla_model **out);

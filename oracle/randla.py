@@ -72,3 +72,49 @@ def pyramid(xyz, num_layers=5, k_n=16, ratios=(4, 4, 4, 4, 2), knn=knn_brute):
         pts.append(cur); neigh.append(nb); pools.append(nb[:, :n_sub]); ups.append(knn(sub, cur, 1))
         cur = sub
     return pts, neigh, pools, ups
+
+
+class CropSamplerOracle:
+    """numpy restatement of RandLA-Net/main_S3DIS.py:116-187 (get_batch_gen / spatially_regular_gen), source-read: the
+    reference module imports TensorFlow and open3d and cannot be imported here.  The KDTree query is restated as what it
+    returns: the k nearest points by float64 squared distance, ascending, exact ties in index order."""
+
+    def __init__(self, clouds, num_points=40960, noise_init=3.5):
+        self.num_points, self.noise_init = num_points, noise_init
+        self.points = [np.ascontiguousarray(c[0], np.float32) for c in clouds]
+        self.colors = [np.asarray(c[1]) for c in clouds]
+        self.labels = [np.asarray(c[2]) for c in clouds]
+        self.possibility = [np.random.rand(p.shape[0]) * 1e-3 for p in self.points]
+        self.min_possibility = [float(np.min(p)) for p in self.possibility]
+
+    def next_crop(self):
+        cloud_idx = int(np.argmin(self.min_possibility))
+        point_ind = np.argmin(self.possibility[cloud_idx])
+        points = self.points[cloud_idx]
+        center_point = points[point_ind, :].reshape(1, -1)
+        noise = np.random.normal(scale=self.noise_init / 10, size=center_point.shape)
+        pick_point = center_point + noise.astype(center_point.dtype)
+        k = min(len(points), self.num_points)
+        d = points.astype(np.float64) - pick_point.astype(np.float64)
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        queried_idx = np.argsort(d2, kind="stable")[:k]
+        idx = np.arange(len(queried_idx))
+        np.random.shuffle(idx)
+        queried_idx = queried_idx[idx]
+        queried_pc_xyz = points[queried_idx] - pick_point
+        queried_pc_colors = self.colors[cloud_idx][queried_idx]
+        queried_pc_labels = self.labels[cloud_idx][queried_idx]
+        dists = np.sum(np.square((points[queried_idx] - pick_point).astype(np.float32)), axis=1)
+        delta = np.square(1 - dists / np.max(dists))
+        self.possibility[cloud_idx][queried_idx] += delta
+        self.min_possibility[cloud_idx] = float(np.min(self.possibility[cloud_idx]))
+        if len(points) < self.num_points:
+            num_in = len(queried_pc_xyz)
+            dup = np.random.choice(num_in, self.num_points - num_in)
+            idx_dup = list(range(num_in)) + list(dup)
+            queried_pc_xyz = np.concatenate([queried_pc_xyz, queried_pc_xyz[dup, ...]], 0)
+            queried_pc_colors = np.concatenate([queried_pc_colors, queried_pc_colors[dup, ...]], 0)
+            queried_idx = queried_idx[idx_dup]
+            queried_pc_labels = queried_pc_labels[idx_dup]
+        return (queried_pc_xyz.astype(np.float32), queried_pc_colors.astype(np.float32), queried_pc_labels,
+                queried_idx.astype(np.int32), np.array([cloud_idx], dtype=np.int32))

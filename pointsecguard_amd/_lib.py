@@ -89,6 +89,12 @@ SIGNATURES = {
     "psg_gcn_edge_ptr": (vp, [vp, ci]),
     "psg_gcn_feats_ptr": (vp, [vp]),
     "psg_knn_points": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "psg_rla_sampler_create": (ci, [vp, vp, vp, ci, ctypes.POINTER(vp)]),
+    "psg_rla_sampler_destroy": (ci, [vp]),
+    "psg_rla_sampler_argmin": (ci, [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double), vp]),
+    "psg_rla_sampler_query": (ci, [vp, vp, ci, vp, vp]),
+    "psg_rla_sampler_update": (ci, [vp, vp, ci, vp, vp, vp]),
+    "psg_rla_sampler_possibility": (ci, [vp, vp]),
     "psg_rla_model_create": (ci, [vp, ctypes.POINTER(vp), ci, ctypes.POINTER(vp)]),
     "psg_rla_model_destroy": (ci, [vp]),
     "psg_rla_ws_create": (ci, [vp, ci, ctypes.POINTER(vp)]),
