@@ -83,6 +83,7 @@ hipError_t knn_launch(const KnnBuffers &buf, int B, int N, int k, int d, int32_t
     a.bp = (const kb_u32x4 *)buf.bp; a.sq = buf.sq; a.out = out; a.N = N; a.k = k; a.d = d; a.KK = f.KK; a.magic = f.magic;
     const int bslack = KB_CAP - a.KK;
     a.LOW = a.KK + bslack / 4;
+    a.LOW = a.LOW > 480 && a.KK < 400 ? 480 : a.LOW;      // (a first cut at 512 candidates finds rows of 512)
     // cut schedule (candidates seen): first when a row holds first_cut entries (everything is admitted until then), then
     // whenever the ~kept entries of the last cut, admitted at the rate kept / n, would fill 0.85 CAP
     static const int first_small = getenv("PSG_KNN_FIRST_CUT_KK") ? atoi(getenv("PSG_KNN_FIRST_CUT_KK")) : 100;

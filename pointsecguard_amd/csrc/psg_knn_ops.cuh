@@ -11,6 +11,11 @@
 
 namespace {
 
+// the per-pair error term of the bf16 prefilter (psg_knn_bf.cuh): |D~ - D| <= A |x_i||x_j| + B |x_j|^2 + G |x_i|^2
+constexpr float KNN_BF_A = 8.631674575031098e-05f;    // 2^-13.5
+constexpr float KNN_BF_B = 2.1579186437577745e-05f;   // 2^-15.5
+constexpr float KNN_BF_G = 9.5367431640625e-07f;      // 2^-20
+
 // round-to-nearest-even bf16 of a finite float (non-finite inputs never reach the bf16 path: the kernel falls back)
 __device__ __forceinline__ unsigned short knn_bf16_rne(float f)
 {
@@ -35,17 +40,19 @@ __device__ __forceinline__ void knn_store_bp(unsigned short *__restrict__ bp, si
     bp[(frag + 4 * 64) * 8 + (c & 7)] = lo;
 }
 
-// augmented k-step of vertex v: -(sq / 2) as three bf16 pieces (24 significant bits: exact) in elements 0..2 of the h = 0
-// lane, zeros elsewhere; the query side multiplies them by 1, 1, 1 (psg_knn_bf.cuh).  One thread per vertex.
+// augmented k-step of vertex v, elements 0..3 of the h = 0 lane (zeros elsewhere): -(1 - B) sq / 2 as three bf16 pieces (24
+// significant bits), multiplied by 1, 1, 1 on the query side, and (A / 2) |x| rounded UP to bf16, multiplied by the query's
+// |x| rounded up: the product term folds the pair's error bound into the accumulator (psg_knn_bf.cuh).  One thread per vertex.
 __device__ __forceinline__ void knn_store_aug(uint4 *__restrict__ bp4, size_t v, float sq)
 {
-    const float hj = -0.5f * sq;
+    const float hj = -0.5f * (1.0f - KNN_BF_B) * sq;
     const unsigned short p1 = knn_bf16_rne(hj);
     const float r1 = hj - knn_bf16_f32(p1);
     const unsigned short p2 = knn_bf16_rne(r1);
     const unsigned short p3 = knn_bf16_rne(r1 - knn_bf16_f32(p2));
+    const unsigned short p4 = (unsigned short)((__float_as_uint(0.5f * KNN_BF_A * sqrtf(sq)) + 0xFFFFu) >> 16);
     const size_t frag = ((v >> 5) * 9 + 8) * 64 + (size_t)(v & 31);
-    bp4[frag] = make_uint4((unsigned)p1 | ((unsigned)p2 << 16), (unsigned)p3, 0u, 0u);
+    bp4[frag] = make_uint4((unsigned)p1 | ((unsigned)p2 << 16), (unsigned)p3 | ((unsigned)p4 << 16), 0u, 0u);
     bp4[frag + 32] = make_uint4(0u, 0u, 0u, 0u);
 }
 

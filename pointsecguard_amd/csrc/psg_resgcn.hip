@@ -522,8 +522,8 @@ struct psg_gcn_ws {
     float *sq;                 // [B*N]
     float *xp;                 // [B*N][64] the current block's features in fp32 MFMA operand order (exact fused kNN)
     void *bp;                  // [B*N/32][9][64] 16-byte bf16 hi / lo / augmented fragments (prefilter kNN, psg_knn_ops.cuh)
-    int knn_mode = 1;          // 1 = exact fused kernel (default), 2 = bf16 prefilter (PSG_GCN_KNN=bf16), 0 = round-1 path (=matrix)
-    int knn_bf_max_d = 1 << 30; // the prefilter kernel serves dilations up to this (PSG_GCN_KNN_BF_MAXD), the exact kernel the rest
+    int knn_mode = 2;          // 1 = exact fused kernel only (PSG_GCN_KNN=f32), 2 = bf16 prefilter up to knn_bf_max_d, 0 = round-1 path (=matrix)
+    int knn_bf_max_d = 3;      // the prefilter kernel serves dilations up to this (PSG_GCN_KNN_BF_MAXD), the exact kernel the rest
     unsigned long long *knn_stats = nullptr;   // PSG_GCN_KNN_STATS=1: device counters of the prefilter kernel
     float *pq, *dpq;           // [B*N][128]
     float *dpq2;               // second [B*N][128] gradient buffer of the default (res / edge) backward's ping-pong
@@ -789,9 +789,11 @@ extern "C" int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n
     {
         const char *kv = getenv("PSG_GCN_KNN");
         const std::string mode = kv ? kv : "";
-        // default: the exact fused kernel.  PSG_GCN_KNN=bf16 selects the bf16-prefilter kernel (same results; slower on the
-        // network's own features), =matrix the round-1 path
-        ws->knn_mode = mode == "matrix" ? 0 : (mode == "bf16" ? 2 : 1);
+        // default: the bf16-prefilter kernel for dilations 1..3, where it is the faster one on the network's own features
+        // (131-150 us against 161-165 us per 4-room call), the exact fused kernel for the rest; both
+        // give the same graph bit for bit.  PSG_GCN_KNN=f32 / =bf16 force one kernel for every dilation, =matrix the round-1 path
+        ws->knn_mode = mode == "matrix" ? 0 : (mode == "f32" ? 1 : 2);
+        ws->knn_bf_max_d = mode == "bf16" ? 1 << 30 : 3;
         if (const char *md = getenv("PSG_GCN_KNN_BF_MAXD")) ws->knn_bf_max_d = atoi(md);
         // the fused kNN kernels need 129 KB of dynamic LDS (raised once, outside any stream capture); a device that does
         // not grant it keeps the round-1 path (distance matrix in HBM + selection kernel)

@@ -22,17 +22,20 @@ def oracle_rooms(f, d):
     return np.stack([resgcn.knn_dilated(f[b], d) for b in range(f.shape[0])])
 
 
-def bf16_workspace(batch, n):
+def bf16_workspace(batch, n, mode="bf16"):
     from pointsecguard_amd import runtime
     old = {k: os.environ.get(k) for k in ("PSG_GCN_KNN", "PSG_GCN_KNN_STATS")}
-    os.environ["PSG_GCN_KNN"] = "bf16"
+    if mode is None:
+        os.environ.pop("PSG_GCN_KNN", None)
+    else:
+        os.environ["PSG_GCN_KNN"] = mode
     os.environ["PSG_GCN_KNN_STATS"] = "1"
     try:
         return runtime.GCNWorkspace(batch, n, 28)
     finally:
         for k, v in old.items():
             if v is None:
-                del os.environ[k]
+                os.environ.pop(k, None)
             else:
                 os.environ[k] = v
 
@@ -93,7 +96,7 @@ def test_degenerate_rooms_take_the_exact_path():
     rng = np.random.default_rng(3)
     n = 512
     ws = bf16_workspace(1, n)
-    ex = runtime.GCNWorkspace(1, n, 28)
+    ex = bf16_workspace(1, n, "f32")
     zero = np.zeros((1, n, 64), np.float32)
     tiny = (rng.standard_normal((1, n, 64)) * 1e-12).astype(np.float32)
     huge = (rng.standard_normal((1, n, 64)) * 1e19).astype(np.float32)       # squared norms overflow to inf
@@ -107,17 +110,23 @@ def test_degenerate_rooms_take_the_exact_path():
     assert torch.equal(ws.knn(dev(huge), 3), ex.knn(dev(huge), 3))
 
 
-def test_default_is_the_exact_kernel_and_both_agree_on_network_like_features():
+def test_default_split_and_both_kernels_agree_on_network_like_features():
     """Features with a few huge-norm points (what the fitted ResGCN-28 produces: largest squared norm 40 x the mean): the
-    default workspace (exact kernel) and the prefilter workspace return identical tables; the latter reports how many
-    tiles it had to hand to the exact path."""
-    from pointsecguard_amd import runtime
+    exact-kernel workspace and the prefilter workspace return identical tables; the latter reports how many tiles it had
+    to hand to the exact path.  The DEFAULT workspace runs the prefilter kernel for dilations 1..3 and the exact kernel
+    above (psg_resgcn.hip: knn_bf_max_d), which its counters show."""
     rng = np.random.default_rng(5)
     f = np.maximum(rng.standard_normal((2, 4096, 64)) * 2 + 1, 0).astype(np.float32)
     f[:, :40] *= 6.0
     ws = bf16_workspace(2, 4096)
-    ex = runtime.GCNWorkspace(2, 4096, 28)
-    assert ex.knn_stats()["tiles"] == 0            # no counters without PSG_GCN_KNN_STATS / on the exact kernel
+    ex = bf16_workspace(2, 4096, "f32")
+    dflt = bf16_workspace(2, 4096, None)
+    for d, tiles in ((1, 256), (3, 256), (4, 0), (27, 0)):
+        dflt.knn_stats()
+        t = dflt.knn(dev(f), d)
+        assert dflt.knn_stats()["tiles"] == tiles, d
+        assert torch.equal(t, ex.knn(dev(f), d)), d
+    assert ex.knn_stats()["tiles"] == 0            # the exact kernel keeps no counters
     for d in (1, 13, 27):
         ws.knn_stats()
         a = ws.knn(dev(f), d)
