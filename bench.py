@@ -224,9 +224,10 @@ def main():
                          "independent, so results are identical and small kernels get more workgroups")
     ap.add_argument("--nu-steps", type=int, default=0,
                     help="tarnu workload: optimiser step cap per attack (0 = 40 per room, SURVEY 8(d)(3); 100 for --nu-mode batch32)")
-    ap.add_argument("--nu-mode", default="per-room", choices=["per-room", "batch32"],
-                    help="tarnu workload: the attack applied per room (the reference's batch-of-one semantics; default) or one "
-                         "call on the whole 32-room batch (its exit test then fires after one step)")
+    ap.add_argument("--nu-mode", default="per-room", choices=["per-room", "per-room-calls", "batch32"],
+                    help="tarnu workload: the attack applied per room (the reference's batch-of-one semantics; default: the rooms "
+                         "of a step advanced in lockstep, per-room-calls: one call per room) or one call on the whole 32-room "
+                         "batch (its exit test then fires after one step)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="tarnu workload: weak = 32 rooms per step on EVERY GPU; strong = the 32 rooms of a step split over the "
                          "GPUs (BASELINE configs[2]: 'batch=32 rooms, sharded 8x' = 4 rooms per GPU)")
@@ -785,6 +786,12 @@ def run_tarnu(args, R):
     result = tarnu_measure(args, R, args.nu_mode)
     if args.nu_mode == "per-room" and R.rank == 0 and R.world == 1 and not args.no_reference:
         import copy
+        a1 = copy.copy(args)
+        a1.steps, a1.warmup, a1.no_cpu_baseline = 1, 0, True
+        q = tarnu_measure(a1, R, "per-room-calls", with_roofline=False)
+        result["uncoalesced_reference"] = {"value": q["value"], "unit": "rooms/s",
+                                           "note": "one call per room (batches of one), %d calls in flight" % q["config"]["attacks_in_flight"]}
+        import copy
         a2 = copy.copy(args)
         a2.steps, a2.warmup, a2.no_cpu_baseline = 3, 1, True
         q = tarnu_measure(a2, R, "batch32", with_roofline=False)
@@ -811,9 +818,11 @@ def tarnu_measure(args, R, mode, with_roofline=True):
     sd = dict(np.load(os.path.join(ROOT, "tests", "golden", "pn2_weights.npz")))
     n_steps = args.steps + args.warmup
     # jobs: (step, first room, rooms) - one attack call each
+    lockstep = mode == "per-room" and per_step >= 2          # one call advances the rooms of a step in lockstep (forward_rooms)
+    per_room = mode in ("per-room", "per-room-calls")
     def jobs_of(step):
-        return [(step, b, 1) for b in range(per_step)] if mode == "per-room" else [(step, 0, per_step)]
-    conc = max(1, min(args.nu_concurrency, len(jobs_of(0)) * args.steps))
+        return [(step, b, 1) for b in range(per_step)] if per_room and not lockstep else [(step, 0, per_step)]
+    conc = max(1, min(args.nu_concurrency if not lockstep else min(args.nu_concurrency, 3), len(jobs_of(0)) * args.steps))
     nets, streams = [], [torch.cuda.Stream() for _ in range(conc)]
     for _ in range(conc):
         net = get_model(13)
@@ -833,12 +842,17 @@ def tarnu_measure(args, R, mode, with_roofline=True):
             n_run[0] += 1
         with torch.cuda.stream(streams[slot]):
             atk = torchattacks.tar_NU_attack(nets[slot], c=1, kappa=0, steps=cap, lr=0.01, target=target, mask=mask)
-            out = nu_mod.nu_attack(atk, d_images[step][b0:b0 + nb], labels[step][b0:b0 + nb].astype(np.float64), mask, target, 5,
-                                   targeted_variant=True, trace=count)
+            if lockstep:
+                masks = labels[step][b0:b0 + nb] == src_cls     # every room masks its own points of the source class
+                out, steps_run = atk.forward_rooms(d_images[step][b0:b0 + nb], labels[step][b0:b0 + nb].astype(np.float64), masks)
+            else:
+                out = nu_mod.nu_attack(atk, d_images[step][b0:b0 + nb], labels[step][b0:b0 + nb].astype(np.float64), mask, target,
+                                       5, targeted_variant=True, trace=count)
+                steps_run = np.array([n_run[0]])
             streams[slot].synchronize()
         with lock:
-            opt_steps[0] += n_run[0]
-            exits[0] += 1 if n_run[0] < cap else 0
+            opt_steps[0] += int(steps_run.sum())
+            exits[0] += int((steps_run < cap).sum())
         return out
 
     def run(lo, hi):
@@ -860,28 +874,31 @@ def tarnu_measure(args, R, mode, with_roofline=True):
     opt_steps[0], exits[0] = 0, 0
     elapsed = R.timed(lambda: run(args.warmup, n_steps))
     total_opt, total_exit = R.sum(opt_steps[0]), R.sum(exits[0])
-    n_attacks = len(jobs_of(0)) * args.steps * R.world
-    rooms_per_attack = 1 if mode == "per-room" else per_step
+    n_attacks = (per_step if per_room else 1) * args.steps * R.world
+    rooms_per_attack = 1 if per_room else per_step
+    rooms_per_call = per_step if lockstep or not per_room else 1
     result = base_line("attacked rooms/sec (tar_NU, 4096 pts, <= %d Adam steps)" % cap, "rooms/s",
                        per_step * args.steps * R.world / elapsed, R, args, elapsed,
                        "tar_NU_attack (c=1, kappa=0, lr=0.01, target=6, neighbour=5) on PointNet++ SSG sem_seg, %s (BASELINE "
                        "configs[2]); fitted fixture weights"
-                       % ("applied per room, %d rooms x 4096 pts per step and GPU" % per_step if mode == "per-room"
+                       % ("applied per room, %d rooms x 4096 pts per step and GPU%s" % (per_step, ", the rooms of a step advanced in "
+                          "lockstep (forward_rooms: one launch per operation)" if lockstep else ", one call per room") if per_room
                           else "one call on a batch of %d rooms x 4096 pts" % per_step),
-                       {"mode": mode, "rooms_per_step_per_gpu": per_step, "optimizer_steps_cap": cap, "attacks_in_flight": conc})
+                       {"mode": mode, "rooms_per_step_per_gpu": per_step, "optimizer_steps_cap": cap,
+                        ("calls_in_flight" if lockstep else "attacks_in_flight"): conc, "rooms_per_call": rooms_per_call})
     result["scaling"] = "strong" if strong else "weak"
     result.update({"optimizer_steps_per_sec": total_opt / elapsed, "optimizer_steps_run": int(total_opt),
                    "optimizer_steps_per_attack": total_opt / n_attacks, "attacks_that_reached_the_target": int(total_exit),
                    "attacks": int(n_attacks), "room_steps_per_sec": rooms_per_attack * total_opt / elapsed})
     if R.rank == 0 and with_roofline:
         # roofline: the network kernels of one more attack, HIP events on its launch stream
-        ws = nets[0]._workspace(rooms_per_attack, NPOINT, nu_mod.CHUNK + 1)
+        ws = nets[0]._workspace(rooms_per_call, NPOINT, nu_mod.CHUNK + 1)
         ws.prof_enable(True)
         attack(jobs_of(0)[0], 0)
         torch.cuda.synchronize()
         prof = ws.prof_read()
         ws.prof_enable(False)
-        result["roofline"] = pn2_roofline(prof, kernel_flops(rooms_per_attack))
+        result["roofline"] = pn2_roofline(prof, kernel_flops(rooms_per_call))
         result["kernel_ms_per_attack"] = {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         if want_cpu(args, R):
             from oracle import attacks as oatk

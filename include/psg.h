@@ -286,6 +286,23 @@ int psg_nu_adam_step(float *w, float *m, float *v, const uint8_t *mask, const fl
                      const float *ori, const float *smooth_grad, float c_smooth, float c_l2, float lr, float beta1,
                      float beta2, float eps, int step, int B, int N, float *l2_sum, psg_stream stream);
 
+/* B INDEPENDENT one-room attacks advanced in lockstep: the reference's NU / tar_NU attack called once per room
+ * (target.py:62-133 and nontarget.py:52-105 at B = 1; BASELINE configs[2] applied per room), served by one launch per
+ * operation instead of B.  Same arithmetic per room as the entry points above; what differs is the bookkeeping: the mask
+ * is [B][N] (every room its own mask row), the smoothness term is evaluated for every room (grad_out [B][N][3]), the
+ * loss sums are per room ([B] floats) and rooms whose loop has ended (room_active[b] == 0, nullable = all active) are
+ * left untouched by the optimiser step.  N must be a multiple of 64 for the f-loss sums. */
+int psg_nu_tanh_color_rooms(const float *w, const uint8_t *mask_rooms, int B, int N, float *x0, psg_stream stream);
+int psg_nu_f_loss_grad_rooms(const float *logp, const int32_t *labels, int target, int B, int N, int n_cls, float kappa,
+                             float tsign, float *dlogp_out, float *f_sum_rooms, int32_t *pred_out, psg_stream stream);
+int psg_smooth_knn_rooms(const float *adv_color, int adv_stride, size_t adv_room_stride, const float *ref_color,
+                         int ref_stride, size_t ref_room_stride, int B, int N, int nb, float *dist_sum_rooms,
+                         float *grad_out, psg_stream stream);
+int psg_nu_adam_step_rooms(float *w, float *m, float *v, const uint8_t *mask_rooms, const float *dx0, const float *x0,
+                           const float *ori, const float *smooth_grad_rooms, float c_smooth, float c_l2, float lr,
+                           float beta1, float beta2, float eps, int step, int B, int N, const uint8_t *room_active,
+                           float *l2_sum_rooms, psg_stream stream);
+
 /* Segmentation statistics of NB_nontarget_test_semseg.py:199-205: for every class l accumulates
  * seen[l] += #(gt==l), inter[l] += #(pred==l & gt==l), uni[l] += #(pred==l | gt==l) where
  * pred = argmax(logp) (first index on ties).  counters: int64 [3][n_cls] = seen, inter, uni.

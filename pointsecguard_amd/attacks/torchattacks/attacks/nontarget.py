@@ -45,3 +45,9 @@ class NU_attack(Attack):
     def forward(self, images, labels):
         from .nu import nu_attack
         return nu_attack(self, images, labels, mask=None, target=None, neighbour=10)
+
+    def forward_rooms(self, images, labels):
+        """Extension of the reference API: the attack applied to every room of `images` [R, 9, N] on its own (R calls with
+        batches of one), all rooms advanced in lockstep; returns (adversarial images, optimiser steps run per room)."""
+        from .nu import nu_attack_rooms
+        return nu_attack_rooms(self, images, labels, None, None, neighbour=10)

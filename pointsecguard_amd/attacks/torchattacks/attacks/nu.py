@@ -27,7 +27,9 @@ BETA1, BETA2, ADAM_EPS = 0.9, 0.999, 1e-8
 CHUNK = 10  # geometry plan horizon: restarts can only happen after steps that are multiples of 10
 
 
-def nu_attack(atk, images, labels, mask, target, neighbour, targeted_variant=False, trace=None):
+def nu_attack(atk, images, labels, mask, target, neighbour, targeted_variant=False, trace=None, starts_fn=None):
+    """`starts_fn(step, n_plan)` (tests) supplies the [n_plan, 4, B] FPS start indices of a geometry window instead of the
+    generator draws."""
     net = psg_model(atk.model)
     dev = atk.device
     images = images.detach().to(dev).float().contiguous()
@@ -75,7 +77,7 @@ def nu_attack(atk, images, labels, mask, target, neighbour, targeted_variant=Fal
             # eleven forwards would then be ten too many; the rest of the first window follows with step 1.
             window_end = 1 if step == 0 else ((step - 1) // CHUNK + 1) * CHUNK + 1      # [0], [1..10], [11..20], ..
             n_plan = min(window_end - step, atk.steps - step)
-            starts = draw_fps_starts(B, N, n_plan).to(dev)
+            starts = (draw_fps_starts(B, N, n_plan) if starts_fn is None else starts_fn(step, n_plan)).to(dev)
             ws.plan_build(x0, starts, n_plan)
             plan_base, planned_until = step, step + n_plan
         slot = step - plan_base
@@ -126,6 +128,145 @@ def nu_attack(atk, images, labels, mask, target, neighbour, targeted_variant=Fal
             extra_l2 = float((d[:, :, 0:3] ** 2).sum().item() + (d[:, :, 6:9] ** 2).sum().item())
             planned_until = step + 1               # xyz may have moved: rebuild the plan before the next forward
     return snapshot()
+
+
+def nu_attack_rooms(atk, images, labels, masks, target, neighbour, targeted_variant=False, trace=None, starts_fn=None):
+    """R independent ONE-ROOM attacks advanced in lockstep: what `nu_attack` does when it is called once per room
+    (`images[r:r+1]`, `labels[r:r+1]`, `masks[r]`), with one launch per operation for all rooms instead of R
+    (psg_*_rooms entry points; the network kernels simply see a batch of R).  This is how BASELINE configs[2] is applied
+    per room: the reference's tar_NU semantics are batch-of-one (target.py:62-133: Smooth term, exit
+    accuracies and the mask all read batch row 0).
+
+    Per room exactly the per-call arithmetic: its own mask row, Smooth term, f / Smooth / L2 sums, cost history, exit test
+    and restart; a room that has left the loop keeps the image it returned and is skipped by the optimiser.  Rooms share
+    the step counter, so all of them re-plan their geometry at the same steps ([0], [1..10], [11..20], ..: where a single
+    call re-plans too).  Two things differ from R sequential calls and are why this is a separate entry: (1) the FPS
+    start indices of a window are drawn for all rooms at once ([n_plan, 4, R] from the CPU generator) instead of room
+    after room, and restart noise is drawn room by room at the step it happens - the same distributions, another order of
+    consumption; (2) the reference halves `self.lr` every 50 steps and leaves it halved for the NEXT call
+    (target.py:123-125), which makes later rooms depend on how long earlier ones ran: that cannot be advanced in lockstep,
+    so more than 50 steps are refused here (call `nu_attack` per room).
+
+    images [R, 9, N], labels [R, N], masks [R, N] bool (None for the non-targeted variant).  Returns (adv [R, 9, N],
+    steps_run [R] int64 numpy: the optimiser steps each room executed).
+    """
+    net = psg_model(atk.model)
+    dev = atk.device
+    images = images.detach().to(dev).float().contiguous()
+    R, C, N = images.shape
+    if R < 2:
+        raise ValueError("nu_attack_rooms advances several rooms in lockstep; call nu_attack for one room")
+    if atk.steps > 50:
+        raise ValueError("nu_attack_rooms: more than 50 steps would need the reference's learning-rate halving, whose state "
+                         "leaks from one call into the next (target.py:123-125); call nu_attack per room")
+    labels_d = labels_to_device(labels, dev)
+    if masks is not None:
+        mk = masks.detach().to(torch.bool).cpu().numpy() if isinstance(masks, torch.Tensor) else np.asarray(masks).astype(bool)
+        if mk.shape != (R, N):
+            raise ValueError("masks must be boolean [%d, %d], got shape %s" % (R, N, mk.shape))
+        mask_d = torch.from_numpy(mk.astype(np.uint8)).to(dev)
+        mask_b = mask_d.bool()
+        n_mask = mk.sum(axis=1).astype(np.float64)
+    else:
+        if targeted_variant:
+            raise ValueError("the targeted variant needs one mask per room")
+        mask_d = mask_b = None
+        n_mask = np.zeros(R)
+    model = net._packed()
+    net._generation += 1
+    ws = net._workspace(R, N, CHUNK + 1)
+    st = runtime.stream
+
+    x0 = torch.empty(R, N, 9, device=dev, dtype=torch.float32)
+    _lib.call("psg_to_point_major", runtime.ptr(images), R, 9, N, runtime.ptr(x0), st())
+    ori = x0[:, :, 3:6].contiguous()
+    x0_orig = x0.clone()
+    w = torch.empty(R, N, 3, device=dev, dtype=torch.float32)
+    _lib.call("psg_nu_inverse_tanh", runtime.ptr(x0), R, N, runtime.ptr(w), st())
+    m, v = torch.zeros_like(w), torch.zeros_like(w)
+    dlogp = torch.empty(R, N, 13, device=dev, dtype=torch.float32)
+    dx0 = torch.empty(R, N, 9, device=dev, dtype=torch.float32)
+    sgrad = torch.empty(R, N, 3, device=dev, dtype=torch.float32)
+    pred = torch.empty(R, N, device=dev, dtype=torch.int32)
+    scal = torch.zeros(3, R, device=dev, dtype=torch.float32)      # rows: f, smooth, l2
+    active_d = torch.ones(R, device=dev, dtype=torch.uint8)
+    active = np.ones(R, bool)
+    steps_run = np.zeros(R, np.int64)
+    extra_l2 = np.zeros(R)
+    prev_cost = np.full((atk.steps, R), 1e10)
+    lr, adam_t = float(atk.lr), 0
+    tsign = float(atk._targeted)
+    use_target = targeted_variant and target is not None
+    out = torch.empty_like(images)
+    planned_until = 0
+
+    def snapshot(rooms):
+        for r in rooms:
+            out[r].copy_(x0[r].t())
+
+    for step in range(atk.steps):
+        # (rooms that are done keep their w: their colours are rewritten with the same values)
+        _lib.call("psg_nu_tanh_color_rooms", runtime.ptr(w), runtime.ptr(mask_d), R, N, runtime.ptr(x0), st())
+        if step >= planned_until:
+            window_end = 1 if step == 0 else ((step - 1) // CHUNK + 1) * CHUNK + 1      # [0], [1..10], [11..20], ..
+            n_plan = min(window_end - step, atk.steps - step)
+            starts = (draw_fps_starts(R, N, n_plan) if starts_fn is None else starts_fn(step, n_plan)).to(dev)
+            ws.plan_build(x0, starts, n_plan)
+            plan_base, planned_until = step, step + n_plan
+        slot = step - plan_base
+        logp = ws.forward(model, slot, x0)
+        scal.zero_()
+        _lib.call("psg_nu_f_loss_grad_rooms", runtime.ptr(logp), None if use_target else runtime.ptr(labels_d),
+                  int(target) if use_target else 0, R, N, 13, float(atk.kappa), tsign, runtime.ptr(dlogp),
+                  runtime.ptr(scal[0]), runtime.ptr(pred), st())
+        ws.backward(model, slot, dlogp, dx0)
+        _lib.call("psg_smooth_knn_rooms", ctypes_off(x0, 3), 9, N * 9, runtime.ptr(ori), 3, N * 3, R, N, int(neighbour),
+                  runtime.ptr(scal[1]), runtime.ptr(sgrad), st())
+        adam_t += 1
+        _lib.call("psg_nu_adam_step_rooms", runtime.ptr(w), runtime.ptr(m), runtime.ptr(v), runtime.ptr(mask_d),
+                  runtime.ptr(dx0), runtime.ptr(x0), runtime.ptr(ori), runtime.ptr(sgrad), float(atk.c), float(atk.c),
+                  lr, BETA1, BETA2, ADAM_EPS, adam_t, R, N, runtime.ptr(active_d), runtime.ptr(scal[2]), st())
+        # ---- the reference's control flow, per room (one read-back per step for all rooms)
+        correct = pred.eq(labels_d)
+        n_correct_d = correct.sum(dim=1).float()
+        if targeted_variant:
+            tgt_hits = ((pred.eq(int(target)) if use_target else correct) & mask_b).sum(dim=1).float()
+        else:
+            tgt_hits = n_correct_d
+        stats = torch.cat([n_correct_d[None], tgt_hits[None], scal]).cpu().numpy().astype(np.float64)   # [5, R]
+        n_correct, n_tgt, f_loss, sm_loss = stats[0], stats[1], stats[2], stats[3]
+        l2_loss = stats[4] + extra_l2
+        cost = f_loss + float(atk.c) * sm_loss + float(atk.c) * l2_loss
+        prev_cost[step] = np.where(active, cost, prev_cost[step])
+        steps_run[active] += 1
+        if trace is not None:
+            trace(step=step, cost=cost, f=f_loss, smooth=sm_loss, l2=l2_loss, w=w, m=m, v=v, dx0=dx0, x0=x0, pred=pred,
+                  active=active.copy())
+        if not targeted_variant:
+            done = active & (n_correct / 4096 < 1 / 13)                     # nontarget.py:87,95-96
+        else:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                target_acc = n_tgt / n_mask
+            done = active & ((target_acc > 0.9) if use_target else (target_acc < 1 / 13))   # target.py:116-121
+        if done.any():
+            snapshot(np.nonzero(done)[0])
+            active &= ~done
+            active_d.copy_(torch.from_numpy(active.astype(np.uint8)))
+            if not active.any():
+                return out, steps_run
+        if targeted_variant and step > 10 and step % 10 == 0:               # target.py:127-132, room by room
+            again = np.nonzero(active & (cost >= prev_cost[step - 10]))[0]
+            for r in again:
+                k = int(n_mask[r])
+                noise = torch.empty(1, 3, k, device=dev, dtype=torch.float32).uniform_(0, 1)
+                col = x0[r:r + 1, :, 3:6].transpose(1, 2)                     # view [1, 3, N]
+                col[:, :, mask_b[r]] = col[:, :, mask_b[r]] + noise
+                x0[r].clamp_(min=0, max=1)                                   # ALL channels, like the reference
+                d = x0[r] - x0_orig[r]
+                extra_l2[r] = float((d[:, 0:3] ** 2).sum().item() + (d[:, 6:9] ** 2).sum().item())
+            # (xyz may have moved: the next window starts with the next step anyway - restarts only follow steps 20, 30, ..)
+    snapshot(np.nonzero(active)[0])
+    return out, steps_run
 
 
 def ctypes_off(t, n_floats):

@@ -48,3 +48,11 @@ class tar_NU_attack(Attack):
     def forward(self, images, labels):
         from .nu import nu_attack
         return nu_attack(self, images, labels, mask=self.mask, target=self.target, neighbour=5, targeted_variant=True)
+
+    def forward_rooms(self, images, labels, masks):
+        """Extension of the reference API: the attack applied to every room of `images` [R, 9, N] on its own (what R calls
+        with batches of one and `mask = masks[r]` compute), all rooms advanced in lockstep with one launch per operation.
+        Returns (adversarial images [R, 9, N], optimiser steps run per room); see nu.nu_attack_rooms for the two
+        bookkeeping differences from R sequential calls (order of RNG consumption; at most 50 steps)."""
+        from .nu import nu_attack_rooms
+        return nu_attack_rooms(self, images, labels, masks, self.target, neighbour=5, targeted_variant=True)

@@ -323,11 +323,11 @@ __global__ void nu_inverse_tanh_kernel(const float *__restrict__ x0, float *__re
 
 // colour = 1/2 * (tanh(w) + 1)  (nontarget.py:107-108) written into channels 3:6 of x0, masked points only
 __global__ void nu_tanh_color_kernel(const float *__restrict__ w, const uint8_t *__restrict__ mask, float *__restrict__ x0,
-                                     int N, size_t rows)
+                                     int N, size_t rows, int mask_per_room)
 {
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < rows * 3; t += (size_t)gridDim.x * blockDim.x) {
         size_t pt = t / 3;
-        if (mask && !mask[pt % N]) continue;
+        if (mask && !mask[mask_per_room ? pt : pt % N]) continue;
         x0[pt * 9 + 3 + (t % 3)] = __fmul_rn(0.5f, __fadd_rn(tanhf(w[t]), 1.0f));
     }
 }
@@ -336,7 +336,7 @@ __global__ void nu_tanh_color_kernel(const float *__restrict__ w, const uint8_t 
 // target.py:148-168): f = clamp(tsign * (p_y - max_{k != y} p_k), min = -kappa), summed over points.
 __global__ void nu_f_loss_grad_kernel(const float *__restrict__ logp, const int32_t *__restrict__ labels, int target,
                                       int rows, int n_cls, float kappa, float tsign, float *__restrict__ dlogp,
-                                      float *__restrict__ f_sum, int32_t *__restrict__ pred)
+                                      float *__restrict__ f_sum, int32_t *__restrict__ pred, int rows_per_sum)
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     float fval = 0.0f;
@@ -370,9 +370,9 @@ __global__ void nu_f_loss_grad_kernel(const float *__restrict__ logp, const int3
             g[c] = p[c] * (gc - dot);
         }
     }
-    // block reduction of the f values, one atomic per wave
+    // block reduction of the f values, one atomic per wave (rows_per_sum > 0: one sum per room, a multiple of 64 rows each)
     for (int o = 32; o >= 1; o >>= 1) fval += __shfl_xor(fval, o);
-    if ((threadIdx.x & 63) == 0 && f_sum) atomicAdd(f_sum, fval);
+    if ((threadIdx.x & 63) == 0 && f_sum && r < rows) atomicAdd(f_sum + (rows_per_sum ? r / rows_per_sum : 0), fval);
 }
 
 // f-loss of the ResGCN NU attacks, on raw logits (ResGCN/.../attacks/colper.py:108-113, tcolper.py:145-163).
@@ -442,8 +442,14 @@ constexpr int SM_QPB = 256 / SM_SUB;        // queries per workgroup
 template <int NBT>
 __global__ __launch_bounds__(256) void smooth_knn_kernel(const float *__restrict__ adv, int adv_stride,
                                                          const float *__restrict__ ref, int ref_stride, int N, int nb,
-                                                         float *__restrict__ dist_sum, float *__restrict__ grad, int symmetric)
+                                                         float *__restrict__ dist_sum, float *__restrict__ grad, int symmetric,
+                                                         size_t adv_room_stride, size_t ref_room_stride)
 {
+    // blockIdx.y = room of a lockstep batch (psg_smooth_knn_rooms; a single launch of the one-room entry has one slice)
+    adv += blockIdx.y * adv_room_stride;
+    ref += blockIdx.y * ref_room_stride;
+    grad += (size_t)blockIdx.y * N * 3;
+    if (dist_sum) dist_sum += blockIdx.y;
     extern __shared__ float4 s_ref[];                       // [N] reference colours + |r|^2
     float *s_d = (float *)(s_ref + N);                      // [SM_QPB][SM_SUB][NBT]
     int *s_i = (int *)(s_d + SM_QPB * SM_SUB * NBT);
@@ -542,8 +548,20 @@ __global__ void nu_adam_step_kernel(float *__restrict__ w, float *__restrict__ m
                                     const float *__restrict__ x0, const float *__restrict__ ori,
                                     const float *__restrict__ smooth_grad, float c_smooth, float c_l2, float beta1,
                                     float beta2, float eps, float step_size, float bc2_sqrt, int N, size_t rows,
-                                    float *__restrict__ l2_sum)
+                                    float *__restrict__ l2_sum, const uint8_t *__restrict__ room_active)
 {
+    // gridDim.y > 1: slice y is one room of a lockstep batch (rows = N) with its own mask row, smoothness gradient and
+    // L2 sum; a room that has left its loop (room_active[y] == 0) is not touched.  gridDim.y == 1: the reference's batch
+    // call (rows = B N, one mask, the smoothness gradient on batch row 0 only, one sum).
+    if (gridDim.y > 1) {
+        const size_t y = blockIdx.y, o3 = y * rows * 3;
+        if (room_active && !room_active[y]) return;
+        w += o3; m += o3; v += o3; ori += o3;
+        dx0 += y * rows * 9; x0 += y * rows * 9;
+        if (mask) mask += y * rows;
+        if (smooth_grad) smooth_grad += o3;
+        if (l2_sum) l2_sum += y;
+    }
     float l2 = 0.0f;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < rows * 3; t += (size_t)gridDim.x * blockDim.x) {
         const size_t pt = t / 3;
@@ -583,7 +601,20 @@ extern "C" int psg_nu_tanh_color(const float *w, const uint8_t *mask, int B, int
     PSG_REQUIRE(w && x0 && B > 0 && N > 0, "psg_nu_tanh_color: bad argument");
     size_t rows = (size_t)B * N;
     hipLaunchKernelGGL(nu_tanh_color_kernel, dim3(grid_for(rows * 3)), dim3(256), 0, (hipStream_t)stream, w, mask, x0, N,
-                       rows);
+                       rows, 0);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+// The "_rooms" entry points serve B INDEPENDENT one-room attacks advanced in lockstep (the reference's tar_NU / NU attack
+// called once per room, target.py:62-133 at B = 1; pointsecguard_amd/attacks/torchattacks/attacks/nu.py: nu_attack_rooms):
+// every room has its own mask row, its own smoothness term and its own loss sums; a room that has left the loop is frozen.
+extern "C" int psg_nu_tanh_color_rooms(const float *w, const uint8_t *mask_rooms, int B, int N, float *x0, psg_stream stream)
+{
+    PSG_REQUIRE(w && x0 && B > 0 && N > 0, "psg_nu_tanh_color_rooms: bad argument");
+    size_t rows = (size_t)B * N;
+    hipLaunchKernelGGL(nu_tanh_color_kernel, dim3(grid_for(rows * 3)), dim3(256), 0, (hipStream_t)stream, w, mask_rooms, x0, N,
+                       rows, 1);
     PSG_LAUNCH_CHECK();
     return PSG_OK;
 }
@@ -595,7 +626,21 @@ extern "C" int psg_nu_f_loss_grad(const float *logp, const int32_t *labels, int 
     PSG_REQUIRE(n_cls > 1 && n_cls <= MAXC, "psg_nu_f_loss_grad: n_cls=%d out of range", n_cls);
     PSG_REQUIRE(labels || (target >= 0 && target < n_cls), "psg_nu_f_loss_grad: target class %d out of range", target);
     hipLaunchKernelGGL(nu_f_loss_grad_kernel, dim3(psg::ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream, logp,
-                       labels, target, rows, n_cls, kappa, tsign, dlogp_out, f_sum, pred_out);
+                       labels, target, rows, n_cls, kappa, tsign, dlogp_out, f_sum, pred_out, 0);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+extern "C" int psg_nu_f_loss_grad_rooms(const float *logp, const int32_t *labels, int target, int B, int N, int n_cls, float kappa,
+                                        float tsign, float *dlogp_out, float *f_sum_rooms, int32_t *pred_out, psg_stream stream)
+{
+    PSG_REQUIRE(logp && dlogp_out && f_sum_rooms && B > 0 && N > 0, "psg_nu_f_loss_grad_rooms: bad argument");
+    PSG_REQUIRE(N % 64 == 0, "psg_nu_f_loss_grad_rooms: N=%d must be a multiple of 64 (one wave never spans two rooms)", N);
+    PSG_REQUIRE(n_cls > 1 && n_cls <= MAXC, "psg_nu_f_loss_grad_rooms: n_cls=%d out of range", n_cls);
+    PSG_REQUIRE(labels || (target >= 0 && target < n_cls), "psg_nu_f_loss_grad_rooms: target class %d out of range", target);
+    const int rows = B * N;
+    hipLaunchKernelGGL(nu_f_loss_grad_kernel, dim3(psg::ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream, logp,
+                       labels, target, rows, n_cls, kappa, tsign, dlogp_out, f_sum_rooms, pred_out, N);
     PSG_LAUNCH_CHECK();
     return PSG_OK;
 }
@@ -614,31 +659,47 @@ extern "C" int psg_gcn_f_loss_grad(const float *logits, const int32_t *labels, i
     return PSG_OK;
 }
 
-extern "C" int psg_smooth_knn(const float *adv_color, int adv_stride, const float *ref_color, int ref_stride, int N,
-                              int nb, float *dist_sum, float *grad_out, psg_stream stream)
+static int smooth_knn_launch(const float *adv_color, int adv_stride, size_t adv_room_stride, const float *ref_color, int ref_stride,
+                             size_t ref_room_stride, int B, int N, int nb, float *dist_sum, float *grad_out, psg_stream stream)
 {
-    PSG_REQUIRE(adv_color && ref_color && grad_out && N > 0, "psg_smooth_knn: bad argument");
+    PSG_REQUIRE(adv_color && ref_color && grad_out && N > 0 && B > 0 && B <= 65535, "psg_smooth_knn: bad argument");
     PSG_REQUIRE(nb > 0 && nb <= SM_MAX_NB, "psg_smooth_knn: neighbour count %d out of range (1..%d)", nb, SM_MAX_NB);
     PSG_REQUIRE(N <= 8192, "psg_smooth_knn: N=%d exceeds the LDS-resident limit 8192", N);
     // ref_color == adv_color selects the ResGCN variants' smooth(adv, adv): gradient through both arguments
     const int symmetric = ref_color == adv_color && ref_stride == adv_stride;
-    if (symmetric) PSG_CHECK_HIP(hipMemsetAsync(grad_out, 0, (size_t)N * 3 * sizeof(float), (hipStream_t)stream));
+    if (symmetric) PSG_CHECK_HIP(hipMemsetAsync(grad_out, 0, (size_t)B * N * 3 * sizeof(float), (hipStream_t)stream));
     const int nbt = nb <= 8 ? 8 : 16;
     const size_t lds = (size_t)N * sizeof(float4) + (size_t)SM_QPB * SM_SUB * nbt * 8;
-    const dim3 grid(psg::ceil_div(N, SM_QPB));
+    const dim3 grid(psg::ceil_div(N, SM_QPB), B);
     if (nbt == 8) {
         if (lds > 48 * 1024)
             PSG_CHECK_HIP(hipFuncSetAttribute((const void *)smooth_knn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(smooth_knn_kernel<8>, grid, dim3(256), lds, (hipStream_t)stream, adv_color, adv_stride, ref_color,
-                           ref_stride, N, nb, dist_sum, grad_out, symmetric);
+                           ref_stride, N, nb, dist_sum, grad_out, symmetric, adv_room_stride, ref_room_stride);
     } else {
         if (lds > 48 * 1024)
             PSG_CHECK_HIP(hipFuncSetAttribute((const void *)smooth_knn_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(smooth_knn_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, adv_color, adv_stride, ref_color,
-                           ref_stride, N, nb, dist_sum, grad_out, symmetric);
+                           ref_stride, N, nb, dist_sum, grad_out, symmetric, adv_room_stride, ref_room_stride);
     }
     PSG_LAUNCH_CHECK();
     return PSG_OK;
+}
+
+extern "C" int psg_smooth_knn(const float *adv_color, int adv_stride, const float *ref_color, int ref_stride, int N,
+                              int nb, float *dist_sum, float *grad_out, psg_stream stream)
+{
+    return smooth_knn_launch(adv_color, adv_stride, 0, ref_color, ref_stride, 0, 1, N, nb, dist_sum, grad_out, stream);
+}
+
+// B rooms at once: room b's colours start at adv_color + b * adv_room_stride floats (likewise ref); dist_sum [B], grad_out [B][N][3]
+extern "C" int psg_smooth_knn_rooms(const float *adv_color, int adv_stride, size_t adv_room_stride, const float *ref_color,
+                                    int ref_stride, size_t ref_room_stride, int B, int N, int nb, float *dist_sum_rooms,
+                                    float *grad_out, psg_stream stream)
+{
+    PSG_REQUIRE(adv_color != ref_color, "psg_smooth_knn_rooms: the symmetric variant is one room at a time");
+    return smooth_knn_launch(adv_color, adv_stride, adv_room_stride, ref_color, ref_stride, ref_room_stride, B, N, nb,
+                             dist_sum_rooms, grad_out, stream);
 }
 
 extern "C" int psg_nu_adam_step(float *w, float *m, float *v, const uint8_t *mask, const float *dx0, const float *x0,
@@ -652,7 +713,24 @@ extern "C" int psg_nu_adam_step(float *w, float *m, float *v, const uint8_t *mas
     const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
     size_t rows = (size_t)B * N;
     hipLaunchKernelGGL(nu_adam_step_kernel, dim3(grid_for(rows * 3)), dim3(256), 0, (hipStream_t)stream, w, m, v, mask,
-                       dx0, x0, ori, smooth_grad, c_smooth, c_l2, beta1, beta2, eps, step_size, bc2_sqrt, N, rows, l2_sum);
+                       dx0, x0, ori, smooth_grad, c_smooth, c_l2, beta1, beta2, eps, step_size, bc2_sqrt, N, rows, l2_sum,
+                       (const uint8_t *)nullptr);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+// the same update for B one-room attacks in lockstep: mask [B][N], smooth_grad [B][N][3], l2_sum [B]; room_active [B] (or NULL)
+extern "C" int psg_nu_adam_step_rooms(float *w, float *m, float *v, const uint8_t *mask_rooms, const float *dx0, const float *x0,
+                                      const float *ori, const float *smooth_grad_rooms, float c_smooth, float c_l2, float lr,
+                                      float beta1, float beta2, float eps, int step, int B, int N, const uint8_t *room_active,
+                                      float *l2_sum_rooms, psg_stream stream)
+{
+    PSG_REQUIRE(w && m && v && dx0 && x0 && ori && B > 1 && B <= 65535 && N > 0 && step >= 1, "psg_nu_adam_step_rooms: bad argument (B >= 2)");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(nu_adam_step_kernel, dim3(grid_for((size_t)N * 3), B), dim3(256), 0, (hipStream_t)stream, w, m, v, mask_rooms,
+                       dx0, x0, ori, smooth_grad_rooms, c_smooth, c_l2, beta1, beta2, eps, step_size, bc2_sqrt, N, (size_t)N, l2_sum_rooms,
+                       room_active);
     PSG_LAUNCH_CHECK();
     return PSG_OK;
 }

@@ -543,6 +543,66 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
 }
 
 // ------------------------------------------------------------------------------------------ FP bwd
+// Transposed 3-NN interpolation of the finer module, for the 32 points of a workgroup: buf[c][j] = sum over the list of
+// point j of w * dint[fine][c] (CSR by coarse point, ascending fine point: the order the sums always had).
+// The lists of a room are as uneven as its point density - a coarse point inside a dense patch is the neighbour of hundreds
+// of fine points while the mean is 12 - so the rows are not dealt to lanes (one lane walking one list, everybody waiting
+// for the longest) but to WAVES by entry count: wave w takes the consecutive rows whose lists start inside the w-th
+// NW-th of the workgroup's entry range, walks their entries in order with all 64 lanes on one gradient row (a coalesced
+// Cout-float read per entry, eight rows in flight) and writes every row it owns exactly once (zeros for an empty list).
+// A wave's share is at most the even share plus one list.  VW = Cout / 64 channels per lane (2 or 4).
+template <int P, int NW, int VW>
+__device__ __forceinline__ void fp_bwd_gather_rows(const FpBwdArgs &a, int b, int n0, float *__restrict__ buf, int lane, int wave)
+{
+    static_assert(P == 32, "one 32-point tile per workgroup");
+    typedef float vwf __attribute__((ext_vector_type(VW)));
+    const int32_t *offp = a.nninv_off + (size_t)b * (a.N + 1) + n0;
+    const int2 *ent = a.nninv_ent + (size_t)b * 3 * a.n_fine;
+    const int offl = offp[lane < 32 ? lane : 32];                       // lanes 32.. hold the end of the range
+    const int e0 = __builtin_amdgcn_readfirstlane(offl), e_end = __builtin_amdgcn_readlane(offl, 32);
+    const int ltot = e_end - e0;
+    const int t_lo = (int)(((long long)ltot * wave) / NW), t_hi = (int)(((long long)ltot * (wave + 1)) / NW);
+    const int r_lo = __popcll(__ballot(lane < 32 && offl - e0 < t_lo));
+    const int r_hi = wave == NW - 1 ? 32 : __popcll(__ballot(lane < 32 && offl - e0 < t_hi));
+    if (r_lo >= r_hi) return;
+    const int lo = __builtin_amdgcn_readlane(offl, r_lo), hi = __builtin_amdgcn_readlane(offl, r_hi);
+    const float *rows = a.dint + (size_t)b * a.n_fine * a.Cout + lane * VW;
+    float *dst = buf + ((lane * VW) >> 3) * Lds<P>::BLK + ((lane * VW) & 7);    // + 8 * point
+    int cur = r_lo, next = __builtin_amdgcn_readlane(offl, r_lo + 1);
+    vwf acc = 0.0f;
+    for (int base = lo; base < hi; base += 64) {
+        const int n = hi - base < 64 ? hi - base : 64;
+        const int2 pe = lane < n ? ent[base + lane] : make_int2(0, 0);  // (an absent entry reads row 0 with weight 0)
+        for (int i = 0; i < n; i += 8) {
+            vwf v[8];
+            float w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int fine = __builtin_amdgcn_readlane(pe.x, i + k);
+                w[k] = __int_as_float(__builtin_amdgcn_readlane(pe.y, i + k));
+                v[k] = *(const vwf *)(rows + (size_t)fine * a.Cout);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (i + k < n) {
+                    const int e = base + i + k;
+                    while (e >= next) {                                 // the row is complete (or empty): write it, take the next
+                        *(vwf *)(dst + 8 * cur) = acc;
+                        acc = 0.0f;
+                        ++cur;
+                        next = __builtin_amdgcn_readlane(offl, cur + 1);
+                    }
+                    acc += w[k] * v[k];
+                }
+            }
+        }
+    }
+    for (; cur < r_hi; ++cur) {
+        *(vwf *)(dst + 8 * cur) = acc;
+        acc = 0.0f;
+    }
+}
+
 // BIG: the gradient of the concatenated input does not fit LDS (MSG fp4: 1536 channels): the last transposed layer
 // is not run in place; NW output tiles at a time go through a staging area behind its input and out to HBM.
 template <int P, int NW, int MAXT, bool BIG = false>
@@ -562,11 +622,25 @@ __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
         // dZ_last = dout * mask_last, loaded tile-wise so the mask bits line up with the forward epilogue
         const int j = lane & 31, h = lane >> 5;
         const int ntask = a.mb_last * PB;
+        // the gathered gradient goes through the activation buffer itself: waves gather whole rows (balanced by entry
+        // count), then every lane masks its own tile elements in place
+        const bool staged = P == 32 && a.nninv_off && (a.Cout == 128 || a.Cout == 256);
+        if constexpr (P == 32) {
+            if (staged) {
+                if (a.Cout == 128) fp_bwd_gather_rows<P, NW, 2>(a, b, n0, buf0, lane, wave);
+                else fp_bwd_gather_rows<P, NW, 4>(a, b, n0, buf0, lane, wave);
+                __syncthreads();
+            }
+        }
         for (int task = wave; task < ntask; task += NW) {
             const int mb = task / PB, pb = task - mb * PB;
             const unsigned m = a.mask_last[(wg * ntask + task) * 64 + lane];
             float4 dq[4];
-            if (a.nninv_off) {
+            if (staged) {
+                const float *o = buf0 + (size_t)(mb * 4) * L::BLK + (pb * 32 + j) * 8 + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) dq[g] = *(const float4 *)(o + (size_t)g * L::BLK);
+            } else if (a.nninv_off) {
                 // deterministic transpose of the finer module's interpolation: sum_w * (its gradient rows)
                 const int32_t *off = a.nninv_off + (size_t)b * (a.N + 1) + n0 + pb * 32 + j;
                 const int2 *ent = a.nninv_ent + (size_t)b * 3 * a.n_fine;

@@ -1647,7 +1647,7 @@ extern "C" int psg_rla_bim_attack(psg_rla_model *m, psg_rla_ws *ws, const float 
     // queue).  Capture is impossible on the legacy default stream; the loop then stays eager.
     if ((rc = iteration())) return rc;
     int it = 1;
-    static const bool use_graph = !(getenv("PSG_RLA_NO_GRAPH") && atoi(getenv("PSG_RLA_NO_GRAPH")));
+    static const bool use_graph = !(getenv("PSG_RLA_NO_GRAPH") && atoi(getenv("PSG_RLA_NO_GRAPH"))) && !trace_sync_enabled();   // (the tracer synchronises after every launch)
     if (use_graph && !ws->prof.on && iters - it >= 2) {
         if (ws->bim_exec && (ws->bim_model != (const void *)m || ws->bim_eps != eps || ws->bim_alpha != alpha || ws->bim_metric != l2_metric)) {
             PSG_CHECK_HIP(hipStreamSynchronize(st));

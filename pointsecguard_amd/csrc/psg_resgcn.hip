@@ -1296,7 +1296,7 @@ extern "C" int psg_gcn_nb_attack(psg_gcn_model *m, psg_gcn_ws *ws, const float *
     // the attack moves colours only: the head's kNN graph on xyz (architecture.py:59) is the same in every iteration
     struct Unfreeze { psg_gcn_ws *w; ~Unfreeze() { w->head_graph_frozen = false; } } unfreeze{ws};
     ws->head_graph_frozen = true;
-    static const bool use_graph = !(getenv("PSG_GCN_NO_GRAPH") && atoi(getenv("PSG_GCN_NO_GRAPH")));
+    static const bool use_graph = !(getenv("PSG_GCN_NO_GRAPH") && atoi(getenv("PSG_GCN_NO_GRAPH"))) && !trace_sync_enabled();   // (the tracer synchronises after every launch)
     if (use_graph && !ws->prof.on && iters - 1 - it >= 2) {
         if (ws->nb_exec && (ws->nb_model != (const void *)m || ws->nb_eps != eps || ws->nb_alpha != alpha ||
                             ws->nb_fixed != ws->fixed_graphs)) {

@@ -6,7 +6,8 @@ the tf.data map function of main_S3DIS.py:189-214 (`tf_map`: for each of the num
 k_n neighbours, the pooling indices of the sub-sampled points and the nearest sub-sampled point of every point).
 Both run `psg_knn_points` (exact brute-force k-NN, hand-written HIP); there is no CPU path.
 
-Only the indices are produced here: the RandLA-Net network itself (TF1 in the reference) is not part of this package.
+Only the indices are produced here; the network (RandLANet.py) is `randla/network.py`, the tester's attacks are
+`randla/attack.py`, and the possibility-based crop sampler of main_S3DIS.py:116-187 is `randla/sampler.py`.
 """
 import numpy as np
 import torch

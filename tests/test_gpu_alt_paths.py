@@ -1,0 +1,43 @@
+"""The opt-in alternative kernels keep the same parity bars as the default ones.
+
+  PSG_FP1_WAVE=1     wave-private fp1 + head chain (psg_chain.cuh) instead of the workgroup-cooperative kernels
+  PSG_RLA_ATOMICS=1  RandLA-Net backward scatters with float atomics instead of the inverse-list gathers
+
+Both switches are read once per process, so each case runs the relevant parity tests in ONE child interpreter with the
+switch set and the launch tracer on (PSG_TRACE_SYNC=1 prints the source line of every launch): the child must pass, and
+its set of launch sites must differ from the default child's - the switch really selected other kernels."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def child(test_file, keyword, extra_env):
+    env = dict(os.environ)
+    env.pop("PSG_FP1_WAVE", None)
+    env.pop("PSG_RLA_ATOMICS", None)
+    env.update(extra_env)
+    env["PSG_TRACE_SYNC"] = "1"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", test_file), "-x", "-q", "-m", "gpu",
+                          "-k", keyword, "-p", "no:cacheprovider"], env=env, cwd=ROOT, capture_output=True, text=True,
+                         timeout=900)
+    sites = set(re.findall(r"\[psg trace\] launch \d+ at (\S+) issued", out.stderr + out.stdout))
+    return out, sites
+
+
+@pytest.mark.parametrize("test_file,keyword,switch", [
+    ("test_gpu_parity.py", "forward_vs_reference or backward_vs_reference or forward_backward_vs_oracle_batch", "PSG_FP1_WAVE"),
+    ("test_randla_net.py", "forward_backward_vs_oracle or bim_attack_vs_oracle", "PSG_RLA_ATOMICS"),
+])
+def test_switch_selects_other_kernels_with_the_same_parity(test_file, keyword, switch):
+    base, base_sites = child(test_file, keyword, {})
+    assert base.returncode == 0, base.stdout[-3000:]
+    alt, alt_sites = child(test_file, keyword, {switch: "1"})
+    assert alt.returncode == 0, alt.stdout[-3000:]
+    assert " passed" in alt.stdout and "skipped" not in alt.stdout.splitlines()[-1]
+    assert base_sites and alt_sites and alt_sites != base_sites, (switch, sorted(alt_sites ^ base_sites))

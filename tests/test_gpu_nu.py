@@ -362,3 +362,101 @@ def test_tar_nu_b1_sixty_steps_vs_reference(weights_sd):
     assert np.array_equal(out[:, :3], refimg[:, :3]) and np.array_equal(out[:, 6:], refimg[:, 6:])
     assert np.array_equal(out[:, 3:6][:, :, ~mask], refimg[:, 3:6][:, :, ~mask])
     assert (np.abs(out[:, 3:6] - refimg[:, 3:6]) <= 2e-2).mean() >= 0.99
+
+
+def _rooms_case(weights_sd, n_rooms, seed):
+    from pointsecguard_amd.models.pointnet2_sem_seg import get_model
+    from pointsecguard_amd.synthetic import make_rooms, rule_labels
+    net = get_model(13)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in weights_sd.items()})
+    net = net.cuda().eval()
+    rooms = make_rooms(n_rooms, seed, structured=True)
+    labels = rule_labels(rooms)
+    return net, rooms, labels, dev(rooms.transpose(0, 2, 1))
+
+
+def test_tar_nu_rooms_lockstep_equals_one_call_per_room(weights_sd):
+    """configs[2] applied per room: `forward_rooms` (R one-room attacks in lockstep, one launch per operation) against R
+    calls of the reference-shaped API with batches of one, on the same FPS start indices (a table indexed by step, level
+    and room replaces the generator draws in both).  24 steps cross the step-20 restart test.  Per room: the same number
+    of steps, the same cost history to the rounding of the float-atomic loss sums, and adversarial colours that are
+    bit-equal (the network kernels compute a room identically in any batch; a restart moves nothing that survives the next
+    tanh_space)."""
+    from pointsecguard_amd.attacks import torchattacks
+    from pointsecguard_amd.attacks.torchattacks.attacks import nu as nu_mod
+    R, steps, target = 4, 24, 6
+    net, rooms, labels, images = _rooms_case(weights_sd, R, 9100)
+    masks = labels == 2
+    assert masks.sum(axis=1).min() > 50
+    rng = np.random.default_rng(17)
+    table = torch.from_numpy(np.stack([rng.integers(0, n, (steps, R)) for n in (4096, 1024, 256, 64)], axis=1).astype(np.int32))
+
+    def starts_for(lo, hi):
+        return lambda step, n_plan: table[step:step + n_plan, :, lo:hi].contiguous()
+
+    single, single_costs = [], []
+    for r in range(R):
+        atk = torchattacks.tar_NU_attack(net, c=1, kappa=0, steps=steps, lr=0.01, target=target, mask=masks[r])
+        costs = []
+        torch.manual_seed(100 + r)
+        adv = nu_mod.nu_attack(atk, images[r:r + 1], labels[r:r + 1].astype(np.float64), masks[r], target, 5, targeted_variant=True,
+                               trace=lambda **kw: costs.append(kw["cost"]), starts_fn=starts_for(r, r + 1))
+        single.append(adv.cpu().numpy()[0])
+        single_costs.append(costs)
+    atk = torchattacks.tar_NU_attack(net, c=1, kappa=0, steps=steps, lr=0.01, target=target, mask=None)
+    hist = []
+    torch.manual_seed(5)
+    adv, steps_run = nu_mod.nu_attack_rooms(atk, images, labels.astype(np.float64), masks, target, 5, targeted_variant=True,
+                                            trace=lambda **kw: hist.append((kw["cost"].copy(), kw["active"])),
+                                            starts_fn=starts_for(0, R))
+    torch.cuda.synchronize()
+    out = adv.cpu().numpy()
+    src = rooms.transpose(0, 2, 1)
+    for r in range(R):
+        assert steps_run[r] == len(single_costs[r]), (r, steps_run, [len(c) for c in single_costs])
+        got = np.array([h[0][r] for h in hist[:steps_run[r]]])
+        assert np.allclose(got, single_costs[r], rtol=1e-5), r
+        assert np.array_equal(out[r], single[r]), (r, np.abs(out[r] - single[r]).max())
+        assert np.array_equal(out[r, :3], src[r, :3]) and np.array_equal(out[r, 3:6][:, ~masks[r]], src[r, 3:6][:, ~masks[r]])
+    assert (out[:, 3:6] != src[:, 3:6]).any()
+    # the class method is the same call
+    torch.manual_seed(5)
+    adv2, steps2 = torchattacks.tar_NU_attack(net, c=1, kappa=0, steps=3, lr=0.01, target=target).forward_rooms(
+        images, labels.astype(np.float64), masks)
+    assert adv2.shape == images.shape and list(steps2) == [3] * R
+    with pytest.raises(ValueError):
+        nu_mod.nu_attack_rooms(torchattacks.tar_NU_attack(net, steps=51, target=target), images, labels, masks, target, 5, True)
+
+
+def test_nu_rooms_a_room_that_exits_early_is_frozen(weights_sd):
+    """Non-targeted variant in lockstep: room 1 is given labels that no prediction matches, so its accuracy is below 1/13
+    at the first step and it leaves the loop there (nontarget.py:87,95-96) with the image of that step, while the other
+    rooms run on and equal their one-call-per-room results."""
+    from pointsecguard_amd.attacks import torchattacks
+    from pointsecguard_amd.attacks.torchattacks.attacks import nu as nu_mod
+    R, steps = 3, 6
+    net, rooms, labels, images = _rooms_case(weights_sd, R, 9200)
+    labels = labels.copy()
+    rng = np.random.default_rng(3)
+    table = torch.from_numpy(np.stack([rng.integers(0, n, (steps, R)) for n in (4096, 1024, 256, 64)], axis=1).astype(np.int32))
+    # labels of room 1: for every point a class the network does not predict there (found with one forward of the API)
+    atk0 = torchattacks.NU_attack(net, c=1, kappa=0, steps=1, lr=0.01)
+    seen = {}
+    nu_mod.nu_attack_rooms(atk0, images, labels.astype(np.float64), None, None, 10, trace=lambda **kw: seen.update(pred=kw["pred"].cpu().numpy()),
+                           starts_fn=lambda step, n_plan: table[step:step + n_plan].contiguous())
+    labels[1] = (seen["pred"][1] + 1) % 13
+    single = []
+    for r in range(R):
+        atk = torchattacks.NU_attack(net, c=1, kappa=0, steps=steps, lr=0.01)
+        n = [0]
+        adv = nu_mod.nu_attack(atk, images[r:r + 1], labels[r:r + 1].astype(np.float64), None, None, 10,
+                               trace=lambda **kw: n.__setitem__(0, n[0] + 1),
+                               starts_fn=lambda step, n_plan, r=r: table[step:step + n_plan, :, r:r + 1].contiguous())
+        single.append((adv.cpu().numpy()[0], n[0]))
+    atk = torchattacks.NU_attack(net, c=1, kappa=0, steps=steps, lr=0.01)
+    adv, steps_run = nu_mod.nu_attack_rooms(atk, images, labels.astype(np.float64), None, None, 10,
+                                            starts_fn=lambda step, n_plan: table[step:step + n_plan].contiguous())
+    out = adv.cpu().numpy()
+    assert list(steps_run) == [s[1] for s in single] and steps_run[1] == 1 and steps_run[0] == steps
+    for r in range(R):
+        assert np.array_equal(out[r], single[r][0]), r
