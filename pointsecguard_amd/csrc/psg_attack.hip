@@ -430,20 +430,48 @@ __global__ void gcn_f_loss_grad_kernel(const float *__restrict__ z, const int32_
     if ((threadIdx.x & 63) == 0 && f_sum) atomicAdd(f_sum, fval);
 }
 
-// Smooth loss (nontarget.py:131-135): for every adversarial colour of room 0 the `nb` smallest
-// Euclidean distances to the reference colours; returns their sum and d(sum)/d(adv colour).
-// 16 lanes share one query: each scans every 16th reference colour keeping its own sorted top-NBT, then lane 0
-// of the group merges the 16 short lists ((distance, index) order: the lower index wins a tie, as a sequential
-// scan with a strict '<' would).  256 workgroups instead of 16, and an insertion network of NBT = 8 instead of
-// 16 steps for the usual nb = 5 (the first version took 3.9 ms per call, 60 % of an NU optimiser step).
+// Smooth loss (nontarget.py:131-135): for every adversarial colour of a room the `nb` smallest Euclidean distances to the
+// reference colours; returns their sum and d(sum)/d(adv colour).
+// A workgroup of 1024 threads stages the room's reference colours (+ |r|^2) in LDS once and serves 256 queries, FOUR lanes per
+// query: each scans every 4th reference keeping its own sorted top-NBT in registers (a sorted insertion with static
+// indexing; after the first few hundred references almost every candidate fails the one compare against the list's last
+// entry), then the four short lists are merged nb times through two DPP-sized shuffles by (distance, index) - the lower
+// index wins a tie, as a sequential scan with a strict '<' would - and the winner shifts its list.  Two workgroups (32
+// waves) share a CU, and a 32-room lockstep launch (psg_smooth_knn_rooms) is exactly one round of 512 workgroups.
+// (Round 2's version gave 16 lanes and a 64-KB staging copy to every 16 queries and merged in one lane: 2 workgroups =
+// 8 waves per CU, 122 us for one room and 2.2 ms for 32 - half of the GPU time of a lockstep tar_NU step.)
 constexpr int SM_MAX_NB = 16;
-constexpr int SM_SUB = 16;                  // lanes per query
-constexpr int SM_QPB = 256 / SM_SUB;        // queries per workgroup
+constexpr int SM_SUB = 4;                   // lanes per query
+constexpr int SM_T = 1024;
+constexpr int SM_QPB = SM_T / SM_SUB;       // queries per workgroup
+constexpr int SM_REFRESH = 64;              // scan iterations between two updates of the query's common threshold
+
+// one step of the 4-way merge: the smallest head of the query's four sorted lists by (distance, index) is returned in
+// every lane of the query and popped from the one list that holds it (reference indices are unique across the lists;
+// exhausted lists show (inf, 0x7FFFFFFF) and may pop together, which changes nothing)
 template <int NBT>
-__global__ __launch_bounds__(256) void smooth_knn_kernel(const float *__restrict__ adv, int adv_stride,
-                                                         const float *__restrict__ ref, int ref_stride, int N, int nb,
-                                                         float *__restrict__ dist_sum, float *__restrict__ grad, int symmetric,
-                                                         size_t adv_room_stride, size_t ref_room_stride)
+__device__ __forceinline__ void smooth_pop_min(float (&bd)[NBT], int (&bi)[NBT], float &best, int &bidx)
+{
+    best = bd[0];
+    bidx = bi[0];
+#pragma unroll
+    for (int o = 1; o < SM_SUB; o <<= 1) {
+        const float od = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bidx, o);
+        if (od < best || (od == best && oi < bidx)) { best = od; bidx = oi; }
+    }
+    if (bi[0] == bidx) {
+#pragma unroll
+        for (int u = 0; u + 1 < NBT; ++u) { bd[u] = bd[u + 1]; bi[u] = bi[u + 1]; }
+        bd[NBT - 1] = INFINITY; bi[NBT - 1] = 0x7FFFFFFF;
+    }
+}
+
+template <int NBT>
+__global__ __launch_bounds__(SM_T) void smooth_knn_kernel(const float *__restrict__ adv, int adv_stride,
+                                                          const float *__restrict__ ref, int ref_stride, int N, int nb,
+                                                          float *__restrict__ dist_sum, float *__restrict__ grad, int symmetric,
+                                                          size_t adv_room_stride, size_t ref_room_stride)
 {
     // blockIdx.y = room of a lockstep batch (psg_smooth_knn_rooms; a single launch of the one-room entry has one slice)
     adv += blockIdx.y * adv_room_stride;
@@ -451,9 +479,7 @@ __global__ __launch_bounds__(256) void smooth_knn_kernel(const float *__restrict
     grad += (size_t)blockIdx.y * N * 3;
     if (dist_sum) dist_sum += blockIdx.y;
     extern __shared__ float4 s_ref[];                       // [N] reference colours + |r|^2
-    float *s_d = (float *)(s_ref + N);                      // [SM_QPB][SM_SUB][NBT]
-    int *s_i = (int *)(s_d + SM_QPB * SM_SUB * NBT);
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    for (int i = threadIdx.x; i < N; i += SM_T) {
         const float x = ref[(size_t)i * ref_stride], y = ref[(size_t)i * ref_stride + 1], z = ref[(size_t)i * ref_stride + 2];
         s_ref[i] = make_float4(x, y, z, x * x + y * y + z * z);
     }
@@ -472,53 +498,63 @@ __global__ __launch_bounds__(256) void smooth_knn_kernel(const float *__restrict
     // vector of rounding noise -- so the same expansion is used here (not bit-identical to MKL's order).
     const float asq = ax * ax + ay * ay + az * az;
     const float m2x = -2.0f * ax, m2y = -2.0f * ay, m2z = -2.0f * az;
-    if (i < N) {
-        for (int j = sub; j < N; j += SM_SUB) {
-            const float4 q = s_ref[j];
-            float d2 = __fmaf_rn(m2z, q.z, __fmaf_rn(m2y, q.y, __fmul_rn(m2x, q.x)));
-            d2 = __fadd_rn(__fadd_rn(d2, asq), q.w);
-            d2 = fmaxf(d2, 0.0f);
-            if (d2 < bd[NBT - 1]) {
-                float cd = d2;
-                int ci = j;
+    // thr: a candidate is looked at only below min(this lane's worst kept distance, the nb-th smallest distance the
+    // query's four lanes hold TOGETHER at the last refresh).  The common bound is what keeps the insertion branch rare:
+    // a wave serves 16 queries x 4 lanes, it runs the insertion network whenever ANY lane passes, and a lane's own
+    // list only tightens as 8 / n.  Exact: everything kept at a refresh has a lower index than anything scanned later,
+    // so a later candidate at exactly the bound loses the (distance, index) tie and '<' drops nothing that is wanted.
+    float thr = i < N ? INFINITY : -1.0f;
+    for (int j0 = sub; j0 < N; j0 += SM_SUB * SM_REFRESH) {
+        const int j1 = j0 + SM_SUB * SM_REFRESH < N ? j0 + SM_SUB * SM_REFRESH : N;
+        // four references per pass: their LDS reads and distance chains are independent, one test covers all four
+        for (int j = j0; j < j1; j += 4 * SM_SUB) {
+            float d2[4];
 #pragma unroll
-                for (int t = 0; t < NBT; ++t) {   // sorted insertion with static indexing (arrays stay in registers)
-                    if (cd < bd[t]) {
-                        float td = bd[t]; int ti = bi[t];
-                        bd[t] = cd; bi[t] = ci;
-                        cd = td; ci = ti;
+            for (int u = 0; u < 4; ++u) {
+                const int ju = j + u * SM_SUB;
+                const float4 q = s_ref[ju < N ? ju : j];
+                float t2 = __fmaf_rn(m2z, q.z, __fmaf_rn(m2y, q.y, __fmul_rn(m2x, q.x)));
+                t2 = __fadd_rn(__fadd_rn(t2, asq), q.w);
+                d2[u] = ju < j1 ? fmaxf(t2, 0.0f) : INFINITY;
+            }
+            if (fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3])) < thr) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (d2[u] < thr) {
+                        float cd = d2[u];
+                        int ci = j + u * SM_SUB;
+#pragma unroll
+                        for (int t = 0; t < NBT; ++t) {   // sorted insertion with static indexing (arrays stay in registers)
+                            if (cd < bd[t]) {
+                                float td = bd[t]; int ti = bi[t];
+                                bd[t] = cd; bi[t] = ci;
+                                cd = td; ci = ti;
+                            }
+                        }
+                        thr = fminf(thr, bd[NBT - 1]);
                     }
                 }
             }
         }
+        if (j0 - sub + SM_SUB * SM_REFRESH < N) {   // another chunk follows (the same answer in the query's four lanes)
+            float cdist[NBT];
+            int cidx[NBT];
+#pragma unroll
+            for (int t = 0; t < NBT; ++t) { cdist[t] = bd[t]; cidx[t] = bi[t]; }
+            float kth = INFINITY;
+            int kidx;
+            for (int t = 0; t < nb; ++t) smooth_pop_min<NBT>(cdist, cidx, kth, kidx);
+            thr = fminf(thr, kth);
+        }
     }
-    float *md = s_d + (size_t)(ql * SM_SUB + sub) * NBT;
-    int *mi = s_i + (size_t)(ql * SM_SUB + sub) * NBT;
-#pragma unroll
-    for (int t = 0; t < NBT; ++t) { md[t] = bd[t]; mi[t] = bi[t]; }
-    __syncthreads();
-    float local = 0.0f;
-    if (sub == 0 && i < N) {
-        // 16-way merge: nb times take the smallest head by (distance, index)
-        int head[SM_SUB];
-#pragma unroll
-        for (int u = 0; u < SM_SUB; ++u) head[u] = 0;
-        const float *qd = s_d + (size_t)ql * SM_SUB * NBT;
-        const int *qi = s_i + (size_t)ql * SM_SUB * NBT;
-        float gx = 0.f, gy = 0.f, gz = 0.f;
-        for (int t = 0; t < nb; ++t) {
-            float best = INFINITY;
-            int bidx = 0x7FFFFFFF, bu = 0;
-#pragma unroll
-            for (int u = 0; u < SM_SUB; ++u) {
-                const int hpos = head[u];
-                const float dv = hpos < NBT ? qd[u * NBT + hpos] : INFINITY;
-                const int iv = hpos < NBT ? qi[u * NBT + hpos] : 0x7FFFFFFF;
-                if (dv < best || (dv == best && iv < bidx)) { best = dv; bidx = iv; bu = u; }
-            }
-#pragma unroll
-            for (int u = 0; u < SM_SUB; ++u) head[u] += (u == bu) ? 1 : 0;
-            if (bidx == 0x7FFFFFFF) break;   // fewer than nb references
+    // 4-way merge: nb times the smallest head by (distance, index); every lane of the query follows the same sequence
+    float local = 0.0f, gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int t = 0; t < nb; ++t) {
+        float best;
+        int bidx;
+        smooth_pop_min<NBT>(bd, bi, best, bidx);
+        if (bidx == 0x7FFFFFFF) break;   // fewer than nb references (uniform over the query's lanes)
+        if (sub == 0 && i < N) {
             const float d = sqrtf(best);
             local += d;
             if (d > 0.0f) {
@@ -532,6 +568,8 @@ __global__ __launch_bounds__(256) void smooth_knn_kernel(const float *__restrict
                 }
             }
         }
+    }
+    if (sub == 0 && i < N) {
         if (symmetric) {
             atomicAdd(grad + (size_t)i * 3, gx); atomicAdd(grad + (size_t)i * 3 + 1, gy); atomicAdd(grad + (size_t)i * 3 + 2, gz);
         } else {
@@ -668,20 +706,22 @@ static int smooth_knn_launch(const float *adv_color, int adv_stride, size_t adv_
     // ref_color == adv_color selects the ResGCN variants' smooth(adv, adv): gradient through both arguments
     const int symmetric = ref_color == adv_color && ref_stride == adv_stride;
     if (symmetric) PSG_CHECK_HIP(hipMemsetAsync(grad_out, 0, (size_t)B * N * 3 * sizeof(float), (hipStream_t)stream));
-    const int nbt = nb <= 8 ? 8 : 16;
-    const size_t lds = (size_t)N * sizeof(float4) + (size_t)SM_QPB * SM_SUB * nbt * 8;
+    // list length per lane: the neighbour count itself for the usual nb = 5 (every step of the insertion network counts:
+    // with 64 lanes a wave enters it in most passes), else 8 or 16
+    const size_t lds = (size_t)N * sizeof(float4);
     const dim3 grid(psg::ceil_div(N, SM_QPB), B);
-    if (nbt == 8) {
-        if (lds > 48 * 1024)
-            PSG_CHECK_HIP(hipFuncSetAttribute((const void *)smooth_knn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(smooth_knn_kernel<8>, grid, dim3(256), lds, (hipStream_t)stream, adv_color, adv_stride, ref_color,
-                           ref_stride, N, nb, dist_sum, grad_out, symmetric, adv_room_stride, ref_room_stride);
-    } else {
-        if (lds > 48 * 1024)
-            PSG_CHECK_HIP(hipFuncSetAttribute((const void *)smooth_knn_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(smooth_knn_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, adv_color, adv_stride, ref_color,
-                           ref_stride, N, nb, dist_sum, grad_out, symmetric, adv_room_stride, ref_room_stride);
-    }
+#define PSG_SMOOTH_LAUNCH(NBT)                                                                                                   \
+    do {                                                                                                                         \
+        if (lds > 48 * 1024)                                                                                                     \
+            PSG_CHECK_HIP(hipFuncSetAttribute((const void *)smooth_knn_kernel<NBT>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                              (int)lds));                                                                        \
+        hipLaunchKernelGGL(smooth_knn_kernel<NBT>, grid, dim3(SM_T), lds, (hipStream_t)stream, adv_color, adv_stride, ref_color, \
+                           ref_stride, N, nb, dist_sum, grad_out, symmetric, adv_room_stride, ref_room_stride);                  \
+    } while (0)
+    if (nb <= 5) PSG_SMOOTH_LAUNCH(5);
+    else if (nb <= 8) PSG_SMOOTH_LAUNCH(8);
+    else PSG_SMOOTH_LAUNCH(16);
+#undef PSG_SMOOTH_LAUNCH
     PSG_LAUNCH_CHECK();
     return PSG_OK;
 }
