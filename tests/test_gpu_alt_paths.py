@@ -4,7 +4,8 @@
   PSG_RLA_ATOMICS=1  RandLA-Net backward scatters with float atomics instead of the inverse-list gathers
 
 Both switches are read once per process, so each case runs the relevant parity tests in ONE child interpreter with the
-switch set and the launch tracer on (PSG_TRACE_SYNC=1 prints the source line of every launch): the child must pass, and
+switch set and the launch tracer on (PSG_TRACE_SYNC=1 prints the source line of every launch; the child runs with -s so
+the library's stderr reaches this process): the child must pass, and
 its set of launch sites must differ from the default child's - the switch really selected other kernels."""
 import os
 import re
@@ -24,7 +25,7 @@ def child(test_file, keyword, extra_env):
     env.update(extra_env)
     env["PSG_TRACE_SYNC"] = "1"
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", test_file), "-x", "-q", "-m", "gpu",
-                          "-k", keyword, "-p", "no:cacheprovider"], env=env, cwd=ROOT, capture_output=True, text=True,
+                          "-k", keyword, "-s", "-p", "no:cacheprovider"], env=env, cwd=ROOT, capture_output=True, text=True,
                          timeout=900)
     sites = set(re.findall(r"\[psg trace\] launch \d+ at (\S+) issued", out.stderr + out.stdout))
     return out, sites
