@@ -723,6 +723,7 @@ def run_randla(args, R):
         # launch from the committed PMC passes of this command (profiles/*_pmc_traffic_randla.json) when they exist
         dom = max(kern, key=lambda k: kern[k][0])
         ms, cnt, fl, by = kern[dom]
+        anon = "(anonymous namespace)::"
         symbol = {"gemm_rows_kernel<2,2,.,.,1,1> (64x64 tiles)": ("void psg::gemm_rows_kernel<2, 2, 0, false, 1, 1>(psg::GemmArgs)",
                                                                  "void psg::gemm_rows_kernel<2, 2, 3, false, 1, 1>(psg::GemmArgs)"),
                   "gemm_rows_kernel<2,2> (128x128 tiles)": ("void psg::gemm_rows_kernel<2, 2, 0, false, 2, 2>(psg::GemmArgs)",
@@ -730,26 +731,32 @@ def run_randla(args, R):
                   "gemm_rows_kernel<4,1> (256x64 tiles)": ("void psg::gemm_rows_kernel<4, 1, 0, false, 2, 2>(psg::GemmArgs)",
                                                            "void psg::gemm_rows_kernel<4, 1, 3, false, 2, 2>(psg::GemmArgs)"),
                   "skinny_gemm_kernel": ("void (anonymous namespace)::skinny_gemm_kernel<0>(psg::GemmArgs)",
-                                         "void (anonymous namespace)::skinny_gemm_kernel<3>(psg::GemmArgs)")}[dom]
+                                         "void (anonymous namespace)::skinny_gemm_kernel<3>(psg::GemmArgs)")}.get(dom, (anon + dom,))
         traffic, src = None, None
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_randla.json")))
         if files:
             with open(files[-1]) as fh:
                 table = json.load(fh)
-            rows_ = [table[s] for s in symbol if s in table]
+            # (the counter summaries key a kernel by its full symbol, arguments included)
+            rows_ = [v for k, v in table.items() if k != "_meta" and any(k == s_ or k.startswith(s_ + "(") for s_ in symbol)]
             if rows_ and table.get("_meta", {}).get("device_batch_rooms") == G:
                 n_l = sum(r["launches_fetch_pass"] for r in rows_)
                 traffic = sum(r["hbm_bytes_per_launch"] * r["launches_fetch_pass"] for r in rows_) / max(n_l, 1)
                 src = "profiles/" + os.path.basename(files[-1])
         gbs = by / (ms * 1e-3) / 1e9
-        result["roofline"] = {"bound": "hbm", "kernel": dom + " (linear and leaky-ReLU epilogues; %d cloud(s) per launch)" % G,
+        is_gemm = dom in network.RandLAWorkspace.PROF_KERNELS[:4]
+        result["roofline"] = {"bound": "hbm", "kernel": dom + (" (linear and leaky-ReLU epilogues" if is_gemm else " (levels 1-4: attention "
+                              "scores T[neigh] + S2, softmax over the 16 neighbours, pooling" if "split" in dom else " (level 0: scores, "
+                              "softmax and pooling of a 16-channel attentive pooling in one kernel") + "; %d cloud(s) per launch)" % G,
                               "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                               "traffic": traffic, "traffic_source": src, "algorithmic_bytes": by / cnt,
                               "avg_launch_us": ms / cnt * 1e3, "launches": cnt,
-                              "mfma_frac_same_launches": fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
-                              "share_of_gemm_time": ms / sum(v[0] for v in kern.values())}
-        result["gemm_kernels_ms_per_iteration"] = {k: round(v[0] / n_prof, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])}
+                              "share_of_profiled_time": ms / sum(v[0] for v in kern.values())}
+        if is_gemm:
+            result["roofline"]["mfma_frac_same_launches"] = fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS
+        result["kernel_family_gbs"] = {k: round(v[3] / (v[0] * 1e-3) / 1e9, 1) for k, v in kern.items()}
+        result["profiled_kernels_ms_per_iteration"] = {k: round(v[0] / n_prof, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])}
         if want_cpu(args, R):
             from oracle import randla, randla_net
             xyz, rgb, lab = host[0]
@@ -787,7 +794,7 @@ def run_tarnu(args, R):
     if args.nu_mode == "per-room" and R.rank == 0 and R.world == 1 and not args.no_reference:
         import copy
         a1 = copy.copy(args)
-        a1.steps, a1.warmup, a1.no_cpu_baseline = 1, 0, True
+        a1.steps, a1.warmup, a1.no_cpu_baseline = 1, 1, True
         q = tarnu_measure(a1, R, "per-room-calls", with_roofline=False)
         result["uncoalesced_reference"] = {"value": q["value"], "unit": "rooms/s",
                                            "note": "one call per room (batches of one), %d calls in flight" % q["config"]["attacks_in_flight"]}

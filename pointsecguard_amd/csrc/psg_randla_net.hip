@@ -112,10 +112,12 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(GemmArgs a)
     if (EPI == EPI_LRELU && a.mask_out) a.mask_out[row] = bits;
 }
 
-// profile of the GEMM launches of the call in progress on this thread (psg_rla_prof_enable), by kernel: tag 0 = 64 x 64
+// profile of the launches of the call in progress on this thread (psg_rla_prof_enable), by kernel: tag 0 = 64 x 64
 // tiles (gemm_rows_kernel<2,2,.,.,1,1>: the point-sized layers), 1 = 128 x 128 tiles, 2 = 256 x 64 tiles, 3 = the
 // row-per-thread kernel of the 8-32 channel layers; each launch with its algorithmic FLOPs and bytes (input rows, output
-// rows - twice when accumulated into -, addend rows, weights, mask words)
+// rows - twice when accumulated into -, addend rows, weights, mask words).  Tags 4-7 = the attentive-pooling kernels
+// (att_pool_split_fwd / _bwd, lfa16_fwd / _bwd) with their algorithmic bytes: every per-edge stream once, every gathered
+// table once per point
 thread_local EvLog *tl_prof = nullptr;
 
 template <int EPI>
@@ -1264,12 +1266,18 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
             GemmArgs g = rl_args(L.fpc, h, E.att1_fc.w, d, T1, d, n, h, d);
             g.bias = E.att1_fc.b;
             if ((rc = rl_gemm<EPI_LINEAR>(g, st))) return rc;
-            hipLaunchKernelGGL(att_pool_split_fwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, T1,
-                               L.cat1, h, (size_t)n * d / 2, L.a1, L.agg1);
+            {
+                EvScope prof(tl_prof, 4, 0.0, st, 4.0 * (2.0 * n * d + (double)n * h + (double)ne * (1.0 + 2.0 * d + h)));
+                hipLaunchKernelGGL(att_pool_split_fwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, T1,
+                                   L.cat1, h, (size_t)n * d / 2, L.a1, L.agg1);
+            }
             PSG_LAUNCH_CHECK();
         } else if (fused16) {
-            hipLaunchKernelGGL(lfa16_fwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, E.att1_fc.w,
-                               E.att1_fc.b, (size_t)n, L.agg1);
+            {
+                EvScope prof(tl_prof, 6, 0.0, st, 4.0 * ((double)n * (h + d) + (double)ne * (1.0 + h)));
+                hipLaunchKernelGGL(lfa16_fwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, E.att1_fc.w,
+                                   E.att1_fc.b, (size_t)n, L.agg1);
+            }
             PSG_LAUNCH_CHECK();
         } else {
             hipLaunchKernelGGL(gather_concat_kernel, dim3(blocks_for(ne * d / 4)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, h, ne * d / 4, L.cat1);
@@ -1284,12 +1292,18 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
             GemmArgs g = rl_args(L.fagg1, h, E.att2_fc.w, d, T2, d, n, h, d);
             g.bias = E.att2_fc.b;
             if ((rc = rl_gemm<EPI_LINEAR>(g, st))) return rc;
-            hipLaunchKernelGGL(att_pool_split_fwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, T2,
-                               L.cat2, h, (size_t)n * d / 2, L.a2, L.agg2);
+            {
+                EvScope prof(tl_prof, 4, 0.0, st, 4.0 * (2.0 * n * d + (double)n * h + (double)ne * (1.0 + 2.0 * d + h)));
+                hipLaunchKernelGGL(att_pool_split_fwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, T2,
+                                   L.cat2, h, (size_t)n * d / 2, L.a2, L.agg2);
+            }
             PSG_LAUNCH_CHECK();
         } else if (fused16) {
-            hipLaunchKernelGGL(lfa16_fwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, E.att2_fc.w,
-                               E.att2_fc.b, (size_t)n, L.agg2);
+            {
+                EvScope prof(tl_prof, 6, 0.0, st, 4.0 * ((double)n * (h + d) + (double)ne * (1.0 + h)));
+                hipLaunchKernelGGL(lfa16_fwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, E.att2_fc.w,
+                                   E.att2_fc.b, (size_t)n, L.agg2);
+            }
             PSG_LAUNCH_CHECK();
         } else {
             hipLaunchKernelGGL(gather_concat_kernel, dim3(blocks_for(ne * d / 4)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, h, ne * d / 4, L.cat2);
@@ -1405,8 +1419,12 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         auto split_bwd = [&](const float *fin_, const float *fxyz_, const float *a_, const float *dagg_, const RLayer &fc, float *df_,
                              const uint32_t *mask_) -> int {
             float *ds = ws->scratch_b, *ddir = ws->scratch_a, *dT = L.m2;
-            hipLaunchKernelGGL(att_pool_split_bwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, fin_, L.neigh, fxyz_, a_, dagg_,
-                               h, (size_t)n * d / 2, ds, ddir);
+            {
+                const double ne_ = 16.0 * n;
+                EvScope prof(tl_prof, 5, 0.0, st, 4.0 * ((double)n * (h + d) + ne_ * (1.0 + 2.0 * d + 2.0 * h)));
+                hipLaunchKernelGGL(att_pool_split_bwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, fin_, L.neigh, fxyz_, a_, dagg_,
+                                   h, (size_t)n * d / 2, ds, ddir);
+            }
             PSG_LAUNCH_CHECK();
             hipLaunchKernelGGL(gather_inv_kernel<true>, dim3(blocks_for((size_t)n * d)), dim3(256), 0, st, ds, d, d, L.inv_off, L.inv_ent,
                                (size_t)n * d, dT);
@@ -1423,8 +1441,11 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         if (split) {
             if ((rc = split_bwd(L.fagg1, L.fxyz2, L.a2, g_agg2, E.att2_fc, L.d_fagg1, L.m_fagg1))) return rc;
         } else if (fused16) {
-            hipLaunchKernelGGL(lfa16_bwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, E.att2_fc.w,
-                               E.att2_fc.b, g_agg2, (size_t)n, L.d_fagg1, ws->use_inv ? ws->scratch_a : (float *)nullptr);
+            {
+                EvScope prof(tl_prof, 7, 0.0, st, 4.0 * ((double)n * (2.0 * h + d) + 16.0 * n * (1.0 + h + 8.0)));
+                hipLaunchKernelGGL(lfa16_bwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, E.att2_fc.w,
+                                   E.att2_fc.b, g_agg2, (size_t)n, L.d_fagg1, ws->use_inv ? ws->scratch_a : (float *)nullptr);
+            }
             PSG_LAUNCH_CHECK();
             if (ws->use_inv) {
                 hipLaunchKernelGGL(gather_inv_kernel<false>, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 8, h, L.inv_off, L.inv_ent,
@@ -1449,8 +1470,11 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         if (split) {
             if ((rc = split_bwd(L.fpc, L.fxyz1, L.a1, g_agg1, E.att1_fc, L.d_fpc, L.m_fpc))) return rc;
         } else if (fused16) {
-            hipLaunchKernelGGL(lfa16_bwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, E.att1_fc.w,
-                               E.att1_fc.b, g_agg1, (size_t)n, L.d_fpc, ws->use_inv ? ws->scratch_a : (float *)nullptr);
+            {
+                EvScope prof(tl_prof, 7, 0.0, st, 4.0 * ((double)n * (2.0 * h + d) + 16.0 * n * (1.0 + h + 8.0)));
+                hipLaunchKernelGGL(lfa16_bwd_kernel, dim3(blocks_for((size_t)n * 8)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, E.att1_fc.w,
+                                   E.att1_fc.b, g_agg1, (size_t)n, L.d_fpc, ws->use_inv ? ws->scratch_a : (float *)nullptr);
+            }
             PSG_LAUNCH_CHECK();
             if (ws->use_inv) {
                 hipLaunchKernelGGL(gather_inv_kernel<false>, dim3(blocks_for((size_t)n * h)), dim3(256), 0, st, ws->scratch_a, 8, h, L.inv_off, L.inv_ent,

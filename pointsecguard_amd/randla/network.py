@@ -78,10 +78,12 @@ class RandLAWorkspace:
         return ms[0], cnt[0], fl[0]
 
     PROF_KERNELS = ("gemm_rows_kernel<2,2,.,.,1,1> (64x64 tiles)", "gemm_rows_kernel<2,2> (128x128 tiles)",
-                    "gemm_rows_kernel<4,1> (256x64 tiles)", "skinny_gemm_kernel")
+                    "gemm_rows_kernel<4,1> (256x64 tiles)", "skinny_gemm_kernel", "att_pool_split_fwd_kernel",
+                    "att_pool_split_bwd_kernel", "lfa16_fwd_kernel", "lfa16_bwd_kernel")
 
     def prof_read_kernels(self):
-        """{kernel: (total ms, launches, algorithmic FLOPs, algorithmic bytes)} of the GEMM launches since prof_enable."""
+        """{kernel: (total ms, launches, algorithmic FLOPs, algorithmic bytes)} of the GEMM and attentive-pooling launches
+        since prof_enable."""
         n = len(self.PROF_KERNELS)
         ms, cnt = (ctypes.c_double * n)(), (ctypes.c_int * n)()
         fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)()
