@@ -460,3 +460,37 @@ def test_nu_rooms_a_room_that_exits_early_is_frozen(weights_sd):
     assert list(steps_run) == [s[1] for s in single] and steps_run[1] == 1 and steps_run[0] == steps
     for r in range(R):
         assert np.array_equal(out[r], single[r][0]), r
+
+
+def test_tar_nu_rooms_configs2_size(weights_sd):
+    """BASELINE configs[2] at its full step size through the lockstep path: 32 rooms x 4096 points, tar_NU (c = 1, kappa = 0,
+    lr = 0.01, target = 6), 12 steps.  Size-independent properties: only the masked colours of every room move and stay
+    inside tanh space's (0, 1), xyz and the normalised coordinates never move, the costs are finite, every room ran all
+    steps (no room reaches the target this early); and rooms 5 and 29, attacked again on their own with the same FPS
+    starts, give the images they got inside the batch bit for bit."""
+    from pointsecguard_amd.attacks import torchattacks
+    from pointsecguard_amd.attacks.torchattacks.attacks import nu as nu_mod
+    R, steps, target = 32, 12, 6
+    net, rooms, labels, images = _rooms_case(weights_sd, R, 9300)
+    masks = labels == 2
+    rng = np.random.default_rng(23)
+    table = torch.from_numpy(np.stack([rng.integers(0, n, (steps, R)) for n in (4096, 1024, 256, 64)], axis=1).astype(np.int32))
+    atk = torchattacks.tar_NU_attack(net, c=1, kappa=0, steps=steps, lr=0.01, target=target)
+    costs = []
+    adv, steps_run = nu_mod.nu_attack_rooms(atk, images, labels.astype(np.float64), masks, target, 5, targeted_variant=True,
+                                            trace=lambda **kw: costs.append(kw["cost"].copy()),
+                                            starts_fn=lambda step, n_plan: table[step:step + n_plan].contiguous())
+    out, src = adv.cpu().numpy(), rooms.transpose(0, 2, 1)
+    assert list(steps_run) == [steps] * R
+    assert np.array_equal(out[:, :3], src[:, :3]) and np.array_equal(out[:, 6:], src[:, 6:])
+    for r in range(R):
+        assert np.array_equal(out[r, 3:6][:, ~masks[r]], src[r, 3:6][:, ~masks[r]]), r
+        moved = out[r, 3:6][:, masks[r]]
+        assert (moved > 0).all() and (moved < 1).all() and (moved != src[r, 3:6][:, masks[r]]).any(), r
+    costs = np.array(costs)
+    assert costs.shape == (steps, R) and np.isfinite(costs).all()
+    for r in (5, 29):
+        a1 = torchattacks.tar_NU_attack(net, c=1, kappa=0, steps=steps, lr=0.01, target=target, mask=masks[r])
+        one = nu_mod.nu_attack(a1, images[r:r + 1], labels[r:r + 1].astype(np.float64), masks[r], target, 5, targeted_variant=True,
+                               starts_fn=lambda step, n_plan, r=r: table[step:step + n_plan, :, r:r + 1].contiguous())
+        assert np.array_equal(one.cpu().numpy()[0], out[r]), r
