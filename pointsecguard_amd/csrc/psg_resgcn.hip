@@ -298,6 +298,83 @@ __global__ void edge_max_fwd_kernel(const float *__restrict__ pq, const int32_t 
     }
 }
 
+// ---- The same pass for 32 vertices per workgroup, followed by the NEXT block's per-vertex product on the matrix cores:
+// the 32 x 64 tile of new features is kept in LDS (k8-block layout of psg_gemm.cuh) and four waves compute
+// [P | Q]_next = y . [W1 - W2 ; W2]_next^T + [b, 0] for those vertices (one 32 x 32 tile each, 32 MFMAs, weights read from L2
+// in operand order) - the [R, 64] x [64, 128] GEMM launch between two blocks and its re-read of the features are gone.
+// The arithmetic of both halves is that of the separate kernels (same lane = channel max pass; same k order and the same
+// mfma4 chain as gemm_rows_kernel's plain path), so features and products are bit-identical to the unfused sequence.
+// 1024 threads = 16 waves, two vertices per wave in the first phase (occupancy hides the 16 gathered Q rows per vertex).
+constexpr int EMF_V = 32, EMF_T = 1024, EMF_BLK = EMF_V * 8 + 8;
+__global__ __launch_bounds__(EMF_T) void edge_max_pq_fwd_kernel(const float *__restrict__ pq, const int32_t *__restrict__ nbr,
+                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                 const float *__restrict__ resid, int ld_res, float *__restrict__ out,
+                                                                 int ld_out, uint8_t *__restrict__ arg, int N, float *__restrict__ sq_out,
+                                                                 float *__restrict__ xp_out, unsigned short *__restrict__ bp_out,
+                                                                 const float *__restrict__ wk8_next, const float *__restrict__ bias_next,
+                                                                 float *__restrict__ pq_next)
+{
+    __shared__ float s_x[8 * EMF_BLK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t v0 = (size_t)blockIdx.x * EMF_V;
+    const int c = lane;
+    const float s = scale[c], sh = shift[c];
+#pragma unroll
+    for (int pass = 0; pass < EMF_V / 16; ++pass) {
+        const int vl = wave + 16 * pass;
+        const size_t v = v0 + vl;
+        const size_t t = v * GC + c;
+        const size_t room_base = (v / N) * N;
+        const float p = pq[v * 2 * GC + c];
+        float best = -INFINITY;
+        int bk = 0;
+        bool bact = false;
+        const int32_t *nb = nbr + v * KNB;
+#pragma unroll 4
+        for (int k = 0; k < KNB; ++k) {
+            const float z = p + pq[(room_base + nb[k]) * 2 * GC + GC + c];
+            const bool act = z > 0.0f;
+            const float y = (act ? z : 0.0f) * s + sh;
+            if (y > best) { best = y; bk = k; bact = act; }
+        }
+        if (resid) best += resid[v * ld_res + c];
+        out[v * ld_out + c] = best;
+        arg[t] = (uint8_t)(bk | (bact ? 0x80 : 0));
+        s_x[(c >> 3) * EMF_BLK + vl * 8 + (c & 7)] = best;
+        if (xp_out) {
+            knn_store_xp(xp_out, v, c, best);
+            if (bp_out) knn_store_bp(bp_out, v, c, best);
+        }
+        if (sq_out) {
+            const float sacc = knn_wave_sumsq(best, lane);
+            if (c == 0) {
+                sq_out[v] = sacc;
+                if (bp_out) knn_store_aug((uint4 *)bp_out, v, sacc);
+            }
+        }
+    }
+    __syncthreads();
+    if (wave >= 4) return;
+    const int j = lane & 31, h = lane >> 5;
+    const int cbase = 32 * wave;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int k8 = 0; k8 < GC / 8; ++k8) {
+        const float4 wa = *(const float4 *)(wk8_next + ((size_t)k8 * 2 * GC + cbase + j) * 8 + 4 * h);
+        const float4 xb = *(const float4 *)(s_x + k8 * EMF_BLK + j * 8 + 4 * h);
+        acc = mfma4<false>(wa, xb, acc);
+    }
+    // lane (j, h) holds channels cbase + 8 g + 4 h + (0..3) of vertex v0 + j (gemm_rows_kernel's epilogue, EPI_LINEAR)
+    float *o = pq_next + (v0 + j) * 2 * GC + cbase + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *(const float4 *)(bias_next + cbase + 8 * g + 4 * h);
+        *(float4 *)(o + 8 * g) = make_float4(acc[4 * g] + b4.x, acc[4 * g + 1] + b4.y, acc[4 * g + 2] + b4.z, acc[4 * g + 3] + b4.w);
+    }
+}
+
 // ---- EdgeConv edge pass (backward): g = dY * s_c where the winning edge was active;  dP[i][c] = g,
 // dQ[nbr(i,k*)][c] += g.  dpq must be zeroed (Q half) before the launch.
 __global__ void edge_max_bwd_kernel(const float *__restrict__ dy, int ld_dy, const int32_t *__restrict__ nbr,
@@ -481,6 +558,7 @@ struct EdgeLayer {
     float *wcat;    // [128][C]: rows 0..63 = W1 - W2, rows 64..127 = W2
     float *bcat;    // [128] = [b, 0]
     float *wcat_t;  // [C][128] (transpose, for the input gradient)
+    float *wcat_k8 = nullptr;   // C == 64: wcat as MFMA operand blocks [k / 8][128][8] (edge_max_pq_fwd_kernel)
     float *scale, *shift;  // eval BatchNorm after the ReLU
     float *w = nullptr, *b = nullptr;   // conv = mr: plain [64][2C] weight and [64] bias of the BasicConv
     float *w_t = nullptr;               // conv = mr: [2C][64] transpose (input gradient)
@@ -526,6 +604,7 @@ struct psg_gcn_ws {
     int knn_bf_max_d = 3;      // the prefilter kernel serves dilations up to this (PSG_GCN_KNN_BF_MAXD), the exact kernel the rest
     unsigned long long *knn_stats = nullptr;   // PSG_GCN_KNN_STATS=1: device counters of the prefilter kernel
     float *pq, *dpq;           // [B*N][128]
+    float *pq2 = nullptr;      // second [P | Q] buffer: a block's edge pass writes the NEXT block's products while it reads its own
     float *dpq2;               // second [B*N][128] gradient buffer of the default (res / edge) backward's ping-pong
     int32_t *nbr;              // [n_blocks][B*N][16]
     uint8_t *arg;              // [n_blocks][B*N][64]
@@ -689,6 +768,12 @@ extern "C" int psg_gcn_model_create_cfg(psg_ctx *ctx, const float *const *tensor
         EdgeLayer L;
         L.C = C;
         L.wcat = dev_upload(m, wcat); L.bcat = dev_upload(m, bcat); L.wcat_t = dev_upload(m, wt);
+        if (C == GC) {
+            std::vector<float> wk((size_t)2 * GC * C);
+            for (int r = 0; r < 2 * GC; ++r)
+                for (int c = 0; c < C; ++c) wk[((size_t)(c >> 3) * 2 * GC + r) * 8 + (c & 7)] = wcat[(size_t)r * C + c];
+            L.wcat_k8 = dev_upload(m, wk);
+        }
         L.scale = dev_upload(m, s); L.shift = dev_upload(m, t);
         if (conv == PSG_GCN_CONV_MR) {
             std::vector<float> wplain(W, W + (size_t)GC * 2 * C), wtr((size_t)2 * C * GC);
@@ -823,6 +908,7 @@ extern "C" int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n
         ws->bp = take(knn_bp_bytes(R));
         ws->knn_stats = getenv("PSG_GCN_KNN_STATS") ? (unsigned long long *)take(8 * sizeof(unsigned long long)) : nullptr;
         ws->pq = (float *)take(R * ws->pq_w * 4);
+        ws->pq2 = (float *)take(R * 2 * GC * 4);
         ws->dpq = (float *)take(R * ws->pq_w * 4);
         ws->dpq2 = (float *)take(R * 2 * GC * 4);
         if (conv == PSG_GCN_CONV_MR) {
@@ -1058,6 +1144,12 @@ extern "C" int psg_gcn_forward(psg_gcn_model *m, psg_gcn_ws *ws, const float *x0
     hipLaunchKernelGGL(extract3_kernel, dim3(ceil_div((int)(R * 3), 256)), dim3(256), 0, st, x0, ws->xyz, R);
     PSG_LAUNCH_CHECK();
     const bool dense = m->block == PSG_GCN_BLOCK_DENSE, res = m->block == PSG_GCN_BLOCK_RES, mr = m->conv == PSG_GCN_CONV_MR;
+    // PSG_GCN_PQ_FUSION=1: a block's edge pass also computes the next block's per-vertex product (edge_max_pq_fwd_kernel).
+    // Measured on MI355X: 0.21 ms less kernel time per 4-room iteration (8.09 -> 7.89) and +2 % with one launch in flight
+    // (10.18 -> 10.39 rooms/s), but -0.7 % at the bench's three launches in flight (12.05 -> 11.96): the small GEMM launches
+    // it removes were running inside the idle slots of another launch's kNN kernel.  Off by default for that reason.
+    static const bool fuse_pq = getenv("PSG_GCN_PQ_FUSION") && atoi(getenv("PSG_GCN_PQ_FUSION"));
+    bool pq_ready = false;     // this block's [P | Q] was written by the previous block's edge pass
     for (int e = 0; e < m->n_blocks; ++e) {
         const EdgeLayer &L = m->edge[e];
         int32_t *nbr = ws->nbr + (size_t)e * R * KNB;
@@ -1073,23 +1165,35 @@ extern "C" int psg_gcn_forward(psg_gcn_model *m, psg_gcn_ws *ws, const float *x0
             return rc;
         float *yout = ws->feats + (size_t)e * GC;
         if (!mr) {
-            // [P | Q] = x . [W1 - W2 ; W2]^T + [b, 0]
-            GemmArgs a = gemm_args(xin, ld, L.wcat, L.C, ws->pq, 2 * GC, (int)R, L.C, 2 * GC);
-            a.bias = L.bcat;
-            {
+            // [P | Q] = x . [W1 - W2 ; W2]^T + [b, 0]: a GEMM launch, unless the previous block's edge pass has produced it
+            float *pq_cur = (e & 1) ? ws->pq2 : ws->pq, *pq_nxt = (e & 1) ? ws->pq : ws->pq2;
+            if (!pq_ready) {
+                GemmArgs a = gemm_args(xin, ld, L.wcat, L.C, pq_cur, 2 * GC, (int)R, L.C, 2 * GC);
+                a.bias = L.bcat;
                 EvScope prof(&ws->prof, GT_VERTEX_GEMM, 2.0 * R * L.C * 2.0 * GC, st);
                 if ((rc = launch_gemm<2, 2, EPI_LINEAR, false>(a, st))) return rc;
             }
             // the next block's kNN kernel decides which operand copies this kernel writes beside the features
             const int next_path = (!ws->fixed_graphs && !dense && e + 1 < m->n_blocks)
                                       ? knn_path(ws, GC, m->block == PSG_GCN_BLOCK_PLAIN ? 1 : e + 1) : -1;
-            EvScope prof(&ws->prof, GT_EDGE_MAX, 0.0, st);
-            hipLaunchKernelGGL(edge_max_fwd_kernel, dim3(g256), dim3(256), 0, st, ws->pq, nbr, L.scale, L.shift,
-                               (e == 0 || !res) ? nullptr : xin, F, yout, F, ws->arg + (size_t)e * R * GC, N,
-                               R * GC, (ws->fixed_graphs || dense) ? nullptr : ws->sq,
-                               next_path >= 0 ? ws->xp : nullptr,
-                               next_path == KNN_PATH_BF16 ? (unsigned short *)ws->bp : nullptr);
-            PSG_LAUNCH_CHECK();
+            // fused with the next block's per-vertex product when that block reads exactly this block's 64 outputs
+            const bool fuse_next = fuse_pq && !dense && e + 1 < m->n_blocks && m->edge[e + 1].wcat_k8 && R % EMF_V == 0;
+            EvScope prof(&ws->prof, GT_EDGE_MAX, fuse_next ? 2.0 * R * GC * 2.0 * GC : 0.0, st);
+            const float *resid = (e == 0 || !res) ? nullptr : xin;
+            float *sq_o = (ws->fixed_graphs || dense) ? nullptr : ws->sq;
+            float *xp_o = next_path >= 0 ? ws->xp : nullptr;
+            unsigned short *bp_o = next_path == KNN_PATH_BF16 ? (unsigned short *)ws->bp : nullptr;
+            if (fuse_next) {
+                hipLaunchKernelGGL(edge_max_pq_fwd_kernel, dim3((unsigned)(R / EMF_V)), dim3(EMF_T), 0, st, pq_cur, nbr, L.scale, L.shift,
+                                   resid, F, yout, F, ws->arg + (size_t)e * R * GC, N, sq_o, xp_o, bp_o, m->edge[e + 1].wcat_k8,
+                                   m->edge[e + 1].bcat, pq_nxt);
+                PSG_LAUNCH_CHECK();
+            } else {
+                hipLaunchKernelGGL(edge_max_fwd_kernel, dim3(g256), dim3(256), 0, st, pq_cur, nbr, L.scale, L.shift, resid, F, yout, F,
+                                   ws->arg + (size_t)e * R * GC, N, R * GC, sq_o, xp_o, bp_o);
+                PSG_LAUNCH_CHECK();
+            }
+            pq_ready = fuse_next;
         } else {
             // MRConv2d: BasicConv(cat[x, max_k (x_j - x_i)]) per vertex (+ x for a residual block)
             const size_t tot = R * (size_t)L.C;

@@ -2,8 +2,9 @@
 
   PSG_FP1_WAVE=1     wave-private fp1 + head chain (psg_chain.cuh) instead of the workgroup-cooperative kernels
   PSG_RLA_ATOMICS=1  RandLA-Net backward scatters with float atomics instead of the inverse-list gathers
+  PSG_GCN_PQ_FUSION=1  ResGCN: a block's edge pass also computes the next block's per-vertex [P | Q] product
 
-Both switches are read once per process, so each case runs the relevant parity tests in ONE child interpreter with the
+The switches are read once per process, so each case runs the relevant parity tests in ONE child interpreter with the
 switch set and the launch tracer on (PSG_TRACE_SYNC=1 prints the source line of every launch; the child runs with -s so
 the library's stderr reaches this process): the child must pass, and
 its set of launch sites must differ from the default child's - the switch really selected other kernels."""
@@ -22,6 +23,7 @@ def child(test_file, keyword, extra_env):
     env = dict(os.environ)
     env.pop("PSG_FP1_WAVE", None)
     env.pop("PSG_RLA_ATOMICS", None)
+    env.pop("PSG_GCN_PQ_FUSION", None)
     env.update(extra_env)
     env["PSG_TRACE_SYNC"] = "1"
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", test_file), "-x", "-q", "-m", "gpu",
@@ -34,6 +36,7 @@ def child(test_file, keyword, extra_env):
 @pytest.mark.parametrize("test_file,keyword,switch", [
     ("test_gpu_parity.py", "forward_vs_reference or backward_vs_reference or forward_backward_vs_oracle_batch", "PSG_FP1_WAVE"),
     ("test_randla_net.py", "forward_backward_vs_oracle or bim_attack_vs_oracle", "PSG_RLA_ATOMICS"),
+    ("test_gpu_resgcn28.py", "not knn_on_reference_features", "PSG_GCN_PQ_FUSION"),
 ])
 def test_switch_selects_other_kernels_with_the_same_parity(test_file, keyword, switch):
     base, base_sites = child(test_file, keyword, {})
