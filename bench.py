@@ -311,11 +311,13 @@ def run_pointnet2(args, R):
 
     sd = dict(np.load(os.path.join(ROOT, "tests", "golden", "pn2_weights.npz")))
     model = runtime.PN2Model(runtime.fold_state_dict(sd))
-    # K steps of BATCH rooms are coalesced G at a time into device batches (launches); when G does not divide K the
-    # last device batch is simply smaller.  Warm-up runs whole device batches (>= W steps, untimed).
-    G = max(1, min(args.coalesce, args.steps))                                    # steps per device batch
+    # K steps of BATCH rooms are coalesced up to G at a time into device batches (launches); when G does not divide K the
+    # K steps are dealt evenly to ceil(K / G) launches (20 steps -> 7, 7, 6 rather than 8, 8, 4: launches that run side
+    # by side then finish together).  Warm-up runs whole device batches (>= W steps, untimed).
+    G = max(1, min(args.coalesce, args.steps))                                    # steps per device batch, at most
     DB = BATCH * G                                                                # rooms per full launch
-    sizes = [G] * (args.steps // G) + ([args.steps % G] if args.steps % G else [])
+    n_l = -(-args.steps // G)
+    sizes = [args.steps // n_l + (1 if i < args.steps % n_l else 0) for i in range(n_l)]
     n_warm = -(-args.warmup // G) if args.warmup > 0 else 0
     sizes = [G] * n_warm + sizes                                                  # steps in device batch i
     n_all, n_groups = len(sizes), len(sizes) - n_warm
@@ -360,10 +362,9 @@ def run_pointnet2(args, R):
     # ---- attack statistics over the timed steps: clean vs adversarial accuracy / mIoU (RCCL all-reduce of counters)
     clean = torch.zeros(3, 13, dtype=torch.int64, device="cuda")
     adv = torch.zeros(3, 13, dtype=torch.int64, device="cuda")
-    ev = runtime.PN2Workspace(DB, NPOINT, 1)
+    evs = {}
     for i in range(n_warm, min(n_all, n_warm + 2)):
-        if sizes[i] != G:
-            continue
+        ev = evs.setdefault(sizes[i], runtime.PN2Workspace(BATCH * sizes[i], NPOINT, 1))
         ev_starts = d_starts[i][:1].contiguous()
         for src, ctr in ((d_images[i], clean), (d_adv[i], adv)):
             x0 = src.transpose(1, 2).contiguous()
@@ -390,9 +391,10 @@ def run_pointnet2(args, R):
             n8 = int(os.environ.get("PSG_BENCH_STRICT_INFLIGHT", "4"))
             st8 = [torch.cuda.Stream() for _ in range(n8)]
             ws8 = [runtime.PN2Workspace(BATCH, NPOINT, ITERS) for _ in range(n8)]
-            x8 = [d_images[n_warm][i * BATCH:(i + 1) * BATCH].contiguous() for i in range(G)]
-            l8 = [d_labels[n_warm][i * BATCH:(i + 1) * BATCH].contiguous() for i in range(G)]
-            s8 = [d_starts[n_warm][:, :, i * BATCH:(i + 1) * BATCH].contiguous() for i in range(G)]
+            g8 = sizes[n_warm]                                                    # steps of the first timed device batch
+            x8 = [d_images[n_warm][i * BATCH:(i + 1) * BATCH].contiguous() for i in range(g8)]
+            l8 = [d_labels[n_warm][i * BATCH:(i + 1) * BATCH].contiguous() for i in range(g8)]
+            s8 = [d_starts[n_warm][:, :, i * BATCH:(i + 1) * BATCH].contiguous() for i in range(g8)]
             o8 = [torch.empty_like(x) for x in x8]
 
             def run8():
@@ -408,15 +410,18 @@ def run_pointnet2(args, R):
                     "note": "one launch per 8-room step, no coalescing, %d steps in flight (this GPU only)" % n8}
             del ws8
         # ---- roofline of the dominant kernel: one extra attack with HIP-event timing of every launch
-        ws.prof_enable(True)
-        ws.nb_attack(model, d_images[n_warm], d_labels[n_warm], d_starts[n_warm], EPS, ALPHA, ITERS, out=d_adv[n_warm])
+        rooms_r = BATCH * sizes[n_warm]                                           # the first timed device batch
+        wsr = workspace(0, rooms_r)
+        wsr.prof_enable(True)
+        wsr.nb_attack(model, d_images[n_warm], d_labels[n_warm], d_starts[n_warm], EPS, ALPHA, ITERS, out=d_adv[n_warm])
         torch.cuda.synchronize()
-        prof = ws.prof_read()
-        ws.prof_enable(False)
-        flops = kernel_flops(DB)
+        prof = wsr.prof_read()
+        wsr.prof_enable(False)
+        flops = kernel_flops(rooms_r)
         roof = pn2_roofline(prof, flops)
-        roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"], DB)
-        roof["algorithmic_bytes"] = FP1_FWD_BYTES_PER_ROOM * DB if roof["kernel"] == "fp1_head_fwd" else None
+        roof["rooms_per_launch"] = rooms_r
+        roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"], rooms_r)
+        roof["algorithmic_bytes"] = FP1_FWD_BYTES_PER_ROOM * rooms_r if roof["kernel"] == "fp1_head_fwd" else None
         total_ms = sum(v[0] for v in prof.values())
         result.update({
             "roofline": roof,
@@ -455,7 +460,7 @@ def pmc_traffic(tag, device_batch, pattern="*_pmc_traffic.json"):
     """HBM bytes per launch of kernel `tag` from the newest committed PMC summary (profiles/<round>_pmc_traffic*.json,
     written by tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes of this bench at the default device
     batch, gfx950 read-doubling correction applied).  PMC cannot be sampled from inside the process, so the
-    figure is the committed one, and only reported when the device batch matches."""
+    figure is the committed one (scaled by the room count when this run's device batch differs from the counted one)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not files or tag not in PMC_SYMBOL:
@@ -463,9 +468,15 @@ def pmc_traffic(tag, device_batch, pattern="*_pmc_traffic.json"):
     with open(files[-1]) as fh:
         table = json.load(fh)
     row = table.get(PMC_SYMBOL[tag])
-    if not row or table.get("_meta", {}).get("device_batch_rooms", 32) != device_batch:
+    if not row:
         return None, None
-    return row["hbm_bytes_per_launch"], "profiles/" + os.path.basename(files[-1])
+    counted = table.get("_meta", {}).get("device_batch_rooms", 32)
+    src = "profiles/" + os.path.basename(files[-1])
+    if counted == device_batch:
+        return row["hbm_bytes_per_launch"], src
+    # the module kernels move a fixed volume per room (one workgroup tile per 32 points, weights from L2): a pass counted
+    # at another device batch is scaled by the room count and says so
+    return row["hbm_bytes_per_launch"] * device_batch / counted, src + " (counted at %d rooms per launch, scaled to %d)" % (counted, device_batch)
 
 
 # ======================================================================================== resgcn (configs[3])
