@@ -228,6 +228,8 @@ def main():
                     help="tarnu workload: the attack applied per room (the reference's batch-of-one semantics; default: the rooms "
                          "of a step advanced in lockstep, per-room-calls: one call per room) or one call on the whole 32-room "
                          "batch (its exit test then fires after one step)")
+    ap.add_argument("--nu-coalesce", type=int, default=2,
+                    help="tarnu workload, per-room mode: consecutive 32-room steps advanced by one lockstep call")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="tarnu workload: weak = 32 rooms per step on EVERY GPU; strong = the 32 rooms of a step split over the "
                          "GPUs (BASELINE configs[2]: 'batch=32 rooms, sharded 8x' = 4 rooms per GPU)")
@@ -266,7 +268,7 @@ def main():
         # line of its own (value, roofline, cpu_baseline) under "secondary"; `python bench.py --workload NAME` runs one alone
         import copy
         sec = {}
-        for name, steps, warm in (("tarnu", 3, 1), ("resgcn", 24, 8), ("pointnet2_msg", 16, 8), ("randla", 48, 8)):
+        for name, steps, warm in (("tarnu", 6, 2), ("resgcn", 24, 8), ("pointnet2_msg", 16, 8), ("randla", 48, 8)):
             a2 = copy.copy(args)
             a2.workload, a2.steps, a2.warmup, a2.cpu_seconds = name, steps, warm, min(args.cpu_seconds, 6.0)
             t0 = time.time()
@@ -838,16 +840,28 @@ def tarnu_measure(args, R, mode, with_roofline=True):
     # jobs: (step, first room, rooms) - one attack call each
     lockstep = mode == "per-room" and per_step >= 2          # one call advances the rooms of a step in lockstep (forward_rooms)
     per_room = mode in ("per-room", "per-room-calls")
-    def jobs_of(step):
-        return [(step, b, 1) for b in range(per_step)] if per_room and not lockstep else [(step, 0, per_step)]
-    conc = max(1, min(args.nu_concurrency if not lockstep else min(args.nu_concurrency, 3), len(jobs_of(0)) * args.steps))
+    # lockstep: --nu-coalesce consecutive steps (independent rooms) share one forward_rooms call, dealt evenly like the
+    # headline workload's launches; the other modes keep one group per step
+    coal = max(1, args.nu_coalesce) if lockstep else 1
+    def split(n):
+        n_l = -(-n // coal) if n else 0
+        return [n // n_l + (1 if i < n % n_l else 0) for i in range(n_l)]
+    g_warm, g_timed = split(args.warmup), split(args.steps)
+    g_sizes, n_warm_g = g_warm + g_timed, len(g_warm)
+    rooms, s0 = [], 0
+    for gs in g_sizes:
+        rooms.append(np.concatenate([make_rooms(per_step, 7000 + 1000 * R.rank + s0 + i, structured=True) for i in range(gs)]))
+        s0 += gs
+    labels = [rule_labels(r) for r in rooms]
+    def jobs_of(g):
+        return [(g, b, 1) for b in range(len(rooms[g]))] if per_room and not lockstep else [(g, 0, len(rooms[g]))]
+    n_jobs_timed = sum(len(jobs_of(g)) for g in range(n_warm_g, len(g_sizes)))
+    conc = max(1, min(args.nu_concurrency if not lockstep else min(args.nu_concurrency, 3), n_jobs_timed))
     nets, streams = [], [torch.cuda.Stream() for _ in range(conc)]
     for _ in range(conc):
         net = get_model(13)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         nets.append(net.cuda().eval())
-    rooms = [make_rooms(per_step, 7000 + 1000 * R.rank + s, structured=True) for s in range(n_steps)]
-    labels = [rule_labels(r) for r in rooms]
     d_images = [torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 1))).cuda() for r in rooms]
     opt_steps, exits, lock = [0], [0], threading.Lock()
 
@@ -887,20 +901,20 @@ def tarnu_measure(args, R, mode, with_roofline=True):
             list(pool.map(worker, range(conc)))
 
     torch.manual_seed(R.rank)
-    run(0, args.warmup)
+    run(0, n_warm_g)
     torch.cuda.synchronize()
     opt_steps[0], exits[0] = 0, 0
-    elapsed = R.timed(lambda: run(args.warmup, n_steps))
+    elapsed = R.timed(lambda: run(n_warm_g, len(g_sizes)))
     total_opt, total_exit = R.sum(opt_steps[0]), R.sum(exits[0])
     n_attacks = (per_step if per_room else 1) * args.steps * R.world
     rooms_per_attack = 1 if per_room else per_step
-    rooms_per_call = per_step if lockstep or not per_room else 1
+    rooms_per_call = len(rooms[n_warm_g]) if lockstep or not per_room else 1
     result = base_line("attacked rooms/sec (tar_NU, 4096 pts, <= %d Adam steps)" % cap, "rooms/s",
                        per_step * args.steps * R.world / elapsed, R, args, elapsed,
                        "tar_NU_attack (c=1, kappa=0, lr=0.01, target=6, neighbour=5) on PointNet++ SSG sem_seg, %s (BASELINE "
                        "configs[2]); fitted fixture weights"
                        % ("applied per room, %d rooms x 4096 pts per step and GPU%s" % (per_step, ", the rooms of a step advanced in "
-                          "lockstep (forward_rooms: one launch per operation)" if lockstep else ", one call per room") if per_room
+                          "lockstep (forward_rooms: one launch per operation), %d step(s) per call" % coal if lockstep else ", one call per room") if per_room
                           else "one call on a batch of %d rooms x 4096 pts" % per_step),
                        {"mode": mode, "rooms_per_step_per_gpu": per_step, "optimizer_steps_cap": cap,
                         ("calls_in_flight" if lockstep else "attacks_in_flight"): conc, "rooms_per_call": rooms_per_call})
@@ -912,7 +926,7 @@ def tarnu_measure(args, R, mode, with_roofline=True):
         # roofline: the network kernels of one more attack, HIP events on its launch stream
         ws = nets[0]._workspace(rooms_per_call, NPOINT, nu_mod.CHUNK + 1)
         ws.prof_enable(True)
-        attack(jobs_of(0)[0], 0)
+        attack(jobs_of(n_warm_g)[0], 0)
         torch.cuda.synchronize()
         prof = ws.prof_read()
         ws.prof_enable(False)
