@@ -834,7 +834,7 @@ def tarnu_measure(args, R, mode, with_roofline=True):
     target, src_cls = 6, 2
     strong = args.scaling == "strong"
     per_step = max(1, 32 // R.world) if strong else 32          # rooms of one step on this rank
-    cap = args.nu_steps if args.nu_steps else (40 if mode == "per-room" else 100)
+    cap = args.nu_steps if args.nu_steps else (40 if mode in ("per-room", "per-room-calls") else 100)
     sd = dict(np.load(os.path.join(ROOT, "tests", "golden", "pn2_weights.npz")))
     n_steps = args.steps + args.warmup
     # jobs: (step, first room, rooms) - one attack call each

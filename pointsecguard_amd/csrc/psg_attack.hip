@@ -441,15 +441,15 @@ __global__ void gcn_f_loss_grad_kernel(const float *__restrict__ z, const int32_
 // (Round 2's version gave 16 lanes and a 64-KB staging copy to every 16 queries and merged in one lane: 2 workgroups =
 // 8 waves per CU, 122 us for one room and 2.2 ms for 32 - half of the GPU time of a lockstep tar_NU step.)
 constexpr int SM_MAX_NB = 16;
-constexpr int SM_SUB = 4;                   // lanes per query
 constexpr int SM_T = 1024;
-constexpr int SM_QPB = SM_T / SM_SUB;       // queries per workgroup
 constexpr int SM_REFRESH = 64;              // scan iterations between two updates of the query's common threshold
+// SUB = lanes per query (4: 256 queries per workgroup, for launches of 16+ rooms; 16: 64 queries per workgroup, so that a
+// one-room call still spreads over 64 workgroups)
 
-// one step of the 4-way merge: the smallest head of the query's four sorted lists by (distance, index) is returned in
+// one step of the SUB-way merge: the smallest head of the query's SUB sorted lists by (distance, index) is returned in
 // every lane of the query and popped from the one list that holds it (reference indices are unique across the lists;
 // exhausted lists show (inf, 0x7FFFFFFF) and may pop together, which changes nothing)
-template <int NBT>
+template <int NBT, int SM_SUB>
 __device__ __forceinline__ void smooth_pop_min(float (&bd)[NBT], int (&bi)[NBT], float &best, int &bidx)
 {
     best = bd[0];
@@ -467,7 +467,7 @@ __device__ __forceinline__ void smooth_pop_min(float (&bd)[NBT], int (&bi)[NBT],
     }
 }
 
-template <int NBT>
+template <int NBT, int SM_SUB>
 __global__ __launch_bounds__(SM_T) void smooth_knn_kernel(const float *__restrict__ adv, int adv_stride,
                                                           const float *__restrict__ ref, int ref_stride, int N, int nb,
                                                           float *__restrict__ dist_sum, float *__restrict__ grad, int symmetric,
@@ -478,6 +478,7 @@ __global__ __launch_bounds__(SM_T) void smooth_knn_kernel(const float *__restric
     ref += blockIdx.y * ref_room_stride;
     grad += (size_t)blockIdx.y * N * 3;
     if (dist_sum) dist_sum += blockIdx.y;
+    constexpr int SM_QPB = SM_T / SM_SUB;                   // queries per workgroup
     extern __shared__ float4 s_ref[];                       // [N] reference colours + |r|^2
     for (int i = threadIdx.x; i < N; i += SM_T) {
         const float x = ref[(size_t)i * ref_stride], y = ref[(size_t)i * ref_stride + 1], z = ref[(size_t)i * ref_stride + 2];
@@ -543,16 +544,16 @@ __global__ __launch_bounds__(SM_T) void smooth_knn_kernel(const float *__restric
             for (int t = 0; t < NBT; ++t) { cdist[t] = bd[t]; cidx[t] = bi[t]; }
             float kth = INFINITY;
             int kidx;
-            for (int t = 0; t < nb; ++t) smooth_pop_min<NBT>(cdist, cidx, kth, kidx);
+            for (int t = 0; t < nb; ++t) smooth_pop_min<NBT, SM_SUB>(cdist, cidx, kth, kidx);
             thr = fminf(thr, kth);
         }
     }
-    // 4-way merge: nb times the smallest head by (distance, index); every lane of the query follows the same sequence
+    // SUB-way merge: nb times the smallest head by (distance, index); every lane of the query follows the same sequence
     float local = 0.0f, gx = 0.f, gy = 0.f, gz = 0.f;
     for (int t = 0; t < nb; ++t) {
         float best;
         int bidx;
-        smooth_pop_min<NBT>(bd, bi, best, bidx);
+        smooth_pop_min<NBT, SM_SUB>(bd, bi, best, bidx);
         if (bidx == 0x7FFFFFFF) break;   // fewer than nb references (uniform over the query's lanes)
         if (sub == 0 && i < N) {
             const float d = sqrtf(best);
@@ -709,18 +710,25 @@ static int smooth_knn_launch(const float *adv_color, int adv_stride, size_t adv_
     // list length per lane: the neighbour count itself for the usual nb = 5 (every step of the insertion network counts:
     // with 64 lanes a wave enters it in most passes), else 8 or 16
     const size_t lds = (size_t)N * sizeof(float4);
-    const dim3 grid(psg::ceil_div(N, SM_QPB), B);
-#define PSG_SMOOTH_LAUNCH(NBT)                                                                                                   \
+    const bool wide = (size_t)B * psg::ceil_div(N, SM_T / 4) >= 256;   // enough 256-query workgroups to fill the chip
+    const dim3 grid(psg::ceil_div(N, SM_T / (wide ? 4 : 16)), B);
+#define PSG_SMOOTH_LAUNCH(NBT, SUB)                                                                                              \
     do {                                                                                                                         \
         if (lds > 48 * 1024)                                                                                                     \
-            PSG_CHECK_HIP(hipFuncSetAttribute((const void *)smooth_knn_kernel<NBT>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                              (int)lds));                                                                        \
-        hipLaunchKernelGGL(smooth_knn_kernel<NBT>, grid, dim3(SM_T), lds, (hipStream_t)stream, adv_color, adv_stride, ref_color, \
-                           ref_stride, N, nb, dist_sum, grad_out, symmetric, adv_room_stride, ref_room_stride);                  \
+            PSG_CHECK_HIP(hipFuncSetAttribute((const void *)smooth_knn_kernel<NBT, SUB>,                                         \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+        hipLaunchKernelGGL((smooth_knn_kernel<NBT, SUB>), grid, dim3(SM_T), lds, (hipStream_t)stream, adv_color, adv_stride,     \
+                           ref_color, ref_stride, N, nb, dist_sum, grad_out, symmetric, adv_room_stride, ref_room_stride);       \
     } while (0)
-    if (nb <= 5) PSG_SMOOTH_LAUNCH(5);
-    else if (nb <= 8) PSG_SMOOTH_LAUNCH(8);
-    else PSG_SMOOTH_LAUNCH(16);
+    if (wide) {
+        if (nb <= 5) PSG_SMOOTH_LAUNCH(5, 4);
+        else if (nb <= 8) PSG_SMOOTH_LAUNCH(8, 4);
+        else PSG_SMOOTH_LAUNCH(16, 4);
+    } else {
+        if (nb <= 5) PSG_SMOOTH_LAUNCH(5, 16);
+        else if (nb <= 8) PSG_SMOOTH_LAUNCH(8, 16);
+        else PSG_SMOOTH_LAUNCH(16, 16);
+    }
 #undef PSG_SMOOTH_LAUNCH
     PSG_LAUNCH_CHECK();
     return PSG_OK;
