@@ -431,7 +431,10 @@ __device__ __noinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFinalA
     return F + Fo;
 }
 
-__global__ __launch_bounds__(KB_WAVES * 64) void knn_bf_kernel(KnnBfArgs a)
+#ifndef KB_MIN_WAVES_EU
+#define KB_MIN_WAVES_EU 4
+#endif
+__global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(KnnBfArgs a)
 {
     constexpr int CAP = KB_CAP, ROW = KB_ROW;
     constexpr int PER_STEP = KB_WAVES * 32;

@@ -627,7 +627,16 @@ __device__ __forceinline__ void knn_exact_block(const KnnFusedArgs &a, const int
 #endif
 }
 
-__global__ __launch_bounds__(KF_WAVES * 64) void knn_fused_kernel(KnnFusedArgs a)
+// Registers: 5 waves per SIMD asked of the compiler although a workgroup only brings 4 - the kernel then takes 96 VGPRs
+// (4 spilled, outside the stream loop) instead of 122, which leaves a quarter of every SIMD's register file and 31 KB of LDS
+// to workgroups of OTHER kernels.  At 122 VGPRs a resident kNN workgroup filled the register file and nothing else could
+// start on its CU: the small GEMMs and edge passes of the other launches in flight waited for the kNN kernel's tail.
+// Same kernel time (4.47 ms per 4-room iteration), 12.02 -> 12.36 rooms/s; at 6 waves (80 VGPRs, 16 spills) the kernel
+// itself slows down by 9 %.
+#ifndef KF_MIN_WAVES_EU
+#define KF_MIN_WAVES_EU 5
+#endif
+__global__ __launch_bounds__(KF_WAVES * 64, KF_MIN_WAVES_EU) void knn_fused_kernel(KnnFusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char kf_smem[];
     // XCD-aware block order: blocks b, b + 8, .. share an XCD (round-robin dispatch), so XCD x takes the contiguous query
