@@ -467,6 +467,8 @@ __device__ __forceinline__ void smooth_pop_min(float (&bd)[NBT], int (&bi)[NBT],
     }
 }
 
+typedef float sm_v2f __attribute__((ext_vector_type(2)));   // operand of the packed-fp32 pipe (v_pk_*_f32)
+
 template <int NBT, int SM_SUB>
 __global__ __launch_bounds__(SM_T) void smooth_knn_kernel(const float *__restrict__ adv, int adv_stride,
                                                           const float *__restrict__ ref, int ref_stride, int N, int nb,
@@ -479,10 +481,22 @@ __global__ __launch_bounds__(SM_T) void smooth_knn_kernel(const float *__restric
     grad += (size_t)blockIdx.y * N * 3;
     if (dist_sum) dist_sum += blockIdx.y;
     constexpr int SM_QPB = SM_T / SM_SUB;                   // queries per workgroup
-    extern __shared__ float4 s_ref[];                       // [N] reference colours + |r|^2
-    for (int i = threadIdx.x; i < N; i += SM_T) {
-        const float x = ref[(size_t)i * ref_stride], y = ref[(size_t)i * ref_stride + 1], z = ref[(size_t)i * ref_stride + 2];
-        s_ref[i] = make_float4(x, y, z, x * x + y * y + z * z);
+    // Reference colours in LDS as four planes x, y, z, |r|^2, each split into SUB runs: run s holds the references
+    // s, s + SUB, s + 2 SUB, .. (the ones lane s of a query scans) contiguously, so one ds_read_b128 per plane brings four of
+    // them and two references share every instruction of the distance arithmetic on the packed-fp32 pipe.  Runs are 8 floats
+    // apart beyond their length (the SUB lanes of a query read different runs at the same offset: different banks); slots
+    // past N hold |r|^2 = inf and are never admitted.
+    const int tps = ((N + SM_SUB - 1) / SM_SUB + 3) & ~3, run = tps + 8;
+    extern __shared__ float s_pl[];
+    float *s_x = s_pl, *s_y = s_pl + SM_SUB * run, *s_z = s_pl + 2 * SM_SUB * run, *s_q = s_pl + 3 * SM_SUB * run;
+    for (int p = threadIdx.x; p < SM_SUB * tps; p += SM_T) {
+        const int sr = p / tps, t = p - sr * tps, i = sr + SM_SUB * t;
+        float x = 0.f, y = 0.f, z = 0.f, q = INFINITY;
+        if (i < N) {
+            x = ref[(size_t)i * ref_stride]; y = ref[(size_t)i * ref_stride + 1]; z = ref[(size_t)i * ref_stride + 2];
+            q = x * x + y * y + z * z;
+        }
+        s_x[sr * run + t] = x; s_y[sr * run + t] = y; s_z[sr * run + t] = z; s_q[sr * run + t] = q;
     }
     __syncthreads();
     const int ql = threadIdx.x / SM_SUB, sub = threadIdx.x % SM_SUB;
@@ -498,37 +512,39 @@ __global__ __launch_bounds__(SM_T) void smooth_knn_kernel(const float *__restric
     // keeps the gradient of a colour that has barely moved from its original near 0 instead of a unit
     // vector of rounding noise -- so the same expansion is used here (not bit-identical to MKL's order).
     const float asq = ax * ax + ay * ay + az * az;
-    const float m2x = -2.0f * ax, m2y = -2.0f * ay, m2z = -2.0f * az;
+    const sm_v2f m2x = {-2.0f * ax, -2.0f * ax}, m2y = {-2.0f * ay, -2.0f * ay}, m2z = {-2.0f * az, -2.0f * az}, asq2 = {asq, asq};
     // thr: a candidate is looked at only below min(this lane's worst kept distance, the nb-th smallest distance the
-    // query's four lanes hold TOGETHER at the last refresh).  The common bound is what keeps the insertion branch rare:
-    // a wave serves 16 queries x 4 lanes, it runs the insertion network whenever ANY lane passes, and a lane's own
-    // list only tightens as 8 / n.  Exact: everything kept at a refresh has a lower index than anything scanned later,
+    // query's SUB lanes hold TOGETHER at the last refresh).  The common bound is what keeps the insertion branch rare:
+    // a wave serves 64 / SUB queries, it runs the insertion network whenever ANY lane passes, and a lane's own
+    // list only tightens as NBT / n.  Exact: everything kept at a refresh has a lower index than anything scanned later,
     // so a later candidate at exactly the bound loses the (distance, index) tie and '<' drops nothing that is wanted.
-    float thr = i < N ? INFINITY : -1.0f;
-    for (int j0 = sub; j0 < N; j0 += SM_SUB * SM_REFRESH) {
-        const int j1 = j0 + SM_SUB * SM_REFRESH < N ? j0 + SM_SUB * SM_REFRESH : N;
-        // four references per pass: their LDS reads and distance chains are independent, one test covers all four
-        for (int j = j0; j < j1; j += 4 * SM_SUB) {
-            float d2[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ju = j + u * SM_SUB;
-                const float4 q = s_ref[ju < N ? ju : j];
-                float t2 = __fmaf_rn(m2z, q.z, __fmaf_rn(m2y, q.y, __fmul_rn(m2x, q.x)));
-                t2 = __fadd_rn(__fadd_rn(t2, asq), q.w);
-                d2[u] = ju < j1 ? fmaxf(t2, 0.0f) : INFINITY;
-            }
+    // (The filter compares the distance BEFORE its clamp at 0: a negative one passes a positive bound either way, and
+    // against a bound of 0 it only enters the insertion code, where the clamped value is refused like every other 0.)
+    float thr = i < N ? INFINITY : -INFINITY;
+    const float *px = s_x + sub * run, *py = s_y + sub * run, *pz = s_z + sub * run, *pq = s_q + sub * run;
+    for (int t0 = 0; t0 < tps; t0 += SM_REFRESH) {
+        const int t1 = t0 + SM_REFRESH < tps ? t0 + SM_REFRESH : tps;
+        for (int t = t0; t < t1; t += 4) {
+            const float4 X = *(const float4 *)(px + t), Y = *(const float4 *)(py + t), Z = *(const float4 *)(pz + t),
+                         Q = *(const float4 *)(pq + t);
+            // two references per instruction; per component exactly fma(m2z, z, fma(m2y, y, m2x * x)) then (+ asq) + q
+            sm_v2f da = m2x * sm_v2f{X.x, X.y}, db = m2x * sm_v2f{X.z, X.w};
+            da = __builtin_elementwise_fma(m2y, sm_v2f{Y.x, Y.y}, da); db = __builtin_elementwise_fma(m2y, sm_v2f{Y.z, Y.w}, db);
+            da = __builtin_elementwise_fma(m2z, sm_v2f{Z.x, Z.y}, da); db = __builtin_elementwise_fma(m2z, sm_v2f{Z.z, Z.w}, db);
+            da = (da + asq2) + sm_v2f{Q.x, Q.y};
+            db = (db + asq2) + sm_v2f{Q.z, Q.w};
+            const float d2[4] = {da[0], da[1], db[0], db[1]};
             if (fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3])) < thr) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (d2[u] < thr) {
-                        float cd = d2[u];
-                        int ci = j + u * SM_SUB;
+                        float cd = fmaxf(d2[u], 0.0f);
+                        int ci = sub + SM_SUB * (t + u);
 #pragma unroll
-                        for (int t = 0; t < NBT; ++t) {   // sorted insertion with static indexing (arrays stay in registers)
-                            if (cd < bd[t]) {
-                                float td = bd[t]; int ti = bi[t];
-                                bd[t] = cd; bi[t] = ci;
+                        for (int k = 0; k < NBT; ++k) {   // sorted insertion with static indexing (arrays stay in registers)
+                            if (cd < bd[k]) {
+                                float td = bd[k]; int ti = bi[k];
+                                bd[k] = cd; bi[k] = ci;
                                 cd = td; ci = ti;
                             }
                         }
@@ -537,7 +553,7 @@ __global__ __launch_bounds__(SM_T) void smooth_knn_kernel(const float *__restric
                 }
             }
         }
-        if (j0 - sub + SM_SUB * SM_REFRESH < N) {   // another chunk follows (the same answer in the query's four lanes)
+        if (t1 < tps) {   // another chunk follows (uniform over the workgroup)
             float cdist[NBT];
             int cidx[NBT];
 #pragma unroll
@@ -559,8 +575,8 @@ __global__ __launch_bounds__(SM_T) void smooth_knn_kernel(const float *__restric
             const float d = sqrtf(best);
             local += d;
             if (d > 0.0f) {
-                const float4 q = s_ref[bidx];
-                const float ux = (ax - q.x) / d, uy = (ay - q.y) / d, uz = (az - q.z) / d;
+                const int pos = (bidx % SM_SUB) * run + bidx / SM_SUB;
+                const float ux = (ax - s_x[pos]) / d, uy = (ay - s_y[pos]) / d, uz = (az - s_z[pos]) / d;
                 gx += ux; gy += uy; gz += uz;
                 if (symmetric) {  // the neighbour is an adversarial colour too: it receives the opposite pull
                     atomicAdd(grad + (size_t)bidx * 3, -ux);
@@ -709,8 +725,9 @@ static int smooth_knn_launch(const float *adv_color, int adv_stride, size_t adv_
     if (symmetric) PSG_CHECK_HIP(hipMemsetAsync(grad_out, 0, (size_t)B * N * 3 * sizeof(float), (hipStream_t)stream));
     // list length per lane: the neighbour count itself for the usual nb = 5 (every step of the insertion network counts:
     // with 64 lanes a wave enters it in most passes), else 8 or 16
-    const size_t lds = (size_t)N * sizeof(float4);
     const bool wide = (size_t)B * psg::ceil_div(N, SM_T / 4) >= 256;   // enough 256-query workgroups to fill the chip
+    const int sub = wide ? 4 : 16;
+    const size_t lds = (size_t)4 * sub * ((((N + sub - 1) / sub + 3) & ~3) + 8) * sizeof(float);
     const dim3 grid(psg::ceil_div(N, SM_T / (wide ? 4 : 16)), B);
 #define PSG_SMOOTH_LAUNCH(NBT, SUB)                                                                                              \
     do {                                                                                                                         \

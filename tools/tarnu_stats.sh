@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 O=gpurun_out/r03
 mkdir -p $O
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ts -o ts -- python3 bench.py --workload tarnu --steps 1 --warmup 1 --nu-concurrency 1 --no-cpu-baseline --no-reference > $O/tarnu_stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ts -o ts -- python3 bench.py --workload tarnu --steps 2 --warmup 2 --nu-concurrency 1 --no-cpu-baseline --no-reference > $O/tarnu_stats.log 2>&1 || exit 1
 cp $(find $O/ts -name '*kernel_stats.csv' | head -1) $O/tarnu_stats_kernel_stats.csv
 rm -rf $O/ts
 python3 - <<PY
