@@ -256,14 +256,18 @@ def nu_attack_rooms(atk, images, labels, masks, target, neighbour, targeted_vari
                 return out, steps_run
         if targeted_variant and step > 10 and step % 10 == 0:               # target.py:127-132, room by room
             again = np.nonzero(active & (cost >= prev_cost[step - 10]))[0]
-            for r in again:
+            for r in again:                                                  # the noise draws stay per room, in room order
                 k = int(n_mask[r])
                 noise = torch.empty(1, 3, k, device=dev, dtype=torch.float32).uniform_(0, 1)
                 col = x0[r:r + 1, :, 3:6].transpose(1, 2)                     # view [1, 3, N]
                 col[:, :, mask_b[r]] = col[:, :, mask_b[r]] + noise
-                x0[r].clamp_(min=0, max=1)                                   # ALL channels, like the reference
-                d = x0[r] - x0_orig[r]
-                extra_l2[r] = float((d[:, 0:3] ** 2).sum().item() + (d[:, 6:9] ** 2).sum().item())
+            if len(again):
+                idx = torch.from_numpy(again).to(dev)
+                clamped = x0[idx].clamp_(min=0, max=1)                       # ALL channels, like the reference
+                x0[idx] = clamped
+                d = clamped - x0_orig[idx]
+                sums = torch.stack([(d[:, :, 0:3] ** 2).sum(dim=(1, 2)), (d[:, :, 6:9] ** 2).sum(dim=(1, 2))]).cpu().numpy()
+                extra_l2[again] = sums[0].astype(np.float64) + sums[1].astype(np.float64)   # one read-back for all rooms
             # (xyz may have moved: the next window starts with the next step anyway - restarts only follow steps 20, 30, ..)
     snapshot(np.nonzero(active)[0])
     return out, steps_run

@@ -370,9 +370,25 @@ __global__ void nu_f_loss_grad_kernel(const float *__restrict__ logp, const int3
             g[c] = p[c] * (gc - dot);
         }
     }
-    // block reduction of the f values, one atomic per wave (rows_per_sum > 0: one sum per room, a multiple of 64 rows each)
+    // reduction of the f values (rows_per_sum > 0: one sum per room, a multiple of 64 rows each).  One atomic per
+    // workgroup when all its rows belong to one sum, else one per wave: thousands of waves adding into a handful of
+    // addresses serialise on them (the per-room launches spent most of their time there).
     for (int o = 32; o >= 1; o >>= 1) fval += __shfl_xor(fval, o);
-    if ((threadIdx.x & 63) == 0 && f_sum && r < rows) atomicAdd(f_sum + (rows_per_sum ? r / rows_per_sum : 0), fval);
+    if (!f_sum) return;
+    if (rows_per_sum == 0 || rows_per_sum % (int)blockDim.x == 0) {
+        __shared__ float s_part[16];
+        const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        if ((threadIdx.x & 63) == 0) s_part[wv] = fval;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = 0.0f;
+            for (int w = 0; w < nw; ++w) tot += s_part[w];
+            const int r0 = blockIdx.x * blockDim.x;
+            if (r0 < rows) atomicAdd(f_sum + (rows_per_sum ? r0 / rows_per_sum : 0), tot);
+        }
+    } else if ((threadIdx.x & 63) == 0 && r < rows) {
+        atomicAdd(f_sum + r / rows_per_sum, fval);
+    }
 }
 
 // f-loss of the ResGCN NU attacks, on raw logits (ResGCN/.../attacks/colper.py:108-113, tcolper.py:145-163).
@@ -637,7 +653,11 @@ __global__ void nu_adam_step_kernel(float *__restrict__ w, float *__restrict__ m
         w[t] = __fadd_rn(w[t], __fmul_rn(-step_size, __fdiv_rn(mm, denom)));
     }
     for (int o = 32; o >= 1; o >>= 1) l2 += __shfl_xor(l2, o);
-    if ((threadIdx.x & 63) == 0 && l2_sum) atomicAdd(l2_sum, l2);
+    if (!l2_sum) return;
+    __shared__ float s_l2[4];                                  // (256 threads) one atomic per workgroup
+    if ((threadIdx.x & 63) == 0) s_l2[threadIdx.x >> 6] = l2;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(l2_sum, (s_l2[0] + s_l2[1]) + (s_l2[2] + s_l2[3]));
 }
 
 }  // namespace
@@ -793,7 +813,8 @@ extern "C" int psg_nu_adam_step_rooms(float *w, float *m, float *v, const uint8_
     PSG_REQUIRE(w && m && v && dx0 && x0 && ori && B > 1 && B <= 65535 && N > 0 && step >= 1, "psg_nu_adam_step_rooms: bad argument (B >= 2)");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
-    hipLaunchKernelGGL(nu_adam_step_kernel, dim3(grid_for((size_t)N * 3), B), dim3(256), 0, (hipStream_t)stream, w, m, v, mask_rooms,
+    // (12 workgroups per room, four elements per thread at 4096 points: 12 atomics per room sum)
+    hipLaunchKernelGGL(nu_adam_step_kernel, dim3(std::min(grid_for((size_t)N * 3), 12), B), dim3(256), 0, (hipStream_t)stream, w, m, v, mask_rooms,
                        dx0, x0, ori, smooth_grad_rooms, c_smooth, c_l2, beta1, beta2, eps, step_size, bc2_sqrt, N, (size_t)N, l2_sum_rooms,
                        room_active);
     PSG_LAUNCH_CHECK();
