@@ -494,3 +494,38 @@ def test_tar_nu_rooms_configs2_size(weights_sd):
         one = nu_mod.nu_attack(a1, images[r:r + 1], labels[r:r + 1].astype(np.float64), masks[r], target, 5, targeted_variant=True,
                                starts_fn=lambda step, n_plan, r=r: table[step:step + n_plan, :, r:r + 1].contiguous())
         assert np.array_equal(one.cpu().numpy()[0], out[r]), r
+
+
+@pytest.mark.parametrize("n,nb", [(77, 5), (1000, 10), (1000, 16), (4096, 5)])
+def test_smooth_knn_kernel_vs_oracle_and_across_launch_shapes(n, nb):
+    """psg_smooth_knn (nontarget.py:131-135) on ragged sizes and every list length (5 / 8 / 16 entries per lane), against the C
+    oracle: the summed distances agree to 1e-5 relative and the gradient rows agree except where a near-tie among the k
+    nearest colours is broken differently (the oracle ranks sqrt(d^2), the kernel d^2).  The rooms entry point then gives
+    every room exactly the rows the one-room entry gives it - also when the launch is large enough to switch from 16 to 4
+    lanes per query (40 rooms of 4096 points)."""
+    from oracle import attacks as oatk
+    from pointsecguard_amd import _lib, runtime
+    rng = np.random.default_rng(n + nb)
+    rooms = 40 if n == 4096 else 3
+    ref = rng.random((rooms, n, 3), dtype=np.float32)
+    adv = np.clip(ref + rng.normal(0, 0.02, ref.shape).astype(np.float32) * (rng.random((rooms, n, 1)) < 0.5), 0, 1).astype(np.float32)
+    d_ref, d_adv = dev(ref), dev(adv)
+    st = runtime.stream
+    single = []
+    for r in range(min(rooms, 3)):
+        grad = torch.empty(n, 3, device="cuda")
+        tot = torch.zeros(1, device="cuda")
+        _lib.call("psg_smooth_knn", runtime.ptr(d_adv[r]), 3, runtime.ptr(d_ref[r]), 3, n, nb, runtime.ptr(tot), runtime.ptr(grad), st())
+        o_sum, o_grad = oatk.smooth_loss_grad(adv[r], ref[r], nb)
+        g = grad.cpu().numpy()
+        assert abs(float(tot) - o_sum) <= 1e-5 * o_sum + 1e-4, (r, float(tot), o_sum)
+        assert (np.abs(g - o_grad).max(axis=1) <= 1e-3).mean() >= 0.99, r
+        single.append(g)
+    grads = torch.empty(rooms, n, 3, device="cuda")
+    tots = torch.zeros(rooms, device="cuda")
+    _lib.call("psg_smooth_knn_rooms", runtime.ptr(d_adv), 3, n * 3, runtime.ptr(d_ref), 3, n * 3, rooms, n, nb, runtime.ptr(tots),
+              runtime.ptr(grads), st())
+    got = grads.cpu().numpy()
+    for r in range(len(single)):
+        assert np.array_equal(got[r], single[r]), r
+    assert np.isfinite(tots.cpu().numpy()).all() and (tots > 0).all()
