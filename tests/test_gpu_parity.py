@@ -279,6 +279,47 @@ def test_forward_backward_vs_oracle_batch(gpu_model, oracle_net):
         check_grad(dx0[b, :, 3:6].cpu().numpy(), oracle_net.backward_color(cache, o_dlogp))
 
 
+def test_forward_backward_vs_oracle_clustered_room(gpu_model, oracle_net):
+    """A room whose density is as uneven as it gets: 3 400 of the 4096 points inside a 2 cm ball, the rest spread over
+    the room.  The few coarse points FPS leaves inside the ball are the 3-NN of thousands of fine points (the transposed
+    interpolation lists of fp_bwd, dealt to waves by entry count, are then hundreds of entries long against a mean of 12),
+    every ball-query group there is full, and distances tie.  Indices must still be bit-exact and the forward / colour
+    gradient within the usual bars of the oracle."""
+    from oracle import pn2
+    from pointsecguard_amd import _lib, runtime
+    from pointsecguard_amd.synthetic import make_rooms, rule_labels
+    rooms = make_rooms(1, 321)
+    rng = np.random.default_rng(9)
+    sel = rng.permutation(4096)[:3400]
+    ball = rng.normal(0, 0.005, (3400, 3)).astype(np.float32)
+    rooms[0, sel, 0:3] = np.array([0.1, -0.2, 1.0], np.float32) + ball
+    rooms[0, sel, 6] = rooms[0, sel, 0] + 0.5
+    rooms[0, sel, 7] = rooms[0, sel, 1] + 0.5
+    rooms[0, sel, 8] = rooms[0, sel, 2] / 3.0
+    labels = rule_labels(rooms)
+    starts = np.stack([rng.integers(0, n, (1, 1)) for n in (4096, 1024, 256, 64)], axis=1).astype(np.int32)   # [1,4,1]
+    ws = runtime.PN2Workspace(1, 4096, 1)
+    x0 = dev(rooms)
+    ws.plan_build(x0, dev(starts), 1)
+    logp = ws.forward(gpu_model, 0, x0)
+    dlogp = torch.empty_like(logp)
+    _lib.call("psg_ce_logp_grad", runtime.ptr(logp), runtime.ptr(dev(labels.astype(np.int32))), 0, 4096, 4096, 13, 1.0 / 4096,
+              runtime.ptr(dlogp), None, runtime.stream())
+    dx0 = ws.backward(gpu_model, 0, dlogp)
+    torch.cuda.synchronize()
+    geom = oracle_net.geometry(rooms[0, :, :3], starts[0, :, 0])
+    for lvl in range(4):
+        assert np.array_equal(ws.plan_tensor(0, lvl, 0, 0).cpu().numpy(), geom["fps"][lvl].astype(np.int32)), lvl
+        assert np.array_equal(ws.plan_tensor(1, lvl, 0, 0).cpu().numpy(), geom["group"][lvl].astype(np.int32)), lvl
+        assert np.array_equal(ws.plan_tensor(2, lvl, 0, 0).cpu().numpy(), geom["nn_idx"][lvl].astype(np.int32)), lvl
+    indeg = np.bincount(geom["nn_idx"][0].reshape(-1), minlength=1024)
+    assert indeg.max() >= 150, indeg.max()                       # the case this test is about (mean: 12)
+    o_logp, cache = oracle_net.forward(rooms[0], geom)
+    assert np.abs(logp[0].cpu().numpy() - o_logp).max() <= LOGP_TOL
+    o_dlogp, _ = pn2.nll_logp_grad(o_logp, labels[0], 1.0 / 4096)
+    check_grad(dx0[0, :, 3:6].cpu().numpy(), oracle_net.backward_color(cache, o_dlogp))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # BASELINE configs[1] at its own batch: tests/golden/pn2_nb_b8.npz = the reference's NB_attack on B = 8 rooms (two
 # batches, 16 rooms, make_golden_big.py: gen_nb_b8)
