@@ -807,7 +807,7 @@ def run_tarnu(args, R):
     if args.nu_mode == "per-room" and R.rank == 0 and R.world == 1 and not args.no_reference:
         import copy
         a1 = copy.copy(args)
-        a1.steps, a1.warmup, a1.no_cpu_baseline = 1, 1, True
+        a1.steps, a1.warmup, a1.no_cpu_baseline = 3, 1, True
         q = tarnu_measure(a1, R, "per-room-calls", with_roofline=False)
         result["uncoalesced_reference"] = {"value": q["value"], "unit": "rooms/s",
                                            "note": "one call per room (batches of one), %d calls in flight" % q["config"]["attacks_in_flight"]}
