@@ -136,7 +136,7 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
             *(float4 *)(buf0 + L::off(8, j)) = make_float4(f[8], xr[0] - cr[0], xr[1] - cr[1], xr[2] - cr[2]);
             *(float4 *)(buf0 + L::off(12, j)) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        // zero the K-padding blocks of the first layer (K is padded to a multiple of 32)
+        // zero any further 8-channel blocks the first layer reads (its K is ceil((D + 3) / 8) blocks: normally none)
         for (int blk = ((a.D + 3) >> 3) + 1 + part; blk < a.l1.k8; blk += NPART) {
             float *z = buf0 + (size_t)blk * L::BLK + j * 8;
             *(float4 *)z = make_float4(0.f, 0.f, 0.f, 0.f);
