@@ -383,7 +383,8 @@ def run_pointnet2(args, R):
     result = base_line("attacked rooms/sec (4096 pts, 40 PGD iters)", "rooms/s", BATCH * world * args.steps / elapsed, R, args,
                        elapsed, "NB non-targeted PGD (eps=0.05, alpha=2/255, 40 iters) on PointNet++ SSG sem_seg, batch=8 "
                        "rooms x 4096 pts x 9 ch per GPU (BASELINE configs[1])",
-                       {"rooms_per_step_per_gpu": BATCH, "steps_coalesced_per_launch": G, "device_batch_rooms": DB,
+                       {"rooms_per_step_per_gpu": BATCH, "steps_coalesced_per_launch_max": G,
+                        "device_batch_rooms": BATCH * max(sizes[n_warm:]),
                         "launch_sizes_in_steps": sizes[n_warm:], "launches_in_flight_per_gpu": conc,
                         "weights": "tests/golden/pn2_weights.npz (fitted fixture)"})
     if rank == 0:
