@@ -295,9 +295,12 @@ int psg_nu_adam_step(float *w, float *m, float *v, const uint8_t *mask, const fl
 int psg_nu_tanh_color_rooms(const float *w, const uint8_t *mask_rooms, int B, int N, float *x0, psg_stream stream);
 int psg_nu_f_loss_grad_rooms(const float *logp, const int32_t *labels, int target, int B, int N, int n_cls, float kappa,
                              float tsign, float *dlogp_out, float *f_sum_rooms, int32_t *pred_out, psg_stream stream);
+/* nn_state (nullable): int32 [B][N][nb], the neighbour indices of every colour; written by every call, and with
+ * have_prev != 0 read first: the largest current distance to last call's neighbours is a rigorous upper bound of the
+ * nb-th smallest distance, so the scan starts from it (same result; the optimiser moves colours a little per step). */
 int psg_smooth_knn_rooms(const float *adv_color, int adv_stride, size_t adv_room_stride, const float *ref_color,
                          int ref_stride, size_t ref_room_stride, int B, int N, int nb, float *dist_sum_rooms,
-                         float *grad_out, psg_stream stream);
+                         float *grad_out, int32_t *nn_state, int have_prev, psg_stream stream);
 int psg_nu_adam_step_rooms(float *w, float *m, float *v, const uint8_t *mask_rooms, const float *dx0, const float *x0,
                            const float *ori, const float *smooth_grad_rooms, float c_smooth, float c_l2, float lr,
                            float beta1, float beta2, float eps, int step, int B, int N, const uint8_t *room_active,

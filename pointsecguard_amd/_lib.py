@@ -73,7 +73,7 @@ SIGNATURES = {
     "psg_nu_adam_step": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, cf, ci, ci, ci, vp, vp]),
     "psg_nu_tanh_color_rooms": (ci, [vp, vp, ci, ci, vp, vp]),
     "psg_nu_f_loss_grad_rooms": (ci, [vp, vp, ci, ci, ci, ci, cf, cf, vp, vp, vp, vp]),
-    "psg_smooth_knn_rooms": (ci, [vp, ci, ctypes.c_size_t, vp, ci, ctypes.c_size_t, ci, ci, ci, vp, vp, vp]),
+    "psg_smooth_knn_rooms": (ci, [vp, ci, ctypes.c_size_t, vp, ci, ctypes.c_size_t, ci, ci, ci, vp, vp, vp, ci, vp]),
     "psg_nu_adam_step_rooms": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, cf, ci, ci, ci, vp, vp, vp]),
     "psg_gcn_model_create": (ci, [vp, ctypes.POINTER(vp), ci, ci, ctypes.POINTER(vp)]),
     "psg_gcn_model_create_cfg": (ci, [vp, ctypes.POINTER(vp), ci, ci, ci, ci, ctypes.POINTER(vp)]),

@@ -189,6 +189,7 @@ def nu_attack_rooms(atk, images, labels, masks, target, neighbour, targeted_vari
     sgrad = torch.empty(R, N, 3, device=dev, dtype=torch.float32)
     pred = torch.empty(R, N, device=dev, dtype=torch.int32)
     scal = torch.zeros(3, R, device=dev, dtype=torch.float32)      # rows: f, smooth, l2
+    nn_state = torch.empty(R, N, int(neighbour), device=dev, dtype=torch.int32)   # Smooth term: last step's neighbours (start bound)
     active_d = torch.ones(R, device=dev, dtype=torch.uint8)
     active = np.ones(R, bool)
     steps_run = np.zeros(R, np.int64)
@@ -221,7 +222,7 @@ def nu_attack_rooms(atk, images, labels, masks, target, neighbour, targeted_vari
                   runtime.ptr(scal[0]), runtime.ptr(pred), st())
         ws.backward(model, slot, dlogp, dx0)
         _lib.call("psg_smooth_knn_rooms", ctypes_off(x0, 3), 9, N * 9, runtime.ptr(ori), 3, N * 3, R, N, int(neighbour),
-                  runtime.ptr(scal[1]), runtime.ptr(sgrad), st())
+                  runtime.ptr(scal[1]), runtime.ptr(sgrad), runtime.ptr(nn_state), 1 if step > 0 else 0, st())
         adam_t += 1
         _lib.call("psg_nu_adam_step_rooms", runtime.ptr(w), runtime.ptr(m), runtime.ptr(v), runtime.ptr(mask_d),
                   runtime.ptr(dx0), runtime.ptr(x0), runtime.ptr(ori), runtime.ptr(sgrad), float(atk.c), float(atk.c),

@@ -489,13 +489,15 @@ template <int NBT, int SM_SUB>
 __global__ __launch_bounds__(SM_T) void smooth_knn_kernel(const float *__restrict__ adv, int adv_stride,
                                                           const float *__restrict__ ref, int ref_stride, int N, int nb,
                                                           float *__restrict__ dist_sum, float *__restrict__ grad, int symmetric,
-                                                          size_t adv_room_stride, size_t ref_room_stride)
+                                                          size_t adv_room_stride, size_t ref_room_stride,
+                                                          int32_t *__restrict__ nn_io, int have_prev)
 {
     // blockIdx.y = room of a lockstep batch (psg_smooth_knn_rooms; a single launch of the one-room entry has one slice)
     adv += blockIdx.y * adv_room_stride;
     ref += blockIdx.y * ref_room_stride;
     grad += (size_t)blockIdx.y * N * 3;
     if (dist_sum) dist_sum += blockIdx.y;
+    if (nn_io) nn_io += (size_t)blockIdx.y * N * nb;
     constexpr int SM_QPB = SM_T / SM_SUB;                   // queries per workgroup
     // Reference colours in LDS as four planes x, y, z, |r|^2, each split into SUB runs: run s holds the references
     // s, s + SUB, s + 2 SUB, .. (the ones lane s of a query scans) contiguously, so one ds_read_b128 per plane brings four of
@@ -537,6 +539,29 @@ __global__ __launch_bounds__(SM_T) void smooth_knn_kernel(const float *__restric
     // (The filter compares the distance BEFORE its clamp at 0: a negative one passes a positive bound either way, and
     // against a bound of 0 it only enters the insertion code, where the clamped value is refused like every other 0.)
     float thr = i < N ? INFINITY : -INFINITY;
+    if (nn_io && have_prev) {
+        // The optimiser moves a colour a little per step, so the nb references that were nearest one step ago are a sharp
+        // and RIGOROUS start: the largest of their current distances bounds the nb-th smallest distance from above
+        // (they are nb distinct references), and only the handful of references inside that ball ever reach the
+        // insertion code.  The bound is taken a few ulps up so that the reference defining it passes the '<'.
+        float m = -1.0f;
+        bool ok = i < N;
+        for (int t = sub; t < nb; t += SM_SUB) {
+            const int jn = ok ? nn_io[(size_t)i * nb + t] : 0;
+            if (jn < 0 || jn >= N) { ok = false; break; }
+            const int pos = (jn % SM_SUB) * run + jn / SM_SUB;
+            float d2 = __fmaf_rn(m2z[0], s_z[pos], __fmaf_rn(m2y[0], s_y[pos], __fmul_rn(m2x[0], s_x[pos])));
+            d2 = __fadd_rn(__fadd_rn(d2, asq), s_q[pos]);
+            m = fmaxf(m, fmaxf(d2, 0.0f));
+        }
+        unsigned bad = ok ? 0u : 1u;
+#pragma unroll
+        for (int o = 1; o < SM_SUB; o <<= 1) {
+            m = fmaxf(m, __shfl_xor(m, o));
+            bad |= (unsigned)__shfl_xor((int)bad, o);
+        }
+        if (!bad && i < N && m >= 0.0f) thr = m * 1.000001f + 1e-30f;
+    }
     const float *px = s_x + sub * run, *py = s_y + sub * run, *pz = s_z + sub * run, *pq = s_q + sub * run;
     for (int t0 = 0; t0 < tps; t0 += SM_REFRESH) {
         const int t1 = t0 + SM_REFRESH < tps ? t0 + SM_REFRESH : tps;
@@ -588,6 +613,7 @@ __global__ __launch_bounds__(SM_T) void smooth_knn_kernel(const float *__restric
         smooth_pop_min<NBT, SM_SUB>(bd, bi, best, bidx);
         if (bidx == 0x7FFFFFFF) break;   // fewer than nb references (uniform over the query's lanes)
         if (sub == 0 && i < N) {
+            if (nn_io) nn_io[(size_t)i * nb + t] = bidx;          // next step's start
             const float d = sqrtf(best);
             local += d;
             if (d > 0.0f) {
@@ -735,7 +761,8 @@ extern "C" int psg_gcn_f_loss_grad(const float *logits, const int32_t *labels, i
 }
 
 static int smooth_knn_launch(const float *adv_color, int adv_stride, size_t adv_room_stride, const float *ref_color, int ref_stride,
-                             size_t ref_room_stride, int B, int N, int nb, float *dist_sum, float *grad_out, psg_stream stream)
+                             size_t ref_room_stride, int B, int N, int nb, float *dist_sum, float *grad_out, psg_stream stream,
+                             int32_t *nn_io = nullptr, int have_prev = 0)
 {
     PSG_REQUIRE(adv_color && ref_color && grad_out && N > 0 && B > 0 && B <= 65535, "psg_smooth_knn: bad argument");
     PSG_REQUIRE(nb > 0 && nb <= SM_MAX_NB, "psg_smooth_knn: neighbour count %d out of range (1..%d)", nb, SM_MAX_NB);
@@ -755,7 +782,8 @@ static int smooth_knn_launch(const float *adv_color, int adv_stride, size_t adv_
             PSG_CHECK_HIP(hipFuncSetAttribute((const void *)smooth_knn_kernel<NBT, SUB>,                                         \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
         hipLaunchKernelGGL((smooth_knn_kernel<NBT, SUB>), grid, dim3(SM_T), lds, (hipStream_t)stream, adv_color, adv_stride,     \
-                           ref_color, ref_stride, N, nb, dist_sum, grad_out, symmetric, adv_room_stride, ref_room_stride);       \
+                           ref_color, ref_stride, N, nb, dist_sum, grad_out, symmetric, adv_room_stride, ref_room_stride,        \
+                           nn_io, have_prev);                                                                                    \
     } while (0)
     if (wide) {
         if (nb <= 5) PSG_SMOOTH_LAUNCH(5, 4);
@@ -780,11 +808,11 @@ extern "C" int psg_smooth_knn(const float *adv_color, int adv_stride, const floa
 // B rooms at once: room b's colours start at adv_color + b * adv_room_stride floats (likewise ref); dist_sum [B], grad_out [B][N][3]
 extern "C" int psg_smooth_knn_rooms(const float *adv_color, int adv_stride, size_t adv_room_stride, const float *ref_color,
                                     int ref_stride, size_t ref_room_stride, int B, int N, int nb, float *dist_sum_rooms,
-                                    float *grad_out, psg_stream stream)
+                                    float *grad_out, int32_t *nn_state, int have_prev, psg_stream stream)
 {
     PSG_REQUIRE(adv_color != ref_color, "psg_smooth_knn_rooms: the symmetric variant is one room at a time");
     return smooth_knn_launch(adv_color, adv_stride, adv_room_stride, ref_color, ref_stride, ref_room_stride, B, N, nb,
-                             dist_sum_rooms, grad_out, stream);
+                             dist_sum_rooms, grad_out, stream, nn_state, nn_state ? have_prev : 0);
 }
 
 extern "C" int psg_nu_adam_step(float *w, float *m, float *v, const uint8_t *mask, const float *dx0, const float *x0,

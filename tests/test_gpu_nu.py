@@ -523,9 +523,23 @@ def test_smooth_knn_kernel_vs_oracle_and_across_launch_shapes(n, nb):
         single.append(g)
     grads = torch.empty(rooms, n, 3, device="cuda")
     tots = torch.zeros(rooms, device="cuda")
+    state = torch.full((rooms, n, nb), -1, dtype=torch.int32, device="cuda")
     _lib.call("psg_smooth_knn_rooms", runtime.ptr(d_adv), 3, n * 3, runtime.ptr(d_ref), 3, n * 3, rooms, n, nb, runtime.ptr(tots),
-              runtime.ptr(grads), st())
+              runtime.ptr(grads), runtime.ptr(state), 0, st())
     got = grads.cpu().numpy()
     for r in range(len(single)):
         assert np.array_equal(got[r], single[r]), r
     assert np.isfinite(tots.cpu().numpy()).all() and (tots > 0).all()
+    # the neighbour lists it left behind start the next call (a rigorous bound: same rows, bit for bit), also after the
+    # colours have moved, and a corrupted list only costs the head start
+    nn = state.cpu().numpy()
+    assert nn.min() >= 0 and nn.max() < n and all(len(set(row)) == nb for row in nn[0, :50])
+    moved = np.clip(adv + rng.normal(0, 0.01, adv.shape).astype(np.float32), 0, 1).astype(np.float32)
+    cold = torch.empty_like(grads)
+    _lib.call("psg_smooth_knn_rooms", runtime.ptr(dev(moved)), 3, n * 3, runtime.ptr(d_ref), 3, n * 3, rooms, n, nb, None,
+              runtime.ptr(cold), None, 0, st())
+    for label, st_in in (("warm", state.clone()), ("garbage", torch.full_like(state, n + 5))):
+        warm = torch.empty_like(grads)
+        _lib.call("psg_smooth_knn_rooms", runtime.ptr(dev(moved)), 3, n * 3, runtime.ptr(d_ref), 3, n * 3, rooms, n, nb, None,
+                  runtime.ptr(warm), runtime.ptr(st_in), 1, st())
+        assert torch.equal(warm, cold), label
