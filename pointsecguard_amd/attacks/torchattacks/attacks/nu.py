@@ -55,6 +55,7 @@ def nu_attack(atk, images, labels, mask, target, neighbour, targeted_variant=Fal
     sgrad = torch.empty(N, 3, device=dev, dtype=torch.float32)
     pred = torch.empty(B, N, device=dev, dtype=torch.int32)
     scal = torch.zeros(3, device=dev, dtype=torch.float32)  # f, smooth, l2
+    nn_state = torch.empty(N, int(neighbour), device=dev, dtype=torch.int32)   # Smooth term: last step's neighbours of row 0
     lr, adam_t = float(atk.lr), 0
     prev_cost = [1e10] * atk.steps
     tsign = float(atk._targeted)
@@ -87,8 +88,10 @@ def nu_attack(atk, images, labels, mask, target, neighbour, targeted_variant=Fal
                   int(target) if use_target else 0, B * N, 13, float(atk.kappa), tsign, runtime.ptr(dlogp),
                   runtime.ptr(scal[0:1]), runtime.ptr(pred), st())
         ws.backward(model, slot, dlogp, dx0)
-        _lib.call("psg_smooth_knn", ctypes_off(x0, 3), 9, runtime.ptr(ori), 3, N, int(neighbour),
-                  runtime.ptr(scal[1:2]), runtime.ptr(sgrad), st())
+        # (the rooms entry with one room: it keeps the neighbour lists, and every step after the first starts its scan from
+        # the rigorous bound they give - same rows as psg_smooth_knn)
+        _lib.call("psg_smooth_knn_rooms", ctypes_off(x0, 3), 9, N * 9, runtime.ptr(ori), 3, N * 3, 1, N, int(neighbour),
+                  runtime.ptr(scal[1:2]), runtime.ptr(sgrad), runtime.ptr(nn_state), 1 if step > 0 else 0, st())
         adam_t += 1
         _lib.call("psg_nu_adam_step", runtime.ptr(w), runtime.ptr(m), runtime.ptr(v), runtime.ptr(mask_d),
                   runtime.ptr(dx0), runtime.ptr(x0), runtime.ptr(ori), runtime.ptr(sgrad), float(atk.c), float(atk.c),
