@@ -189,8 +189,37 @@ def main_rehearse(args):
     return result
 
 
+ENV_SWITCHES = []     # filled by check_env_switches(): what the line reports as config.env_switches
+
+
+def check_env_switches(allow_paths, diag_ok=False):
+    """The benchmark must not be able to skip its work by environment.  The library reports the switches it knows that are
+    set (`psg_env_switches`, include/psg.h).  A library built with the work-skipping timing switches compiled in
+    (-DPSG_DIAG_BUILD, tools/diag_*.sh) or a result-changing switch stops the run; a path-selecting switch ('p': another
+    tested kernel path, same results) stops it too unless --allow-env-switches says the A/B run is intended; everything
+    set is printed in the line as config.env_switches ([] = the shipped defaults)."""
+    from pointsecguard_amd import _lib
+    lib = _lib.load()
+    sw = _lib.env_switches()
+    for name in sorted(os.environ):
+        if name.startswith("PSG_BENCH_"):
+            sw.append((name, os.environ[name], "b"))
+    ENV_SWITCHES[:] = ["%s=%s (%s)" % s for s in sw]
+    if lib.psg_diag_build() and diag_ok:
+        ENV_SWITCHES.append("DIAGNOSTIC BUILD (-DPSG_DIAG_BUILD): value withheld")
+        return
+    if lib.psg_diag_build():
+        raise SystemExit("bench.py: libpsg.so was built with -DPSG_DIAG_BUILD (kernels can skip work): not a benchmark library; "
+                         "rebuild with `make -C pointsecguard_amd/csrc clean all`")
+    bad = [s for s in sw if s[2] == "r" or (s[2] == "p" and not allow_paths)]
+    if bad:
+        raise SystemExit("bench.py: refusing to run with non-default library switches %s (use --allow-env-switches for an "
+                         "A/B run of a tested alternative path; result-changing switches are never accepted)" % bad)
+
+
 def base_line(metric, unit, value, R, args, elapsed, workload, extra_config=None):
-    cfg = {"workload": workload, "sharding": "independent rooms / clouds sharded by rank, no data-path collective"}
+    cfg = {"workload": workload, "sharding": "independent rooms / clouds sharded by rank, no data-path collective",
+           "env_switches": list(ENV_SWITCHES)}
     if extra_config:
         cfg.update(extra_config)
     # n_ranks_seen: a sum of ones over the process group (RCCL on GPUs): evidence in the line itself that N ranks took part
@@ -253,12 +282,19 @@ def main():
                          "independent (every index stays inside its cloud), one launch of each kernel serves all of them")
     ap.add_argument("--concurrency", type=int, default=3,
                     help="device batches in flight per GPU (one HIP stream + workspace each)")
+    ap.add_argument("--allow-env-switches", action="store_true",
+                    help="accept PSG_* switches that select another TESTED code path (A/B runs); they are listed in "
+                         "config.env_switches either way, result-changing ones are always refused")
+    ap.add_argument("--diag-build-ok", action="store_true",
+                    help="tools/diag_*.sh only: run on a -DPSG_DIAG_BUILD library for its per-kernel times; the line then "
+                         "carries value = null and invalid = 'diagnostic build'")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
     if os.environ.get("PSG_BENCH_REHEARSE") == "1":
         return main_rehearse(args)
+    check_env_switches(args.allow_env_switches, args.diag_build_ok)
     R = Ranks(args)
     runners = {"pointnet2": run_pointnet2, "resgcn": run_resgcn, "tarnu": run_tarnu, "pointnet2_msg": run_msg,
                "randla": run_randla}
@@ -279,6 +315,8 @@ def main():
                 import traceback
                 sec[name] = {"error": "%s: %s" % (type(exc).__name__, exc), "traceback": traceback.format_exc()[-1500:]}
         result["secondary"] = sec
+    if args.diag_build_ok and any(e.startswith("DIAGNOSTIC BUILD") for e in ENV_SWITCHES):
+        result["value"], result["invalid"] = None, "diagnostic build: kernels may have skipped work"
     if R.rank == 0:
         print(json.dumps(result), flush=True)
     R.done()

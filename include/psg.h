@@ -37,6 +37,14 @@ typedef void *psg_stream; /* hipStream_t */
 
 const char *psg_last_error(void);
 const char *psg_version(void);
+/* Environment switches (all optional; they select between tested code paths or turn on diagnosis output).  Writes
+ * "NAME=value:kind;..." for every switch libpsg knows that is SET in this process's environment ("" when none) and
+ * returns their number (< 0: error).  kind: 'p' = another tested path with the same results (to rounding where a sum
+ * changes order), 'd' = diagnosis output only, 'r' = changes results - timing bisection switches that exist only in
+ * libraries built with -DPSG_DIAG_BUILD (psg_diag_build() == 1; the default library has none, and bench.py refuses to
+ * run on such a library).  The reference has no counterpart: it is a measurement-hygiene entry point. */
+int psg_env_switches(char *buf, int cap);
+int psg_diag_build(void);
 
 /* One context per (process, device). */
 int psg_ctx_create(int device, psg_ctx **out);

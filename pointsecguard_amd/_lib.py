@@ -21,6 +21,8 @@ cf = ctypes.c_float
 SIGNATURES = {
     "psg_last_error": (ctypes.c_char_p, []),
     "psg_version": (ctypes.c_char_p, []),
+    "psg_env_switches": (ci, [ctypes.c_char_p, ci]),
+    "psg_diag_build": (ci, []),
     "psg_ctx_create": (ci, [ci, ctypes.POINTER(vp)]),
     "psg_ctx_destroy": (ci, [vp]),
     "psg_square_distance": (ci, [vp, vp, vp, ci, ci, ci, vp, vp]),
@@ -146,6 +148,21 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def env_switches():
+    """[(name, value, kind)] of the libpsg environment switches set in this process (include/psg.h: psg_env_switches)."""
+    buf = ctypes.create_string_buffer(4096)
+    n = load().psg_env_switches(buf, len(buf))
+    if n < 0:
+        check(n, "psg_env_switches")
+    out = []
+    for item in buf.value.decode().split(";"):
+        if item:
+            nv, kind = item.rsplit(":", 1)
+            name, value = nv.split("=", 1)
+            out.append((name, value, kind))
+    return out
 
 
 def check(rc, what=""):

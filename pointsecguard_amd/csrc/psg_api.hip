@@ -10,9 +10,37 @@ thread_local char g_err[512] = "";
 }
 
 namespace psg {
+// The switches libpsg knows, with what they are allowed to change: 'p' = selects another TESTED path (same results, to
+// rounding where the path sums in another order), 'd' = diagnosis output only, 'r' = changes results (timing bisection:
+// present in -DPSG_DIAG_BUILD libraries only, so the default library lists none).
+struct EnvSwitch { const char *name; char kind; };
+static const EnvSwitch kEnvSwitches[] = {
+    {"PSG_TRACE_SYNC", 'd'},       {"PSG_GCN_KNN_STATS", 'd'},   {"PSG_KNN_XCD_ORDER", 'p'},  {"PSG_KNN_FIRST_CUT_KK", 'p'},
+    {"PSG_FP1_WAVE", 'p'},         {"PSG_RLA_NO_FUSE16", 'p'},   {"PSG_RLA_ATOMICS", 'p'},    {"PSG_RLA_NO_SPLIT", 'p'},
+    {"PSG_RLA_NO_GRAPH", 'p'},     {"PSG_GEMM_SMALL_BELOW", 'p'}, {"PSG_GCN_KNN", 'p'},        {"PSG_GCN_KNN_BF_MAXD", 'p'},
+    {"PSG_GCN_PQ_FUSION", 'p'},    {"PSG_GCN_NO_GRAPH", 'p'},    {"PSG_GCN_EDGE_BWD", 'p'},   {"PSG_RLA_NO_TAIL", 'p'},
+#ifdef PSG_DIAG_BUILD
+    {"PSG_DIAG", 'r'},
+#endif
+};
+
+const char *env_str(const char *name)
+{
+    bool known = false;
+    for (const EnvSwitch &e : kEnvSwitches) known = known || strcmp(e.name, name) == 0;
+    if (!known) fprintf(stderr, "[psg] environment switch %s is read but not registered in psg_api.hip\n", name);
+    return getenv(name);
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = env_str(name);
+    return v ? atoi(v) : dflt;
+}
+
 bool trace_sync_enabled()
 {
-    static const bool on = getenv("PSG_TRACE_SYNC") && atoi(getenv("PSG_TRACE_SYNC"));
+    static const bool on = env_int("PSG_TRACE_SYNC", 0) != 0;
     return on;
 }
 
@@ -37,6 +65,33 @@ void set_error(const char *fmt, ...)
 }  // namespace psg
 
 extern "C" const char *psg_last_error(void) { return g_err; }
+
+// "NAME=value:kind;..." for every registered switch that is set in this process's environment ("" = all defaults).
+extern "C" int psg_env_switches(char *buf, int cap)
+{
+    PSG_REQUIRE(buf && cap > 0, "psg_env_switches: null / empty buffer");
+    std::string out;
+    int n = 0;
+    for (const psg::EnvSwitch &e : psg::kEnvSwitches) {
+        const char *v = getenv(e.name);
+        if (!v) continue;
+        out += std::string(e.name) + "=" + v + ":" + e.kind + ";";
+        ++n;
+    }
+    PSG_REQUIRE((int)out.size() < cap, "psg_env_switches: buffer of %d bytes is too small (%d needed)", cap, (int)out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return n;
+}
+
+// 1 when this library was built with -DPSG_DIAG_BUILD (work-skipping timing switches compiled in), else 0.
+extern "C" int psg_diag_build(void)
+{
+#ifdef PSG_DIAG_BUILD
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" const char *psg_version(void) { return "libpsg 0.1 (gfx950, fp32 MFMA)"; }
 

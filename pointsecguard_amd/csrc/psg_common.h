@@ -29,6 +29,13 @@ void set_error(const char *fmt, ...);
         }                                                                                        \
     } while (0)
 
+// Every environment switch the library reads goes through these two (psg_api.hip): they return the variable's value and
+// record its NAME, so that psg_env_switches() can tell a caller (bench.py prints them and refuses the result-changing
+// ones) which non-default switches this process runs under.  Switches select between tested paths or turn on diagnosis;
+// the only ones that change RESULTS exist in -DPSG_DIAG_BUILD libraries.
+const char *env_str(const char *name);
+int env_int(const char *name, int dflt);
+
 // Diagnosis only (PSG_TRACE_SYNC=1, eager launches outside any stream capture): after every checked launch the device is
 // synchronised and the launch site is written to stderr, so that a run that stops shows the last launch that completed
 // and the one that did not (tools/profile_round.sh gmfma_trace; DESIGN.md section 4, "the counter-pass hang").

@@ -73,7 +73,7 @@ hipError_t knn_launch(const KnnBuffers &buf, int B, int N, int k, int d, int32_t
     const int slack = KF_CAP - f.KK;
     f.TOL = slack / 16;
     f.LOW = f.KK + slack / 4;
-    static const int xcd_order = getenv("PSG_KNN_XCD_ORDER") ? atoi(getenv("PSG_KNN_XCD_ORDER")) : 1;
+    static const int xcd_order = psg::env_int("PSG_KNN_XCD_ORDER", 1);
     f.xcd_order = xcd_order;
     if (path == KNN_PATH_F32) {
         hipLaunchKernelGGL(knn_fused_kernel, dim3((unsigned)((size_t)B * N / KF_Q)), dim3(KF_WAVES * 64), knn_fused_lds_bytes(), st, f);
@@ -86,7 +86,7 @@ hipError_t knn_launch(const KnnBuffers &buf, int B, int N, int k, int d, int32_t
     a.LOW = a.LOW > 480 && a.KK < 400 ? 480 : a.LOW;      // (a first cut at 512 candidates finds rows of 512)
     // cut schedule (candidates seen): first when a row holds first_cut entries (everything is admitted until then), then
     // whenever the ~kept entries of the last cut, admitted at the rate kept / n, would fill 0.85 CAP
-    static const int first_small = getenv("PSG_KNN_FIRST_CUT_KK") ? atoi(getenv("PSG_KNN_FIRST_CUT_KK")) : 100;
+    static const int first_small = psg::env_int("PSG_KNN_FIRST_CUT_KK", 100);
     a.first_cut = a.KK <= first_small ? 512 : 1024;
     a.grow = 0.85f * (float)KB_CAP / (float)(a.KK + a.KK / 8 + 32);
     a.exact = f;

@@ -87,7 +87,7 @@ __device__ __forceinline__ f32x16 mfma4(const float4 a, const float4 b, f32x16 a
 // The last four chunks run in a peeled pass without re-loads, so nothing is fetched past the tile.  Fixed VGPRs v[64:87] are used for the operand ring and
 // declared as clobbers (keeps the kernels at <= 128 VGPRs = 4 waves per SIMD).
 // FLIP swaps the MFMA operands: D[point][channel] instead of D[channel][point].
-#ifdef PSG_DIAG_NOLOAD  // timing experiment only: the k-loop re-uses the first four weight chunks
+#if defined(PSG_DIAG_BUILD) && defined(PSG_DIAG_NOLOAD)  // timing experiment only: the k-loop re-uses the first four weight chunks
 #define PSG_RELOAD(x) ""
 #else
 #define PSG_RELOAD(x) x

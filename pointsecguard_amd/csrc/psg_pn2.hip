@@ -30,6 +30,18 @@ constexpr int MAXL = PSG_PN2_MSG_NUM_LAYERS;   // the larger of the two layer co
 constexpr int NCLS = PSG_PN2_NUM_CLASSES;
 const int kS[4] = {1024, 256, 64, 16};
 
+// Section-skipping timing switches of the module kernels: compiled in by `make EXTRA=-DPSG_DIAG_BUILD` only
+// (tools/diag_*.sh); the default library has no way to skip work (psg_pn2_kernels.cuh: PSG_DIAGBIT == 0).
+static inline int diag_build_bits()
+{
+#ifdef PSG_DIAG_BUILD
+    static const int bits = psg::env_int("PSG_DIAG", 0);
+    return bits;
+#else
+    return 0;
+#endif
+}
+
 // One ball-query scale of an SA level: its three conv layers, the column of its pooled output inside the level's
 // rows, and the kernel configuration (points / waves per workgroup, tiles a wave may hold across a layer's barrier).
 struct ScaleDesc {
@@ -178,7 +190,7 @@ struct psg_pn2_ws {
     float *dx0;           // [B][N][9]
     // attack state
     float *x0, *ori;      // [B][N][9], [B][N][3]
-    unsigned long long *dbg;  // diagnostics scratch (PSG_DIAG=256), 4 words per workgroup
+    unsigned long long *dbg;  // diagnostics scratch (diagnostic builds, bit 256), 4 words per workgroup
     int fwd_slot = -1;
     // optional per-launch HIP-event timing (psg_pn2_prof_enable); off in normal operation
     bool prof_on = false;
@@ -344,8 +356,7 @@ int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, const
     const PackedLayer *L = &m->L[d.l0];
     const size_t prob = (size_t)fwd * B;
     SaFwdArgs a;
-    static const int sa_diag = getenv("PSG_DIAG") ? atoi(getenv("PSG_DIAG")) : 0;
-    a.diag = sa_diag;
+    a.diag = diag_build_bits();
     a.xyz = lvl == 0 ? x0 : ws->xyz[lvl] + prob * Np * 3;
     a.xyz_stride = lvl == 0 ? 9 : 3;
     a.feat = lvl == 0 ? x0 : ws->act[lvl - 1];
@@ -394,8 +405,7 @@ int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, int c
     const PackedLayer *L = &m->L[d.l0];
     const size_t prob = (size_t)fwd * B;
     SaBwdArgs a;
-    static const int sa_diag = getenv("PSG_DIAG") ? atoi(getenv("PSG_DIAG")) : 0;
-    a.diag = sa_diag;
+    a.diag = diag_build_bits();
     a.ld = A.C[lvl + 1];
     a.c_off = d.c_off;
     a.dout = ws->dact[lvl];   // skip-link gradient rows written by fp_bwd level lvl + 1
@@ -478,7 +488,7 @@ template <> struct FpCfg<0> { static constexpr int P = 32, NW = 4; };
 // cooperative kernels stay the default (DESIGN.md section 4 has the analysis).
 inline bool fp1_wave()
 {
-    static const bool v = getenv("PSG_FP1_WAVE") && atoi(getenv("PSG_FP1_WAVE")) != 0;
+    static const bool v = psg::env_int("PSG_FP1_WAVE", 0) != 0;
     return v;
 }
 
@@ -532,7 +542,7 @@ int run_fp_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *logp, hipStream
         a.Cout = m->L[first + nl - 1].cout;
     }
     a.n_layers = nl;
-    static const int diag = getenv("PSG_DIAG") ? atoi(getenv("PSG_DIAG")) : 0;
+    const int diag = diag_build_bits();
     a.diag = diag;
     if ((diag & 512) && ((diag >> 16) & 7) != LVL + 1) a.diag &= ~512;   // phase stamps for one module only
     a.dbg = ws->dbg;

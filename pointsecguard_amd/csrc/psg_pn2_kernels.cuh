@@ -12,6 +12,15 @@
 #pragma once
 #include "psg_mlp.cuh"
 
+// Timing-diagnosis switches (tools/diag_*.sh: skip a kernel section to see what it costs; the results are then wrong).
+// They exist ONLY in a diagnostic build (make EXTRA=-DPSG_DIAG_BUILD): in the default library every test below is the
+// constant 0, the compiler removes the branches, and no environment variable can make a kernel skip its work.
+#ifdef PSG_DIAG_BUILD
+#define PSG_DIAGBIT(a, bit) ((a).diag & (bit))
+#else
+#define PSG_DIAGBIT(a, bit) 0
+#endif
+
 namespace psg {
 
 struct SaFwdArgs {
@@ -27,7 +36,7 @@ struct SaFwdArgs {
     int k8_3, nb3;
     int xyz_stride, D, Np, S, C3;
     int ld_out, c_out;
-    int diag;              // timing diagnostics only (PSG_DIAG env): skip sections, results are then wrong
+    int diag;              // timing diagnostics only (-DPSG_DIAG_BUILD libraries only): skip sections, results are then wrong
 };
 
 struct SaBwdArgs {
@@ -56,7 +65,7 @@ struct SaBwdArgs {
     int D, Np, S, C3;
     int c_lo, c_hi;       // feature channels [c_lo, c_hi) of the grouped-input gradient are scattered
     int dsrc_blk;         // LDS block where the gathered pooled-output gradient is staged
-    int diag;             // timing diagnostics only (PSG_DIAG env)
+    int diag;             // timing diagnostics only (-DPSG_DIAG_BUILD libraries only)
 };
 
 struct FpFwdArgs {
@@ -69,7 +78,7 @@ struct FpFwdArgs {
     FwdLayer layer[MAX_LAYERS];
     int n_layers;
     int C1, C2, N, S, Cout, n_cls;
-    int diag;               // timing diagnostics only (PSG_DIAG env): skip sections, results are then wrong
+    int diag;               // timing diagnostics only (-DPSG_DIAG_BUILD libraries only): skip sections, results are then wrong
     unsigned long long *dbg; // diag & 256: per-workgroup {memtime, memrealtime} at entry and exit
 };
 
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
     const int s0 = bx * G;
     const size_t wg = (size_t)b * gridDim.x + bx;
 
-    if (!(a.diag & 1)) {   // gather the P grouped points
+    if (!PSG_DIAGBIT(a, 1)) {   // gather the P grouped points
         const int j = tid % P, part = tid / P;
         const int s = s0 + j / KS;
         const int src = a.gidx[((size_t)b * a.S + s) * KS + (j & (KS - 1))];
@@ -154,11 +163,11 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
         const int task = wave + i * NW;
         bias3[i] = task < a.nb3 * PB ? a.b3[(task / PB) * 32 + jj] : 0.0f;
     }
-    if (!(a.diag & 8)) layer_fwd<P, NW, MAXT>(a.l1, buf0, wg);
-    if (!(a.diag & 16)) __syncthreads();
-    if (!(a.diag & 8)) layer_fwd<P, NW, MAXT>(a.l2, buf0, wg);
-    if (!(a.diag & 16)) __syncthreads();
-    if (a.diag & 32) return;
+    if (!PSG_DIAGBIT(a, 8)) layer_fwd<P, NW, MAXT>(a.l1, buf0, wg);
+    if (!PSG_DIAGBIT(a, 16)) __syncthreads();
+    if (!PSG_DIAGBIT(a, 8)) layer_fwd<P, NW, MAXT>(a.l2, buf0, wg);
+    if (!PSG_DIAGBIT(a, 16)) __syncthreads();
+    if (PSG_DIAGBIT(a, 32)) return;
 
     // last layer with the tile flipped (D[point][channel]) so the max over the 32 samples of a
     // group is an in-lane max over 16 accumulators + one exchange between lane halves.
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     for (int i = 0; i < NTASK; ++i) {
         const int t = tid + i * NT;
         am_pre[i] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (t < P * nblk && !(a.diag & 1)) {
+        if (t < P * nblk && !PSG_DIAGBIT(a, 1)) {
             const int pnt = t % P, blk = t / P;
             am_pre[i] = *(const uint2 *)(a.arg + ((size_t)b * a.S + s0 + pnt / KS) * a.C3 + blk * 8);
         }
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
 #pragma unroll
     for (int i = 0; i < NTASK; ++i) {
         const int t = tid + i * NT;
-        if (t >= P * nblk || (a.diag & 1)) break;
+        if (t >= P * nblk || PSG_DIAGBIT(a, 1)) break;
         const int pnt = t % P, blk = t / P;
         const int g = pnt / KS, k = pnt & (KS - 1);
         const uint2 am = am_pre[i];
@@ -321,13 +330,13 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
         *(float4 *)(dst + 4) = v1;
     }
     __syncthreads();
-    if (!(a.diag & 8)) layer_bwd<P, NW, MAXT>(a.l3t, buf0, wg);
-    if (!(a.diag & 16)) __syncthreads();
-    if (!(a.diag & 8)) layer_bwd<P, NW, MAXT>(a.l2t, buf0, wg);
-    if (!(a.diag & 16)) __syncthreads();
-    if (!(a.diag & 8)) layer_bwd<P, NW, MAXT>(a.l1t, buf0, wg);
+    if (!PSG_DIAGBIT(a, 8)) layer_bwd<P, NW, MAXT>(a.l3t, buf0, wg);
+    if (!PSG_DIAGBIT(a, 16)) __syncthreads();
+    if (!PSG_DIAGBIT(a, 8)) layer_bwd<P, NW, MAXT>(a.l2t, buf0, wg);
+    if (!PSG_DIAGBIT(a, 16)) __syncthreads();
+    if (!PSG_DIAGBIT(a, 8)) layer_bwd<P, NW, MAXT>(a.l1t, buf0, wg);
     __syncthreads();
-    if (a.diag & 32) return;
+    if (PSG_DIAGBIT(a, 32)) return;
     // index_points backward (pointnet_util.py:119,131): the feature rows [c_lo, c_hi) of the grouped-input gradient
     // are stored as plain rows; the consumer (previous level's sa_bwd, or dx0_gather_kernel) sums them through the
     // inverse group lists.  (LDS channel order is [feats, rel_xyz]: LDS channel c is feature channel c.)
@@ -375,8 +384,8 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
     xcd_tile(bx, b);
     const int n0 = bx * P;
     const size_t wg = (size_t)b * gridDim.x + bx;
-    if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 15] = __builtin_amdgcn_s_memtime();
-    if ((a.diag & 256) && tid == 0) {
+    if (PSG_DIAGBIT(a, 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 15] = __builtin_amdgcn_s_memtime();
+    if (PSG_DIAGBIT(a, 256) && tid == 0) {
         a.dbg[wg * 4 + 0] = __builtin_amdgcn_s_memtime();
         a.dbg[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     }
@@ -441,7 +450,7 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
             store_tile<P>(buf0, first, jj, h, c);
         }
         __syncthreads();
-    } else if (!(a.diag & 1)) {
+    } else if (!PSG_DIAGBIT(a, 1)) {
         // 32 consecutive lanes read consecutive float4 of ONE source row (512 contiguous bytes per row group), so a
         // wave-wide load touches 8 cache lines instead of 64; neighbour indices / weights are broadcast loads.
         constexpr int RG = NT / 32, JI = P / RG;
@@ -490,12 +499,12 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
     }
     __syncthreads();
     float *in = buf0;
-    if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 0] = __builtin_amdgcn_s_memtime();
+    if (PSG_DIAGBIT(a, 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 0] = __builtin_amdgcn_s_memtime();
     for (int l = BIG ? 1 : 0; l < a.n_layers; ++l) {
-        if (!(a.diag & 8)) layer_fwd<P, NW, 1>(a.layer[l], in, wg);
-        if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 1 + 2 * l] = __builtin_amdgcn_s_memtime();
-        if (!(a.diag & 16)) __syncthreads();
-        if ((a.diag & 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 2 + 2 * l] = __builtin_amdgcn_s_memtime();
+        if (!PSG_DIAGBIT(a, 8)) layer_fwd<P, NW, 1>(a.layer[l], in, wg);
+        if (PSG_DIAGBIT(a, 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 1 + 2 * l] = __builtin_amdgcn_s_memtime();
+        if (!PSG_DIAGBIT(a, 16)) __syncthreads();
+        if (PSG_DIAGBIT(a, 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 2 + 2 * l] = __builtin_amdgcn_s_memtime();
     }
     // `in` now holds the last layer's output
     if (a.out) {
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
             }
         }
     }
-    if (a.logp && !(a.diag & 4)) {
+    if (a.logp && !PSG_DIAGBIT(a, 4)) {
         // log_softmax over the n_cls (<= 16) head rows: 8 lanes per point, classes q and q + 8 per lane
         for (int t = tid; t < P * 8; t += NT) {
             const int j = t >> 3, q = t & 7;
@@ -536,7 +545,7 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
             if (has1) o[q + 8] = (z1 - m) - lse;
         }
     }
-    if ((a.diag & 256) && tid == 0) {
+    if (PSG_DIAGBIT(a, 256) && tid == 0) {
         a.dbg[wg * 4 + 2] = __builtin_amdgcn_s_memtime();
         a.dbg[wg * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }

@@ -1015,9 +1015,9 @@ extern "C" int psg_rla_ws_create_batch(psg_ctx *ctx, int n_points, int batch, ps
     PSG_CHECK_HIP(hipSetDevice(ctx->device));
     auto *ws = new psg_rla_ws();
     ws->ctx = ctx; ws->B = batch; ws->Nc = n_points; ws->N = batch * n_points;
-    { const char *nf = getenv("PSG_RLA_NO_FUSE16"); ws->fuse16 = !(nf && atoi(nf)); }
-    { const char *at = getenv("PSG_RLA_ATOMICS"); ws->use_inv = !(at && atoi(at)); }
-    { const char *ns = getenv("PSG_RLA_NO_SPLIT"); ws->split = !(ns && atoi(ns)) && ws->use_inv; }
+    { const char *nf = psg::env_str("PSG_RLA_NO_FUSE16"); ws->fuse16 = !(nf && atoi(nf)); }
+    { const char *at = psg::env_str("PSG_RLA_ATOMICS"); ws->use_inv = !(at && atoi(at)); }
+    { const char *ns = psg::env_str("PSG_RLA_NO_SPLIT"); ws->split = !(ns && atoi(ns)) && ws->use_inv; }
     for (int pass = 0; pass < 2; ++pass) {
         size_t off = 0;
         auto take = [&](size_t bytes) {
@@ -1671,7 +1671,7 @@ extern "C" int psg_rla_bim_attack(psg_rla_model *m, psg_rla_ws *ws, const float 
     // queue).  Capture is impossible on the legacy default stream; the loop then stays eager.
     if ((rc = iteration())) return rc;
     int it = 1;
-    static const bool use_graph = !(getenv("PSG_RLA_NO_GRAPH") && atoi(getenv("PSG_RLA_NO_GRAPH"))) && !trace_sync_enabled();   // (the tracer synchronises after every launch)
+    static const bool use_graph = !((psg::env_int("PSG_RLA_NO_GRAPH", 0) != 0)) && !trace_sync_enabled();   // (the tracer synchronises after every launch)
     if (use_graph && !ws->prof.on && iters - it >= 2) {
         if (ws->bim_exec && (ws->bim_model != (const void *)m || ws->bim_eps != eps || ws->bim_alpha != alpha || ws->bim_metric != l2_metric)) {
             PSG_CHECK_HIP(hipStreamSynchronize(st));

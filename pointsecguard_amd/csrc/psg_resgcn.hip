@@ -40,7 +40,7 @@ int launch_gemm(const GemmArgs &a, hipStream_t st)
 {
     constexpr int BR = 64 * WM, BN = 64 * WN;
     dim3 grid(ceil_div(a.rows, BR), ceil_div(a.M, BN));
-    static const size_t small_below = getenv("PSG_GEMM_SMALL_BELOW") ? (size_t)atoi(getenv("PSG_GEMM_SMALL_BELOW")) : 384;
+    static const size_t small_below = (size_t)psg::env_int("PSG_GEMM_SMALL_BELOW", 384);
     if (!ASC && (size_t)grid.x * grid.y < small_below) {
         // too few 128-wide tiles to fill 256 CUs with more than one workgroup each (the per-vertex GEMMs of up to ~8 rooms:
         // K = 64, so a tile is two short k-steps and the launch is latency-bound): 64 x 64 tiles, one MFMA tile per wave,
@@ -872,14 +872,14 @@ extern "C" int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n
     ws->ctx = ctx; ws->B = batch; ws->N = n_point; ws->n_blocks = n_blocks; ws->fdim = GC * n_blocks;
     ws->block = block; ws->conv = conv;
     {
-        const char *kv = getenv("PSG_GCN_KNN");
+        const char *kv = psg::env_str("PSG_GCN_KNN");
         const std::string mode = kv ? kv : "";
         // default: the bf16-prefilter kernel for dilations 1..3, where it is the faster one on the network's own features
         // (131-150 us against 161-165 us per 4-room call), the exact fused kernel for the rest; both
         // give the same graph bit for bit.  PSG_GCN_KNN=f32 / =bf16 force one kernel for every dilation, =matrix the round-1 path
         ws->knn_mode = mode == "matrix" ? 0 : (mode == "f32" ? 1 : 2);
         ws->knn_bf_max_d = mode == "bf16" ? 1 << 30 : 3;
-        if (const char *md = getenv("PSG_GCN_KNN_BF_MAXD")) ws->knn_bf_max_d = atoi(md);
+        if (const char *md = psg::env_str("PSG_GCN_KNN_BF_MAXD")) ws->knn_bf_max_d = atoi(md);
         // the fused kNN kernels need 129 KB of dynamic LDS (raised once, outside any stream capture); a device that does
         // not grant it keeps the round-1 path (distance matrix in HBM + selection kernel)
         if (ws->knn_mode && knn_setup() != hipSuccess) { (void)hipGetLastError(); ws->knn_mode = 0; }
@@ -906,7 +906,7 @@ extern "C" int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n
         ws->sq = (float *)take(R * 4);
         ws->xp = (float *)take(knn_xp_bytes(R));
         ws->bp = take(knn_bp_bytes(R));
-        ws->knn_stats = getenv("PSG_GCN_KNN_STATS") ? (unsigned long long *)take(8 * sizeof(unsigned long long)) : nullptr;
+        ws->knn_stats = psg::env_str("PSG_GCN_KNN_STATS") ? (unsigned long long *)take(8 * sizeof(unsigned long long)) : nullptr;
         ws->pq = (float *)take(R * ws->pq_w * 4);
         ws->pq2 = (float *)take(R * 2 * GC * 4);
         ws->dpq = (float *)take(R * ws->pq_w * 4);
@@ -1148,7 +1148,7 @@ extern "C" int psg_gcn_forward(psg_gcn_model *m, psg_gcn_ws *ws, const float *x0
     // Measured on MI355X: 0.21 ms less kernel time per 4-room iteration (8.09 -> 7.89) and +2 % with one launch in flight
     // (10.18 -> 10.39 rooms/s), but -0.7 % at the bench's three launches in flight (12.05 -> 11.96): the small GEMM launches
     // it removes were running inside the idle slots of another launch's kNN kernel.  Off by default for that reason.
-    static const bool fuse_pq = getenv("PSG_GCN_PQ_FUSION") && atoi(getenv("PSG_GCN_PQ_FUSION"));
+    static const bool fuse_pq = (psg::env_int("PSG_GCN_PQ_FUSION", 0) != 0);
     bool pq_ready = false;     // this block's [P | Q] was written by the previous block's edge pass
     for (int e = 0; e < m->n_blocks; ++e) {
         const EdgeLayer &L = m->edge[e];
@@ -1400,7 +1400,7 @@ extern "C" int psg_gcn_nb_attack(psg_gcn_model *m, psg_gcn_ws *ws, const float *
     // the attack moves colours only: the head's kNN graph on xyz (architecture.py:59) is the same in every iteration
     struct Unfreeze { psg_gcn_ws *w; ~Unfreeze() { w->head_graph_frozen = false; } } unfreeze{ws};
     ws->head_graph_frozen = true;
-    static const bool use_graph = !(getenv("PSG_GCN_NO_GRAPH") && atoi(getenv("PSG_GCN_NO_GRAPH"))) && !trace_sync_enabled();   // (the tracer synchronises after every launch)
+    static const bool use_graph = !((psg::env_int("PSG_GCN_NO_GRAPH", 0) != 0)) && !trace_sync_enabled();   // (the tracer synchronises after every launch)
     if (use_graph && !ws->prof.on && iters - 1 - it >= 2) {
         if (ws->nb_exec && (ws->nb_model != (const void *)m || ws->nb_eps != eps || ws->nb_alpha != alpha ||
                             ws->nb_fixed != ws->fixed_graphs)) {

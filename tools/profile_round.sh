@@ -10,7 +10,7 @@ O=gpurun_out/prof_$TAG
 mkdir -p $O
 stats() {   # name, bench args...
     local name=$1; shift
-    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -o $name -- python3 bench.py "$@" > $O/$name.log 2>&1 || return 1
+    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -o $name -- python3 bench.py --allow-env-switches "$@" > $O/$name.log 2>&1 || return 1
     grep '^{' $O/$name.log > $O/${name}_bench.json
     cp $(find $O/$name -name '*kernel_stats.csv' | head -1) $O/${name}_kernel_stats.csv
     rm -rf $O/$name
@@ -25,7 +25,7 @@ fi
 pmc() {     # name, counters (quoted), bench args...
     local name=$1 ctr=$2; shift 2
     # (the attack loops stay eager in PMC passes: per-dispatch counter rows need per-dispatch launches)
-    PSG_GCN_NO_GRAPH=1 PSG_RLA_NO_GRAPH=1 timeout -k 10 150 rocprofv3 --pmc $ctr --output-format csv -d $O/$name -o p -- python3 bench.py "$@" > $O/$name.log 2>&1 || return 1
+    PSG_GCN_NO_GRAPH=1 PSG_RLA_NO_GRAPH=1 timeout -k 10 150 rocprofv3 --pmc $ctr --output-format csv -d $O/$name -o p -- python3 bench.py --allow-env-switches "$@" > $O/$name.log 2>&1 || return 1
 }
 PN2="--steps 8 --warmup 8 --coalesce 8 --concurrency 1 --no-cpu-baseline --no-reference --no-secondary"
 # (a counter pass serialises every dispatch: one 4-room launch of the ResGCN attack = 15k dispatches is plenty)

@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 O=gpurun_out/r03
 mkdir -p $O
-PSG_RLA_NO_GRAPH=1 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/rg -o rg -- python3 bench.py --workload randla --steps 8 --warmup 0 --concurrency 1 --randla-iters 6 --no-cpu-baseline --no-reference > $O/rla_gemm.log 2>&1 || exit 1
+PSG_RLA_NO_GRAPH=1 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/rg -o rg -- python3 bench.py --allow-env-switches --workload randla --steps 8 --warmup 0 --concurrency 1 --randla-iters 6 --no-cpu-baseline --no-reference > $O/rla_gemm.log 2>&1 || exit 1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$O/rg/*kernel_trace.csv")[0]
