@@ -222,7 +222,8 @@ int psg_mrconv_gather_fwd(const float *x, int ld_x, int R, int N, int C, const i
                           psg_stream stream);
 int psg_mrconv_gather_bwd(const float *dcat, int R, int N, int C, const int32_t *nbr, const uint8_t *arg, float *dx, int ld_dx,
                           psg_stream stream);
-/* its input gradient: dx [R][ld_dx] (C columns); wcat_t [C][128]; dpq scratch [R][128]. */
+/* its input gradient: dx [R][ld_dx] (C columns); wcat_t [C][128]; dpq: scratch [R][128], holds [dP | dQ] when the
+ * call returns (every element is written by the call: nothing needs zeroing; the result is bit-reproducible). */
 int psg_edgeconv_bwd(const float *dy, int ld_dy, int R, int N, int C, const int32_t *nbr, const uint8_t *arg,
                      const float *scale, const float *wcat_t, float *dpq, float *dx, int ld_dx, psg_stream stream);
 

@@ -141,6 +141,10 @@ def load():
             raise PsgError(
                 "%s not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C pointsecguard_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+        # torch first: PyTorch-ROCm ships its own libamdhip64, and libpsg.so must bind to THAT copy (the process then
+        # has one HIP runtime, the one that owns torch's allocator and streams).  Loading libpsg.so before torch pulled in
+        # /opt/rocm's copy as a second runtime, and device discovery failed ("no ROCm-capable device is detected").
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

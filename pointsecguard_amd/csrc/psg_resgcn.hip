@@ -396,6 +396,278 @@ __global__ void edge_max_bwd_kernel(const float *__restrict__ dy, int ld_dy, con
     }
 }
 
+// ---- The same pass WITHOUT atomics (round 4; default): the transpose of the neighbour gather as a gather through the
+// inverse graph, built on the fly, in ONE launch.  A workgroup owns 64 destination vertices j of one room.
+// (1) Its 16 waves scan the room's N x 16 edge table once (256 KB from L2, all 16 loads of a thread in flight together) and
+//     mark every edge v -> j that lands in the range in an LDS bitmap [64][N bits] (LDS atomicOr: the result does not
+//     depend on the order).
+// (2) Popcounts + DPP wave scans turn the bitmap rows into ONE flat list of source vertices, destination-major, ascending
+//     v per destination (the in-edges of the 64 destinations: ~1024 entries), staged in LDS.
+// (3) The flat list is cut into 64 EQUAL slices, one per quarter-wave (16 lanes x 4 channels) - in-degrees of a kNN graph
+//     are heavy-tailed (median 15, maximum 77 in the network's graphs), and a quarter that walks one whole list waits for
+//     the longest.  Per edge v -> j a lane loads v's neighbour entry `ql` (a ballot over the quarter gives j's slot in v's
+//     row), the four arg bytes and the four output gradients of its channels, and adds dY * s_c where the arg byte names
+//     that slot as the active winner: four edges per instruction, no per-edge records in memory.  A slice that crosses a
+//     destination boundary closes a PIECE (partial row in LDS) and goes on with the next destination.
+// (4) Quarter d adds the pieces of destination d in slice order and writes the dQ row; the dP row (the vertex's own term)
+//     is written by the same lanes.
+// What bounds this pass is instruction issue and dependent-instruction latency of the walking waves, not bandwidth
+// (tools/edge_bwd_probe.py with the stamp build: a ds_bpermute scan instead of the DPP one alone cost 12k cycles per wave;
+// one edge per wave-instruction with scalar addressing 250 cycles per edge) - hence few, wide, independent instructions per
+// edge (raw buffer loads: one 32-bit offset per row instead of 64-bit address arithmetic) and equal work per wave.
+// One writer per row and a summation order that depends on the graph only (ascending v inside a piece, pieces in order):
+// no memset, no float atomics, and the ResGCN input gradient is bit-reproducible run to run.  Lists of any length are
+// served: more than EBG_CAP in-edges per workgroup run as several passes over the flat list.
+#ifndef EBG_UNROLL_N
+#define EBG_UNROLL_N 4
+#endif
+constexpr int EBG_D = 64, EBG_T = 1024, EBG_WORDS = 128, EBG_CAP = 8192, EBG_UNROLL = EBG_UNROLL_N, EBG_Q = EBG_D / (EBG_T / 64);
+static_assert(EBG_Q == 4, "a wave owns four bitmap rows and has four quarters");
+
+// inclusive scan over the 64 lanes on the DPP network (row_shr 1 / 2 / 4 / 8, then row_bcast15 / row_bcast31), no LDS
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v)
+{
+    v += dpp_get<0x111, 0xF>(v);
+    v += dpp_get<0x112, 0xF>(v);
+    v += dpp_get<0x114, 0xF>(v);
+    v += dpp_get<0x118, 0xF>(v);
+    v += dpp_get<0x142, 0xA>(v);
+    v += dpp_get<0x143, 0xC>(v);
+    return v;
+}
+
+#ifdef EBG_STAMP   // diagnostic variant (tools/build_variant.sh): s_memtime at the phase boundaries of every wave
+__device__ unsigned long long ebg_stamps[256 * 16 * 8];
+#define EBG_MARK(k) do { if (lane == 0 && blockIdx.x < 256) ebg_stamps[(blockIdx.x * 16 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define EBG_MARK(k) do { } while (0)
+#endif
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ebg_rsrc(const void *p, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)bytes, 0x00020000);   // raw buffer: offsets past `bytes` read 0
+}
+
+__global__ __launch_bounds__(EBG_T) void edge_max_bwd_gather_kernel(const float *__restrict__ dy, int ld_dy,
+                                                                     const int32_t *__restrict__ nbr,
+                                                                     const uint8_t *__restrict__ arg,
+                                                                     const float *__restrict__ scale, float *__restrict__ dpq,
+                                                                     int N, int chunks)
+{
+    __shared__ unsigned s_bm[EBG_D * EBG_WORDS];
+    __shared__ unsigned short s_stage[EBG_CAP];                  // the flat list (one pass of it): source vertices
+    __shared__ float s_part[2 * EBG_D][GC];                      // piece (destination d, slice k) -> row d + k
+    __shared__ int s_cnt[EBG_D], s_offend[EBG_D + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);   // an XCD serves consecutive chunks: one room's tables per L2
+    const int room = b / chunks, j0 = (b % chunks) * EBG_D;
+    const size_t rb = (size_t)room * N;
+    const int quarter = lane >> 4, ql = lane & 15, qw = EBG_Q * wave + quarter;   // qw: this quarter-wave, 0..63
+    // one room's tables as raw buffers; this lane's piece of a row: neighbour entry ql / arg bytes and gradients 4 ql .. 4 ql + 3
+    const __amdgpu_buffer_rsrc_t r_nb = ebg_rsrc(nbr + rb * KNB, (size_t)N * KNB * 4);
+    const __amdgpu_buffer_rsrc_t r_arg = ebg_rsrc(arg + rb * GC, (size_t)N * GC);
+    const __amdgpu_buffer_rsrc_t r_dy = ebg_rsrc(dy + rb * ld_dy, (size_t)N * ld_dy * 4);
+    const unsigned ld_bytes = (unsigned)ld_dy * 4u;
+    const float4 sc = *(const float4 *)(scale + 4 * ql);
+    const int shift = 16 * quarter;
+    EBG_MARK(0);
+    for (int i = tid; i < EBG_D * EBG_WORDS / 4; i += EBG_T) ((uint4 *)s_bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    {
+        const int4 *nb4 = (const int4 *)(nbr + rb * KNB);
+        const int n4 = N * (KNB / 4);
+        for (int base = tid; base < n4; base += 16 * EBG_T) {
+            int4 q[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int i = base + u * EBG_T;
+                q[u] = nb4[i < n4 ? i : base];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int i = base + u * EBG_T;
+                if (i < n4) {
+                    const int v = i >> 2;
+                    const unsigned bit = 1u << (v & 31);
+                    // word of destination x = s_bm + (x - j0) * 128 + (v >> 5): one shift-add per entry on a per-load base
+                    unsigned *wbase = s_bm + (v >> 5) - j0 * EBG_WORDS;
+                    if ((unsigned)(q[u].x - j0) < (unsigned)EBG_D) atomicOr(wbase + q[u].x * EBG_WORDS, bit);
+                    if ((unsigned)(q[u].y - j0) < (unsigned)EBG_D) atomicOr(wbase + q[u].y * EBG_WORDS, bit);
+                    if ((unsigned)(q[u].z - j0) < (unsigned)EBG_D) atomicOr(wbase + q[u].z * EBG_WORDS, bit);
+                    if ((unsigned)(q[u].w - j0) < (unsigned)EBG_D) atomicOr(wbase + q[u].w * EBG_WORDS, bit);
+                }
+            }
+        }
+    }
+    EBG_MARK(1);
+    __syncthreads();
+    EBG_MARK(2);
+    // the vertex's own term (quarter-wave qw <-> vertex j0 + qw): dP[j][c] = dY[j][c] * s_c where the winning edge was active
+    const int jq = j0 + qw;
+    unsigned a_self = 0u;
+    float4 y_self = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (jq < N) {
+        a_self = __builtin_amdgcn_raw_buffer_load_b32(r_arg, (unsigned)jq * (unsigned)GC + 4u * ql, 0, 0);
+        y_self = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_dy, (unsigned)jq * ld_bytes + 16u * ql, 0, 0));
+    }
+    // list lengths of the wave's four bitmap rows (two DPP scans of two 16-bit counts each: a list has at most N <= 4096
+    // entries); per lane the rank of its first bit in each row
+    uint2 w2[EBG_Q];
+    unsigned first[EBG_Q];
+    {
+        unsigned cnt[EBG_Q];
+#pragma unroll
+        for (int q = 0; q < EBG_Q; ++q) {
+            w2[q] = *(const uint2 *)&s_bm[(EBG_Q * wave + q) * EBG_WORDS + 2 * lane];
+            cnt[q] = __popc(w2[q].x) + __popc(w2[q].y);
+        }
+        const unsigned inc01 = wave_incl_scan_u32(cnt[0] | cnt[1] << 16), inc23 = wave_incl_scan_u32(cnt[2] | cnt[3] << 16);
+#pragma unroll
+        for (int q = 0; q < EBG_Q; ++q) {
+            const unsigned inc = ((q < 2 ? inc01 : inc23) >> (16 * (q & 1))) & 0xFFFFu;
+            first[q] = inc - cnt[q];
+            if (lane == 63) s_cnt[EBG_Q * wave + q] = (int)inc;
+        }
+    }
+    __syncthreads();
+    // flat offsets: lane d holds the rank where destination d's list ends (every wave computes them for itself)
+    const int offend = (int)wave_incl_scan_u32((unsigned)s_cnt[lane]);
+    const int total = __builtin_amdgcn_readlane(offend, 63);
+    if (wave == 0) { s_offend[lane] = offend; if (lane == 0) s_offend[EBG_D] = 0x7FFFFFFF; }
+    int base_q[EBG_Q];                                           // flat rank where the wave's q-th row starts
+#pragma unroll
+    for (int q = 0; q < EBG_Q; ++q)
+        base_q[q] = EBG_Q * wave + q == 0 ? 0 : __builtin_amdgcn_readlane(offend, (EBG_Q * wave + q + 63) & 63);
+    EBG_MARK(3);
+    float accd[4] = {0.0f, 0.0f, 0.0f, 0.0f};                    // dQ[j0 + qw][4 ql ..], summed over pieces (and passes)
+    for (int c0 = 0; c0 < total; c0 += EBG_CAP) {
+        const int cend = total - c0 < EBG_CAP ? total : c0 + EBG_CAP;
+        const int S = (cend - c0 + EBG_D - 1) / EBG_D;           // slice length of this pass
+        // ---- stage the pass's part of the flat list
+#pragma unroll
+        for (int q = 0; q < EBG_Q; ++q) {
+            unsigned long long bits = ((unsigned long long)w2[q].y << 32) | w2[q].x;
+            int r = base_q[q] + (int)first[q] - c0;
+            while (bits) {
+                if ((unsigned)r < (unsigned)EBG_CAP) s_stage[r] = (unsigned short)(64 * lane + __ffsll(bits) - 1);
+                ++r;
+                bits &= bits - 1;
+            }
+        }
+        __syncthreads();
+        EBG_MARK(4);
+        // ---- walk this quarter-wave's slice [e, eend)
+        {
+            int e = c0 + qw * S;
+            const int eend = e + S < cend ? e + S : cend;
+            const bool any = e < eend;
+            // the destination that holds rank e: the number of lists that end at or before it
+            int d = 0;
+#pragma unroll
+            for (int q = 0; q < EBG_Q; ++q) {
+                const int x = c0 + (EBG_Q * wave + q) * S;
+                const int dq = __popcll(__ballot(offend <= x));
+                d = quarter == q ? dq : d;
+            }
+            d = d < EBG_D ? d : EBG_D - 1;
+            int rend = any ? s_offend[d] : 0x7FFFFFFF;
+            int j = j0 + d;
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int i0 = 0; i0 < S; i0 += EBG_UNROLL) {
+                float4 y[EBG_UNROLL];
+                unsigned a[EBG_UNROLL];
+                int nb[EBG_UNROLL];
+#pragma unroll
+                for (int u = 0; u < EBG_UNROLL; ++u) {
+                    const int ee = e + u;
+                    const int ec = ee < eend ? ee : (any ? eend - 1 : c0);   // past the end: a staged entry again, masked below
+                    const unsigned v = s_stage[ec - c0];
+                    const unsigned o = v * (unsigned)GC + 4u * ql;       // a neighbour row and an arg row are both 64 bytes
+                    nb[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(r_nb, o, 0, 0);
+                    a[u] = __builtin_amdgcn_raw_buffer_load_b32(r_arg, o, 0, 0);
+                    y[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_dy, v * ld_bytes + 16u * ql, 0, 0));
+                }
+#pragma unroll
+                for (int u = 0; u < EBG_UNROLL; ++u) {
+                    const int ee = e + u;
+                    if (ee < eend && ee >= rend) {                      // the slice crosses into the next destination(s): close the piece
+                        *(float4 *)&s_part[d + qw][4 * ql] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                        acc[0] = acc[1] = acc[2] = acc[3] = 0.0f;
+                        do { ++d; rend = s_offend[d]; } while (rend <= ee);
+                        j = j0 + d;
+                    }
+                    const int jm = ee < eend ? j : -2;                  // (a neighbour index is >= 0)
+                    const unsigned mq = (unsigned)(__ballot(nb[u] == jm) >> shift) & 0xFFFFu;
+                    const unsigned key = 0x80u | (mq ? (unsigned)__ffs(mq) - 1u : 0x7Fu);   // j's (first) slot in v's row; none: no byte matches
+                    acc[0] += (a[u] & 0xFFu) == key ? y[u].x * sc.x : 0.0f;
+                    acc[1] += ((a[u] >> 8) & 0xFFu) == key ? y[u].y * sc.y : 0.0f;
+                    acc[2] += ((a[u] >> 16) & 0xFFu) == key ? y[u].z * sc.z : 0.0f;
+                    acc[3] += (a[u] >> 24) == key ? y[u].w * sc.w : 0.0f;
+                }
+                e += EBG_UNROLL;
+            }
+            if (any) *(float4 *)&s_part[d + qw][4 * ql] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        EBG_MARK(5);
+        __syncthreads();
+        // ---- destination qw: its pieces of this pass, in slice order
+        {
+            const int my_lo = qw == 0 ? 0 : s_offend[qw - 1], my_hi = s_offend[qw];   // destination qw's flat range
+            const int lo = my_lo > c0 ? my_lo : c0, hi = my_hi < cend ? my_hi : cend;
+            if (lo < hi) {
+                const int k2 = (hi - 1 - c0) / S;
+                for (int k = (lo - c0) / S; k <= k2; ++k) {
+                    const float4 p = *(const float4 *)&s_part[qw + k][4 * ql];
+                    accd[0] += p.x; accd[1] += p.y; accd[2] += p.z; accd[3] += p.w;
+                }
+            }
+        }
+        if (cend < total) __syncthreads();                       // (another pass re-uses the stage and the piece rows)
+    }
+#ifdef EBG_STAMP
+    if (lane == 0 && blockIdx.x < 256) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        ebg_stamps[(blockIdx.x * 16 + wave) * 8 + 6] = ((unsigned long long)xcc << 32) | hw;
+        ebg_stamps[(blockIdx.x * 16 + wave) * 8 + 7] = (unsigned long long)total;
+    }
+#endif
+    if (jq < N) {
+        float *row = dpq + (rb + jq) * 2 * GC + 4 * ql;
+        *(float4 *)row = make_float4((a_self & 0x80u) ? y_self.x * sc.x : 0.0f, (a_self & 0x8000u) ? y_self.y * sc.y : 0.0f,
+                                     (a_self & 0x800000u) ? y_self.z * sc.z : 0.0f, (a_self & 0x80000000u) ? y_self.w * sc.w : 0.0f);
+        *(float4 *)(row + GC) = make_float4(accd[0], accd[1], accd[2], accd[3]);
+    }
+}
+
+#ifdef EBG_STAMP
+extern "C" int psg_debug_ebg_stamps(unsigned long long *host, int n_words)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ebg_stamps), (size_t)n_words * 8) == hipSuccess ? 0 : -2;
+}
+#endif
+
+// [dP | dQ] of one EdgeConv max pass: the gather kernel above (N <= 4096, any number of rooms, ld_dy a multiple of 4), or
+// the atomic scatter (larger rooms, or PSG_GCN_EDGE_BWD=atomic for A/B runs: it needs dpq's Q half zeroed, done here).
+int launch_edge_max_bwd(const float *dy, int ld_dy, const int32_t *nbr, const uint8_t *arg, const float *scale, float *dpq,
+                        int N, size_t R, hipStream_t st)
+{
+    static const bool atomic = []() { const char *v = psg::env_str("PSG_GCN_EDGE_BWD"); return v && std::string(v) == "atomic"; }();
+    if (!atomic && N <= 32 * EBG_WORDS && ld_dy % 4 == 0 && ((uintptr_t)dy & 15) == 0) {
+        const int chunks = ceil_div(N, EBG_D);
+        hipLaunchKernelGGL(edge_max_bwd_gather_kernel, dim3((unsigned)((R / N) * chunks)), dim3(EBG_T), 0, st, dy, ld_dy, nbr, arg,
+                           scale, dpq, N, chunks);
+    } else {
+        PSG_CHECK_HIP(hipMemsetAsync(dpq, 0, R * 2 * GC * 4, st));
+        hipLaunchKernelGGL(edge_max_bwd_kernel, dim3(ceil_div((int)(R * GC), 256)), dim3(256), 0, st, dy, ld_dy, nbr, arg, scale, dpq,
+                           N, R * GC, (float *)nullptr);
+    }
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
 __global__ void add_slice_kernel(float *__restrict__ g, const float *__restrict__ src, int ld_src, size_t rows)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1094,10 +1366,7 @@ extern "C" int psg_edgeconv_bwd(const float *dy, int ld_dy, int R, int N, int C,
     PSG_REQUIRE(dy && nbr && arg && scale && wcat_t && dpq && dx && R > 0 && N > 0 && C > 0 && R % N == 0,
                 "psg_edgeconv_bwd: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    PSG_CHECK_HIP(hipMemsetAsync(dpq, 0, (size_t)R * 2 * GC * 4, st));
-    hipLaunchKernelGGL(edge_max_bwd_kernel, dim3(ceil_div((int)((size_t)R * GC), 256)), dim3(256), 0, st, dy, ld_dy, nbr, arg, scale,
-                       dpq, N, (size_t)R * GC);
-    PSG_LAUNCH_CHECK();
+    { const int rc0 = launch_edge_max_bwd(dy, ld_dy, nbr, arg, scale, dpq, N, (size_t)R, st); if (rc0) return rc0; }
     GemmArgs a = gemm_args(dpq, 2 * GC, wcat_t, 2 * GC, dx, ld_dx, R, 2 * GC, C);
     return launch_gemm<4, 1, EPI_LINEAR, false>(a, st);
 }
@@ -1264,9 +1533,7 @@ static int backward_alt(psg_gcn_model *m, psg_gcn_ws *ws, float *dx0_out, hipStr
         const int ld_t = e == 0 ? 9 : F;
         const int32_t *nbr = ws->nbr + (size_t)e * R * KNB;
         if (!mr) {
-            PSG_CHECK_HIP(hipMemsetAsync(ws->dpq, 0, R * 2 * GC * 4, st));
-            hipLaunchKernelGGL(edge_max_bwd_kernel, dim3(g256), dim3(256), 0, st, dy, F, nbr, ws->arg + (size_t)e * R * GC,
-                               L.scale, ws->dpq, N, R * GC);
+            if ((rc = launch_edge_max_bwd(dy, F, nbr, ws->arg + (size_t)e * R * GC, L.scale, ws->dpq, N, R, st))) return rc;
             PSG_LAUNCH_CHECK();
             GemmArgs a = gemm_args(ws->dpq, 2 * GC, L.wcat_t, 2 * GC, tgt, ld_t, (int)R, 2 * GC, L.C);
             if (e > 0) {
@@ -1303,7 +1570,6 @@ extern "C" int psg_gcn_backward(psg_gcn_model *m, psg_gcn_ws *ws, const float *d
     hipStream_t st = (hipStream_t)stream;
     const int B = ws->B, N = ws->N, F = ws->fdim;
     const size_t R = (size_t)B * N;
-    const int g256 = ceil_div((int)(R * GC), 256);
     int rc;
     EvScope prof(&ws->prof, GT_BACKWARD, 0.0, st);
     // prediction.3^T, then through ReLU/BN of prediction.1 (mask2; its scale s2 is folded into wp2_st)
@@ -1337,16 +1603,14 @@ extern "C" int psg_gcn_backward(psg_gcn_model *m, psg_gcn_ws *ws, const float *d
     // backbone in reverse: G_e = d/d x_e
     PSG_CHECK_HIP(hipMemcpy2DAsync(ws->gcur, GC * 4, ws->dfeats + (size_t)(m->n_blocks - 1) * GC, (size_t)F * 4, GC * 4, R,
                                    hipMemcpyDeviceToDevice, st));
-    // [dP | dQ] buffers alternate between two blocks: the scatter kernel of block e also zeroes the Q half that block
-    // e - 1 will add into (its own buffer is still read by block e's GEMM), so one memset per backward instead of 28
+    // [dP | dQ] buffers alternate between two blocks (block e's GEMM may still read its buffer while block e - 1's edge
+    // pass writes the other); every row of both halves has exactly one writer in the gather kernel: nothing to zero
     float *pp[2] = {ws->dpq, ws->dpq2};
-    PSG_CHECK_HIP(hipMemsetAsync(pp[(m->n_blocks - 1) & 1], 0, R * 2 * GC * 4, st));
     for (int e = m->n_blocks - 1; e >= 0; --e) {
         const EdgeLayer &L = m->edge[e];
         float *dpq = pp[e & 1];
-        hipLaunchKernelGGL(edge_max_bwd_kernel, dim3(g256), dim3(256), 0, st, ws->gcur, GC, ws->nbr + (size_t)e * R * KNB,
-                           ws->arg + (size_t)e * R * GC, L.scale, dpq, N, R * GC, e > 0 ? pp[(e - 1) & 1] : (float *)nullptr);
-        PSG_LAUNCH_CHECK();
+        if ((rc = launch_edge_max_bwd(ws->gcur, GC, ws->nbr + (size_t)e * R * KNB, ws->arg + (size_t)e * R * GC, L.scale, dpq, N, R,
+                                      st))) return rc;
         if (e > 0) {
             // x_e = EdgeConv_e(x_{e-1}) + x_{e-1}:  G_{e-1} = dfeats[e-1] + G_e + [dP | dQ] . [W1-W2 ; W2]
             // (the residual's gradient slice dfeats[e-1] is added inside the GEMM's accumulate epilogue)

@@ -3,6 +3,8 @@
   PSG_FP1_WAVE=1     wave-private fp1 + head chain (psg_chain.cuh) instead of the workgroup-cooperative kernels
   PSG_RLA_ATOMICS=1  RandLA-Net backward scatters with float atomics instead of the inverse-list gathers
   PSG_GCN_PQ_FUSION=1  ResGCN: a block's edge pass also computes the next block's per-vertex [P | Q] product
+  PSG_GCN_EDGE_BWD=atomic  ResGCN: the EdgeConv max-pass backward scatters with float atomics (rounds 1-3) instead of the
+                     inverse-graph gather
 
 The switches are read once per process, so each case runs the relevant parity tests in ONE child interpreter with the
 switch set and the launch tracer on (PSG_TRACE_SYNC=1 prints the source line of every launch; the child runs with -s so
@@ -24,6 +26,7 @@ def child(test_file, keyword, extra_env):
     env.pop("PSG_FP1_WAVE", None)
     env.pop("PSG_RLA_ATOMICS", None)
     env.pop("PSG_GCN_PQ_FUSION", None)
+    env.pop("PSG_GCN_EDGE_BWD", None)
     env.update(extra_env)
     env["PSG_TRACE_SYNC"] = "1"
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", test_file), "-x", "-q", "-m", "gpu",
@@ -37,11 +40,13 @@ def child(test_file, keyword, extra_env):
     ("test_gpu_parity.py", "forward_vs_reference or backward_vs_reference or forward_backward_vs_oracle_batch", "PSG_FP1_WAVE"),
     ("test_randla_net.py", "forward_backward_vs_oracle or bim_attack_vs_oracle", "PSG_RLA_ATOMICS"),
     ("test_gpu_resgcn28.py", "not knn_on_reference_features", "PSG_GCN_PQ_FUSION"),
+    ("test_gpu_resgcn.py", "forward_backward or nb_attack", "PSG_GCN_EDGE_BWD=atomic"),
 ])
 def test_switch_selects_other_kernels_with_the_same_parity(test_file, keyword, switch):
     base, base_sites = child(test_file, keyword, {})
     assert base.returncode == 0, base.stdout[-3000:]
-    alt, alt_sites = child(test_file, keyword, {switch: "1"})
+    name, _, value = switch.partition("=")
+    alt, alt_sites = child(test_file, keyword, {name: value or "1"})
     assert alt.returncode == 0, alt.stdout[-3000:]
     assert " passed" in alt.stdout and "skipped" not in alt.stdout.splitlines()[-1]
     assert base_sites and alt_sites and alt_sites != base_sites, (switch, sorted(alt_sites ^ base_sites))

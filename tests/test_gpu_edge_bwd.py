@@ -1,0 +1,103 @@
+"""The EdgeConv max-pass backward without atomics (edge_max_bwd_gather_kernel, psg_resgcn.hip): the transpose of
+`batched_index_select` + `max` (ResGCN/gcn_lib/dense/torch_nn.py:82-98, torch_vertex.py:31-35) as a gather through the
+inverse graph.  Checked through the C ABI (psg_edgeconv_bwd leaves [dP | dQ] in its scratch argument) against a numpy
+restatement that sums every destination's in-edges in the kernel's documented order (equal slices of the workgroup's flat
+edge list, pieces added in order) - so the comparison is BIT-exact, and the launch is bit-reproducible."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GC, K = 64, 16
+
+
+def reference(dy, nbr, arg, scale, N, cap=8192):
+    """[dP | dQ] with the kernel's documented summation order: per workgroup (64 consecutive destinations of a room) the
+    in-edges form one flat list, destination-major, ascending source vertex; a pass takes `cap` entries of it and cuts them
+    into 64 equal slices; inside a slice every destination's entries are added in order from zero (a piece); a destination
+    adds its pieces in slice order, pass after pass."""
+    R = dy.shape[0]
+    g = np.where((arg & 0x80) != 0, dy * scale[None, :], np.float32(0)).astype(np.float32)
+    dq = np.zeros((R, GC), np.float32)
+    slot = (arg & 0x7F).astype(np.int64)
+    for room in range(R // N):
+        rb = room * N
+        nb = nbr[rb:rb + N]
+        first = np.full((N, N), -1, np.int64)                    # first slot of j in v's row (the forward's max keeps the first)
+        for k in range(K - 1, -1, -1):
+            first[np.arange(N), nb[:, k]] = k
+        for j0 in range(0, N, 64):
+            dests, srcs = [], []
+            for j in range(j0, min(j0 + 64, N)):
+                src = np.nonzero(first[:, j] >= 0)[0]
+                dests.append(np.full(src.size, j))
+                srcs.append(src)
+            dests, srcs = np.concatenate(dests), np.concatenate(srcs)
+            total = dests.size
+            if total == 0:
+                continue
+            terms = np.where(slot[rb + srcs] == first[srcs, dests][:, None], g[rb + srcs], np.float32(0))
+            for c0 in range(0, total, cap):
+                cend = min(total, c0 + cap)
+                S = (cend - c0 + 63) // 64
+                for k in range(64):
+                    lo, hi = c0 + k * S, min(c0 + (k + 1) * S, cend)
+                    e = lo
+                    while e < hi:
+                        j = dests[e]
+                        acc = np.zeros(GC, np.float32)
+                        while e < hi and dests[e] == j:
+                            acc = acc + terms[e]
+                            e += 1
+                        dq[rb + j] = dq[rb + j] + acc
+    return g, dq
+
+
+def run(dy, nbr, arg, scale, N):
+    import torch
+    from pointsecguard_amd import _lib, runtime
+    R = dy.shape[0]
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    t_dy, t_nbr, t_arg, t_sc = d(dy), d(nbr.astype(np.int32)), d(arg), d(scale)
+    wt = torch.zeros(GC, 2 * GC, device="cuda")
+    dpq = torch.full((R * 128,), float("nan"), device="cuda")           # every element must be written: no memset is relied on
+    dx = torch.empty(R, GC, device="cuda")
+    _lib.call("psg_edgeconv_bwd", runtime.ptr(t_dy), GC, R, N, GC, runtime.ptr(t_nbr), runtime.ptr(t_arg), runtime.ptr(t_sc),
+              runtime.ptr(wt), runtime.ptr(dpq), runtime.ptr(dx), GC, runtime.stream())
+    torch.cuda.synchronize()
+    out = dpq[:R * 2 * GC].reshape(R, 2 * GC).cpu().numpy()
+    return out[:, :GC], out[:, GC:]
+
+
+def make_case(rng, R, N, hub=False, dup=False):
+    nbr = np.stack([rng.choice(N, K, replace=False) for _ in range(R)]).astype(np.int64)
+    if hub:       # every vertex of a room points at the same few destinations (in-degree N) + random others
+        nbr[:, :5] = np.array([3, 64, 65, N - 1, N // 2])[None, :] % N
+        for r in range(R):
+            rest = rng.choice(np.setdiff1d(np.arange(N), nbr[r, :5]), K - 5, replace=False)
+            nbr[r, 5:] = rest
+    if dup:       # repeated neighbours in a row (teacher-forced tables may hold them): the first slot is the one that can win
+        nbr[:, 9] = nbr[:, 2]
+    slot = rng.integers(0, K, (R, GC))
+    if dup:
+        slot[slot == 9] = 2
+    act = rng.random((R, GC)) < 0.8
+    arg = (slot | np.where(act, 0x80, 0)).astype(np.uint8)
+    dy = rng.standard_normal((R, GC)).astype(np.float32)
+    scale = (rng.standard_normal(GC) * 0.5 + 1).astype(np.float32)
+    return dy, nbr, arg, scale
+
+
+@pytest.mark.parametrize("rooms,N,hub,dup", [(2, 4096, False, False), (1, 1024, True, False), (3, 1000, False, True),
+                                             (1, 96, True, True), (4, 4096, True, False)])
+def test_gather_backward_is_exact_and_reproducible(rooms, N, hub, dup):
+    rng = np.random.default_rng(rooms * 1000 + N)
+    dy, nbr, arg, scale = make_case(rng, rooms * N, N, hub, dup)
+    dp, dq = run(dy, nbr, arg, scale, N)
+    g, ref = reference(dy, nbr, arg, scale, N)
+    assert np.array_equal(dp.view(np.uint32), g.view(np.uint32))
+    nz = ref != 0
+    assert np.array_equal(dq[nz].view(np.uint32), ref[nz].view(np.uint32)) and not np.any(dq[~nz])     # (+0 / -0 both fine)
+    dp2, dq2 = run(dy, nbr, arg, scale, N)
+    assert np.array_equal(dq.view(np.uint32), dq2.view(np.uint32)) and np.array_equal(dp.view(np.uint32), dp2.view(np.uint32))
+    # conservation: every active (v, c) gradient lands on exactly one destination
+    assert np.allclose(dq.astype(np.float64).sum(0), g.astype(np.float64).sum(0), rtol=1e-4, atol=1e-3)
