@@ -25,6 +25,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP runtime setting, before anything initialises the GPU: hardware queues per process (ROCm's default is 4).  Only the
+# one-call-per-room NU protocol (--nu-mode per-room-calls: 12 host threads, one small attack each) has more than 4 streams
+# with work; its throughput goes from 84 to ~120 rooms/s, the headline (3 streams) is unchanged (576.8 vs 576.9 rooms/s).
+# Reported in the line as config.hip_runtime.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 EPS, ALPHA, ITERS = 0.05, 2 / 255, 40
 BATCH, NPOINT = 8, 4096
@@ -204,6 +209,8 @@ def check_env_switches(allow_paths, diag_ok=False):
     for name in sorted(os.environ):
         if name.startswith("PSG_BENCH_"):
             sw.append((name, os.environ[name], "b"))
+    if os.environ.get("PSG_LIBRARY_OVERRIDE"):
+        sw.append(("PSG_LIBRARY_OVERRIDE", os.environ["PSG_LIBRARY_OVERRIDE"], "p"))     # a variant build of libpsg.so
     ENV_SWITCHES[:] = ["%s=%s (%s)" % s for s in sw]
     if lib.psg_diag_build() and diag_ok:
         ENV_SWITCHES.append("DIAGNOSTIC BUILD (-DPSG_DIAG_BUILD): value withheld")
@@ -219,7 +226,7 @@ def check_env_switches(allow_paths, diag_ok=False):
 
 def base_line(metric, unit, value, R, args, elapsed, workload, extra_config=None):
     cfg = {"workload": workload, "sharding": "independent rooms / clouds sharded by rank, no data-path collective",
-           "env_switches": list(ENV_SWITCHES)}
+           "env_switches": list(ENV_SWITCHES), "hip_runtime": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}
     if extra_config:
         cfg.update(extra_config)
     # n_ranks_seen: a sum of ones over the process group (RCCL on GPUs): evidence in the line itself that N ranks took part
@@ -264,10 +271,9 @@ def main():
                          "GPUs (BASELINE configs[2]: 'batch=32 rooms, sharded 8x' = 4 rooms per GPU)")
     ap.add_argument("--randla-iters", type=int, default=100,
                     help="randla workload: BIM iterations per attacked cloud (BASELINE configs[4]: 100)")
-    ap.add_argument("--nu-concurrency", type=int, default=6,
-                    help="tarnu workload: attacks in flight, one host thread + HIP stream + model instance each (an NU "
-                         "step reads one scalar tensor back for the reference's early-exit test; a second attack fills "
-                         "the GPU while the first one's host thread waits for it)")
+    ap.add_argument("--nu-concurrency", type=int, default=12,
+                    help="tarnu workload: attacks in flight, one host thread + HIP stream + model instance each (a one-room "
+                         "attack is ~30 short launches per optimiser step: several of them side by side fill the GPU)")
     ap.add_argument("--gcn-concurrency", type=int, default=3, help="resgcn workload: attacks in flight (streams)")
     ap.add_argument("--gcn-block", default="res", choices=["res", "plain", "dense"],
                     help="resgcn workload: backbone block (architecture.py:26-39 of the reference); default = BASELINE's")
@@ -907,19 +913,15 @@ def tarnu_measure(args, R, mode, with_roofline=True):
     def attack(job, slot):
         step, b0, nb = job
         mask = labels[step][b0] == src_cls                      # the harness masks by the batch's first room (mask[0])
-        n_run = [0]
-
-        def count(**kw):
-            n_run[0] += 1
         with torch.cuda.stream(streams[slot]):
             atk = torchattacks.tar_NU_attack(nets[slot], c=1, kappa=0, steps=cap, lr=0.01, target=target, mask=mask)
             if lockstep:
                 masks = labels[step][b0:b0 + nb] == src_cls     # every room masks its own points of the source class
                 out, steps_run = atk.forward_rooms(d_images[step][b0:b0 + nb], labels[step][b0:b0 + nb].astype(np.float64), masks)
             else:
-                out = nu_mod.nu_attack(atk, d_images[step][b0:b0 + nb], labels[step][b0:b0 + nb].astype(np.float64), mask, target,
-                                       5, targeted_variant=True, trace=count)
-                steps_run = np.array([n_run[0]])
+                out, n_run = nu_mod.nu_attack(atk, d_images[step][b0:b0 + nb], labels[step][b0:b0 + nb].astype(np.float64), mask, target,
+                                              5, targeted_variant=True, return_steps=True)
+                steps_run = np.array([n_run])
             streams[slot].synchronize()
         with lock:
             opt_steps[0] += int(steps_run.sum())

@@ -315,6 +315,57 @@ int psg_nu_adam_step_rooms(float *w, float *m, float *v, const uint8_t *mask_roo
                            float beta1, float beta2, float eps, int step, int B, int N, const uint8_t *room_active,
                            float *l2_sum_rooms, psg_stream stream);
 
+/* Per-step statistics and exit latch of the NU attacks: what the reference evaluates on the host after every optimiser
+ * step - nontarget.py:87,95-96 (`correct / 4096 < 1 / 13`), target.py:105-121 (`target_acc` > 0.9, or < 1 / 13 for the
+ * untargeted goal) - for G attacks of `rows` batch rows each (rows = B: one call on a batch; rows = 1: rooms in lockstep).
+ * mode 0 = NU_attack, 1 = tar_NU_attack without a target (hits = correct points on the mask), 2 = with a target (hits =
+ * points on the mask predicted as `target`).  scal [3][G]: the step's f / Smooth / L2 sums, moved into hist_step [5][G]
+ * = {n_correct, n_hits, f, Smooth, L2} and zeroed.  The first step whose test fires copies the group's x0 rows
+ * [rows][N][9] into out_cn [rows][9][N], stores the step in exit_step [G] (-1 before) and clears active [G]. */
+int psg_nu_step_latch(const int32_t *pred, const int32_t *labels, int target, const uint8_t *mask_groups,
+                      const int32_t *n_mask, int G, int rows, int N, int mode, float *scal, float *hist_step,
+                      const float *x0, float *out_cn, uint8_t *active, int32_t *exit_step, int step, psg_stream stream);
+
+/* A WINDOW of consecutive optimiser steps of NU_attack / tar_NU_attack on a PointNet++ network, enqueued by ONE call:
+ * per step exactly the sequence the host loop of the reference runs (nontarget.py:77-96, target.py:93-121) -
+ * psg_nu_tanh_color(_rooms), psg_pn2_forward on plan slot slot0 + i, psg_nu_f_loss_grad(_rooms), psg_pn2_backward,
+ * psg_smooth_knn_rooms, psg_nu_adam_step(_rooms), psg_nu_step_latch - with the same arguments those entry points take.
+ * (G, rows) = (1, B): one attack on a batch of B rows; (R, 1): R one-room attacks in lockstep.  The reference's host work
+ * (restart test, learning-rate halving, exit) sits between windows; inside one nothing returns to the host. */
+typedef struct psg_nu_window_args {
+    psg_pn2_model *model;
+    psg_pn2_ws *ws;
+    int slot0, step0, n_steps;   /* steps step0 .. step0 + n_steps - 1 use plan slots slot0 .. */
+    int G, rows, N, mode;        /* mode: see psg_nu_step_latch */
+    int use_target, target;      /* the f-loss takes `target` instead of the labels */
+    int neighbour, warm_first;   /* Smooth term: neighbour count; 1 = nn_state holds the previous step's lists */
+    int adam_t0;                 /* optimiser steps taken since the optimiser was created */
+    float kappa, tsign, c_smooth, c_l2, lr, beta1, beta2, eps;
+    float *w, *m, *v;            /* [G*rows][N][3] */
+    const uint8_t *mask;         /* [G][N] (rows = 1) or [N] (G = 1), nullable for NU_attack */
+    const int32_t *n_mask;       /* [G], modes 1 and 2 */
+    float *x0;                   /* [G*rows][N][9] */
+    const float *ori;            /* [G*rows][N][3] */
+    const int32_t *labels;       /* [G*rows][N] */
+    float *logp, *dlogp, *dx0;   /* [G*rows][N][13], [..][13], [..][9] scratch */
+    float *sgrad;                /* [G][N][3] */
+    int32_t *pred;               /* [G*rows][N] */
+    float *scal;                 /* [3][G], zero before the first window */
+    int32_t *nn_state;           /* [G][N][neighbour] */
+    float *hist;                 /* history rows [5][G] of the window's steps, row of step0 first */
+    float *out;                  /* [G*rows][9][N] */
+    uint8_t *active;             /* [G] */
+    int32_t *exit_step;          /* [G] */
+} psg_nu_window_args;
+/* `graph` (nullable): a handle that lets windows of one SHAPE (same buffers, plan slots and step count; only step0, adam_t0
+ * and lr differ) be replayed as a hipGraph - the first such window runs eagerly, the second is captured, later ones are
+ * replayed with their step constants read from a device row.  Same results as the eager sequence. */
+#define PSG_NU_GRAPH_MAX_STEPS 16
+typedef struct psg_nu_graph psg_nu_graph;
+int psg_nu_graph_create(psg_nu_graph **out);
+int psg_nu_graph_destroy(psg_nu_graph *graph);
+int psg_pn2_nu_window(const psg_nu_window_args *args, psg_nu_graph *graph, psg_stream stream);
+
 /* Segmentation statistics of NB_nontarget_test_semseg.py:199-205: for every class l accumulates
  * seen[l] += #(gt==l), inter[l] += #(pred==l & gt==l), uni[l] += #(pred==l | gt==l) where
  * pred = argmax(logp) (first index on ties).  counters: int64 [3][n_cls] = seen, inter, uni.

@@ -7,7 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpsg.so")
+# PSG_LIBRARY_OVERRIDE: a variant build (tools/build_variant.sh -> build/libpsg_NAME.so) for probes; bench.py refuses to
+# run with it unless --allow-env-switches is given, and then lists it in config.env_switches
+LIB_PATH = os.environ.get("PSG_LIBRARY_OVERRIDE") or os.path.join(_HERE, "libpsg.so")
 
 c_f = ctypes.POINTER(ctypes.c_float)
 c_i = ctypes.POINTER(ctypes.c_int32)
@@ -73,6 +75,10 @@ SIGNATURES = {
     "psg_gcn_f_loss_grad": (ci, [vp, vp, ci, vp, ci, ci, ci, ci, cf, cf, cf, vp, vp, vp, vp]),
     "psg_smooth_knn": (ci, [vp, ci, vp, ci, ci, ci, vp, vp, vp]),
     "psg_nu_adam_step": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, cf, cf, cf, cf, ci, ci, ci, vp, vp]),
+    "psg_pn2_nu_window": (ci, [vp, vp, vp]),
+    "psg_nu_graph_create": (ci, [ctypes.POINTER(vp)]),
+    "psg_nu_graph_destroy": (ci, [vp]),
+    "psg_nu_step_latch": (ci, [vp, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]),
     "psg_nu_tanh_color_rooms": (ci, [vp, vp, ci, ci, vp, vp]),
     "psg_nu_f_loss_grad_rooms": (ci, [vp, vp, ci, ci, ci, ci, cf, cf, vp, vp, vp, vp]),
     "psg_smooth_knn_rooms": (ci, [vp, ci, ctypes.c_size_t, vp, ci, ctypes.c_size_t, ci, ci, ci, vp, vp, vp, ci, vp]),
@@ -125,6 +131,18 @@ SIGNATURES = {
     "psg_vote_stats": (ci, [vp, vp, ci, ci, vp, vp, vp]),
     "psg_l2_dist": (ci, [vp, vp, ctypes.c_size_t, vp, vp, vp]),
 }
+
+
+
+class NuWindowArgs(ctypes.Structure):
+    """psg_nu_window_args of include/psg.h, field for field."""
+    _fields_ = ([("model", vp), ("ws", vp)] +
+                [(n, ci) for n in ("slot0", "step0", "n_steps", "G", "rows", "N", "mode", "use_target", "target", "neighbour",
+                                   "warm_first", "adam_t0")] +
+                [(n, cf) for n in ("kappa", "tsign", "c_smooth", "c_l2", "lr", "beta1", "beta2", "eps")] +
+                [(n, vp) for n in ("w", "m", "v", "mask", "n_mask", "x0", "ori", "labels", "logp", "dlogp", "dx0", "sgrad", "pred",
+                                   "scal", "nn_state", "hist", "out", "active", "exit_step")])
+
 
 _lib = None
 

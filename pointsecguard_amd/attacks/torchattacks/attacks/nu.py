@@ -4,10 +4,15 @@ Reference: PointNet/attacks/torchattacks/attacks/nontarget.py:52-135 (NU_attack.
 target.py:62-175 (tar_NU_attack.forward/non_f/tar_f/smooth).  Per step:
   colour = 1/2 (tanh w + 1) -> model forward -> f-loss on softmax(log-probs) + c*Smooth + c*L2 ->
   input-gradient backward -> Adam step on w.
-Everything numeric runs in HIP kernels (psg_nu_*, psg_smooth_knn, psg_pn2_forward/backward); the host
-only evaluates the reference's control flow (early exits on accuracy, learning-rate halving with a fresh
-optimiser every 50 steps, the every-10-steps restart), which needs one scalar read-back per step exactly
-like the reference's `.item()` calls.
+Everything numeric runs in HIP kernels (psg_nu_*, psg_smooth_knn, psg_pn2_forward/backward), and since round 4 so
+does the per-step part of the reference's control flow: `psg_nu_step_latch` counts the correct points / target hits,
+files them with the step's loss sums in a device-side history and evaluates the accuracy exit test in double
+precision exactly as the host did; the first step whose test fires snapshots the image and clears the attack's
+active flag.  The host reads the history only where the reference itself must touch the host - after step 0
+(at batch 32 the targeted attack always exits there), after every 10th step (restart test + noise draw,
+learning-rate halving with a fresh optimiser every 50) and at the end: an attack that exits at step s returns
+its step-s image, at most 9 later steps are speculation that is thrown away.  With a `trace` callback (tests)
+the history is read after every step, like the reference's `.item()` calls.
 
 Reference behaviours kept on purpose: the Smooth term and `other_acc`
 use batch row 0 only; `acc` divides by 4096 whatever the batch; the returned image lags the optimiser by
@@ -15,6 +20,8 @@ one step; `_targeted` stays +1 unless set_attack_mode() is called; the restart a
 masked colours (overwritten by tanh_space on the next step) and clamps ALL nine channels to [0,1], which
 moves the xyz coordinates -- the geometry plan is rebuilt from the current coordinates after it.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -27,110 +34,182 @@ BETA1, BETA2, ADAM_EPS = 0.9, 0.999, 1e-8
 CHUNK = 10  # geometry plan horizon: restarts can only happen after steps that are multiples of 10
 
 
-def nu_attack(atk, images, labels, mask, target, neighbour, targeted_variant=False, trace=None, starts_fn=None):
-    """`starts_fn(step, n_plan)` (tests) supplies the [n_plan, 4, B] FPS start indices of a geometry window instead of the
-    generator draws."""
+class _NuState:
+    """Device buffers of one attack shape (G attacks of `rows` batch rows, N points), kept with the model instance between
+    calls: the addresses stay the same, so a 10-step window captured as a hipGraph by one call is replayed by the next
+    (one model instance serves one host thread / stream at a time, like its network workspace)."""
+
+    def __init__(self, dev, G, rows, N, neighbour):
+        B = G * rows
+        f32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        self.key = (G, rows, N, int(neighbour))
+        self.x0, self.x0_orig, self.ori = f32(B, N, 9), f32(B, N, 9), f32(B, N, 3)
+        self.w, self.m, self.v = f32(B, N, 3), f32(B, N, 3), f32(B, N, 3)
+        self.logp, self.dlogp, self.dx0 = f32(B, N, 13), f32(B, N, 13), f32(B, N, 9)
+        self.sgrad = f32(G, N, 3)
+        self.pred = torch.empty(B, N, device=dev, dtype=torch.int32)
+        self.labels = torch.empty(B, N, device=dev, dtype=torch.int32)
+        self.mask = torch.empty(G, N, device=dev, dtype=torch.uint8)
+        self.scal = f32(3, G)                                        # rows: f, smooth, l2
+        self.nn_state = torch.empty(G, N, int(neighbour), device=dev, dtype=torch.int32)   # Smooth term: last step's neighbours
+        self.hist = f32(CHUNK, 5, G)                                 # one window of history rows: n_correct, n_hits, f, smooth, l2
+        self.active = torch.empty(G, device=dev, dtype=torch.uint8)
+        self.exit = torch.empty(G, device=dev, dtype=torch.int32)
+        self.n_mask = torch.empty(G, device=dev, dtype=torch.int32)
+        self.out = f32(B, 9, N)
+        self.graph = ctypes.c_void_p()
+        _lib.call("psg_nu_graph_create", ctypes.byref(self.graph))
+
+    def __del__(self):
+        try:
+            if self.graph:
+                _lib.load().psg_nu_graph_destroy(self.graph)
+        except Exception:
+            pass
+
+
+def _state(net, dev, G, rows, N, neighbour):
+    cache = net.__dict__.setdefault("_psg_nu_states", {})
+    key = (str(dev), G, rows, N, int(neighbour))
+    if key not in cache:
+        cache[key] = _NuState(dev, G, rows, N, neighbour)
+    return cache[key]
+
+
+def _nu_core(atk, images, labels, masks, target, neighbour, targeted_variant, trace, starts_fn, G, rows):
+    """G attacks of `rows` batch rows each, advanced together: (1, B) = the reference's call on a batch of B rows (its batch
+    semantics: Smooth term and mask of batch row 0, counts over all rows), (R, 1) = R one-room calls in lockstep.
+    masks: bool numpy [G, N] or None.  Returns (out [G*rows, 9, N], exited [G] = step of the exit test or -1, steps done)."""
     net = psg_model(atk.model)
     dev = atk.device
     images = images.detach().to(dev).float().contiguous()
     B, C, N = images.shape
-    labels_d = labels_to_device(labels, dev)
-    mask_d = mask_to_device(mask, N, dev) if mask is not None else None
-    mask_b = mask_d.bool() if mask_d is not None else None
+    assert B == G * rows
+    st = runtime.stream
+    S = _state(net, dev, G, rows, N, neighbour)
     model = net._packed()
     net._generation += 1
     ws = net._workspace(B, N, CHUNK + 1)
-    st = runtime.stream
-
-    x0 = torch.empty(B, N, 9, device=dev, dtype=torch.float32)
-    _lib.call("psg_to_point_major", runtime.ptr(images), B, 9, N, runtime.ptr(x0), st())
-    ori = x0[:, :, 3:6].contiguous()
-    x0_orig = x0.clone()
-    extra_l2 = 0.0  # (adv - images)^2 over the non-colour channels: non-zero only after a restart clamped them
-    w = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
-    _lib.call("psg_nu_inverse_tanh", runtime.ptr(x0), B, N, runtime.ptr(w), st())
-    m, v = torch.zeros_like(w), torch.zeros_like(w)
-    dlogp = torch.empty(B, N, 13, device=dev, dtype=torch.float32)
-    dx0 = torch.empty(B, N, 9, device=dev, dtype=torch.float32)
-    sgrad = torch.empty(N, 3, device=dev, dtype=torch.float32)
-    pred = torch.empty(B, N, device=dev, dtype=torch.int32)
-    scal = torch.zeros(3, device=dev, dtype=torch.float32)  # f, smooth, l2
-    nn_state = torch.empty(N, int(neighbour), device=dev, dtype=torch.int32)   # Smooth term: last step's neighbours of row 0
-    lr, adam_t = float(atk.lr), 0
-    prev_cost = [1e10] * atk.steps
-    tsign = float(atk._targeted)
     use_target = targeted_variant and target is not None
+    mode = 0 if not targeted_variant else (2 if use_target else 1)
+    S.labels.copy_(labels_to_device(labels, dev))
+    if masks is not None:
+        S.mask.copy_(torch.from_numpy(masks.astype(np.uint8)))
+        n_mask = masks.sum(axis=1).astype(np.float64)
+        mask_b = S.mask.bool()
+        if targeted_variant and (n_mask == 0).any():
+            # the reference divides the hits by the mask count (target.py:104-105): an empty mask raises there too
+            raise ZeroDivisionError("tar_NU_attack: attacks %s have an empty mask (target.py:104: division by the mask count)"
+                                    % np.nonzero(n_mask == 0)[0].tolist())
+    else:
+        if targeted_variant:
+            raise ValueError("the targeted variant needs a mask")
+        n_mask, mask_b = np.zeros(G), None
+    S.n_mask.copy_(torch.from_numpy(n_mask.astype(np.int32)))
+    x0, w, m, v = S.x0, S.w, S.m, S.v
+    _lib.call("psg_to_point_major", runtime.ptr(images), B, 9, N, runtime.ptr(x0), st())
+    S.ori.copy_(x0[:, :, 3:6])
+    S.x0_orig.copy_(x0)
+    _lib.call("psg_nu_inverse_tanh", runtime.ptr(x0), B, N, runtime.ptr(w), st())
+    m.zero_(); v.zero_(); S.scal.zero_()
+    S.active.fill_(1); S.exit.fill_(-1)
+    extra_l2 = np.zeros(G)  # (adv - images)^2 over the non-colour channels: non-zero only after a restart clamped them
+    prev_cost = np.full((atk.steps, G), 1e10)
+    lr, adam_t = float(atk.lr), 0
+    tsign = float(atk._targeted)
     planned_until = 0
-    n_mask = int(mask_b.sum().item()) if mask_b is not None else 0   # once: the loop reads back ONE tensor per step
-    out = torch.empty_like(images)
+    exited = np.full(G, -1, np.int64)                                # step at which an attack's exit test fired (-1: running)
+    win = _lib.NuWindowArgs(
+        model=model.handle.value, ws=ws.handle.value, G=G, rows=rows, N=N, mode=mode, use_target=int(use_target),
+        target=int(target) if use_target else 0, neighbour=int(neighbour), kappa=float(atk.kappa), tsign=tsign, c_smooth=float(atk.c),
+        c_l2=float(atk.c), beta1=BETA1, beta2=BETA2, eps=ADAM_EPS, w=w.data_ptr(), m=m.data_ptr(), v=v.data_ptr(),
+        mask=S.mask.data_ptr() if masks is not None else None, n_mask=S.n_mask.data_ptr(), x0=x0.data_ptr(), ori=S.ori.data_ptr(),
+        labels=S.labels.data_ptr(), logp=S.logp.data_ptr(), dlogp=S.dlogp.data_ptr(), dx0=S.dx0.data_ptr(), sgrad=S.sgrad.data_ptr(),
+        pred=S.pred.data_ptr(), scal=S.scal.data_ptr(), nn_state=S.nn_state.data_ptr(), hist=S.hist.data_ptr(), out=S.out.data_ptr(),
+        active=S.active.data_ptr(), exit_step=S.exit.data_ptr())
 
-    def snapshot():
-        _lib.call("psg_to_channel_major", runtime.ptr(x0), B, 9, N, runtime.ptr(out), st())
-        return out
-
-    for step in range(atk.steps):
-        _lib.call("psg_nu_tanh_color", runtime.ptr(w), runtime.ptr(mask_d), B, N, runtime.ptr(x0), st())
+    step = 0
+    while step < atk.steps:
         if step >= planned_until:
             # Geometry windows end after steps 10, 20, 30, ..: a restart (which draws from the RNG and may move xyz) can
             # only follow a step that is a multiple of 10 greater than 10, so the FPS draws of a window come out of the
             # generator in the reference's order.  The first forward is planned ALONE: the accuracy exits can end the
             # attack right after it (at batch 32 the targeted one always does, target.py:105-121), and a plan for
             # eleven forwards would then be ten too many; the rest of the first window follows with step 1.
+            # (the plan reads the coordinates only; the colours of a step are written inside the window call)
             window_end = 1 if step == 0 else ((step - 1) // CHUNK + 1) * CHUNK + 1      # [0], [1..10], [11..20], ..
             n_plan = min(window_end - step, atk.steps - step)
             starts = (draw_fps_starts(B, N, n_plan) if starts_fn is None else starts_fn(step, n_plan)).to(dev)
             ws.plan_build(x0, starts, n_plan)
             plan_base, planned_until = step, step + n_plan
-        slot = step - plan_base
-        logp = ws.forward(model, slot, x0)
-        scal.zero_()
-        _lib.call("psg_nu_f_loss_grad", runtime.ptr(logp), None if use_target else runtime.ptr(labels_d),
-                  int(target) if use_target else 0, B * N, 13, float(atk.kappa), tsign, runtime.ptr(dlogp),
-                  runtime.ptr(scal[0:1]), runtime.ptr(pred), st())
-        ws.backward(model, slot, dlogp, dx0)
-        # (the rooms entry with one room: it keeps the neighbour lists, and every step after the first starts its scan from
-        # the rigorous bound they give - same rows as psg_smooth_knn)
-        _lib.call("psg_smooth_knn_rooms", ctypes_off(x0, 3), 9, N * 9, runtime.ptr(ori), 3, N * 3, 1, N, int(neighbour),
-                  runtime.ptr(scal[1:2]), runtime.ptr(sgrad), runtime.ptr(nn_state), 1 if step > 0 else 0, st())
-        adam_t += 1
-        _lib.call("psg_nu_adam_step", runtime.ptr(w), runtime.ptr(m), runtime.ptr(v), runtime.ptr(mask_d),
-                  runtime.ptr(dx0), runtime.ptr(x0), runtime.ptr(ori), runtime.ptr(sgrad), float(atk.c), float(atk.c),
-                  lr, BETA1, BETA2, ADAM_EPS, adam_t, B, N, runtime.ptr(scal[2:3]), st())
-        # ---- control flow of the reference (one read-back per step, like its .item() calls)
-        correct = pred.eq(labels_d)
-        if targeted_variant:
-            # masked count as a logical AND (boolean-mask indexing would synchronise and launch a nonzero every step)
-            tgt_hits = ((pred.eq(int(target)) if use_target else correct) & mask_b.unsqueeze(0)).sum()
-            stats = torch.stack([correct.sum().float(), tgt_hits.float(), scal[0], scal[1], scal[2]]).cpu()
-        else:
-            stats = torch.stack([correct.sum().float(), scal[0], scal[0], scal[1], scal[2]]).cpu()
-        n_correct, n_tgt, f_loss, sm_loss, l2_loss = (float(z) for z in stats)
-        l2_loss += extra_l2
-        cost = f_loss + float(atk.c) * sm_loss + float(atk.c) * l2_loss
-        prev_cost[step] = cost
-        if trace is not None:
-            trace(step=step, cost=cost, f=f_loss, smooth=sm_loss, l2=l2_loss, w=w, m=m, v=v, dx0=dx0, x0=x0, pred=pred)
+        # ---- the steps up to the end of the geometry window (= up to the next point where the reference's host work needs
+        # values) in ONE call: colours, forward, f-loss, backward, Smooth term, Adam step, statistics + exit latch per step;
+        # full windows of the same shape are replayed as a hipGraph (psg_pn2_nu_window)
+        n_run = 1 if trace is not None else planned_until - step
+        win.slot0, win.step0, win.n_steps = step - plan_base, step, n_run
+        win.adam_t0, win.lr, win.warm_first = adam_t, lr, 1 if step > 0 else 0
+        _lib.call("psg_pn2_nu_window", ctypes.byref(win), S.graph if n_run == CHUNK else None, st())
+        adam_t += n_run
+        last = step + n_run - 1
+        # ---- the reference's control flow, per attack, where the reference's host work needs the values (ONE read-back)
+        got = torch.cat([S.hist[:n_run].reshape(-1), S.exit.float()]).cpu().numpy().astype(np.float64)
+        hrows, exited = got[:-G].reshape(n_run, 5, G), got[-G:].astype(np.int64)
+        for s_i in range(step, last + 1):
+            was_active = (exited < 0) | (exited >= s_i)                  # attacks whose loop was still running at step s_i
+            f_loss, sm_loss = hrows[s_i - step, 2], hrows[s_i - step, 3]
+            l2_loss = hrows[s_i - step, 4] + extra_l2
+            cost = f_loss + float(atk.c) * sm_loss + float(atk.c) * l2_loss
+            prev_cost[s_i] = np.where(was_active, cost, prev_cost[s_i])
+            if trace is not None:
+                trace(s_i, cost, f_loss, sm_loss, l2_loss, was_active, S)
+        step = last + 1
+        active = exited < 0                              # after this step's exits (nontarget.py:95-96, target.py:116-121)
+        if not active.any():
+            break
         if not targeted_variant:
-            if n_correct / 4096 < 1 / 13:          # nontarget.py:87,95-96
-                return snapshot()
             continue
-        target_acc = n_tgt / float(n_mask)
-        if (not use_target and target_acc < 1 / 13) or (use_target and target_acc > 0.9):   # target.py:116-121
-            return snapshot()
-        if step > 0 and step % 50 == 0:             # target.py:123-125: halve lr, NEW optimiser (moments reset)
+        if last > 0 and last % 50 == 0:                  # target.py:123-125: halve lr, NEW optimiser (moments reset)
             atk.lr = atk.lr / 2
             lr, adam_t = float(atk.lr), 0
             m.zero_()
             v.zero_()
-        if step > 10 and step % 10 == 0 and cost >= prev_cost[step - 10]:   # target.py:127-132
-            noise = torch.empty(B, 3, n_mask, device=dev, dtype=torch.float32).uniform_(0, 1)
-            col = x0[:, :, 3:6].transpose(1, 2)      # view [B,3,N]
-            col[:, :, mask_b] = col[:, :, mask_b] + noise
-            x0.clamp_(min=0, max=1)                 # ALL channels, like the reference
-            d = x0 - x0_orig
-            extra_l2 = float((d[:, :, 0:3] ** 2).sum().item() + (d[:, :, 6:9] ** 2).sum().item())
-            planned_until = step + 1               # xyz may have moved: rebuild the plan before the next forward
-    return snapshot()
+        if last > 10 and last % 10 == 0:                 # target.py:127-132, attack by attack
+            again = np.nonzero(active & (cost >= prev_cost[last - 10]))[0]
+            for g in again:                              # the noise draws stay per attack, in order
+                k = int(n_mask[g])
+                noise = torch.empty(rows, 3, k, device=dev, dtype=torch.float32).uniform_(0, 1)
+                col = x0[g * rows:(g + 1) * rows, :, 3:6].transpose(1, 2)        # view [rows, 3, N]
+                col[:, :, mask_b[g]] = col[:, :, mask_b[g]] + noise
+            if len(again):
+                ridx = torch.from_numpy(np.concatenate([np.arange(g * rows, (g + 1) * rows) for g in again])).to(dev)
+                clamped = x0[ridx].clamp_(min=0, max=1)                   # ALL channels, like the reference
+                x0[ridx] = clamped
+                d = clamped - S.x0_orig[ridx]
+                sums = ((d[:, :, 0:3] ** 2).sum(dim=(1, 2)) + (d[:, :, 6:9] ** 2).sum(dim=(1, 2))).reshape(len(again), rows)
+                extra_l2[again] = sums.sum(dim=1).cpu().numpy().astype(np.float64)   # one read-back for all of them
+                planned_until = step                     # xyz may have moved: rebuild the plan before the next forward
+    out = S.out.clone()                                  # (the caller owns what it gets; the state buffer is reused)
+    for g in np.nonzero(exited < 0)[0]:                  # attacks that ran to the cap: the current image
+        _lib.call("psg_to_channel_major", runtime.ptr(x0[g * rows:(g + 1) * rows]), rows, 9, N, runtime.ptr(out[g * rows:(g + 1) * rows]), st())
+    return out, exited, step
+
+
+def nu_attack(atk, images, labels, mask, target, neighbour, targeted_variant=False, trace=None, starts_fn=None, return_steps=False):
+    """NU_attack.forward / tar_NU_attack.forward on a batch (the reference's call).  `starts_fn(step, n_plan)` (tests) supplies
+    the [n_plan, 4, B] FPS start indices of a geometry window instead of the generator draws; `trace` (tests) is called
+    after every step with the step's scalars and the state tensors (and makes the loop read back after every step);
+    `return_steps`: also return the number of optimiser steps the reference's loop ran."""
+    B, _, N = images.shape
+    masks = None
+    if mask is not None:
+        masks = mask_to_device(mask, N, "cpu").numpy().astype(bool)[None]
+    tr = None
+    if trace is not None:
+        def tr(step, cost, f, sm, l2, was_active, S):
+            trace(step=step, cost=float(cost[0]), f=float(f[0]), smooth=float(sm[0]), l2=float(l2[0]), w=S.w, m=S.m, v=S.v, dx0=S.dx0,
+                  x0=S.x0, pred=S.pred)
+    out, exited, steps_done = _nu_core(atk, images, labels, masks, target, neighbour, targeted_variant, tr, starts_fn, 1, B)
+    return (out, int(exited[0]) + 1 if exited[0] >= 0 else steps_done) if return_steps else out
 
 
 def nu_attack_rooms(atk, images, labels, masks, target, neighbour, targeted_variant=False, trace=None, starts_fn=None):
@@ -153,128 +232,26 @@ def nu_attack_rooms(atk, images, labels, masks, target, neighbour, targeted_vari
     images [R, 9, N], labels [R, N], masks [R, N] bool (None for the non-targeted variant).  Returns (adv [R, 9, N],
     steps_run [R] int64 numpy: the optimiser steps each room executed).
     """
-    net = psg_model(atk.model)
-    dev = atk.device
-    images = images.detach().to(dev).float().contiguous()
-    R, C, N = images.shape
+    R, _, N = images.shape
     if R < 2:
         raise ValueError("nu_attack_rooms advances several rooms in lockstep; call nu_attack for one room")
     if atk.steps > 50:
         raise ValueError("nu_attack_rooms: more than 50 steps would need the reference's learning-rate halving, whose state "
                          "leaks from one call into the next (target.py:123-125); call nu_attack per room")
-    labels_d = labels_to_device(labels, dev)
+    mk = None
     if masks is not None:
         mk = masks.detach().to(torch.bool).cpu().numpy() if isinstance(masks, torch.Tensor) else np.asarray(masks).astype(bool)
         if mk.shape != (R, N):
             raise ValueError("masks must be boolean [%d, %d], got shape %s" % (R, N, mk.shape))
-        mask_d = torch.from_numpy(mk.astype(np.uint8)).to(dev)
-        mask_b = mask_d.bool()
-        n_mask = mk.sum(axis=1).astype(np.float64)
-    else:
-        if targeted_variant:
-            raise ValueError("the targeted variant needs one mask per room")
-        mask_d = mask_b = None
-        n_mask = np.zeros(R)
-    model = net._packed()
-    net._generation += 1
-    ws = net._workspace(R, N, CHUNK + 1)
-    st = runtime.stream
-
-    x0 = torch.empty(R, N, 9, device=dev, dtype=torch.float32)
-    _lib.call("psg_to_point_major", runtime.ptr(images), R, 9, N, runtime.ptr(x0), st())
-    ori = x0[:, :, 3:6].contiguous()
-    x0_orig = x0.clone()
-    w = torch.empty(R, N, 3, device=dev, dtype=torch.float32)
-    _lib.call("psg_nu_inverse_tanh", runtime.ptr(x0), R, N, runtime.ptr(w), st())
-    m, v = torch.zeros_like(w), torch.zeros_like(w)
-    dlogp = torch.empty(R, N, 13, device=dev, dtype=torch.float32)
-    dx0 = torch.empty(R, N, 9, device=dev, dtype=torch.float32)
-    sgrad = torch.empty(R, N, 3, device=dev, dtype=torch.float32)
-    pred = torch.empty(R, N, device=dev, dtype=torch.int32)
-    scal = torch.zeros(3, R, device=dev, dtype=torch.float32)      # rows: f, smooth, l2
-    nn_state = torch.empty(R, N, int(neighbour), device=dev, dtype=torch.int32)   # Smooth term: last step's neighbours (start bound)
-    active_d = torch.ones(R, device=dev, dtype=torch.uint8)
-    active = np.ones(R, bool)
-    steps_run = np.zeros(R, np.int64)
-    extra_l2 = np.zeros(R)
-    prev_cost = np.full((atk.steps, R), 1e10)
-    lr, adam_t = float(atk.lr), 0
-    tsign = float(atk._targeted)
-    use_target = targeted_variant and target is not None
-    out = torch.empty_like(images)
-    planned_until = 0
-
-    def snapshot(rooms):
-        for r in rooms:
-            out[r].copy_(x0[r].t())
-
-    for step in range(atk.steps):
-        # (rooms that are done keep their w: their colours are rewritten with the same values)
-        _lib.call("psg_nu_tanh_color_rooms", runtime.ptr(w), runtime.ptr(mask_d), R, N, runtime.ptr(x0), st())
-        if step >= planned_until:
-            window_end = 1 if step == 0 else ((step - 1) // CHUNK + 1) * CHUNK + 1      # [0], [1..10], [11..20], ..
-            n_plan = min(window_end - step, atk.steps - step)
-            starts = (draw_fps_starts(R, N, n_plan) if starts_fn is None else starts_fn(step, n_plan)).to(dev)
-            ws.plan_build(x0, starts, n_plan)
-            plan_base, planned_until = step, step + n_plan
-        slot = step - plan_base
-        logp = ws.forward(model, slot, x0)
-        scal.zero_()
-        _lib.call("psg_nu_f_loss_grad_rooms", runtime.ptr(logp), None if use_target else runtime.ptr(labels_d),
-                  int(target) if use_target else 0, R, N, 13, float(atk.kappa), tsign, runtime.ptr(dlogp),
-                  runtime.ptr(scal[0]), runtime.ptr(pred), st())
-        ws.backward(model, slot, dlogp, dx0)
-        _lib.call("psg_smooth_knn_rooms", ctypes_off(x0, 3), 9, N * 9, runtime.ptr(ori), 3, N * 3, R, N, int(neighbour),
-                  runtime.ptr(scal[1]), runtime.ptr(sgrad), runtime.ptr(nn_state), 1 if step > 0 else 0, st())
-        adam_t += 1
-        _lib.call("psg_nu_adam_step_rooms", runtime.ptr(w), runtime.ptr(m), runtime.ptr(v), runtime.ptr(mask_d),
-                  runtime.ptr(dx0), runtime.ptr(x0), runtime.ptr(ori), runtime.ptr(sgrad), float(atk.c), float(atk.c),
-                  lr, BETA1, BETA2, ADAM_EPS, adam_t, R, N, runtime.ptr(active_d), runtime.ptr(scal[2]), st())
-        # ---- the reference's control flow, per room (one read-back per step for all rooms)
-        correct = pred.eq(labels_d)
-        n_correct_d = correct.sum(dim=1).float()
-        if targeted_variant:
-            tgt_hits = ((pred.eq(int(target)) if use_target else correct) & mask_b).sum(dim=1).float()
-        else:
-            tgt_hits = n_correct_d
-        stats = torch.cat([n_correct_d[None], tgt_hits[None], scal]).cpu().numpy().astype(np.float64)   # [5, R]
-        n_correct, n_tgt, f_loss, sm_loss = stats[0], stats[1], stats[2], stats[3]
-        l2_loss = stats[4] + extra_l2
-        cost = f_loss + float(atk.c) * sm_loss + float(atk.c) * l2_loss
-        prev_cost[step] = np.where(active, cost, prev_cost[step])
-        steps_run[active] += 1
-        if trace is not None:
-            trace(step=step, cost=cost, f=f_loss, smooth=sm_loss, l2=l2_loss, w=w, m=m, v=v, dx0=dx0, x0=x0, pred=pred,
-                  active=active.copy())
-        if not targeted_variant:
-            done = active & (n_correct / 4096 < 1 / 13)                     # nontarget.py:87,95-96
-        else:
-            with np.errstate(divide="ignore", invalid="ignore"):
-                target_acc = n_tgt / n_mask
-            done = active & ((target_acc > 0.9) if use_target else (target_acc < 1 / 13))   # target.py:116-121
-        if done.any():
-            snapshot(np.nonzero(done)[0])
-            active &= ~done
-            active_d.copy_(torch.from_numpy(active.astype(np.uint8)))
-            if not active.any():
-                return out, steps_run
-        if targeted_variant and step > 10 and step % 10 == 0:               # target.py:127-132, room by room
-            again = np.nonzero(active & (cost >= prev_cost[step - 10]))[0]
-            for r in again:                                                  # the noise draws stay per room, in room order
-                k = int(n_mask[r])
-                noise = torch.empty(1, 3, k, device=dev, dtype=torch.float32).uniform_(0, 1)
-                col = x0[r:r + 1, :, 3:6].transpose(1, 2)                     # view [1, 3, N]
-                col[:, :, mask_b[r]] = col[:, :, mask_b[r]] + noise
-            if len(again):
-                idx = torch.from_numpy(again).to(dev)
-                clamped = x0[idx].clamp_(min=0, max=1)                       # ALL channels, like the reference
-                x0[idx] = clamped
-                d = clamped - x0_orig[idx]
-                sums = torch.stack([(d[:, :, 0:3] ** 2).sum(dim=(1, 2)), (d[:, :, 6:9] ** 2).sum(dim=(1, 2))]).cpu().numpy()
-                extra_l2[again] = sums[0].astype(np.float64) + sums[1].astype(np.float64)   # one read-back for all rooms
-            # (xyz may have moved: the next window starts with the next step anyway - restarts only follow steps 20, 30, ..)
-    snapshot(np.nonzero(active)[0])
-    return out, steps_run
+    elif targeted_variant:
+        raise ValueError("the targeted variant needs one mask per room")
+    tr = None
+    if trace is not None:
+        def tr(step, cost, f, sm, l2, was_active, S):
+            trace(step=step, cost=cost, f=f, smooth=sm, l2=l2, w=S.w, m=S.m, v=S.v, dx0=S.dx0, x0=S.x0, pred=S.pred,
+                  active=was_active.copy())
+    out, exited, steps_done = _nu_core(atk, images, labels, mk, target, neighbour, targeted_variant, tr, starts_fn, R, 1)
+    return out, np.where(exited >= 0, exited + 1, steps_done).astype(np.int64)
 
 
 def ctypes_off(t, n_floats):

@@ -6,6 +6,8 @@
 //   PointNet/attacks/torchattacks/attacks/nontarget.py:26,34-39   NB_attack loss + update
 //   PointNet/attacks/torchattacks/attacks/target.py:27,36-43      tar_NB_attack loss + update
 //   PointNet/NB_nontarget_test_semseg.py:188-211                  acc / per-class I, U, seen
+#include <string.h>
+
 #include "psg_common.h"
 
 namespace {
@@ -640,13 +642,21 @@ __global__ __launch_bounds__(SM_T) void smooth_knn_kernel(const float *__restric
 }
 
 // Gradient assembly + torch.optim.Adam single-tensor update on w (fp32, torch's operation order).
+// Set by psg_pn2_nu_window while it enqueues the steps of a window that is (or will be) replayed as a hipGraph: the Adam
+// step and the latch of step i then read {step, lr / (1 - beta1^t), sqrt(1 - beta2^t)} from this device row instead of their
+// arguments.  Null everywhere else.
+static thread_local const float *g_nu_dconsts = nullptr;
+
 __global__ void nu_adam_step_kernel(float *__restrict__ w, float *__restrict__ m, float *__restrict__ v,
                                     const uint8_t *__restrict__ mask, const float *__restrict__ dx0,
                                     const float *__restrict__ x0, const float *__restrict__ ori,
                                     const float *__restrict__ smooth_grad, float c_smooth, float c_l2, float beta1,
                                     float beta2, float eps, float step_size, float bc2_sqrt, int N, size_t rows,
-                                    float *__restrict__ l2_sum, const uint8_t *__restrict__ room_active)
+                                    float *__restrict__ l2_sum, const uint8_t *__restrict__ room_active,
+                                    const float *__restrict__ dconsts)
 {
+    // (a replayed hipGraph cannot change kernel arguments: the step-dependent constants of a captured window come from memory)
+    if (dconsts) { step_size = dconsts[1]; bc2_sqrt = dconsts[2]; }
     // gridDim.y > 1: slice y is one room of a lockstep batch (rows = N) with its own mask row, smoothness gradient and
     // L2 sum; a room that has left its loop (room_active[y] == 0) is not touched.  gridDim.y == 1: the reference's batch
     // call (rows = B N, one mask, the smoothness gradient on batch row 0 only, one sum).
@@ -687,6 +697,89 @@ __global__ void nu_adam_step_kernel(float *__restrict__ w, float *__restrict__ m
 }
 
 }  // namespace
+
+__device__ __forceinline__ unsigned wave_reduce_add_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (unsigned)__shfl_down((int)v, o);
+    return v;            // lane 0 holds the sum
+}
+
+// ---- Per-step statistics and EXIT LATCH of the NU attacks on the device (round 4): what the reference evaluates on the
+// host after every optimiser step (nontarget.py:87,95-96 `correct / 4096 < 1 / 13`; target.py:105-121 `target_acc`
+// against 0.9 or 1 / 13) and what made the host loop wait for a read-back per step.  One workgroup per attack (a group of
+// `rows` batch rows: rows = B for one call on a batch, rows = 1 for the lockstep rooms).  It counts the correct points and
+// the target hits, files them with the step's f / Smooth / L2 sums (scal [3][G], zeroed here for the next step) into the
+// history row hist_step [5][G], and evaluates the exit test in double precision exactly as the host did; the FIRST step
+// whose test fires snapshots the group's image (x0 point-major -> out channel-major), records the step and clears the
+// group's active byte (the lockstep optimiser skips inactive rooms).  The host then only reads the history where the
+// reference itself has to touch the host: after step 0, after every 10th step (restart test + noise draw, lr halving)
+// and at the end; a group that exits at step s returns its step-s image, at most 9 later steps are speculation.
+__global__ __launch_bounds__(256) void nu_step_latch_kernel(const int32_t *__restrict__ pred, const int32_t *__restrict__ labels,
+                                                             int target, const uint8_t *__restrict__ mask,
+                                                             const int32_t *__restrict__ n_mask, int rows, int N, int mode,
+                                                             float *__restrict__ scal, float *__restrict__ hist_step,
+                                                             const float *__restrict__ x0, float *__restrict__ out,
+                                                             uint8_t *__restrict__ active, int32_t *__restrict__ exit_step, int step,
+                                                             int G, const float *__restrict__ dconsts)
+{
+    if (dconsts) step = __float_as_int(dconsts[0]);
+    __shared__ unsigned s_cnt[2];
+    __shared__ int s_exit;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    if (tid < 2) s_cnt[tid] = 0u;
+    __syncthreads();
+    const size_t base = (size_t)g * rows * N;
+    unsigned nc = 0, nt = 0;
+    for (size_t i = tid; i < (size_t)rows * N; i += blockDim.x) {
+        const int p = pred[base + i];
+        const bool ok = p == labels[base + i];
+        const bool in_mask = mask ? mask[(size_t)g * N + i % N] != 0 : true;
+        nc += ok ? 1u : 0u;
+        // mode 0: the non-targeted attack (hits = correct); 1: the targeted class's untargeted goal (correct, on the mask);
+        // 2: targeted (predicted == target, on the mask)
+        nt += (mode == 2 ? p == target : ok) && (mode == 0 || in_mask) ? 1u : 0u;
+    }
+    nc = wave_reduce_add_u32(nc);
+    nt = wave_reduce_add_u32(nt);
+    if ((tid & 63) == 0) { atomicAdd(&s_cnt[0], nc); atomicAdd(&s_cnt[1], nt); }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned n_correct = s_cnt[0], n_tgt = s_cnt[1];
+        hist_step[0 * G + g] = (float)n_correct;
+        hist_step[1 * G + g] = (float)n_tgt;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { hist_step[(2 + k) * G + g] = scal[k * G + g]; scal[k * G + g] = 0.0f; }
+        bool fire;
+        if (mode == 0) fire = (double)n_correct / 4096.0 < 1.0 / 13.0;                       // nontarget.py:87,95
+        else {
+            const double acc = (double)n_tgt / (double)n_mask[g];                            // target.py:105,113 (0 / 0 = NaN: never fires)
+            fire = mode == 2 ? acc > 0.9 : acc < 1.0 / 13.0;                                 // target.py:116-121
+        }
+        s_exit = fire && active[g] && exit_step[g] < 0 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_exit) return;
+    if (rows == 1) {                       // (a batch of rows is copied by nu_latch_snapshot_kernel, a full grid)
+        const float *src = x0 + base * 9;
+        float *dst = out + base * 9;
+        for (int i = tid; i < N * 9; i += blockDim.x) dst[(i % 9) * N + i / 9] = src[i];
+    }
+    if (tid == 0) { exit_step[g] = step; active[g] = 0; }
+}
+
+// the snapshot of a group of several batch rows whose exit test has just fired (exit_step[g] == step): x0 -> out, transposed
+__global__ void nu_latch_snapshot_kernel(const float *__restrict__ x0, float *__restrict__ out, const int32_t *__restrict__ exit_step,
+                                         int step, int rows, int N, size_t total, const float *__restrict__ dconsts)
+{
+    if (dconsts) step = __float_as_int(dconsts[0]);
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const size_t per_group = (size_t)rows * N * 9;
+    if (exit_step[t / per_group] != step) return;
+    const size_t row = t / ((size_t)N * 9), i = t % ((size_t)N * 9);       // destination element i = c * N + n of this row
+    out[t] = x0[row * N * 9 + (i % N) * 9 + i / N];
+}
 
 extern "C" int psg_nu_inverse_tanh(const float *x0, int B, int N, float *w_out, psg_stream stream)
 {
@@ -827,7 +920,7 @@ extern "C" int psg_nu_adam_step(float *w, float *m, float *v, const uint8_t *mas
     size_t rows = (size_t)B * N;
     hipLaunchKernelGGL(nu_adam_step_kernel, dim3(grid_for(rows * 3)), dim3(256), 0, (hipStream_t)stream, w, m, v, mask,
                        dx0, x0, ori, smooth_grad, c_smooth, c_l2, beta1, beta2, eps, step_size, bc2_sqrt, N, rows, l2_sum,
-                       (const uint8_t *)nullptr);
+                       (const uint8_t *)nullptr, g_nu_dconsts);
     PSG_LAUNCH_CHECK();
     return PSG_OK;
 }
@@ -844,7 +937,153 @@ extern "C" int psg_nu_adam_step_rooms(float *w, float *m, float *v, const uint8_
     // (12 workgroups per room, four elements per thread at 4096 points: 12 atomics per room sum)
     hipLaunchKernelGGL(nu_adam_step_kernel, dim3(std::min(grid_for((size_t)N * 3), 12), B), dim3(256), 0, (hipStream_t)stream, w, m, v, mask_rooms,
                        dx0, x0, ori, smooth_grad_rooms, c_smooth, c_l2, beta1, beta2, eps, step_size, bc2_sqrt, N, (size_t)N, l2_sum_rooms,
-                       room_active);
+                       room_active, g_nu_dconsts);
     PSG_LAUNCH_CHECK();
     return PSG_OK;
+}
+
+// Per-step statistics + exit latch of the NU attacks (see nu_step_latch_kernel): G attacks of `rows` batch rows each.
+// pred / labels [G*rows][N]; mask [G][N] or NULL (mode 0); n_mask [G] (modes 1, 2); scal [3][G] = this step's f, Smooth, L2
+// sums (zeroed by the call); hist_step [5][G] receives n_correct, n_hits, f, Smooth, L2; x0 [G*rows][N][9], out
+// [G*rows][9][N]; active [G] bytes, exit_step [G] (-1 until the group's exit test fires).
+extern "C" int psg_nu_step_latch(const int32_t *pred, const int32_t *labels, int target, const uint8_t *mask_groups,
+                                 const int32_t *n_mask, int G, int rows, int N, int mode, float *scal, float *hist_step,
+                                 const float *x0, float *out_cn, uint8_t *active, int32_t *exit_step, int step, psg_stream stream)
+{
+    PSG_REQUIRE(pred && labels && scal && hist_step && x0 && out_cn && active && exit_step && G > 0 && rows > 0 && N > 0,
+                "psg_nu_step_latch: null / empty argument");
+    PSG_REQUIRE(mode == 0 || (mode >= 1 && mode <= 2 && mask_groups && n_mask), "psg_nu_step_latch: modes 1 and 2 need mask and n_mask");
+    hipLaunchKernelGGL(nu_step_latch_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, pred, labels, target, mask_groups, n_mask, rows,
+                       N, mode, scal, hist_step, x0, out_cn, active, exit_step, step, G, g_nu_dconsts);
+    PSG_LAUNCH_CHECK();
+    if (rows > 1) {
+        const size_t total = (size_t)G * rows * N * 9;
+        hipLaunchKernelGGL(nu_latch_snapshot_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x0, out_cn,
+                           exit_step, step, rows, N, total, g_nu_dconsts);
+        PSG_LAUNCH_CHECK();
+    }
+    return PSG_OK;
+}
+
+// One step sequence of a window (shared by the eager and the captured path); dconsts: the step's device row or null.
+static int nu_window_steps(const psg_nu_window_args *a, const float *dconsts_rows, psg_stream stream)
+{
+    const bool rooms = a->G > 1;
+    const int B = a->G * a->rows, N = a->N, G = a->G;
+    int rc = PSG_OK;
+    for (int i = 0; i < a->n_steps && rc == PSG_OK; ++i) {
+        const int step = a->step0 + i, slot = a->slot0 + i, adam_t = a->adam_t0 + i + 1;
+        const int32_t *f_labels = a->use_target ? nullptr : a->labels;
+        const int f_target = a->use_target ? a->target : 0;
+        if ((rc = rooms ? psg_nu_tanh_color_rooms(a->w, a->mask, B, N, a->x0, stream) : psg_nu_tanh_color(a->w, a->mask, B, N, a->x0, stream)))
+            break;
+        if ((rc = psg_pn2_forward(a->model, a->ws, slot, a->x0, a->logp, nullptr, stream))) break;
+        if ((rc = rooms ? psg_nu_f_loss_grad_rooms(a->logp, f_labels, f_target, B, N, PSG_PN2_NUM_CLASSES, a->kappa, a->tsign, a->dlogp,
+                                                   a->scal, a->pred, stream)
+                        : psg_nu_f_loss_grad(a->logp, f_labels, f_target, B * N, PSG_PN2_NUM_CLASSES, a->kappa, a->tsign, a->dlogp, a->scal,
+                                             a->pred, stream)))
+            break;
+        if ((rc = psg_pn2_backward(a->model, a->ws, slot, a->dlogp, a->dx0, stream))) break;
+        if ((rc = psg_smooth_knn_rooms(a->x0 + 3, 9, (size_t)N * 9, a->ori, 3, (size_t)N * 3, G, N, a->neighbour, a->scal + G, a->sgrad,
+                                       a->nn_state, (i > 0 || a->warm_first) ? 1 : 0, stream)))
+            break;
+        g_nu_dconsts = dconsts_rows ? dconsts_rows + 4 * i : nullptr;
+        rc = rooms ? psg_nu_adam_step_rooms(a->w, a->m, a->v, a->mask, a->dx0, a->x0, a->ori, a->sgrad, a->c_smooth, a->c_l2, a->lr,
+                                            a->beta1, a->beta2, a->eps, adam_t, B, N, a->active, a->scal + 2 * G, stream)
+                   : psg_nu_adam_step(a->w, a->m, a->v, a->mask, a->dx0, a->x0, a->ori, a->sgrad, a->c_smooth, a->c_l2, a->lr, a->beta1,
+                                      a->beta2, a->eps, adam_t, B, N, a->scal + 2, stream);
+        if (rc == PSG_OK)
+            rc = psg_nu_step_latch(a->pred, a->labels, f_target, a->mode ? a->mask : nullptr, a->mode ? a->n_mask : nullptr, G, a->rows, N,
+                                   a->mode, a->scal, a->hist + (size_t)i * 5 * G, a->x0, a->out, a->active, a->exit_step, step, stream);
+        g_nu_dconsts = nullptr;
+    }
+    g_nu_dconsts = nullptr;
+    return rc;
+}
+
+// A window replayed as a hipGraph.  A one-room attack step is ~30 short launches, and the host's launch rate - not the GPU
+// - bounded the reference's one-call-per-room protocol; windows of the same shape (same buffers, same plan slots) differ only
+// in {step number, Adam bias corrections, lr}, which the captured kernels read from a device row written before each
+// replay.  The handle remembers ONE window shape: the first window of a shape runs eagerly (it also sets kernel
+// attributes outside any capture), the second is captured, later ones are replayed.
+struct psg_nu_graph {
+    hipGraphExec_t exec = nullptr;
+    psg_nu_window_args key;
+    bool have_key = false;
+    float *dconsts = nullptr;       // device [PSG_NU_GRAPH_MAX_STEPS][4]
+    float host[PSG_NU_GRAPH_MAX_STEPS * 4];
+};
+
+extern "C" int psg_nu_graph_create(psg_nu_graph **out)
+{
+    PSG_REQUIRE(out, "psg_nu_graph_create: null out pointer");
+    psg_nu_graph *g = new psg_nu_graph();
+    if (hipMalloc(&g->dconsts, sizeof(g->host)) != hipSuccess) { delete g; psg::set_error("psg_nu_graph_create: hipMalloc failed"); return PSG_ERR_HIP; }
+    *out = g;
+    return PSG_OK;
+}
+
+extern "C" int psg_nu_graph_destroy(psg_nu_graph *g)
+{
+    if (!g) return PSG_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    (void)hipFree(g->dconsts);
+    delete g;
+    return PSG_OK;
+}
+
+static bool nu_same_shape(psg_nu_window_args x, psg_nu_window_args y)
+{
+    x.step0 = y.step0 = 0; x.adam_t0 = y.adam_t0 = 0; x.lr = y.lr = 0.0f;      // what the device row carries
+    return memcmp(&x, &y, sizeof(x)) == 0;
+}
+
+extern "C" int psg_pn2_nu_window(const psg_nu_window_args *a, psg_nu_graph *graph, psg_stream stream)
+{
+    PSG_REQUIRE(a && a->model && a->ws && a->w && a->m && a->v && a->x0 && a->ori && a->labels && a->logp && a->dlogp && a->dx0 &&
+                    a->sgrad && a->pred && a->scal && a->nn_state && a->hist && a->out && a->active && a->exit_step,
+                "psg_pn2_nu_window: null argument");
+    PSG_REQUIRE(a->n_steps > 0 && a->G > 0 && a->rows > 0 && (a->G == 1 || a->rows == 1), "psg_pn2_nu_window: (G, rows) must be (1, B) or (R, 1)");
+    hipStream_t st = (hipStream_t)stream;
+    if (!graph || a->n_steps > PSG_NU_GRAPH_MAX_STEPS || psg::trace_sync_enabled()) return nu_window_steps(a, nullptr, stream);
+    // the step-dependent constants of this window (torch.optim.Adam: step_size = lr / (1 - beta1^t), sqrt(1 - beta2^t))
+    for (int i = 0; i < a->n_steps; ++i) {
+        const int t = a->adam_t0 + i + 1;
+        const double bc1 = 1.0 - pow((double)a->beta1, (double)t), bc2 = 1.0 - pow((double)a->beta2, (double)t);
+        graph->host[4 * i] = __builtin_bit_cast(float, a->step0 + i);
+        graph->host[4 * i + 1] = (float)((double)a->lr / bc1);
+        graph->host[4 * i + 2] = (float)sqrt(bc2);
+        graph->host[4 * i + 3] = 0.0f;
+    }
+    PSG_CHECK_HIP(hipMemcpyAsync(graph->dconsts, graph->host, (size_t)a->n_steps * 16, hipMemcpyHostToDevice, st));
+    if (graph->exec && nu_same_shape(graph->key, *a)) {
+        PSG_CHECK_HIP(hipGraphLaunch(graph->exec, st));
+        return PSG_OK;
+    }
+    if (graph->have_key && nu_same_shape(graph->key, *a) && !graph->exec) {
+        // second window of this shape: capture it, then replay
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int crc = nu_window_steps(a, graph->dconsts, stream);
+            hipGraph_t gr = nullptr;
+            const hipError_t e = hipStreamEndCapture(st, &gr);
+            if (crc == PSG_OK && e == hipSuccess && gr && hipGraphInstantiate(&graph->exec, gr, nullptr, nullptr, 0) != hipSuccess)
+                graph->exec = nullptr;
+            if (gr) (void)hipGraphDestroy(gr);
+            if (crc != PSG_OK) return crc;
+        }
+        (void)hipGetLastError();        // a refused capture (legacy default stream) is not an error of this call
+        if (graph->exec) {
+            PSG_CHECK_HIP(hipGraphLaunch(graph->exec, st));
+            return PSG_OK;
+        }
+        return nu_window_steps(a, graph->dconsts, stream);
+    }
+    if (graph->exec) {                  // another shape: forget the old one
+        PSG_CHECK_HIP(hipStreamSynchronize(st));
+        (void)hipGraphExecDestroy(graph->exec);
+        graph->exec = nullptr;
+    }
+    graph->key = *a;
+    graph->have_key = true;
+    return nu_window_steps(a, graph->dconsts, stream);
 }

@@ -659,12 +659,13 @@ int launch_edge_max_bwd(const float *dy, int ld_dy, const int32_t *nbr, const ui
         const int chunks = ceil_div(N, EBG_D);
         hipLaunchKernelGGL(edge_max_bwd_gather_kernel, dim3((unsigned)((R / N) * chunks)), dim3(EBG_T), 0, st, dy, ld_dy, nbr, arg,
                            scale, dpq, N, chunks);
+        PSG_LAUNCH_CHECK();
     } else {
         PSG_CHECK_HIP(hipMemsetAsync(dpq, 0, R * 2 * GC * 4, st));
         hipLaunchKernelGGL(edge_max_bwd_kernel, dim3(ceil_div((int)(R * GC), 256)), dim3(256), 0, st, dy, ld_dy, nbr, arg, scale, dpq,
                            N, R * GC, (float *)nullptr);
+        PSG_LAUNCH_CHECK();
     }
-    PSG_LAUNCH_CHECK();
     return PSG_OK;
 }
 

@@ -543,3 +543,64 @@ def test_smooth_knn_kernel_vs_oracle_and_across_launch_shapes(n, nb):
         _lib.call("psg_smooth_knn_rooms", runtime.ptr(dev(moved)), 3, n * 3, runtime.ptr(d_ref), 3, n * 3, rooms, n, nb, None,
                   runtime.ptr(warm), runtime.ptr(st_in), 1, st())
         assert torch.equal(warm, cold), label
+
+
+def test_nu_windows_without_host_sync_equal_the_per_step_loop(weights_sd):
+    """Round 4: without a trace callback the steps of a geometry window run in ONE call (psg_pn2_nu_window: statistics and
+    the exit latch on the device, full windows replayed as a hipGraph) and the host only looks after step 0 and every 10th
+    step.  The result must be what the per-step loop (trace given: one read-back per step, no graph) returns: bit-equal
+    images and the same number of optimiser steps per room - for rooms in lockstep and for one call per room, over 34
+    steps (the windows [1..10] eager, [11..20] captured, [21..30] replayed, [31..33] eager; restarts at steps 20 and 30),
+    and again on a second call that replays from its first full window on."""
+    from pointsecguard_amd.attacks import torchattacks
+    from pointsecguard_amd.attacks.torchattacks.attacks import nu as nu_mod
+    R, steps, target = 3, 34, 6
+    net, rooms, labels, images = _rooms_case(weights_sd, R, 9300)
+    masks = labels == 2
+    rng = np.random.default_rng(23)
+    table = torch.from_numpy(np.stack([rng.integers(0, n, (steps, R)) for n in (4096, 1024, 256, 64)], axis=1).astype(np.int32))
+
+    def starts_for(lo, hi):
+        return lambda step, n_plan: table[step:step + n_plan, :, lo:hi].contiguous()
+
+    def rooms_run(trace):
+        atk = torchattacks.tar_NU_attack(net, c=1, kappa=0, steps=steps, lr=0.01, target=target, mask=None)
+        torch.manual_seed(5)
+        adv, n = nu_mod.nu_attack_rooms(atk, images, labels.astype(np.float64), masks, target, 5, targeted_variant=True, trace=trace,
+                                        starts_fn=starts_for(0, R))
+        torch.cuda.synchronize()
+        return adv.cpu().numpy(), n
+
+    ref, n_ref = rooms_run(lambda **kw: None)
+    for _ in range(2):                                   # second pass: the graph captured by the first is replayed
+        got, n_got = rooms_run(None)
+        assert np.array_equal(n_ref, n_got), (n_ref, n_got)
+        assert np.array_equal(ref.view(np.uint32), got.view(np.uint32))
+
+    def single_run(r, trace):
+        atk = torchattacks.tar_NU_attack(net, c=1, kappa=0, steps=steps, lr=0.01, target=target, mask=masks[r])
+        torch.manual_seed(100 + r)
+        adv = nu_mod.nu_attack(atk, images[r:r + 1], labels[r:r + 1].astype(np.float64), masks[r], target, 5, targeted_variant=True,
+                               trace=trace, starts_fn=starts_for(r, r + 1))
+        torch.cuda.synchronize()
+        return adv.cpu().numpy()
+
+    for r in range(R):
+        a = single_run(r, lambda **kw: None)
+        b = single_run(r, None)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), r
+        assert np.array_equal(a[0], ref[r]), r                     # and one call per room == the room in lockstep
+
+
+def test_tar_nu_empty_mask_raises_like_the_reference(weights_sd):
+    """target.py:104-105 divides the hits by the mask count: an empty mask is a ZeroDivisionError there, and here."""
+    from pointsecguard_amd.attacks import torchattacks
+    from pointsecguard_amd.attacks.torchattacks.attacks import nu as nu_mod
+    net, rooms, labels, images = _rooms_case(weights_sd, 2, 9400)
+    masks = np.zeros_like(labels, dtype=bool)
+    masks[0, :100] = True
+    atk = torchattacks.tar_NU_attack(net, c=1, kappa=0, steps=3, lr=0.01, target=6, mask=None)
+    with pytest.raises(ZeroDivisionError):
+        nu_mod.nu_attack_rooms(atk, images, labels.astype(np.float64), masks, 6, 5, targeted_variant=True)
+    with pytest.raises(ZeroDivisionError):
+        nu_mod.nu_attack(atk, images[1:2], labels[1:2].astype(np.float64), masks[1], 6, 5, targeted_variant=True)
