@@ -792,16 +792,28 @@ __global__ void colper_grad_kernel(const float *__restrict__ z, const int32_t *_
 }
 
 // BIM update of the colours (bim.py:84-98), goal 'ut' (ascent).  l_inf: clip(adv + alpha*sign(g), x-eps, x+eps);
-// l_2: x + clip_by_norm(adv - x + alpha * g/|g|, eps); then clip to [0, 1].  norms[0] = |g|^2, norms[1] = |delta|^2.
-__global__ void sq_norm_kernel(const float *__restrict__ a, int ld, int c0, size_t n, float *__restrict__ out)
+// l_2: x + clip_by_norm(adv - x + alpha * g/|g|, eps); then clip to [0, 1], PER CLOUD: norms[b] = |g_b|^2,
+// norms[B + b] = |delta_b|^2 for the B clouds of a cloud-batch workspace.
+// squared norm of the colour part of ONE CLOUD per workgroup (blockIdx.x = cloud): every thread adds its strided elements in
+// double, then a fixed tree - one writer, a fixed order: the l_2 update is bit-reproducible (the atomic sum it replaces was
+// reproducible to rounding only) and a cloud-batch workspace gets one norm per cloud, as bim.py:84-98 normalises per sample.
+__global__ __launch_bounds__(1024) void sq_norm_kernel(const float *__restrict__ a, int ld, int c0, size_t nc, float *__restrict__ out)
 {
-    float s = 0.0f;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * 3; t += (size_t)gridDim.x * blockDim.x) {
-        const float v = a[(t / 3) * ld + c0 + (t % 3)];
-        s += v * v;
+    __shared__ double s_part[16];
+    const float *p = a + (size_t)blockIdx.x * nc * ld;
+    double s = 0.0;
+    for (size_t t = threadIdx.x; t < nc * 3; t += blockDim.x) {
+        const float v = p[(t / 3) * ld + c0 + (t % 3)];
+        s += (double)v * (double)v;
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_part[w];
+        out[blockIdx.x] = (float)tot;
+    }
 }
 
 __global__ void bim_linf_kernel(float *__restrict__ feat, const float *__restrict__ dfeat, const float *__restrict__ ori, size_t n,
@@ -819,24 +831,24 @@ __global__ void bim_linf_kernel(float *__restrict__ feat, const float *__restric
 }
 
 __global__ void bim_l2_delta_kernel(const float *__restrict__ feat, const float *__restrict__ dfeat, const float *__restrict__ ori,
-                                    size_t n, float alpha, const float *__restrict__ gnorm2, float *__restrict__ delta)
+                                    size_t n, size_t nc, float alpha, const float *__restrict__ gnorm2, float *__restrict__ delta)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * 3) return;
     const size_t i = t / 3;
     const int c = (int)(t % 3);
-    const float gn = fmaxf(1e-12f, sqrtf(gnorm2[0]));
+    const float gn = fmaxf(1e-12f, sqrtf(gnorm2[i / nc]));            // the cloud's own gradient norm
     delta[t] = feat[i * 6 + 3 + c] - ori[t] + alpha * (dfeat[i * 6 + 3 + c] / gn);
 }
 
 __global__ void bim_l2_apply_kernel(float *__restrict__ feat, const float *__restrict__ ori, const float *__restrict__ delta, size_t n,
-                                    float eps, const float *__restrict__ dnorm2)
+                                    size_t nc, float eps, const float *__restrict__ dnorm2)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * 3) return;
     const size_t i = t / 3;
     const int c = (int)(t % 3);
-    const float dn = sqrtf(dnorm2[0]);
+    const float dn = sqrtf(dnorm2[i / nc]);
     const float scale = dn > eps ? eps / dn : 1.0f;
     feat[i * 6 + 3 + c] = fminf(fmaxf(ori[t] + delta[t] * scale, 0.0f), 1.0f);
 }
@@ -900,7 +912,7 @@ struct psg_rla_ws {
     float *scratch_a, *scratch_b;   // [max edges * d] gradient scratch (dcat / ds), also decoder d_cat
     float *d_f0, *d_dec0, *d_dec_out[RL], *d_fc1o, *d_fc2o;
     char *acc = nullptr; size_t acc_bytes = 0;   // the contiguous block of gradient accumulators
-    float *feat, *dfeat, *ori, *delta, *norms;   // attack state: [N][6], [N][6], [N][3], [N][3], [4]
+    float *feat, *dfeat, *ori, *delta, *norms;   // attack state: [N][6], [N][6], [N][3], [N][3], [2][B] (l_2: squared gradient / delta norm per cloud)
     int32_t *labels;
     bool cloud_set = false, have_fwd = false;
     bool fuse16 = true;           // PSG_RLA_NO_FUSE16=1: the unfused chain at level 0 too (A/B runs, tests)
@@ -1093,7 +1105,7 @@ extern "C" int psg_rla_ws_create_batch(psg_ctx *ctx, int n_points, int batch, ps
         ws->acc_bytes = off - acc_begin;
         ws->d_fc1o = (float *)take(N * 64 * 4); ws->d_fc2o = (float *)take(N * 32 * 4);
         ws->feat = (float *)take(N * 6 * 4); ws->dfeat = (float *)take(N * 6 * 4); ws->ori = (float *)take(N * 3 * 4);
-        ws->delta = (float *)take(N * 3 * 4); ws->norms = (float *)take(4 * 4); ws->labels = (int32_t *)take(N * 4);
+        ws->delta = (float *)take(N * 3 * 4); ws->norms = (float *)take((size_t)(2 * batch > 4 ? 2 * batch : 4) * 4); ws->labels = (int32_t *)take(N * 4);
         if (!pass) {
             ws->bytes = (off + 255) & ~(size_t)255;
             hipError_t e = hipMalloc(&ws->arena, ws->bytes);
@@ -1538,14 +1550,13 @@ extern "C" int psg_rla_bim_step(float *feat, const float *dfeat, const float *or
         PSG_LAUNCH_CHECK();
         return PSG_OK;
     }
-    PSG_CHECK_HIP(hipMemsetAsync(norms, 0, 8, st));
-    hipLaunchKernelGGL(sq_norm_kernel, dim3(256), dim3(256), 0, st, dfeat, 6, 3, N, norms);
+    hipLaunchKernelGGL(sq_norm_kernel, dim3(1), dim3(1024), 0, st, dfeat, 6, 3, N, norms);
     PSG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bim_l2_delta_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, feat, dfeat, ori, N, alpha, norms, delta);
+    hipLaunchKernelGGL(bim_l2_delta_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, feat, dfeat, ori, N, N, alpha, norms, delta);
     PSG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sq_norm_kernel, dim3(256), dim3(256), 0, st, delta, 3, 0, N, norms + 1);
+    hipLaunchKernelGGL(sq_norm_kernel, dim3(1), dim3(1024), 0, st, delta, 3, 0, N, norms + 1);
     PSG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bim_l2_apply_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, feat, ori, delta, N, eps, norms + 1);
+    hipLaunchKernelGGL(bim_l2_apply_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, feat, ori, delta, N, N, eps, norms + 1);
     PSG_LAUNCH_CHECK();
     return PSG_OK;
 }
@@ -1629,7 +1640,6 @@ extern "C" int psg_rla_bim_attack(psg_rla_model *m, psg_rla_ws *ws, const float 
                                   float alpha, int iters, int l2_metric, float *adv_features_out, psg_stream stream)
 {
     PSG_REQUIRE(m && ws && features && labels && adv_features_out && iters > 0, "psg_rla_bim_attack: bad argument");
-    PSG_REQUIRE(ws->B == 1 || !l2_metric, "psg_rla_bim_attack: the l_2 metric normalises per cloud; use one cloud per workspace (batch=%d)", ws->B);
     ProfBind bind(ws);
     hipStream_t st = (hipStream_t)stream;
     const size_t N = ws->N;
@@ -1650,16 +1660,17 @@ extern "C" int psg_rla_bim_attack(psg_rla_model *m, psg_rla_ws *ws, const float 
             hipLaunchKernelGGL(bim_linf_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, ws->feat, ws->dfeat, ws->ori, N, alpha, eps);
             PSG_LAUNCH_CHECK();
         } else {
-            PSG_CHECK_HIP(hipMemsetAsync(ws->norms, 0, 16, st));
-            hipLaunchKernelGGL(sq_norm_kernel, dim3(256), dim3(256), 0, st, ws->dfeat, 6, 3, N, ws->norms);
+            // per cloud (bim.py:84-98 normalises every sample of the batch by its own norms): norms [2][B]
+            const size_t Nc = (size_t)ws->Nc;
+            hipLaunchKernelGGL(sq_norm_kernel, dim3(ws->B), dim3(1024), 0, st, ws->dfeat, 6, 3, Nc, ws->norms);
             PSG_LAUNCH_CHECK();
-            hipLaunchKernelGGL(bim_l2_delta_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, ws->feat, ws->dfeat, ws->ori, N, alpha,
+            hipLaunchKernelGGL(bim_l2_delta_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, ws->feat, ws->dfeat, ws->ori, N, Nc, alpha,
                                ws->norms, ws->delta);
             PSG_LAUNCH_CHECK();
-            hipLaunchKernelGGL(sq_norm_kernel, dim3(256), dim3(256), 0, st, ws->delta, 3, 0, N, ws->norms + 1);
+            hipLaunchKernelGGL(sq_norm_kernel, dim3(ws->B), dim3(1024), 0, st, ws->delta, 3, 0, Nc, ws->norms + ws->B);
             PSG_LAUNCH_CHECK();
-            hipLaunchKernelGGL(bim_l2_apply_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, ws->feat, ws->ori, ws->delta, N, eps,
-                               ws->norms + 1);
+            hipLaunchKernelGGL(bim_l2_apply_kernel, dim3(blocks_for(N * 3)), dim3(256), 0, st, ws->feat, ws->ori, ws->delta, N, Nc, eps,
+                               ws->norms + ws->B);
             PSG_LAUNCH_CHECK();
         }
         return PSG_OK;

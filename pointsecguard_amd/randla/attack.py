@@ -24,10 +24,8 @@ class BIM:
             raise TypeError("model must be a pointsecguard_amd.randla.network.RandLAModel")
         if goal != "ut" or distance_metric not in ("l_inf", "l_2") or iteration_callback is not None:
             raise NotImplementedError("BIM / NBattack: goal='ut', l_inf / l_2 (the targeted attack is TBIM / tar_NBattack)")
-        if batch_size < 1 or (batch_size > 1 and distance_metric != "l_inf"):
-            raise NotImplementedError("batch_size > 1 (clouds attacked together in one cloud-batch workspace) is implemented "
-                                      "for l_inf; the l_2 step normalises per cloud: use batch_size=1 "
-                                      "(ConfigS3DIS.val_batch_size)")
+        if batch_size < 1:
+            raise ValueError("batch_size must be positive")
         self.model, self.distance_metric, self.batch_size = model, distance_metric, batch_size
         self.eps = self.alpha = None
         self.iteration = None

@@ -168,8 +168,9 @@ def test_gpu_cloud_batch_equals_single_clouds(cloud):
     """A workspace of 3 clouds (psg_rla_ws_create_batch: one launch of every kernel serves all of them) against three
     one-cloud workspaces: the index pyramids are the per-cloud ones shifted by the cloud's row offset, logits agree to
     fp32 rounding (row-wise kernels, no cross-row arithmetic; the GEMM tile shape, hence the summation order, is chosen
-    by the row count), colour gradients to float-atomic order, and the l_inf attack (sign steps) ends within the same
-    eps ball with >= 98 % of the entries identical."""
+    by the row count), colour gradients to float-atomic order, the l_inf attack (sign steps) ends within the same
+    eps ball with >= 98 % of the entries identical, and the l_2 attack (round 4: norms per cloud) moves every cloud as it
+    moves alone, bit-reproducibly."""
     import torch
     from pointsecguard_amd.randla import network
     xyz, rgb, labels, _ = cloud
@@ -187,6 +188,11 @@ def test_gpu_cloud_batch_equals_single_clouds(cloud):
     _, dl_b = network.colper_grad(logits_b, lab_b)
     g_b = wsb.backward(model, dl_b).cpu().numpy()
     adv_b = wsb.bim_attack(model, feats_b, lab_b, 0.08, 0.02, 3).cpu().numpy()
+    # l_2 (what the reference's tester selects, tester_S3DIS.py:37): every cloud is normalised by ITS OWN gradient / delta norm
+    eps2, alpha2 = 3.0, 1.2
+    adv2_b = wsb.bim_attack(model, feats_b, lab_b, eps2, alpha2, 3, metric="l_2").cpu().numpy()
+    adv2_again = wsb.bim_attack(model, feats_b, lab_b, eps2, alpha2, 3, metric="l_2").cpu().numpy()
+    assert np.array_equal(adv2_b.view(np.uint32), adv2_again.view(np.uint32))          # fixed-order norms: bit-reproducible
     idx_b = [[wsb.index(w, l).cpu().numpy() for l in range(5)] for w in (0, 1)]
     # no cross-talk: new colours in the LAST cloud leave the other clouds' logits bit-identical (same launch shapes)
     feats_c = feats_b.clone()
@@ -215,14 +221,23 @@ def test_gpu_cloud_batch_equals_single_clouds(cloud):
         part = adv_b[b * N:(b + 1) * N]
         assert np.array_equal(part[:, :3], xyzs[b]) and np.abs(part[:, 3:] - rgbs[b]).max() <= 0.08 + 1e-6
         assert (part == adv1).mean() >= 0.98           # (sign flips of near-zero gradient entries, compounding over 3 steps)
+        # l_2: the cloud inside the batch moves like the cloud alone (its own norms), inside its own eps ball
+        adv2_1 = ws1.bim_attack(model, f1, y1, eps2, alpha2, 3, metric="l_2").cpu().numpy()
+        part2 = adv2_b[b * N:(b + 1) * N]
+        d_b, d_1 = part2[:, 3:] - rgbs[b], adv2_1[:, 3:] - rgbs[b]
+        assert np.array_equal(part2[:, :3], xyzs[b]) and np.linalg.norm(d_b.astype(np.float64)) <= eps2 * (1 + 1e-5)
+        assert np.linalg.norm(d_b.astype(np.float64)) >= 0.5 * min(eps2, alpha2)        # it did move
+        assert np.linalg.norm((d_b - d_1).astype(np.float64)) <= 0.02 * np.linalg.norm(d_1.astype(np.float64))
     # the BIM class with the reference's batch_size argument drives the same cloud-batch workspace
     from pointsecguard_amd.randla import attack
     atk = attack.BIM(model, B, "colper", "ut", "l_inf")
     atk.config(magnitude=0.08, alpha=0.02, iteration=2)   # bim.py:204-232: one update before the loop -> 3 updates like adv_b
     rgb_b = atk.batch_attack(feats_b.reshape(B, N, 6), lab_b.reshape(B, N))
     assert tuple(rgb_b.shape) == (B, N, 3) and (rgb_b.reshape(-1, 3).cpu().numpy() == adv_b[:, 3:]).mean() >= 0.98
-    with pytest.raises(NotImplementedError):
-        attack.BIM(model, B, "colper", "ut", "l_2")
+    atk2 = attack.BIM(model, B, "colper", "ut", "l_2")           # the tester's metric in the cloud-batch workspace
+    atk2.config(magnitude=eps2, alpha=alpha2, iteration=2)
+    rgb2_b = atk2.batch_attack(feats_b.reshape(B, N, 6), lab_b.reshape(B, N))
+    assert np.array_equal(rgb2_b.reshape(-1, 3).cpu().numpy().view(np.uint32), adv2_b[:, 3:].copy().view(np.uint32))
 
 
 @pytest.mark.gpu
