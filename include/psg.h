@@ -498,8 +498,8 @@ int psg_rla_sampler_create(psg_ctx *ctx, const float *points_host, const double 
                            psg_rla_sampler **out);
 int psg_rla_sampler_destroy(psg_rla_sampler *s);
 int psg_rla_sampler_argmin(psg_rla_sampler *s, int *index_out, double *value_out, psg_stream stream);
-int psg_rla_sampler_query(psg_rla_sampler *s, const float *pick_host3, int k, int32_t *out_idx, psg_stream stream);
-int psg_rla_sampler_update(psg_rla_sampler *s, const int32_t *idx, int k, const float *pick_host3, float *scratch, psg_stream stream);
+int psg_rla_sampler_query(psg_rla_sampler *s, const double *pick_host3, int k, int32_t *out_idx, psg_stream stream);
+int psg_rla_sampler_update(psg_rla_sampler *s, const int32_t *idx, int k, const double *pick_host3, float *scratch, psg_stream stream);
 int psg_rla_sampler_possibility(psg_rla_sampler *s, double *host_out);
 
 typedef struct psg_rla_model psg_rla_model;

@@ -90,12 +90,14 @@ class CropSamplerOracle:
     def next_crop(self):
         cloud_idx = int(np.argmin(self.min_possibility))
         point_ind = np.argmin(self.possibility[cloud_idx])
-        points = self.points[cloud_idx]
+        # main_S3DIS.py:141: `points` is the sklearn KDTree's copy of the cloud, which is float64 (tests/test_randla_sampler.py
+        # checks that against sklearn itself): centre, jitter, pick point and the differences below are float64
+        points = self.points[cloud_idx].astype(np.float64)
         center_point = points[point_ind, :].reshape(1, -1)
         noise = np.random.normal(scale=self.noise_init / 10, size=center_point.shape)
         pick_point = center_point + noise.astype(center_point.dtype)
         k = min(len(points), self.num_points)
-        d = points.astype(np.float64) - pick_point.astype(np.float64)
+        d = points - pick_point
         d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
         queried_idx = np.argsort(d2, kind="stable")[:k]
         idx = np.arange(len(queried_idx))

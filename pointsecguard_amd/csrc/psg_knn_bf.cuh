@@ -375,6 +375,7 @@ __device__ __noinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFinalA
     const float4 *xp4 = (const float4 *)a.xp;
     const float4 *q4 = (const float4 *)qbuf;
     const unsigned long long m44 = (1ull << 44) - 1ull;
+    bool bound_broken = false;
     for (unsigned f0 = 0; f0 < Fmax; f0 += 32) {
         const unsigned f = f0 + (unsigned)l5;
         const unsigned ent = f < F ? (unsigned)fin[f] : 0u;
@@ -408,7 +409,14 @@ __device__ __noinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFinalA
         // (|x_i|^2 + (-2 x_i.x_j)) + |x_j|^2, torch_edge.py:41-43, as in the exact kernel
         const float dd = __fadd_rn(__fmaf_rn(-2.0f, z, sq), sqj);
         if (f < F) fin[f] = tag | ((unsigned long long)key_of(dd) << 12) | (unsigned long long)idx;
+        // The bound everything above rests on, L <= D <= L + 2 e_ij, assumes how the bf16 MFMA rounds internally (measured,
+        // not documented).  Both sides are in registers here, so it is CHECKED for every finalist: the exact distance in key
+        // units must lie in [key - 2, key + margin] (2 = the key's own rounding); a violation (or a NaN) sends the tile to the
+        // exact path like any other failure, instead of ranking on a bound that did not hold.
+        const float dk = __fmaf_rn(dd, inv_unit, KB_OFF), kf = (float)(ent >> 12);
+        bound_broken |= f < F && !(dk >= kf - 2.0f && dk <= kf + (float)margin + 1.0f);
     }
+    if (__ballot(bound_broken) != 0ull) return 0xFFFFFFFFu;
     wave_lds_fence();
     KB_PH(11);
     int32_t *out = a.out + (size_t)(h * KB_WAVES) * a.k;

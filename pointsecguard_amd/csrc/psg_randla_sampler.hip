@@ -6,7 +6,8 @@
 // possibility of the points it took by (1 - d / max d)^2 (d in float32).  The tree query of 40 960 neighbours out of a few
 // hundred thousand points is the expensive part; on the device it is a distance pass + one radix sort.
 //
-// Device side (one sampler object per cloud): points [M][3] f32 and possibility [M] f64 resident; argmin = two atomic
+// Device side (one sampler object per cloud): points [M][3] f32 (the tree holds their exact float64 promotion; the pick
+// point - a tree point plus float64 noise - is float64 and is passed as such) and possibility [M] f64 resident; argmin = two atomic
 // passes (the value, then the lowest index that holds it: np.argmin's first-index rule); query = float64 squared
 // distances in the tree's arithmetic (data and query promoted to double, (dx^2 + dy^2) + dz^2), their bit patterns as
 // sort keys (non-negative doubles order like their bits), stable hipcub radix sort -> ascending (distance, index), the
@@ -69,15 +70,18 @@ __global__ void min_index_kernel(const double *__restrict__ p, int n, const unsi
     if (i < n && (unsigned long long)__double_as_longlong(p[i]) == bits[0]) atomicMin(out, i);
 }
 
-// float32 distances of the taken points in the reference's arithmetic (main_S3DIS.py:163): ((dx^2 + dy^2) + dz^2) on
-// float32 differences; their maximum through ordered bits (non-negative floats)
-__global__ void upd_max_kernel(const float *__restrict__ pts, const int32_t *__restrict__ idx, int k, float px, float py, float pz,
+// float32 distances of the taken points in the reference's arithmetic (main_S3DIS.py:163): the points are the KDTree's
+// float64 copy of the cloud and the pick point is float64, so the DIFFERENCE is taken in float64 and then rounded to
+// float32 (`(points[idx] - pick_point).astype(np.float32)`), squared and summed ((dx^2 + dy^2) + dz^2) in float32; their
+// maximum through ordered bits (non-negative floats)
+__global__ void upd_max_kernel(const float *__restrict__ pts, const int32_t *__restrict__ idx, int k, double px, double py, double pz,
                                float *__restrict__ d_out, unsigned *__restrict__ dmax_bits)
 {
     float mx = 0.0f;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < k; j += gridDim.x * blockDim.x) {
         const int i = idx[j];
-        const float dx = __fsub_rn(pts[3 * i], px), dy = __fsub_rn(pts[3 * i + 1], py), dz = __fsub_rn(pts[3 * i + 2], pz);
+        const float dx = (float)__dsub_rn((double)pts[3 * i], px), dy = (float)__dsub_rn((double)pts[3 * i + 1], py),
+                    dz = (float)__dsub_rn((double)pts[3 * i + 2], pz);
         const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
         d_out[j] = d;
         mx = fmaxf(mx, d);
@@ -97,10 +101,13 @@ __global__ void upd_apply_kernel(const int32_t *__restrict__ idx, const float *_
 
 }  // namespace
 
+extern "C" int psg_rla_sampler_destroy(psg_rla_sampler *s);
+
 extern "C" int psg_rla_sampler_create(psg_ctx *ctx, const float *points_host, const double *possibility_host, int n_points,
                                       psg_rla_sampler **out)
 {
     PSG_REQUIRE(ctx && points_host && possibility_host && out && n_points > 0, "psg_rla_sampler_create: bad argument");
+    PSG_CHECK_HIP(hipSetDevice(ctx->device));
     psg_rla_sampler *s = new psg_rla_sampler();
     s->ctx = ctx; s->M = n_points;
     const size_t M = (size_t)n_points;
@@ -120,11 +127,19 @@ extern "C" int psg_rla_sampler_create(psg_ctx *ctx, const float *points_host, co
             return PSG_ERR_HIP;
         }
     }
-    PSG_CHECK_HIP(hipMemcpy(s->pts, points_host, M * 12, hipMemcpyHostToDevice));
-    PSG_CHECK_HIP(hipMemcpy(s->poss, possibility_host, M * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(iota_kernel, dim3((n_points + 255) / 256), dim3(256), 0, 0, s->iota, n_points);
-    PSG_LAUNCH_CHECK();
-    PSG_CHECK_HIP(hipDeviceSynchronize());
+    // (from here on a failure releases the sampler and its buffers)
+    hipError_t e = hipMemcpy(s->pts, points_host, M * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->poss, possibility_host, M * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(iota_kernel, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)0, s->iota, n_points);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        set_error("psg_rla_sampler_create: %s", hipGetErrorString(e));
+        (void)psg_rla_sampler_destroy(s);
+        return PSG_ERR_HIP;
+    }
     *out = s;
     return PSG_OK;
 }
@@ -142,6 +157,7 @@ extern "C" int psg_rla_sampler_destroy(psg_rla_sampler *s)
 extern "C" int psg_rla_sampler_argmin(psg_rla_sampler *s, int *index_out, double *value_out, psg_stream stream)
 {
     PSG_REQUIRE(s && index_out && value_out, "psg_rla_sampler_argmin: null argument");
+    PSG_CHECK_HIP(hipSetDevice(s->ctx->device));
     hipStream_t st = (hipStream_t)stream;
     PSG_CHECK_HIP(hipMemsetAsync(s->min_bits, 0xFF, 8, st));
     PSG_CHECK_HIP(hipMemsetAsync(s->min_idx, 0x7F, 4, st));
@@ -160,12 +176,13 @@ extern "C" int psg_rla_sampler_argmin(psg_rla_sampler *s, int *index_out, double
 }
 
 // the k points nearest to `pick` (KDTree.query(pick, k)[1][0]): out_idx [k] device, ascending (float64 distance, index)
-extern "C" int psg_rla_sampler_query(psg_rla_sampler *s, const float *pick_host3, int k, int32_t *out_idx, psg_stream stream)
+extern "C" int psg_rla_sampler_query(psg_rla_sampler *s, const double *pick_host3, int k, int32_t *out_idx, psg_stream stream)
 {
     PSG_REQUIRE(s && pick_host3 && out_idx && k > 0 && k <= s->M, "psg_rla_sampler_query: k=%d outside [1, %d]", k, s ? s->M : 0);
+    PSG_CHECK_HIP(hipSetDevice(s->ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(dist_keys_kernel, dim3((s->M + 255) / 256), dim3(256), 0, st, s->pts, s->M, (double)pick_host3[0],
-                       (double)pick_host3[1], (double)pick_host3[2], s->keys);
+    hipLaunchKernelGGL(dist_keys_kernel, dim3((s->M + 255) / 256), dim3(256), 0, st, s->pts, s->M, pick_host3[0], pick_host3[1],
+                       pick_host3[2], s->keys);
     PSG_LAUNCH_CHECK();
     size_t tb = s->tmp_bytes;
     PSG_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(s->tmp, tb, s->keys, s->keys_sorted, s->iota, s->order, s->M, 0, 64, st));
@@ -174,10 +191,11 @@ extern "C" int psg_rla_sampler_query(psg_rla_sampler *s, const float *pick_host3
 }
 
 // possibility[idx] += (1 - d / max d)^2 for the k taken points (main_S3DIS.py:163-165); idx [k] device, scratch [k] floats
-extern "C" int psg_rla_sampler_update(psg_rla_sampler *s, const int32_t *idx, int k, const float *pick_host3, float *scratch,
+extern "C" int psg_rla_sampler_update(psg_rla_sampler *s, const int32_t *idx, int k, const double *pick_host3, float *scratch,
                                       psg_stream stream)
 {
     PSG_REQUIRE(s && idx && pick_host3 && scratch && k > 0, "psg_rla_sampler_update: bad argument");
+    PSG_CHECK_HIP(hipSetDevice(s->ctx->device));
     hipStream_t st = (hipStream_t)stream;
     PSG_CHECK_HIP(hipMemsetAsync(s->dmax, 0, 4, st));
     hipLaunchKernelGGL(upd_max_kernel, dim3(128), dim3(256), 0, st, s->pts, idx, k, pick_host3[0], pick_host3[1], pick_host3[2], scratch,

@@ -2,8 +2,9 @@
 
 Mirrors `S3DIS.get_batch_gen(split)` / `spatially_regular_gen` of RandLA-Net/main_S3DIS.py:116-187: every crop starts at the
 least-visited point of the least-visited cloud, jitters it (noise_init / 10), takes the `num_points` nearest points of that
-cloud (the reference: a 40 960-neighbour query of an sklearn KDTree on the host), shuffles them, centres them on the pick point
-and raises their possibility by (1 - d / max d)^2.  Here the argmin, the nearest-point query (float64 distances + one radix
+cloud (the reference: a 40 960-neighbour query of an sklearn KDTree on the host, whose float64 copy of the cloud also makes the
+pick point and the centring float64), shuffles them, centres them on the pick point and raises their possibility by
+(1 - d / max d)^2.  Here the argmin, the nearest-point query (float64 distances + one radix
 sort) and the possibility update run in libpsg (csrc/psg_randla_sampler.hip); the host draws exactly what the reference draws
 from numpy's global generator, in its order (initial possibilities, jitter, shuffle, duplication for small clouds), so a seeded
 run visits the same crops.  Equal distances come out in index order (a KDTree's order of exact ties is unspecified).
@@ -61,18 +62,20 @@ class CropSampler:
         cloud_idx = int(np.argmin(self.min_possibility))
         h, points = self.handles[cloud_idx], self.points[cloud_idx]
         point_ind, _ = self._argmin(cloud_idx)
-        center_point = points[point_ind, :].reshape(1, -1)
+        # main_S3DIS.py:141 takes the points from the sklearn KDTree, whose copy of the cloud is float64: the centre, the
+        # jitter and the pick point are float64, and so are the differences below before they are rounded to float32
+        center_point = points[point_ind, :].astype(np.float64).reshape(1, -1)
         noise = np.random.normal(scale=self.noise_init / 10, size=center_point.shape)
         pick_point = center_point + noise.astype(center_point.dtype)
         k = min(len(points), self.num_points)
-        pick = np.ascontiguousarray(pick_point[0], np.float32)
+        pick = np.ascontiguousarray(pick_point[0], np.float64)
         idx_dev = torch.empty(k, dtype=torch.int32, device=self.device)
         _lib.call("psg_rla_sampler_query", h, pick.ctypes.data_as(ctypes.c_void_p), k, runtime.ptr(idx_dev), runtime.stream())
         queried_idx = idx_dev.cpu().numpy().astype(np.int64)
         perm = np.arange(len(queried_idx))                    # DP.shuffle_idx (helper_tool.py:183-187)
         np.random.shuffle(perm)
         queried_idx = queried_idx[perm]
-        queried_pc_xyz = points[queried_idx] - pick_point
+        queried_pc_xyz = points[queried_idx].astype(np.float64) - pick_point
         queried_pc_colors = self.colors[cloud_idx][queried_idx]
         queried_pc_labels = self.labels[cloud_idx][queried_idx]
         scratch = torch.empty(k, dtype=torch.float32, device=self.device)

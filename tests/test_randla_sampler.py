@@ -39,6 +39,31 @@ def test_oracle_generator_properties():
     assert xyz.shape == (1024, 3) and len(np.unique(idx)) == 700 and np.array_equal(np.sort(idx[:700]), np.arange(700))
 
 
+def test_oracle_query_is_the_sklearn_tree_query():
+    """The reference's neighbour source is `sklearn.neighbors.KDTree(sub_xyz)` (utils/data_prepare_s3dis.py:62) queried with
+    the float64 pick point (main_S3DIS.py:141-153).  sklearn is installed here, so the restatement's two assumptions are
+    checked against it directly: the tree's copy of a float32 cloud is float64 (which makes `points`, the pick point and
+    the centring float64), and `query(pick, k)` returns the k smallest float64 squared distances in ascending order."""
+    KDTree = pytest.importorskip("sklearn.neighbors").KDTree
+    cl = clouds(5, (6000,))
+    tree = KDTree(cl[0][0])
+    assert np.asarray(tree.data).dtype == np.float64 and np.array_equal(np.asarray(tree.data), cl[0][0].astype(np.float64))
+    np.random.seed(21)
+    orc = randla.CropSamplerOracle(cl, num_points=1500)
+    state = np.random.get_state()
+    point_ind = np.argmin(orc.possibility[0])
+    points = np.asarray(tree.data)
+    center = points[point_ind, :].reshape(1, -1)
+    pick = center + np.random.normal(scale=orc.noise_init / 10, size=center.shape).astype(center.dtype)
+    want = tree.query(pick, k=1500)[1][0]
+    perm = np.arange(1500)
+    np.random.shuffle(perm)
+    np.random.set_state(state)
+    xyz, _, _, idx, _ = orc.next_crop()
+    assert np.array_equal(idx, want[perm].astype(np.int32))                       # same points, same order (no exact ties here)
+    assert np.array_equal(xyz, (points[want[perm]] - pick).astype(np.float32))    # float64 difference, rounded once
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("sizes,num_points,n_crops", [((30000, 41000, 25000), 8192, 9), ((60000,), 40960, 3), ((900, 5000), 2048, 5)])
 def test_gpu_sampler_equals_restatement(sizes, num_points, n_crops):
