@@ -11,14 +11,15 @@ def psg_model(model):
     return model
 
 
-def labels_to_device(labels, device):
+def labels_to_device(labels, device, pin=False):
     """The harness hands labels over as float64 numpy (NB_nontarget_test_semseg.py:171); the reference
     casts with torch.tensor(labels, dtype=int64) (nontarget.py:25)."""
     if isinstance(labels, torch.Tensor):
         t = labels.detach()
     else:
         t = torch.from_numpy(np.ascontiguousarray(labels))
-    return t.to(torch.int32).to(device).contiguous()
+    from pointsecguard_amd.models.pointnet2_sem_seg import upload
+    return upload(t.to(torch.int32).contiguous(), device, pin=pin)
 
 
 def mask_to_device(mask, n_point, device):
@@ -28,4 +29,5 @@ def mask_to_device(mask, n_point, device):
         m = np.asarray(mask).astype(bool)
     if m.shape != (n_point,):
         raise ValueError("mask must be a boolean vector of length %d, got shape %s" % (n_point, m.shape))
-    return torch.from_numpy(m.astype(np.uint8)).to(device)
+    from pointsecguard_amd.models.pointnet2_sem_seg import upload
+    return upload(torch.from_numpy(m.astype(np.uint8)), device)

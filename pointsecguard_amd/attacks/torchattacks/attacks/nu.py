@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from pointsecguard_amd import _lib, runtime
-from pointsecguard_amd.models.pointnet2_sem_seg import draw_fps_starts
+from pointsecguard_amd.models.pointnet2_sem_seg import draw_fps_starts, upload
 
 from ._common import labels_to_device, mask_to_device, psg_model
 
@@ -139,7 +139,7 @@ def _nu_core(atk, images, labels, masks, target, neighbour, targeted_variant, tr
             # (the plan reads the coordinates only; the colours of a step are written inside the window call)
             window_end = 1 if step == 0 else ((step - 1) // CHUNK + 1) * CHUNK + 1      # [0], [1..10], [11..20], ..
             n_plan = min(window_end - step, atk.steps - step)
-            starts = (draw_fps_starts(B, N, n_plan) if starts_fn is None else starts_fn(step, n_plan)).to(dev)
+            starts = upload(draw_fps_starts(B, N, n_plan) if starts_fn is None else starts_fn(step, n_plan), dev)
             ws.plan_build(x0, starts, n_plan)
             plan_base, planned_until = step, step + n_plan
         # ---- the steps up to the end of the geometry window (= up to the next point where the reference's host work needs

@@ -2,7 +2,7 @@
 (PointNet/attacks/torchattacks/attacks/target.py: tar_NB_attack :7-45, tar_NU_attack :52-175)."""
 import torch
 
-from pointsecguard_amd.models.pointnet2_sem_seg import draw_fps_starts
+from pointsecguard_amd.models.pointnet2_sem_seg import draw_fps_starts, upload
 
 from ..attack import Attack
 from ._common import mask_to_device, psg_model
@@ -28,7 +28,7 @@ class tar_NB_attack(Attack):
         images = images.detach().to(self.device).float().contiguous()
         B, C, N = images.shape
         mask = mask_to_device(self.mask, N, self.device)
-        starts = draw_fps_starts(B, N, self.iters).to(self.device)
+        starts = upload(draw_fps_starts(B, N, self.iters, pinned=True), self.device, pin=True)
         ws = net._workspace(B, N, self.iters)
         net._generation += 1
         return ws.nb_attack(net._packed(), images, None, starts, self.eps, self.alpha, self.iters, mask=mask,

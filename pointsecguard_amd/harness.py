@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib, runtime
+from .models.pointnet2_sem_seg import upload
 from .sharding import reduce_counters, shard_scenes
 
 NUM_CLASSES = runtime.NUM_CLASSES
@@ -106,11 +107,13 @@ def _cuda(t, name, dtype):
     return runtime.require_cuda(t, name, dtype)
 
 
-def add_vote(vote_label_pool, point_idx, pred_label, weight):
+def add_vote(vote_label_pool, point_idx, pred_label, weight, bad=None):
     """vote_label_pool[point_idx[b, n], pred_label[b, n]] += 1 where weight[b, n] != 0
     (NB_nontarget_test_semseg.py:55-62), on the device.  vote_label_pool int32 [n_points, 13]; point_idx int32
     [B, N]; weight float32 [B, N] or None; pred_label int32 [B, N], or the [B, N, 13] log-probs themselves (the
-    arg-max, first index on ties, is then taken in the same kernel).  Returns vote_label_pool."""
+    arg-max, first index on ties, is then taken in the same kernel).  Returns vote_label_pool.  An index or label out of
+    range raises IndexError - at once, or, when the caller passes its own device counter `bad` (int32 [1], zeroed), when the
+    caller checks it with check_votes(bad): the loop over a scene's batches then runs without a host synchronisation."""
     _cuda(vote_label_pool, "vote_label_pool", torch.int32)
     _cuda(point_idx, "point_idx", torch.int32)
     if weight is not None:
@@ -122,13 +125,20 @@ def add_vote(vote_label_pool, point_idx, pred_label, weight):
     else:
         pred = _cuda(pred_label, "pred_label", torch.int32)
     rows = point_idx.numel()
-    bad = torch.zeros(1, dtype=torch.int32, device=vote_label_pool.device)
+    deferred = bad is not None
+    if not deferred:
+        bad = torch.zeros(1, dtype=torch.int32, device=vote_label_pool.device)
     _lib.call("psg_vote_add", runtime.ptr(logp), runtime.ptr(pred), runtime.ptr(point_idx), runtime.ptr(weight), rows,
               vote_label_pool.shape[1], vote_label_pool.shape[0], runtime.ptr(vote_label_pool), runtime.ptr(bad),
               runtime.stream())
+    if not deferred:
+        check_votes(bad)
+    return vote_label_pool
+
+
+def check_votes(bad):
     if int(bad.item()):
         raise IndexError("add_vote: a point index or a label is out of range")
-    return vote_label_pool
 
 
 def vote_stats(vote_label_pool, labels, counters=None, want_pred=False):
@@ -196,16 +206,19 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
         scene_labels = torch.from_numpy(labels_np.astype(np.int32)).to(dev)
         pool = torch.zeros(n_scene, NUM_CLASSES, dtype=torch.int32, device=dev)
         adv_pool = torch.zeros_like(pool)
+        pending = []                                 # rows of this scene's log: device scalars, read back once per scene
+        vote_bad = torch.zeros(1, dtype=torch.int32, device=dev)
         for _ in range(num_votes):
             scene_data, scene_label, scene_smpw, scene_point_index = dataset[si]
             num_blocks = scene_data.shape[0]
             for sbatch in range((num_blocks + batch_size - 1) // batch_size):
                 lo, hi = sbatch * batch_size, min((sbatch + 1) * batch_size, num_blocks)
-                torch_data = torch.from_numpy(scene_data[lo:hi]).float().to(dev).transpose(2, 1).contiguous()
+                # (numpy does the float64 -> float32 conversion: a torch CPU op of this size wakes the whole OpenMP pool)
+                torch_data = upload(torch.from_numpy(scene_data[lo:hi].astype(np.float32)), dev, pin=True).transpose(2, 1).contiguous()
                 gt_np = scene_label[lo:hi]
-                gt = torch.from_numpy(gt_np.astype(np.int32)).to(dev)
-                idx = torch.from_numpy(scene_point_index[lo:hi].astype(np.int32)).to(dev)
-                smpw = torch.from_numpy(scene_smpw[lo:hi].astype(np.float32)).to(dev)
+                gt = upload(torch.from_numpy(gt_np.astype(np.int32)), dev, pin=True)
+                idx = upload(torch.from_numpy(scene_point_index[lo:hi].astype(np.int32)), dev, pin=True)
+                smpw = upload(torch.from_numpy(scene_smpw[lo:hi].astype(np.float32)), dev, pin=True)
                 seg_pred, _ = classifier(torch_data)
                 seg_pred = seg_pred.detach().contiguous()
                 count, mask_np = 0, None
@@ -221,25 +234,38 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
                     adv_seg_pred = adv_seg_pred.detach().contiguous()
                 else:
                     adv_images, adv_seg_pred = torch_data, seg_pred
-                add_vote(pool, idx, seg_pred, smpw)
-                add_vote(adv_pool, idx, adv_seg_pred, smpw)
+                add_vote(pool, idx, seg_pred, smpw, bad=vote_bad)
+                add_vote(adv_pool, idx, adv_seg_pred, smpw, bad=vote_bad)
                 c_clean, _ = runtime.seg_stats(seg_pred, gt)
                 c_adv, _ = runtime.seg_stats(adv_seg_pred, gt)
                 dis = l2_distance(adv_images, torch_data)
-                rows = float((hi - lo) * n_pt)
-                acc = float(c_clean[1].sum().item()) / rows
-                adv_acc = float(c_adv[1].sum().item()) / rows
+                # The batch's TSV row needs five scalars; they stay on the device until the scene is done (ONE read-back per
+                # scene instead of four or five host synchronisations per batch: the host slices the next blocks while
+                # the GPU attacks these - the rows and their order are what the reference writes, :213-215)
+                hits = None
+                if targeted is not None and count:
+                    m = upload(torch.from_numpy(mask_np), dev, pin=True)
+                    hits = ((adv_seg_pred.argmax(dim=2) == targeted["target"]) & m).sum()
+                if targeted is None or count:
+                    pending.append((sbatch, (hi - lo) * n_pt, count, dis, c_clean, c_adv, hits))
+        check_votes(vote_bad)
+        if pending:
+            scal = torch.stack([torch.cat([p[3].double().reshape(1), (p[6] if p[6] is not None else p[3].new_zeros(())).double().reshape(1)])
+                                for p in pending]).cpu().numpy()
+            ctr = torch.stack([torch.stack([p[4], p[5]]) for p in pending]).cpu()
+            for k, (sbatch, rows, count, _, _, _, hits) in enumerate(pending):
+                c_clean, c_adv = ctr[k, 0], ctr[k, 1]
+                acc = float(c_clean[1].sum().item()) / float(rows)
+                adv_acc = float(c_adv[1].sum().item()) / float(rows)
+                dis_f = float(np.float32(scal[k, 0]))
                 if targeted is None:
-                    line = LOG_ROW % (sbatch, float(dis.item()), adv_acc, acc, _miou(c_adv), _miou(c_clean))
-                elif count:
-                    m = torch.from_numpy(mask_np).to(dev)
-                    target_acc = float((adv_seg_pred.argmax(dim=2)[m] == targeted["target"]).sum().item()) / count
-                    line = TARGETED_LOG_ROW % (targeted["origin"], sbatch, float(dis.item()), count, target_acc, adv_acc, acc,
-                                               _miou(c_adv), _miou(c_clean))
+                    line = LOG_ROW % (sbatch, dis_f, adv_acc, acc, _miou(c_adv), _miou(c_clean))
                 else:
-                    line = None
-                if fh is not None and line is not None:
+                    line = TARGETED_LOG_ROW % (targeted["origin"], sbatch, dis_f, count, float(scal[k, 1]) / count, adv_acc, acc,
+                                               _miou(c_adv), _miou(c_clean))
+                if fh is not None:
                     fh.write(line)
+            pending.clear()
         c_scene = vote_stats(pool, scene_labels)
         c_scene_adv = vote_stats(adv_pool, scene_labels)
         total[0] += c_scene

@@ -23,15 +23,31 @@ from pointsecguard_amd import _lib, runtime
 LEVEL_N = (None, 1024, 256, 64)  # population each farthest_point_sample draws its start from
 
 
-def draw_fps_starts(batch, n_point, n_forward=1):
+def draw_fps_starts(batch, n_point, n_forward=1, pinned=False):
     """The torch.randint draws of pointnet_util.py:75, in reference call order (4 per forward) from
-    the global CPU generator, so a seeded run consumes the RNG stream exactly like the reference."""
-    out = torch.empty(n_forward, 4, batch, dtype=torch.int32)
+    the global CPU generator, so a seeded run consumes the RNG stream exactly like the reference.
+    Returns an int32 tensor [n_forward, 4, batch]; pinned=True puts it in pinned host memory, so that
+    `upload(..., pin=True)` below is a copy the host does not wait for."""
+    raw = torch.empty(n_forward, 4, batch, dtype=torch.long)
     for f in range(n_forward):
         for lvl in range(4):
             n = n_point if lvl == 0 else LEVEL_N[lvl]
-            out[f, lvl] = torch.randint(0, n, (batch,), dtype=torch.long).to(torch.int32)
+            torch.randint(0, n, (batch,), dtype=torch.long, out=raw[f, lvl])      # (the same draws as one call per level)
+    out = torch.empty(n_forward, 4, batch, dtype=torch.int32, pin_memory=pinned and torch.cuda.is_available())
+    out.copy_(raw)
     return out
+
+
+def upload(t, device, pin=False):
+    """Host tensor -> device.  pin=True: through pinned memory, so the copy is enqueued on the current stream and the call
+    returns without waiting for what is queued before it (torch's host allocator keeps the pinned block until the copy has
+    run) - the one-thread API paths (NB_attack, the model's forward, the whole-scene harness) use it so that the host
+    prepares call i + 1 while the GPU runs call i.  NOT for code that runs beside a hipGraph capture on another thread
+    (the NU windows): the pinned allocator polls its events, and polling one that belongs to a capturing stream is an
+    error (hipErrorCapturedEvent); those paths copy from pageable memory."""
+    if pin and t.device.type == "cpu" and torch.device(device).type == "cuda":
+        return (t if t.is_pinned() else t.pin_memory()).to(device, non_blocking=True)
+    return t.to(device)
 
 
 class _PN2Function(torch.autograd.Function):
@@ -40,7 +56,7 @@ class _PN2Function(torch.autograd.Function):
         B, C, N = x.shape
         model = module._packed()
         ws = module._workspace(B, N, 1)
-        starts = draw_fps_starts(B, N).to(x.device, non_blocking=True)
+        starts = upload(draw_fps_starts(B, N, pinned=True), x.device, pin=True)
         xin = x.detach().contiguous().float()
         x0 = torch.empty(B, N, C, device=x.device, dtype=torch.float32)
         _lib.call("psg_to_point_major", runtime.ptr(xin), B, C, N, runtime.ptr(x0), runtime.stream())

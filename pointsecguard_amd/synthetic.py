@@ -52,6 +52,19 @@ def make_rooms(batch, seed, num_point=NUM_POINT, structured=False):
     return rooms.numpy()
 
 
+
+def make_rooms_with_duplicates(batch, seed):
+    """Rooms that contain EXACT duplicates of points, the way the reference's loader makes them (S3DISDataLoader.py:149-154
+    samples a block's points with replacement): every room keeps 3072 distinct points of make_rooms(batch, seed) and fills the
+    other 1024 slots with copies (whole 9-channel rows) drawn with replacement, then is shuffled."""
+    room = make_rooms(batch, seed)
+    rng = np.random.default_rng(seed + 1000)
+    for b in range(batch):
+        keep = rng.permutation(4096)[:3072]
+        idx = np.concatenate([keep, rng.choice(keep, 1024, replace=True)])
+        room[b] = room[b][rng.permutation(idx)]
+    return room
+
 def rule_labels(rooms):
     """Deterministic 13-class labels for synthetic rooms: 3*floor(4z/3) + argmax(rgb), class 12 where x*y > 0.15.
 

@@ -6,9 +6,13 @@ distances, whose cancellation noise differs in the last bits from MKL's summatio
 gradient w.r.t. w: median relative error < 1e-3 and 99.9 % of entries within 1e-2 of max|g|;
 updated w: 99.5 % of entries within 1e-4 (Adam's first steps are ~lr*sign(g): entries whose gradient is
 ~0 can differ by 2*lr)."""
+import os
+
 import numpy as np
 import pytest
 import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 pytestmark = pytest.mark.gpu
 
@@ -252,6 +256,49 @@ def test_tar_nu_b4_api_costs(weights_sd, golden_tarnu_b4):
     assert np.array_equal(out[:, :3], ref[:, :3]) and np.array_equal(out[:, 6:], ref[:, 6:])
     assert np.array_equal(out[:, 3:6][:, :, ~g["mask"]], ref[:, 3:6][:, :, ~g["mask"]])
     assert (np.abs(out[:, 3:6] - ref[:, 3:6]) <= 1e-3).mean() >= 0.99
+
+
+def test_tar_nu_b32_one_call_vs_reference(weights_sd):
+    """BASELINE configs[2] as ONE call of the reference on its batch of 32 rooms, against a run of the reference itself
+    (tests/golden/pn2_tarnu_b32.npz, make_golden_r4.py): the exit test - hits of all 32 rows over ONE row's mask count,
+    target.py:105-121 - fires after the first optimiser step there (ratio 2.6), and so it must here: one step run, its cost,
+    the optimiser state it left on the mask (rows 0 and 31) and the returned image (the colours of step 0: the image lags
+    the optimiser by one step).  This pins the `batch32_quirk` line of the bench."""
+    from pointsecguard_amd.attacks import torchattacks
+    from pointsecguard_amd.attacks.torchattacks.attacks import nu as nu_mod
+    from pointsecguard_amd.models.pointnet2_sem_seg import get_model
+    from pointsecguard_amd.synthetic import make_rooms
+    g = dict(np.load(os.path.join(GOLDEN, "pn2_tarnu_b32.npz")))
+    rooms = make_rooms(32, int(g["seed_room"]))
+    mask, labels = g["mask"], g["labels"].astype(np.float64)
+    net = get_model(13)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in weights_sd.items()})
+    net = net.cuda().eval()
+    images = dev(rooms.transpose(0, 2, 1))
+    atk = torchattacks.tar_NU_attack(net, c=float(g["c"]), kappa=float(g["kappa"]), steps=int(g["steps"]), lr=float(g["lr"]),
+                                     target=int(g["target"]), mask=mask)
+    table = torch.from_numpy(g["starts"])                   # the reference's own FPS draws, forward by forward
+    seen = []
+
+    def trace(**kw):
+        seen.append((kw["cost"], kw["w"].cpu().numpy().copy()))
+    adv = nu_mod.nu_attack(atk, images, labels, mask, int(g["target"]), 5, targeted_variant=True, trace=trace,
+                           starts_fn=lambda step, n_plan: table[step:step + n_plan].contiguous())
+    torch.cuda.synchronize()
+    assert int(g["n_steps_run"]) == 1 and len(seen) == 1                       # the quirk: one step, then the exit
+    assert abs(seen[0][0] - float(g["costs"][0])) <= 2e-3 * abs(float(g["costs"][0])), (seen[0][0], g["costs"])
+    w = seen[0][1].transpose(0, 2, 1)[:, :, mask]                              # [32, 3, M] like the reference's parameter
+    for row, key in ((0, "w_after_row0"), (31, "w_after_row31")):
+        assert (np.abs(w[row] - g[key]) <= 1e-4).mean() >= 0.99, row
+    out = adv.cpu().numpy()
+    src = rooms.transpose(0, 2, 1)
+    assert bool(g["xyz_equal"]) and np.array_equal(out[:, :3], src[:, :3]) and np.array_equal(out[:, 6:], src[:, 6:])
+    assert bool(g["other_equal"]) and np.array_equal(out[:, 3:6][:, :, ~mask], src[:, 3:6][:, :, ~mask])
+    assert np.abs(out[:, 3:6][:, :, mask] - g["adv_mask_color"]).max() <= 2e-6   # tanh(atanh(.)) of the original colours
+    # without a trace (windows in one call, device latch): the same image, one step
+    adv2, n_run = nu_mod.nu_attack(atk, images, labels, mask, int(g["target"]), 5, targeted_variant=True, return_steps=True,
+                                   starts_fn=lambda step, n_plan: table[step:step + n_plan].contiguous())
+    assert n_run == 1 and torch.equal(adv2, adv)
 
 
 def test_tar_nu_b32_invariants(weights_sd):

@@ -337,32 +337,73 @@ def _b8_batch(g, bi):
     return rooms, rule_labels(rooms)
 
 
-def test_nb_b8_steps_vs_reference(gpu_model, golden_nb_b8):
+@pytest.mark.parametrize("fixture", ["pn2_nb_b8.npz", "pn2_nb_dup.npz"])
+def test_nb_b8_steps_vs_reference(gpu_model, fixture):
+    """Teacher-forced PGD steps at configs[1]'s own batch against the reference's recorded states; the second fixture's rooms
+    contain ~900 EXACT duplicates of points each (sampling with replacement, S3DISDataLoader.py:149-154): equal coordinates
+    are where the reference's `sort` / `max` are least defined, so the tie rules (lowest index first) are exercised on
+    FPS, the ball query and the 3-NN interpolation at once."""
+    import os
+    from conftest import GOLDEN
     from pointsecguard_amd import runtime
-    g = golden_nb_b8
+    from pointsecguard_amd.synthetic import make_rooms_with_duplicates, rule_labels
+    g = dict(np.load(os.path.join(GOLDEN, fixture)))
     iters = int(g["iters"])
-    rooms, lab = _b8_batch(g, 0)
+    if fixture == "pn2_nb_dup.npz":
+        rooms = make_rooms_with_duplicates(8, int(g["seed_room"]))
+        lab = rule_labels(rooms)
+        n_dup = [4096 - len(np.unique(r.view([("", r.dtype)] * 9))) for r in rooms]
+        assert np.array_equal(n_dup, g["duplicates_per_room"]) and min(n_dup) > 500
+        starts, kept = g["starts"][0:iters], (0, 1, 39)
+    else:
+        rooms, lab = _b8_batch(g, 0)
+        starts, kept = g["b0_starts"][1:1 + iters], (0, 1, 5, 39)
     labels = dev(lab.astype(np.int32))
     x0 = dev(rooms)
     ori = x0[:, :, 3:6].contiguous()
     ws = runtime.PN2Workspace(8, 4096, iters)
-    ws.plan_build(x0, dev(g["b0_starts"][1:1 + iters], torch.int32), iters)
-    assert np.array_equal(g["state_it0"], rooms.transpose(0, 2, 1)[:, 3:6])
+    ws.plan_build(x0, dev(starts, torch.int32), iters)
+    assert np.array_equal(g["state_it0"], rooms.transpose(0, 2, 1)[:, 3:6]) and 39 in kept
+    dup_point = None
+    if fixture == "pn2_nb_dup.npz":
+        dup_point = np.zeros((8, 4096), bool)                 # points whose coordinates occur more than once in their room
+        for b in range(8):
+            _, inv, cnt = np.unique(rooms[b, :, :3], axis=0, return_inverse=True, return_counts=True)
+            dup_point[b] = cnt[inv.reshape(-1)] > 1
     for t, nxt in ((0, g["state_it1"]), (39, g["adv_color_final"])):
         _set_color(x0, g["state_it%d" % t])
         got = _one_step(ws, gpu_model, x0, ori, labels, t, g["alpha"], g["eps"], last=(t == iters - 1))
-        check_flips(got, nxt, _one_step.last_grad)
+        if dup_point is None or t == 0:
+            # (iteration 0 of the duplicate fixture: twins are EXACT copies, every tie is exact, the tie rules decide - and
+            # all 98 304 colours come out bit-equal to the reference's)
+            same = check_flips(got, nxt, _one_step.last_grad)
+            assert dup_point is None or same == 1.0
+        else:
+            # Iteration 39: the twins' colours have drifted apart by up to eps, their coordinates are still equal - they sit
+            # in the same groups with almost equal activations, so every max-pool they share is a NEAR-tie that the last
+            # bits decide, and the winner takes the whole gradient of that channel.  Entries of duplicated points may
+            # therefore flip at any |g| (measured: 5 entries of 98 304, |g| up to 0.17 max|g|); everywhere else the usual bar.
+            diff = got.view(np.uint32) != nxt.view(np.uint32)
+            on_dup = np.broadcast_to(dup_point[:, None, :], diff.shape)
+            assert 1.0 - diff.mean() >= 0.999 and (diff & on_dup).sum() <= 0.001 * on_dup.sum()
+            grad = _one_step.last_grad
+            rest = diff & ~on_dup
+            assert not rest.any() or np.abs(grad[rest]).max() <= 3e-3 * np.abs(grad).max()
 
 
-def test_nb_b8_statistical_parity_16_rooms(gpu_model, golden_nb_b8):
-    """Fused 40-iteration attack on the reference's two batches of 8 rooms with the reference's FPS draws: clean counters
-    equal (up to the handful of arg-max ties), adversarial accuracy / mIoU of each batch and of the 16 rooms together
-    within 0.01 of the reference's, per-room adversarial accuracy within 0.03, L2 distance within 1 %."""
+def test_nb_b8_statistical_parity_32_rooms(gpu_model, golden_nb_b8):
+    """Fused 40-iteration attack on the reference's FOUR batches of 8 rooms (pn2_nb_b8.npz + round 4's pn2_nb_more.npz) with
+    the reference's FPS draws: clean counters equal (up to the handful of arg-max ties), adversarial accuracy / mIoU of
+    each batch within 0.01 of the reference's, of the 32 rooms together within 0.005, per-room adversarial accuracy within
+    0.03, L2 distance within 1 %."""
+    import os
+    from conftest import GOLDEN
     from pointsecguard_amd import runtime
-    g = golden_nb_b8
-    iters, eps, alpha = int(g["iters"]), float(g["eps"]), float(g["alpha"])
+    more = dict(np.load(os.path.join(GOLDEN, "pn2_nb_more.npz")))
+    iters, eps, alpha = int(golden_nb_b8["iters"]), float(golden_nb_b8["eps"]), float(golden_nb_b8["alpha"])
+    assert int(more["iters"]) == iters and float(more["eps"]) == eps and float(more["alpha"]) == alpha
     tot_ref, tot_got = np.zeros((3, 13)), np.zeros((3, 13))
-    for bi in range(2):
+    for g, bi in ((golden_nb_b8, 0), (golden_nb_b8, 1), (more, 0), (more, 1)):
         rooms, lab = _b8_batch(g, bi)
         p = "b%d_" % bi
         starts = g[p + "starts"]
@@ -382,7 +423,9 @@ def test_nb_b8_statistical_parity_16_rooms(gpu_model, golden_nb_b8):
         ev.plan_build(x0c, dev(starts[0:1], torch.int32), 1)
         logp = ev.forward(gpu_model, 0, x0c)
         pred = logp.argmax(2).cpu().numpy()
-        assert (pred != g[p + "clean_pred"]).mean() <= 2e-4
+        if p + "clean_pred" in g:
+            assert (pred != g[p + "clean_pred"]).mean() <= 2e-4
+        assert abs((pred == lab).mean() - g[p + "room_acc"].mean()) <= 2e-4
         # adversarial forward on the reference's slot
         x0a = adv.transpose(1, 2).contiguous()
         ev.plan_build(x0a, dev(starts[iters + 1:iters + 2], torch.int32), 1)
