@@ -214,6 +214,199 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float *__r
 }
 
 // ---------------------------------------------------------------------------------------------
+// Ball query through a uniform grid (round 4), for clouds of 2048 to 4096 points (SA level 0).  The scan above tests every centroid
+// against every point (1024 x 4096 pairs per problem at level 0: the kernel sat at ~45 % of the vector peak and was 3 %
+// of an attack); a ball of radius r holds a few dozen points.  Per workgroup: the cloud is staged as before, its
+// bounding box is reduced, points are binned into cells of edge >= 1.05 r (LDS counting sort: histogram, scan,
+// scatter; the order inside a cell is arbitrary), and a wave then serves a centroid from the 27 cells around it
+// (9 contiguous runs of the sorted index list): the candidates - typically 40 to 150 instead of 4096 - get the SAME
+// distance arithmetic as the scan (sqdist: the reference's expansion, whose rounding decides membership at the ball
+// boundary), hits set their bit in a per-wave bitmap over the N points, and the first K set bits ARE the reference's
+// "first nsample indices in ascending order" (pointnet_util.py:100-106).  Pruning can only drop points that the exact
+// test would reject: the expansion's rounding error is below 2.4e-7 (|c| + |p|)^2 <= 3e-6 max|coordinate|^2, so a point
+// that passes the test has a true squared distance below r^2 + 1e-5 max|coordinate|^2 - and the cell edge is 1.05 x the
+// root of exactly that, i.e. the point is less than one cell edge away per axis - and both cell indices come from the same
+// monotone formula (a centroid outside the cloud's box is clamped to the border cell: what it can reach lies in the border
+// cells).  A cloud with non-finite coordinates is one cell, i.e. the full scan.  Same indices, bit for bit
+// (tests/test_gpu_parity.py: reference fixtures; test_unit_geometry_vs_oracle; tests/test_gpu_edge.py).
+// ---------------------------------------------------------------------------------------------
+constexpr int BQG_CELLS = 4096;     // cells per cloud at most (the edge grows by 1.25x until the box fits)
+constexpr int BQG_CPB = 1024;       // centroids per workgroup (64 per wave): the grid build is shared by all queries of a level-0 problem
+
+// inclusive prefix sum over the 64 lanes on the DPP network (row_shr 1 / 2 / 4 / 8, then row_bcast15 / row_bcast31); lanes
+// shifted in from outside a row read 0.  (A __shfl_up scan is six dependent LDS round trips: three of them per centroid
+// were most of this kernel's first version.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned bq_dpp0(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ unsigned bq_wave_incl_scan(unsigned v)
+{
+    v += bq_dpp0<0x111, 0xF>(v);
+    v += bq_dpp0<0x112, 0xF>(v);
+    v += bq_dpp0<0x114, 0xF>(v);
+    v += bq_dpp0<0x118, 0xF>(v);
+    v += bq_dpp0<0x142, 0xA>(v);
+    v += bq_dpp0<0x143, 0xC>(v);
+    return v;
+}
+
+__global__ __launch_bounds__(BQ_THREADS) void ball_query_grid_kernel(const float *__restrict__ xyz, int n_clouds,
+                                                                     const float *__restrict__ new_xyz, int N, int S,
+                                                                     float r2, int K, int32_t *__restrict__ out)
+{
+    extern __shared__ float s_soa[];   // x[NP] y[NP] z[NP] |p|^2[NP] | cell starts [CELLS + 1] | cursors [CELLS] = bitmaps | sorted [NP] u16
+    const int NP = (N + 255) & ~255;
+    float *s_x = s_soa, *s_y = s_soa + NP, *s_z = s_soa + 2 * NP, *s_q = s_soa + 3 * NP;
+    int *s_start = (int *)(s_soa + 4 * NP);
+    int *s_cur = s_start + BQG_CELLS + 1;
+    unsigned short *s_sorted = (unsigned short *)(s_cur + BQG_CELLS);
+    __shared__ float s_red[BQ_THREADS / 64][6];
+    __shared__ float s_box[4];          // min x, y, z, 1 / cell edge
+    __shared__ int s_dim[4];            // nx, ny, nz, cells
+    __shared__ int s_wsum[BQ_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = blockIdx.y;
+    const float *src = xyz + (size_t)(p % n_clouds) * N * 3;
+    float mn0 = INFINITY, mn1 = INFINITY, mn2 = INFINITY, mx0 = -INFINITY, mx1 = -INFINITY, mx2 = -INFINITY;
+    for (int i = tid; i < NP; i += BQ_THREADS) {
+        float x = 0.f, y = 0.f, z = 0.f, q = INFINITY;
+        if (i < N) {
+            x = src[3 * i]; y = src[3 * i + 1]; z = src[3 * i + 2]; q = sumsq3(x, y, z);
+            mn0 = fminf(mn0, x); mn1 = fminf(mn1, y); mn2 = fminf(mn2, z);
+            mx0 = fmaxf(mx0, x); mx1 = fmaxf(mx1, y); mx2 = fmaxf(mx2, z);
+        }
+        s_x[i] = x; s_y[i] = y; s_z[i] = z; s_q[i] = q;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mn0 = fminf(mn0, __shfl_xor(mn0, o)); mn1 = fminf(mn1, __shfl_xor(mn1, o)); mn2 = fminf(mn2, __shfl_xor(mn2, o));
+        mx0 = fmaxf(mx0, __shfl_xor(mx0, o)); mx1 = fmaxf(mx1, __shfl_xor(mx1, o)); mx2 = fmaxf(mx2, __shfl_xor(mx2, o));
+    }
+    if (lane == 0) { s_red[wave][0] = mn0; s_red[wave][1] = mn1; s_red[wave][2] = mn2; s_red[wave][3] = mx0; s_red[wave][4] = mx1; s_red[wave][5] = mx2; }
+    __syncthreads();
+    if (tid == 0) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int w = 0; w < BQ_THREADS / 64; ++w)
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], s_red[w][a]); hi[a] = fmaxf(hi[a], s_red[w][3 + a]); }
+        float maxabs = 0.0f;
+        for (int a = 0; a < 3; ++a) maxabs = fmaxf(maxabs, fmaxf(fabsf(lo[a]), fabsf(hi[a])));
+        maxabs += sqrtf(r2);                                           // (a centroid that reaches the cloud is at most r outside its box)
+        float edge = 1.05f * sqrtf(r2 + 1e-5f * maxabs * maxabs);
+        const bool finite = maxabs < 1e18f;                            // (false for NaN and infinities)
+        int nx, ny, nz;
+        for (;;) {
+            if (!finite) { nx = ny = nz = 1; edge = 1.0f; break; }
+            nx = (int)((hi[0] - lo[0]) / edge) + 1; ny = (int)((hi[1] - lo[1]) / edge) + 1; nz = (int)((hi[2] - lo[2]) / edge) + 1;
+            if ((long long)nx * ny * nz <= BQG_CELLS) break;
+            edge *= 1.25f;
+        }
+        s_box[0] = lo[0]; s_box[1] = lo[1]; s_box[2] = lo[2]; s_box[3] = 1.0f / edge;
+        s_dim[0] = nx; s_dim[1] = ny; s_dim[2] = nz; s_dim[3] = nx * ny * nz;
+    }
+    __syncthreads();
+    const float bx = s_box[0], by = s_box[1], bz = s_box[2], inv = s_box[3];
+    const int nx = s_dim[0], ny = s_dim[1], nz = s_dim[2], ncell = s_dim[3];
+    auto cell1 = [&](float v, float b, int n) {
+        if (n == 1) return 0;
+        const int c = (int)((v - b) * inv);
+        return c < 0 ? 0 : (c >= n ? n - 1 : c);
+    };
+    for (int c = tid; c <= ncell; c += BQ_THREADS) s_start[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += BQ_THREADS)
+        atomicAdd(&s_start[(cell1(s_z[i], bz, nz) * ny + cell1(s_y[i], by, ny)) * nx + cell1(s_x[i], bx, nx) + 1], 1);
+    __syncthreads();
+    {   // inclusive scan of s_start[1 .. ncell] in place (s_start[c + 1] = end of cell c): four cells per thread
+        const int c0 = 1 + 4 * tid;
+        int v[4], sum = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { v[u] = c0 + u <= ncell ? s_start[c0 + u] : 0; sum += v[u]; v[u] = sum; }
+        const int inc = (int)bq_wave_incl_scan((unsigned)sum);
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        int base = inc - sum;
+        for (int w = 0; w < wave; ++w) base += s_wsum[w];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c0 + u <= ncell) s_start[c0 + u] = base + v[u];
+    }
+    __syncthreads();
+    for (int c = tid; c < ncell; c += BQ_THREADS) s_cur[c] = s_start[c];
+    __syncthreads();
+    for (int i = tid; i < N; i += BQ_THREADS) {
+        const int cell = (cell1(s_z[i], bz, nz) * ny + cell1(s_y[i], by, ny)) * nx + cell1(s_x[i], bx, nx);
+        s_sorted[atomicAdd(&s_cur[cell], 1)] = (unsigned short)i;
+    }
+    __syncthreads();
+    // ---- queries: one wave per centroid; the cursors are dead, their memory holds the per-wave bitmaps
+    const int words = NP >> 5;
+    unsigned *bm = (unsigned *)s_cur + wave * words;
+    const int c_end = min(S, (int)(blockIdx.x + 1) * BQG_CPB);
+    for (int c = blockIdx.x * BQG_CPB + wave; c < c_end; c += BQ_THREADS / 64) {
+        for (int w = lane; w < words; w += 64) bm[w] = 0u;
+        const float *cp = new_xyz + ((size_t)p * S + c) * 3;
+        const float cx = cp[0], cy = cp[1], cz = cp[2];
+        const float csq = sumsq3(cx, cy, cz);
+        const int ix = cell1(cx, bx, nx), iy = cell1(cy, by, ny), iz = cell1(cz, bz, nz);
+        // the 9 runs of the sorted list: rows (iz + dz, iy + dy), cells ix - 1 .. ix + 1 (contiguous: x runs fastest)
+        int start = 0, len = 0;
+        if (lane < 9) {
+            const int z = iz + lane / 3 - 1, y = iy + lane % 3 - 1;
+            if (z >= 0 && z < nz && y >= 0 && y < ny) {
+                const int x0 = ix > 0 ? ix - 1 : 0, x1 = ix + 1 < nx ? ix + 1 : nx - 1;
+                const int lin = (z * ny + y) * nx + x0;
+                start = s_start[lin];
+                len = s_start[lin + (x1 - x0) + 1] - start;
+            }
+        }
+        const int incl = (int)bq_wave_incl_scan((unsigned)len);
+        const int T = __builtin_amdgcn_readlane(incl, 8);
+        const int off = incl - len;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i0 = 0; i0 < T; i0 += 64) {
+            const int i = i0 + lane;
+            int pos = -1;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int o = __builtin_amdgcn_readlane(off, r), l = __builtin_amdgcn_readlane(len, r),
+                          st = __builtin_amdgcn_readlane(start, r);
+                pos = (i >= o && i < o + l) ? st + (i - o) : pos;
+            }
+            if (pos >= 0) {
+                const int j = s_sorted[pos];
+                const float dd = sqdist(cx, cy, cz, csq, s_x[j], s_y[j], s_z[j], s_q[j]);
+                if (!(dd > r2)) atomicOr(&bm[j >> 5], 1u << (j & 31));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // the first K set bits, ascending; pad with the first hit (pointnet_util.py:104-106); an empty ball emits N
+        int32_t *o = out + ((size_t)p * S + c) * K;
+        int cnt = 0, first = N;
+        for (int w0 = 0; w0 < words && cnt < K; w0 += 64) {
+            unsigned word = w0 + lane < words ? bm[w0 + lane] : 0u;
+            const int pc = __popc(word);
+            const int inc = (int)bq_wave_incl_scan((unsigned)pc);
+            const int tot = __builtin_amdgcn_readlane(inc, 63);
+            if (tot == 0) continue;
+            if (cnt == 0) {
+                const int fl = __builtin_ctzll(__ballot(word != 0u));
+                first = (w0 + fl) * 32 + __builtin_ctz((unsigned)__builtin_amdgcn_readlane((int)word, fl));
+            }
+            int rank = cnt + inc - pc;
+            while (word && rank < K) {
+                o[rank++] = (w0 + lane) * 32 + __builtin_ctz(word);
+                word &= word - 1u;
+            }
+            cnt += tot;
+        }
+        for (int pos = min(cnt, K) + lane; pos < K; pos += 64) o[pos] = first;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+// ---------------------------------------------------------------------------------------------
 // 3-NN: one thread per fine point, coarse cloud broadcast from LDS, top-3 kept in registers with
 // strict '<' so equal distances keep the lower index first (stable ascending order).
 // ---------------------------------------------------------------------------------------------
@@ -355,11 +548,27 @@ extern "C" int psg_ball_query(psg_ctx *ctx, const float *xyz, int n_clouds, cons
     PSG_REQUIRE(ctx && xyz && new_xyz && out_idx, "psg_ball_query: null argument");
     PSG_REQUIRE(P > 0 && n_clouds > 0 && N > 0 && S > 0 && K > 0, "psg_ball_query: bad sizes");
     PSG_REQUIRE(N <= 8192, "psg_ball_query: N=%d exceeds the LDS-resident limit 8192", N);
-    size_t lds = (size_t)((N + 255) & ~255) * 4 * sizeof(float);
-    if (lds > 48 * 1024)
+    // Clouds of 2048 .. 4096 points: the grid kernel (same indices; see its header).  Measured per launch of 2560 problems
+    // (tools/ball_query_probe.py): N = 4096, S = 1024: 1.44 ms against 2.87 ms for the scan; N = 1024, S = 256: 0.29 against
+    // 0.27 (the build is not repaid), so smaller clouds keep the scan.  PSG_BALL_QUERY=scan forces the scan (A/B runs).
+    static const bool scan_only = []() { const char *v = psg::env_str("PSG_BALL_QUERY"); return v && std::string(v) == "scan"; }();
+    const size_t soa = (size_t)((N + 255) & ~255) * 4 * sizeof(float);
+    if (!scan_only && N >= 2048 && N <= 4096 && r2 > 0.0f && r2 < 1e30f) {
+        const size_t lds = soa + (size_t)(2 * BQG_CELLS + 1) * 4 + (size_t)((N + 255) & ~255) * 2;
+        static bool big = false;
+        if (!big) {
+            PSG_CHECK_HIP(hipFuncSetAttribute((const void *)ball_query_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            big = true;
+        }
+        hipLaunchKernelGGL(ball_query_grid_kernel, dim3(psg::ceil_div(S, BQG_CPB), P), dim3(BQ_THREADS), lds, (hipStream_t)stream, xyz,
+                           n_clouds, new_xyz, N, S, r2, K, out_idx);
+        PSG_LAUNCH_CHECK();
+        return PSG_OK;
+    }
+    if (soa > 48 * 1024)
         PSG_CHECK_HIP(hipFuncSetAttribute((const void *)ball_query_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds));
-    hipLaunchKernelGGL(ball_query_kernel, dim3(psg::ceil_div(S, BQ_CPB), P), dim3(BQ_THREADS), lds,
+                                          (int)soa));
+    hipLaunchKernelGGL(ball_query_kernel, dim3(psg::ceil_div(S, BQ_CPB), P), dim3(BQ_THREADS), soa,
                        (hipStream_t)stream, xyz, n_clouds, new_xyz, N, S, r2, K, out_idx);
     PSG_LAUNCH_CHECK();
     return PSG_OK;
