@@ -11,6 +11,8 @@ struct KnnBuffers {
     float *xp = nullptr;              // [rows][64] fp32 operand copy (v_mfma_f32_16x16x4_f32 order), exact path
     void *bp = nullptr;               // [rows / 32][9][64] x 16 bytes: bf16 hi / lo / augmented fragments, prefilter path
     float *sq = nullptr;              // [rows] squared norms in torch.sum's order
+    const float *x = nullptr;         // the features themselves, row-major [rows][ld] (16-byte aligned rows): the prefilter path reads
+    int ld = 0;                       // its few finalists' 64 floats from here (256 contiguous bytes instead of 16 pieces of xp)
     unsigned long long *stats = nullptr;   // optional device counters of the prefilter kernel ([8], see psg_knn_bf.cuh)
 };
 

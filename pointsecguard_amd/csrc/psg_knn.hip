@@ -5,8 +5,10 @@
 #include "psg_knn.h"
 #include "psg_common.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <mutex>
+#include <unordered_map>
 
 #include "psg_wave.cuh"
 #include "psg_knn_ops.cuh"
@@ -32,6 +34,36 @@ __global__ void knn_prep_kernel(const float *__restrict__ x, int ld, size_t rows
         if (bp) knn_store_aug((uint4 *)bp, v, s);
     }
 }
+
+// The prefilter kernel's sample cut (psg_knn_bf.cuh): step 0 of a workgroup sees S = 32 * nv0 of the room's N candidates;
+// the row's threshold is the r-th smallest sample key (+ margin).  The row ends short of KK keys below it iff the sample
+// holds at least r of the row's KK - 1 nearest candidates: X ~ Hypergeometric(N, KK - 1, S) for candidates in random
+// order.  r = the smallest value with P(X >= r) <= 1e-7 (S = N: r = KK, the plain exact cut).
+unsigned knn_sample_rank(int N, int KK)
+{
+    static std::mutex mu;
+    static std::unordered_map<unsigned long long, unsigned> cache;
+    const unsigned long long key = ((unsigned long long)(unsigned)N << 32) | (unsigned)KK;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    const int tpr = N >> 5, n_steps = (tpr + KB_WAVES - 1) / KB_WAVES, nv0 = (tpr + n_steps - 1) / n_steps;
+    const int S = 32 * nv0, K1 = KK - 1;
+    auto lchoose = [](int n, int m) { return std::lgamma((double)n + 1.0) - std::lgamma((double)m + 1.0) - std::lgamma((double)(n - m) + 1.0); };
+    const double denom = lchoose(N, S);
+    const int hi = K1 < S ? K1 : S;
+    int r = hi + 1;
+    double tail = 0.0;
+    for (int x = hi; x >= 0; --x) {
+        const double p = (S - x > N - K1) ? 0.0 : std::exp(lchoose(K1, x) + lchoose(N - K1, S - x) - denom);
+        if (tail + p > 1e-7) break;
+        tail += p;
+        r = x;
+    }
+    r = r < 1 ? 1 : (r > S ? S : r);
+    cache[key] = (unsigned)r;
+    return (unsigned)r;
+}
 }  // namespace
 
 namespace psg {
@@ -53,7 +85,7 @@ hipError_t knn_setup()
 
 bool knn_shape_ok(int N, int k, int d, KnnPath path)
 {
-    if (N <= 0 || N > 4096 || (k - 1) * d + 1 > 448) return false;
+    if (N <= 0 || N > 4096 || k > 16 || (k - 1) * d + 1 > 448) return false;
     return path == KNN_PATH_BF16 ? (N % 32) == 0 : (N % 16) == 0;
 }
 
@@ -81,14 +113,8 @@ hipError_t knn_launch(const KnnBuffers &buf, int B, int N, int k, int d, int32_t
     }
     KnnBfArgs a;
     a.bp = (const kb_u32x4 *)buf.bp; a.sq = buf.sq; a.out = out; a.N = N; a.k = k; a.d = d; a.KK = f.KK; a.magic = f.magic;
-    const int bslack = KB_CAP - a.KK;
-    a.LOW = a.KK + bslack / 4;
-    a.LOW = a.LOW > 480 && a.KK < 400 ? 480 : a.LOW;      // (a first cut at 512 candidates finds rows of 512)
-    // cut schedule (candidates seen): first when a row holds first_cut entries (everything is admitted until then), then
-    // whenever the ~kept entries of the last cut, admitted at the rate kept / n, would fill 0.85 CAP
-    static const int first_small = psg::env_int("PSG_KNN_FIRST_CUT_KK", 100);
-    a.first_cut = a.KK <= first_small ? 512 : 1024;
-    a.grow = 0.85f * (float)KB_CAP / (float)(a.KK + a.KK / 8 + 32);
+    a.rsel = knn_sample_rank(N, a.KK);
+    a.x = buf.x; a.ld = buf.ld;
     a.exact = f;
     a.stats = buf.stats;
     hipLaunchKernelGGL(knn_bf_kernel, dim3((unsigned)((size_t)B * N / KB_Q)), dim3(KB_WAVES * 64), knn_bf_lds_bytes(), st, a);

@@ -24,30 +24,36 @@
 //
 // Keys.  key = round((L + 16 u_i) / u_i) with the row's own unit u_i = E_i(|x_i|^2) / 8 ~ 2^-13.9 |x_i|^2 (one FMA whose
 // constant carries 2^23: the key is the result's mantissa); a row entry is key << 12 | index (32 bits: twice the rows of
-// the exact kernel in the same LDS).  Candidates farther than 2^20 units (71 |x_i|^2) are never admitted; a row that
-// needs them ends with fewer than KK entries and takes the exact path.
+// the exact kernel in the same LDS).  Candidates farther than 2^20 units (71 |x_i|^2) are never kept; a row that
+// needs them takes the exact path.
 //
-// Stream (as in the exact kernel: 16 waves, shared row buffers, slots by one LDS atomic per lane and step, cuts on a
-// data-independent schedule, no barrier in between) for 32 queries per workgroup; a candidate is admitted by one float
-// compare acc >= th_i (a superset of key <= tau_i).  A cut finds thr with #(keys <= thr) >= KK (the histogram bin in
-// which the cumulative count reaches KK); at least KK candidates then have D <= thr u + E_i(thr u), so the true KK-th
-// distance is below that and every candidate that matters has L below it: tau = thr + E_i / u keeps them all.  A counter
-// above CAP (adversarial orders, massive ties) sends the tile to the exact path.
+// Threshold from a SAMPLE (round 4; rounds 2-3 cut the rows on a growth schedule, 1-3 histogram cuts of 512-1024
+// entries per row, each a workgroup-wide stop).  Wave w streams the candidate tiles w S, w S + 1, .. (S steps), so step
+// 0 of the 16 waves is a STRIDED sample of the room: up to 512 candidates spread over it.  Step 0 stores every pair's
+// entry (fixed slots, no atomics); ONE cut then finds keyX with #(sample keys <= keyX) >= r and sets the row's
+// threshold for the rest of the stream, tau = keyX + E_i(keyX) / u_i.  r is chosen on the host so that, for candidates
+// in random order, fewer than 1 row in 10^7 ends with less than KK keys <= keyX (the hypergeometric tail: the row
+// falls short iff the sample holds r of the KK - 1 nearest); the row then holds ~N r / 512 entries (1.6 KK at d = 27,
+// ~100 at d = 1) and is never cut again - no barrier until the stream ends.  EXACTNESS does not rest on the sample: the
+// final phase COUNTS the entries with key <= keyX; if there are at least KK, at least KK candidates have D <= keyX u +
+// E_i, so the true KK-th distance is below that and every candidate that matters has L below it, i.e. is in the row.  A
+// row with fewer (candidates sorted by distance, a sample that missed), or more than CAP entries, sends its tile to the
+// exact path: adversarial orders cost time, never correctness (tests/test_gpu_knn_bf16.py).
 //
 // Final ranks.  Wanted: exact ranks 0, d, .., (k-1) d.  With l_m the m-th smallest L of the row, l_m <= D_(m) <= l_m + E,
 // so the element of exact rank m has its L within E of l_m; everything with L below l_m - E is smaller than it,
-// everything above l_m + E larger.  Entries are binned by key (bin 0 = the query's own neighbourhood, bins 1.. of a
-// power-of-two width: exact integer edges), the bin that holds approximate rank m and w = ceil(E / width) bins to each side
-// are flagged, overlapping windows merge into RUNS, the members of flagged bins ("finalists", a few per wanted rank) get
-// their exact distance (ascending-k fmaf chain from the fp32 copy, the exact kernel's arithmetic) and rank themselves
-// inside their run: first rank of the run + the number of smaller finalists of the same run IS the exact rank.  More than
-// 256 finalists in a row send the tile to the exact path.
+// everything above l_m + E larger.  Entries are binned by key (256 or 1024 bins of a power-of-two width: exact integer
+// edges), the bin that holds approximate rank m and w = ceil(E / width) bins to each side are flagged, overlapping
+// windows merge into RUNS, the members of flagged bins ("finalists", a few per wanted rank) get their exact distance
+// (ascending-k fmaf chain from the fp32 copy, the exact kernel's arithmetic) and rank themselves inside their run: first
+// rank of the run + the number of smaller finalists of the same run IS the exact rank.  More than 256 finalists in a
+// row send the tile to the exact path.
 //
-// Cuts and final ranking run one row per HALF wave (the wave's rows wave and wave + 16 side by side, every wave of the
-// workgroup at the same time): per-row reductions are 16-lane DPP steps plus one cross-row exchange and serve both rows
-// with one instruction stream; what is left is per-entry work, 32 lanes per row.  (These phases are bound by vector
-// instruction issue - 4 cycles per wave instruction and SIMD -, not by latency: a version with one row per wave, and
-// one with the two rows interleaved, cost twice the instructions.)
+// The cut and the final ranking run one row per HALF wave (the wave's rows wave and wave + 16 side by side, every wave
+// of the workgroup at the same time): per-row reductions are 16-lane DPP steps plus one cross-row exchange and serve
+// both rows with one instruction stream; what is left is per-entry work, 32 lanes per row, over as many registers as the
+// longer of the two rows needs (these phases are bound by vector instruction issue - 4 cycles per wave instruction and
+// SIMD -, so they are written for instruction count: no sentinel work beyond the rows' lengths, 256 bins for short rows).
 #pragma once
 
 constexpr int KB_WAVES = 16;
@@ -56,8 +62,10 @@ constexpr int KB_CAP = 1024;                  // entries per row buffer
 constexpr int KB_ROW = KB_CAP + 2;            // dwords between rows: 8-byte aligned, skewed over the LDS banks
 constexpr float KB_A = KNN_BF_A, KB_B = KNN_BF_B, KB_G = KNN_BF_G;   // 2^-13.5, 2^-15.5, 2^-20 (psg_knn_ops.cuh)
 constexpr float KB_OFF = 16.0f;               // key offset in units: L of the query itself (>= -2 e_ii ~ -3.2 u) stays positive
-constexpr unsigned KB_KEYMAX = 0xFFFFEu;      // largest admissible key
+constexpr unsigned KB_KEYMAX = 0xFFFFEu;      // key of a candidate beyond the key range (never kept)
+constexpr unsigned KB_TAUMAX = 0xFFFF0u;      // largest row threshold (admission lets keys up to tau + 3 through: they must fit 20 bits)
 constexpr int KB_MAXFIN = 256;
+constexpr int KB_SCR = 128;                   // dwords of scratch per row in the final ranking: 64 query features, 32 bitmap, 32 run table
 constexpr int KB_RP = 8;                      // floats of row parameters: |x|^2, |x|, unit, 1 / unit, key constant, spare x3
 
 typedef __bf16 kb_bf16x8 __attribute__((ext_vector_type(8)));
@@ -65,17 +73,22 @@ typedef float kb_f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned kb_u32x4 __attribute__((ext_vector_type(4)));     // one 16-byte operand fragment
 
 // Diagnostic build (EXTRA=-DPSG_KF_TL, tools/knn_timeline.py): thread 0 adds the time since kernel start at the workgroup's
-// barrier exits into the exact kernel's g_kf_tl table (same slots: 0 start, 1-6 first three cuts, 8 stream end, 9 wave 0
-// ranked, 10 all ranked)
+// barrier exits into the exact kernel's g_kf_tl table (slots: 0 start, 1 sample step stored, 2 cut done, 8 stream end,
+// 9 wave 0 ranked, 10 all ranked)
 #ifdef PSG_KF_TL
 #define KB_TL(idx) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
     atomicAdd(&g_kf_tl[(idx)], t_ - tl0); atomicAdd(&g_kf_tl[16 + (idx)], 1ull); } } while (0)
-__device__ unsigned long long g_kb_ph[32];      // phase cycle sums of the final ranking / cuts (wave 0 of every workgroup)
+__device__ unsigned long long g_kb_ph[32];      // phase cycle sums of the final ranking / cut (wave 0 of every workgroup)
+#else
+#define KB_TL(idx)
+#endif
+// (third build, -DPSG_KF_TL -DPSG_KF_PH: stamps inside the cut / final ranking of wave 0; they wait for their own global
+// atomics, so read the shares of the phases, not the lengths, and take the barrier timeline from a build without them)
+#if defined(PSG_KF_TL) && defined(PSG_KF_PH)
 #define KB_PH_BEGIN unsigned long long ph_t0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_t0_) :: "memory")
 #define KB_PH(idx) do { unsigned long long t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
     if (threadIdx.x == 0) { atomicAdd(&g_kb_ph[(idx)], t_ - ph_t0_); atomicAdd(&g_kb_ph[16 + (idx)], 1ull); } ph_t0_ = t_; } while (0)
 #else
-#define KB_TL(idx)
 #define KB_PH_BEGIN
 #define KB_PH(idx)
 #endif
@@ -83,15 +96,15 @@ __device__ unsigned long long g_kb_ph[32];      // phase cycle sums of the final
 struct KnnBfArgs {
     const kb_u32x4 *bp;   // [rows / 32][9][64] fragments (psg_knn_ops.cuh)
     const float *sq;      // [rows]
+    const float *x;       // [rows][ld] the fp32 features, row-major (finalists' exact distances)
+    int ld;
     int32_t *out;         // [rows][k]
     int N;                // points per room, multiple of 32
     int k, d, KK;
     unsigned magic;       // ceil(2^18 / d)
-    int LOW;              // a cut shortens the rows that hold more than LOW entries
-    int first_cut;        // candidates seen at the first cut (a multiple of 512)
-    float grow;           // a cut at n candidates seen is followed by one at grow * n
+    unsigned rsel;        // the cut after step 0 keeps the sample keys up to the rsel-th smallest (+ the row margin)
     KnnFusedArgs exact;            // the exact path's arguments (xp, sq, out, ...)
-    unsigned long long *stats;     // optional [8]: tiles, fallback tiles, rows, finalists, cut events, entries at the end
+    unsigned long long *stats;     // optional [8]: tiles, fallback tiles, rows, finalists, rows cut, entries at the end
 };
 
 // ---- helpers on the two 32-lane halves of a wave (a row per half)
@@ -103,6 +116,15 @@ __device__ __forceinline__ unsigned kb_half_max_u32(unsigned v)          // resu
     o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false); v = o > v ? o : v;
     o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false); v = o > v ? o : v;
     o = (unsigned)__shfl_xor((int)v, 16); v = o > v ? o : v;
+    return v;
+}
+__device__ __forceinline__ unsigned kb_half_sum_u32(unsigned v)          // result in every lane of the half
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false);
+    v += (unsigned)__shfl_xor((int)v, 16);
     return v;
 }
 __device__ __forceinline__ unsigned kb_half_incl_scan_u32(unsigned v)    // inclusive prefix sum inside each half
@@ -134,281 +156,344 @@ __device__ __forceinline__ unsigned kb_margin_keys(float a, float sq, float inv_
     return m < 1.0e6f ? (unsigned)m + 1u : 1000000u;
 }
 
-// ---- cuts and final ranking: the wave's two rows side by side, one per half wave; lane l of a half holds the entries
-// 32 i + l of its row (slots beyond T hold the sentinel 0xFFFFFFFF: real entries are below 2^31); the row's own LDS is
-// scratch once the entries are in registers.  (Not inlined: with them and the exact path inlined the kernel spilled inside
-// its stream loop.  LDS locations travel as dword offsets into the workgroup's dynamic LDS, so that every access stays a ds_
-// instruction: a pointer parameter would be a generic pointer and turn them into flat_ accesses.)
+// ---- the cut and the final ranking: the wave's two rows side by side, one per half wave; lane l of a half holds the
+// entries 32 i + l of its row; the row's own LDS is scratch once the entries are in registers.  LDS locations travel as
+// dword offsets into the workgroup's dynamic LDS, so that every access stays a ds_ instruction.
 struct KbRowArgs {
     unsigned row_dw;        // the first row's entries; the second row's are 16 rows further
     unsigned rp_dw;         // row parameters [KB_Q][KB_RP] floats
-    unsigned cnt_dw, thr_dw, tau_dw;   // per-row counters, admission thresholds on acc, key thresholds
-    unsigned T[2];          // entries held (0: the row takes no part)
+    unsigned cnt_dw, thr_dw, tau_dw, keyx_dw;   // per-row counters, admission thresholds on acc, key thresholds, keyX of the cut
+    unsigned T[2];          // entries held
     unsigned KK;
     int wave;
 };
 
-// Cut: 256 linear bins of 32-bit counters over the entry values above the query's own neighbourhood (bin 0); the bin in
-// which the cumulative count reaches KK gives thr; tau = thr + E_i(thr) / u_i (+ 2 for the float bin edges); every entry
-// with key <= tau is kept, compacted in place.  Lane 0 of each half stores the row's new count and thresholds.
-template <int NV>
-__device__ __noinline__ void kb_cut_rows(const KbRowArgs c, int lane)
+// The cut after step 0: nv0 full registers of sample entries per lane (32 nv0 per row, the same for every row).  256 bins
+// of a power-of-two width over [smallest key, largest key]; the bin in which the cumulative count reaches rsel gives
+// keyX = that bin's upper edge (exact integers); tau = keyX + E_i(keyX) / u_i; every entry with key <= tau is kept,
+// compacted in place.  Lane 0 of each half stores the row's count and thresholds; returns true (in every lane of the
+// half) when the row cannot go on (fewer than rsel sample keys in range, or a threshold beyond the key range).
+__device__ __forceinline__ bool kb_cut_sample(const KbRowArgs c, int lane, int nv0, unsigned rsel)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char kb_smem[];
     const int h = lane >> 5, l5 = lane & 31;
     const int ridx = c.wave + KB_WAVES * h;
     unsigned *row = (unsigned *)kb_smem + c.row_dw + h * KB_WAVES * KB_ROW;
     const float *rp = (const float *)kb_smem + c.rp_dw + ridx * KB_RP;
-    const unsigned T = h ? c.T[1] : c.T[0];
-    unsigned v[NV];
-    unsigned mx1 = 0u;
+    unsigned v[16];
+    unsigned mx = 0u, mnn = 0u;                             // mnn = max of ~v = ~min v
     KB_PH_BEGIN;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const unsigned e = (unsigned)(i * 32 + l5);
-        const unsigned x = row[e];
-        v[i] = e < T ? x : 0xFFFFFFFFu;
-        mx1 = v[i] + 1u > mx1 ? v[i] + 1u : mx1;               // (the sentinel wraps to 0)
+    for (int i = 0; i < 16; ++i) {
+        v[i] = 0xFFFFFFFFu;
+        if (i < nv0) {
+            v[i] = row[i * 32 + l5];
+            mx = v[i] > mx ? v[i] : mx;
+            mnn = ~v[i] > mnn ? ~v[i] : mnn;
+        }
     }
     const float sq = rp[0], a = rp[1], unit = rp[2], inv_unit = rp[3], ci = rp[4];
     wave_lds_fence();
     KB_PH(0);
-    const unsigned mx = kb_half_max_u32(mx1) - 1u;
-    // the query's own neighbourhood: keys up to offset + E_i(0) / u_i
-    const unsigned lowE = (((unsigned)KB_OFF + kb_margin_keys(a, sq, inv_unit, 0.0f)) << 12) | 0xFFFu;
-    const unsigned mn2 = mx > lowE ? lowE : mx;
-    const float span = (float)(mx - mn2 + 1u);
-    const float scale = 254.0f / span, inv_scale = span * (1.0f / 254.0f);
-    // 256 counters per row; the lane owns bins 8 l .. 8 l + 7.  (A half whose row takes no part, T = 0, must leave that row's
-    // entries alone: nothing of it is in registers.)
-    if (T != 0u) {
+    const unsigned kmx = kb_half_max_u32(mx) >> 12, kmn = (~kb_half_max_u32(mnn)) >> 12;
+    const unsigned range = kmx - kmn;
+    unsigned sh = range > 253u ? (unsigned)(32 - __builtin_clz(range)) - 8u : 0u;
+    if ((range >> sh) > 253u) ++sh;                         // bins 0 .. range >> sh <= 253
+    const unsigned base = kmn << 12, s2 = 12u + sh;
+    // 256 counters per row; the lane owns bins 8 l .. 8 l + 7
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ((uint2 *)row)[4 * l5 + j] = make_uint2(0u, 0u);
-    }
+    for (int j = 0; j < 4; ++j) ((uint2 *)row)[4 * l5 + j] = make_uint2(0u, 0u);
     wave_lds_fence();
     KB_PH(1);
-    if (T != 0u) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            unsigned bb = 1u + (unsigned)((float)(v[i] - mn2) * scale);      // (sentinels land in bin 255 and are taken out below)
-            bb = v[i] <= lowE ? 0u : (bb > 255u ? 255u : bb);
-            atomicAdd(&row[bb], 1u);
-        }
-    }
+    for (int i = 0; i < 16; ++i)
+        if (i < nv0) atomicAdd(&row[(v[i] - base) >> s2], 1u);
     wave_lds_fence();
     KB_PH(2);
-    unsigned cw[8];
+    // the bin in which the cumulative count of the 256 counters reaches `target`, and the entries below that bin
+    unsigned ownh = 0u;
+    auto find_bin = [&](unsigned target, unsigned &below_out) -> unsigned {
+        unsigned cw[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const uint2 t = ((const uint2 *)row)[4 * l5 + j]; cw[2 * j] = t.x; cw[2 * j + 1] = t.y; }
-    if (l5 == 31) cw[7] -= (unsigned)(NV * 32) - T;
-    unsigned tot = 0;
+        for (int j = 0; j < 4; ++j) { const uint2 t = ((const uint2 *)row)[4 * l5 + j]; cw[2 * j] = t.x; cw[2 * j + 1] = t.y; }
+        unsigned tot = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) tot += cw[j];
-    const unsigned incl = kb_half_incl_scan_u32(tot), start = incl - tot;
-    unsigned mybin = (unsigned)(8 * l5), s = start;
+        for (int j = 0; j < 8; ++j) tot += cw[j];
+        const unsigned incl = kb_half_incl_scan_u32(tot), start = incl - tot;
+        unsigned mybin = (unsigned)(8 * l5), s = start, sb = start;
 #pragma unroll
-    for (int j = 0; j < 7; ++j) { s += cw[j]; mybin += s < c.KK ? 1u : 0u; }
-    const unsigned long long own = __ballot(T != 0u && start < c.KK && c.KK <= incl);       // one lane per half (KK <= T)
-    const unsigned ownh = h ? (unsigned)(own >> 32) : (unsigned)own;
-    const int owner = (ownh ? __builtin_ctz(ownh) : 0) + 32 * h;
-    const unsigned binB = (unsigned)__shfl((int)mybin, owner);
-    // an entry of a bin <= binB (>= 1) has 1 + (v - mn2) * scale < binB + 1 in float: v - mn2 < binB / scale * (1 + 2^-22), less
-    // than one key above; key(thr) + 2 covers that and the floor of the shift
-    const unsigned X = binB ? mn2 + (unsigned)((float)binB * inv_scale) : lowE;
-    const unsigned keyX = (X >> 12) + 2u;
-    const unsigned margin = kb_margin_keys(a, sq, inv_unit, ((float)keyX - KB_OFF) * unit);
-    unsigned tauk = keyX + margin;
-    tauk = tauk > KB_KEYMAX ? KB_KEYMAX : tauk;
-    const unsigned keepmax = (tauk << 12) | 0xFFFu;
-    KB_PH(3);
-    unsigned base = 0;
+        for (int j = 0; j < 7; ++j) { s += cw[j]; const bool lt = s < target; mybin += lt ? 1u : 0u; sb = lt ? s : sb; }
+        const unsigned long long own = __ballot(start < target && target <= incl);       // at most one lane per half
+        ownh = h ? (unsigned)(own >> 32) : (unsigned)own;
+        const int owner = (ownh ? __builtin_ctz(ownh) : 0) + 32 * h;
+        const unsigned pk = (unsigned)__shfl((int)(mybin | (sb << 16)), owner);
+        below_out = pk >> 16;
+        return pk & 0xFFFFu;
+    };
+    unsigned below1 = 0u;
+    const unsigned binB = find_bin(rsel, below1);
+    const bool none = ownh == 0u;
+    // second level inside bin binB (bins wider than one key): 2^(sh - sh2) sub-bins of width 2^sh2 (one key when sh <= 8), so
+    // that keyX is the rsel-th smallest sample key itself, not the edge of a bin that may hold a dozen of them
+    unsigned keyX = kmn + ((binB + 1u) << sh) - 1u;
+    if (__ballot(sh != 0u) != 0ull) {
+        const unsigned sh2 = sh > 8u ? sh - 8u : 0u, smask = (1u << (sh - sh2)) - 1u;
+        wave_lds_fence();
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const bool keep = v[i] <= keepmax;                      // (sentinels are above any keepmax)
-        const unsigned long long bl = __ballot(keep);
-        if (keep) row[base + kb_half_prefix(bl, h)] = v[i];
-        base += kb_half_count(bl, h);
+        for (int j = 0; j < 4; ++j) ((uint2 *)row)[4 * l5 + j] = make_uint2(0u, 0u);
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < nv0) {
+                if (((v[i] - base) >> s2) == binB) atomicAdd(&row[((v[i] - base) >> (12u + sh2)) & smask], 1u);
+            }
+        wave_lds_fence();
+        unsigned below2 = 0u;
+        const unsigned subB = find_bin(rsel - below1, below2);
+        keyX = kmn + (binB << sh) + ((subB + 1u) << sh2) - 1u;
     }
-    if (l5 == 0 && T != 0u) {
-        ((unsigned *)kb_smem)[c.cnt_dw + ridx] = base;
+    const unsigned margin = kb_margin_keys(a, sq, inv_unit, ((float)keyX - KB_OFF) * unit);
+    const unsigned tauk = keyX + margin;
+    const bool bad = none || ownh == 0u || keyX >= KB_TAUMAX || tauk > KB_TAUMAX;
+    const unsigned keepmax = bad ? 0u : ((tauk << 12) | 0xFFFu);
+    KB_PH(3);
+    unsigned cb = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < nv0) {
+            const bool keep = v[i] <= keepmax;
+            const unsigned long long bl = __ballot(keep);
+            if (keep) row[cb + kb_half_prefix(bl, h)] = v[i];
+            cb += kb_half_count(bl, h);
+        }
+    }
+    if (l5 == 0) {
+        ((unsigned *)kb_smem)[c.cnt_dw + ridx] = cb;
         ((unsigned *)kb_smem)[c.tau_dw + ridx] = tauk;
+        ((unsigned *)kb_smem)[c.keyx_dw + ridx] = keyX;
         // admit iff key <= tauk, i.e. acc * m2 + ci < tauk + 1; two more units cover the float evaluation
         ((float *)kb_smem)[c.thr_dw + ridx] = (ci - (float)(tauk + 3u)) * (0.5f * unit);
     }
     KB_PH(4);
+    return bad;
 }
 
-// Final ranking (see the header).  Row LDS: 1024 bins of 16 bits (counts, then first ranks) + 256 finalists; scr = 96 words
-// of wave-private LDS per row (the query's 64 features, 32 words of flagged-bin bitmap).  Returns the number of finalists of
-// the two rows, or 0xFFFFFFFF when a row must take the exact path.
-struct KbFinalArgs {          // by value: a reference to the kernel's argument struct would force it (and every pointer in it) through the stack
-    const float *xp, *sq;
+// Final ranking (see the header).  Row LDS: NB bins of 16 bits (counts, then first ranks, then - advanced by the collect
+// pass - the position of every finalist in bin order) in dwords [0, 512), 256 finalists (entry, position) from dword
+// 512; after the collect pass dwords [0, 512) hold the finalists' exact composites sorted by run.  scr = KB_SCR words of
+// wave-private LDS per row: the query's 64 features, up to 32 words of flagged-bin bitmap, the run table (first rank,
+// first finalist | finalists << 16 per run).  nv = the registers per lane the longer of the two rows needs (<= NV).
+// Returns the number of finalists of the two rows, or 0xFFFFFFFF when a row must take the exact path.
+//
+// Runs.  The windows of the wanted ranks are ordered; window j opens a new run when it neither overlaps nor touches window
+// j - 1.  A run is a stretch of bins; EVERY entry of its bins is a finalist, so the finalists of run R are exactly the
+// entries of ranks-by-bin [cs_R, ce_R) (cs = entries below the run's first bin).  The collect pass hands every finalist
+// its position q in bin order (one returning LDS atomic on the bin's first rank), the exact pass stores its composite
+// at fs_R + q - cs_R (fs = finalists of earlier runs): finalists end up grouped by run, and a finalist ranks itself
+// against its own run only: exact rank = cs_R + the number of smaller composites among the run's len_R (rounds 2-3 compared
+// every finalist with every other: 36 instructions per pair of the row, 60 % of the phase at d >= 12).
+struct KbFinalArgs {
+    const float *x, *sq;      // row-major features [rows][ld], squared norms
+    unsigned ld;
     int32_t *out;             // the first row's output; the second row's is 16 k further
     size_t room_row0, qglob;  // global row of the room's first point and of the first row's query (second: + 16)
     unsigned scr_dw, k, d, magic;
 };
 
-template <int NV>
-__device__ __noinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFinalArgs a, int lane)
+template <int NV, int NB>
+__device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFinalArgs a, int lane, int nv)
 {
+    constexpr int LOGNB = NB == 1024 ? 10 : 8;
+    constexpr int DW = NB / 64;                             // dwords of packed bins per lane (2 bins each)
+    static_assert(NB == 1024 || NB == 256, "bins");
     extern __shared__ __attribute__((aligned(16))) unsigned char kb_smem[];
     const int h = lane >> 5, l5 = lane & 31;
     const int ridx = c.wave + KB_WAVES * h;
     unsigned *row = (unsigned *)kb_smem + c.row_dw + h * KB_WAVES * KB_ROW;
     const float *rp = (const float *)kb_smem + c.rp_dw + ridx * KB_RP;
-    float *qbuf = (float *)kb_smem + a.scr_dw + h * 96;
-    unsigned *bitmap = (unsigned *)kb_smem + a.scr_dw + h * 96 + 64;
+    float *qbuf = (float *)kb_smem + a.scr_dw + h * KB_SCR;
+    unsigned *bitmap = (unsigned *)kb_smem + a.scr_dw + h * KB_SCR + 64;
+    uint2 *rt = (uint2 *)((unsigned *)kb_smem + a.scr_dw + h * KB_SCR + 96);       // [16] {cs, fs | len << 16}
     const unsigned T = h ? c.T[1] : c.T[0];
+    const unsigned tl5 = T > (unsigned)l5 ? T - (unsigned)l5 : 0u;      // entry 32 i + l5 exists iff 32 i < tl5
+    const unsigned keyx_ent = (((const unsigned *)kb_smem)[c.keyx_dw + ridx] << 12) | 0xFFFu;
+    const unsigned tau_row = ((const unsigned *)kb_smem)[c.tau_dw + ridx];
     unsigned v[NV], bn[NV];
-    unsigned mx1 = 0u;
+    unsigned mx = 0u, mnn = 0u, nle = 0u;
     KB_PH_BEGIN;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const unsigned e = (unsigned)(i * 32 + l5);
-        const unsigned x = row[e];
-        v[i] = e < T ? x : 0xFFFFFFFFu;
-        mx1 = v[i] + 1u > mx1 ? v[i] + 1u : mx1;
-    }
-    const float sq = rp[0], aa = rp[1], unit = rp[2], inv_unit = rp[3];
-    const unsigned tau_row = ((const unsigned *)kb_smem)[c.tau_dw + ridx];
-    // the query's 64 features in k order for the exact chains (feature k = 16 i + 4 e + g: element e of float4 [i][g])
-    const size_t qg = a.qglob + (size_t)(h * KB_WAVES);
-    {
-        const float *xq = a.xp + ((qg >> 4) * 256 + (qg & 15)) * 4;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int kf = l5 + 32 * u;
-            qbuf[kf] = xq[((kf >> 4) * 64 + 16 * (kf & 3)) * 4 + ((kf >> 2) & 3)];
+        v[i] = 0xFFFFFFFFu;
+        if (i < nv) {
+            const unsigned x = row[i * 32 + l5];
+            const bool valid = (unsigned)(32 * i) < tl5;
+            v[i] = valid ? x : 0xFFFFFFFFu;
+            mx = valid && x > mx ? x : mx;
+            mnn = ~v[i] > mnn ? ~v[i] : mnn;
+            nle += v[i] <= keyx_ent ? 1u : 0u;
         }
     }
-    bitmap[l5] = 0u;
+    const float sq = rp[0], aa = rp[1], unit = rp[2], inv_unit = rp[3];
+    // the query's 64 features for the exact chains
+    const size_t qg = a.qglob + (size_t)(h * KB_WAVES);
+    {
+        const float *xq = a.x + qg * a.ld;
+        qbuf[l5] = xq[l5];
+        qbuf[l5 + 32] = xq[l5 + 32];
+    }
+    if (l5 < NB / 32) bitmap[l5] = 0u;
+    if (l5 < 16) rt[l5] = make_uint2(0xFFFFFFFFu, 0u);             // (runs the row does not have: never at or below a position)
+    // packed 16-bit counters: the lane owns bins (NB / 32) l .. + NB / 32 - 1
+#pragma unroll
+    for (int j = 0; j < DW / 2; ++j) ((uint2 *)row)[(DW / 2) * l5 + j] = make_uint2(0u, 0u);
     wave_lds_fence();
     KB_PH(5);
-    const unsigned kmx = (kb_half_max_u32(mx1) - 1u) >> 12;
-    // the gap between L and D for everything the row holds: from its threshold, or (never cut) from its largest key
+    const unsigned kmx = kb_half_max_u32(mx) >> 12, kmn = (~kb_half_max_u32(mnn)) >> 12;
+    // the exactness test (see the header): at least KK entries at or below the cut's keyX
+    const bool short_row = kb_half_sum_u32(nle) < c.KK;
+    if (__ballot(short_row) != 0ull) return 0xFFFFFFFFu;
+    // the gap between L and D for everything the row holds: from its threshold, or from its largest key
     const unsigned ktop = tau_row < kmx ? tau_row : kmx;
     const unsigned margin = kb_margin_keys(aa, sq, inv_unit, ((float)ktop - KB_OFF) * unit);
-    const unsigned lowmax = (unsigned)KB_OFF + kb_margin_keys(aa, sq, inv_unit, 0.0f);      // the query's own neighbourhood: bin 0
-    unsigned k2 = 0xFFFFFFFFu;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const unsigned kq = v[i] >> 12;
-        k2 = (kq > lowmax && kq < k2) ? kq : k2;                    // (a sentinel's key 0xFFFFF is above every real key)
-    }
-    k2 = ~kb_half_max_u32(~k2);
-    const unsigned range = (k2 <= kmx) ? kmx - k2 : 0u;
-    unsigned sh = range > 1022u ? (unsigned)(32 - __builtin_clz(range)) - 10u : 0u;
-    if ((range >> sh) > 1022u) ++sh;                                // bins 1 .. 1 + (range >> sh) <= 1023
+    const unsigned range = kmx - kmn;
+    unsigned sh = range > (unsigned)(NB - 2) ? (unsigned)(32 - __builtin_clz(range)) - (unsigned)LOGNB : 0u;
+    if ((range >> sh) > (unsigned)(NB - 2)) ++sh;                   // bins 0 .. range >> sh <= NB - 2
     const unsigned w = (margin + (1u << sh) - 1u) >> sh;            // window half width in bins
-    const unsigned c0 = (1u << sh) - k2;                            // bin = ((v >> 12) + c0) >> sh above lowmax
-    const unsigned low_ent = (lowmax << 12) | 0xFFFu;
+    const unsigned base = kmn << 12, s2 = 12u + sh;
     unsigned short *cum16 = (unsigned short *)row;
-    unsigned long long *fin = (unsigned long long *)(row + 512);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ((uint2 *)row)[8 * l5 + j] = make_uint2(0u, 0u);
-    wave_lds_fence();
+    unsigned long long *sorted = (unsigned long long *)row;         // [256] composites grouped by run (after the collect pass)
+    uint2 *fin = (uint2 *)(row + 512);                              // [256] {entry, position in bin order}
     KB_PH(6);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        unsigned bb = ((v[i] >> 12) + c0) >> sh;                  // (keys reach 2^20: no room to shift the entry itself)
-        bb = v[i] <= low_ent ? 0u : (bb > 1023u ? 1023u : bb);   // (sentinels: bin 1023, taken out below)
-        bn[i] = bb;
-        atomicAdd(&row[bb >> 1], 1u + (bb & 1u) * 0xFFFFu);
+        bn[i] = 0u;
+        if (i < nv) {
+            if ((unsigned)(32 * i) < tl5) {
+                const unsigned bb = (v[i] - base) >> s2;
+                bn[i] = bb;
+                atomicAdd(&row[bb >> 1], 1u << ((bb & 1u) << 4));
+            }
+        }
     }
     wave_lds_fence();
     KB_PH(7);
-    // the lane's own 32 bins (32 l .. 32 l + 31) -> the number of entries below each bin, written back in place
+    // the lane's own bins -> the number of entries below each bin, written back in place
     {
-        unsigned wd[16];
+        unsigned wd[DW];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const uint2 t = ((const uint2 *)row)[8 * l5 + j]; wd[2 * j] = t.x; wd[2 * j + 1] = t.y; }
-        if (l5 == 31) wd[15] -= ((unsigned)(NV * 32) - T) << 16;
+        for (int j = 0; j < DW / 2; ++j) { const uint2 t = ((const uint2 *)row)[(DW / 2) * l5 + j]; wd[2 * j] = t.x; wd[2 * j + 1] = t.y; }
         unsigned tot = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) tot += (wd[j] & 0xFFFFu) + (wd[j] >> 16);
+        for (int j = 0; j < DW; ++j) tot += (wd[j] & 0xFFFFu) + (wd[j] >> 16);
         unsigned s = kb_half_incl_scan_u32(tot) - tot;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < DW; ++j) {
             const unsigned lo = wd[j] & 0xFFFFu, hi = wd[j] >> 16;
             wd[j] = s | ((s + lo) << 16);
             s += lo + hi;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ((uint2 *)row)[8 * l5 + j] = make_uint2(wd[2 * j], wd[2 * j + 1]);
+        for (int j = 0; j < DW / 2; ++j) ((uint2 *)row)[(DW / 2) * l5 + j] = make_uint2(wd[2 * j], wd[2 * j + 1]);
     }
     wave_lds_fence();
     KB_PH(8);
-    // lane j < k of each half: the bin that holds approximate rank j d = the last bin with at most j d entries below it; flag
-    // its window
-    if (l5 < (int)a.k && T != 0u) {
+    // lane j < k of each half: the bin that holds approximate rank j d = the last bin with at most j d entries below it; its
+    // window is flagged, and the windows that neither overlap nor touch their predecessor open the runs
+    {
+        const bool win = l5 < (int)a.k;
         const unsigned m = (unsigned)l5 * a.d;
-        unsigned lo = 0u, hi = 1023u;
+        unsigned lo = 0u, hi = (unsigned)(NB - 1);
+        if (win) {
 #pragma unroll 1
-        for (int it = 0; it < 10; ++it) {
-            const unsigned mid = (lo + hi + 1u) >> 1;
-            const bool le = (unsigned)cum16[mid] <= m;
-            lo = le ? mid : lo;
-            hi = le ? hi : mid - 1u;
+            for (int it = 0; it < LOGNB; ++it) {
+                const unsigned mid = (lo + hi + 1u) >> 1;
+                const bool le = (unsigned)cum16[mid] <= m;
+                lo = le ? mid : lo;
+                hi = le ? hi : mid - 1u;
+            }
         }
-        const unsigned L = lo > w ? lo - w : 0u, H = lo + w < 1023u ? lo + w : 1023u;
-        for (unsigned wi = L >> 5; wi <= (H >> 5); ++wi) {
-            const unsigned first = wi == (L >> 5) ? (L & 31u) : 0u, lastb = wi == (H >> 5) ? (H & 31u) : 31u;
-            atomicOr(&bitmap[wi], (0xFFFFFFFFu >> (31u - lastb)) & (0xFFFFFFFFu << first));
+        const unsigned L = lo > w ? lo - w : 0u, H = lo + w < (unsigned)(NB - 1) ? lo + w : (unsigned)(NB - 1);
+        if (win) {
+            for (unsigned wi = L >> 5; wi <= (H >> 5); ++wi) {
+                const unsigned first = wi == (L >> 5) ? (L & 31u) : 0u, lastb = wi == (H >> 5) ? (H & 31u) : 31u;
+                atomicOr(&bitmap[wi], (0xFFFFFFFFu >> (31u - lastb)) & (0xFFFFFFFFu << first));
+            }
         }
+        const unsigned prevH = dpp_get<0x111, 0xF>(H);               // row_shr:1 (lanes 0 and 32 read 0)
+        const bool leader = win && (l5 == 0 || L > prevH + 1u);
+        const unsigned long long lb = __ballot(leader);
+        const unsigned lmask = h ? (unsigned)(lb >> 32) : (unsigned)lb;       // bit j: window j opens a run
+        // the run's last window = the one before the next leader (or window k - 1)
+        const unsigned above = l5 < 31 ? lmask >> (l5 + 1) : 0u;
+        const unsigned nextl = above ? (unsigned)l5 + 1u + (unsigned)__builtin_ctz(above) : a.k;
+        const unsigned Hend = (unsigned)__shfl((int)H, (int)(nextl - 1u) + 32 * h);
+        unsigned cs = 0u, len = 0u;
+        if (leader) {
+            cs = cum16[L];
+            const unsigned ce = Hend + 1u < (unsigned)NB ? (unsigned)cum16[Hend + 1u] : T;
+            len = ce - cs;
+        }
+        const unsigned fs = kb_half_incl_scan_u32(len) - len;
+        if (leader) rt[__popc(lmask & ((1u << l5) - 1u))] = make_uint2(cs, fs | (len << 16));
     }
     wave_lds_fence();
     KB_PH(9);
+    // collect: every entry of a flagged bin takes its position in bin order from the bin's first rank (advanced by one)
     unsigned F = 0;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const bool take = ((bitmap[bn[i] >> 5] >> (bn[i] & 31u)) & 1u) && (int)v[i] >= 0;
-        const unsigned long long bl = __ballot(take);
-        const unsigned pos = F + kb_half_prefix(bl, h);
-        if (take && pos < (unsigned)KB_MAXFIN) fin[pos] = (unsigned long long)v[i];
-        F += kb_half_count(bl, h);
+        if (i < nv) {
+            const bool take = (unsigned)(32 * i) < tl5 && ((bitmap[bn[i] >> 5] >> (bn[i] & 31u)) & 1u);
+            const unsigned long long bl = __ballot(take);
+            if (bl != 0ull) {
+                const unsigned pos = F + kb_half_prefix(bl, h);
+                if (take) {
+                    const unsigned sft = (bn[i] & 1u) << 4;
+                    const unsigned q = (atomicAdd(&row[bn[i] >> 1], 1u << sft) >> sft) & 0xFFFFu;
+                    if (pos < (unsigned)KB_MAXFIN) fin[pos] = make_uint2(v[i], q);
+                }
+                F += kb_half_count(bl, h);
+            }
+        }
     }
     wave_lds_fence();
     KB_PH(10);
     const unsigned Fo = (unsigned)__shfl_xor((int)F, 32);
     const unsigned Fmax = F > Fo ? F : Fo;
     if (Fmax > (unsigned)KB_MAXFIN) return 0xFFFFFFFFu;
-    const float4 *xp4 = (const float4 *)a.xp;
     const float4 *q4 = (const float4 *)qbuf;
-    const unsigned long long m44 = (1ull << 44) - 1ull;
     bool bound_broken = false;
     for (unsigned f0 = 0; f0 < Fmax; f0 += 32) {
         const unsigned f = f0 + (unsigned)l5;
-        const unsigned ent = f < F ? (unsigned)fin[f] : 0u;
+        const uint2 fe = f < F ? fin[f] : make_uint2(base, 0u);
+        const unsigned ent = fe.x, q = fe.y;
         const unsigned idx = ent & 0xFFFu;
         const size_t vc = a.room_row0 + idx;
-        const float4 *pc = xp4 + (vc >> 4) * 256 + (vc & 15);
+        const float4 *pc = (const float4 *)(a.x + vc * a.ld);
         float4 C[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) C[j] = pc[(j >> 2) * 64 + 16 * (j & 3)];
+        for (int j = 0; j < 16; ++j) C[j] = pc[j];
         const float sqj = a.sq[vc];
-        // first rank of the finalist's run = entries below the first bin of the unbroken stretch of flagged bins it sits in
-        unsigned bb = ((ent >> 12) + c0) >> sh;
-        bb = ent <= low_ent ? 0u : (bb > 1023u ? 1023u : bb);
-        int wi = (int)(bb >> 5);
-        unsigned zeros = ~bitmap[wi] & (0xFFFFFFFFu >> (31u - (bb & 31u)));      // unflagged bins at or below bb in its word
-        while (__ballot(zeros == 0u && wi > 0) != 0ull) {
-            if (zeros == 0u && wi > 0) { --wi; zeros = ~bitmap[wi]; }
+        // the finalist's run: the last one whose first rank is at most q (runs beyond the row's last read as 0xFFFFFFFF)
+        unsigned rho = 0u;
+#pragma unroll
+        for (int st = 8; st >= 1; st >>= 1) {
+            const unsigned cand = rho + (unsigned)st;
+            rho = (cand < 16u && rt[cand & 15u].x <= q) ? cand : rho;
         }
-        const unsigned b0 = zeros ? (unsigned)(wi * 32 + 32 - __builtin_clz(zeros)) : 0u;
-        const unsigned long long tag = (unsigned long long)cum16[b0] << 44;
-        // ascending-k fmaf chain from 0 (k = 16 i + 4 e + g), the exact kernel's arithmetic
+        const uint2 re = rt[rho];
+        const unsigned p = (re.y & 0xFFFFu) + q - re.x;
+        // ascending-k fmaf chain from 0, the exact kernel's arithmetic (and a CPU sgemm's)
         float z = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 qa = q4[4 * i], qb = q4[4 * i + 1], qc = q4[4 * i + 2], qd = q4[4 * i + 3];
-            z = __fmaf_rn(qa.x, C[4 * i].x, z); z = __fmaf_rn(qa.y, C[4 * i + 1].x, z); z = __fmaf_rn(qa.z, C[4 * i + 2].x, z); z = __fmaf_rn(qa.w, C[4 * i + 3].x, z);
-            z = __fmaf_rn(qb.x, C[4 * i].y, z); z = __fmaf_rn(qb.y, C[4 * i + 1].y, z); z = __fmaf_rn(qb.z, C[4 * i + 2].y, z); z = __fmaf_rn(qb.w, C[4 * i + 3].y, z);
-            z = __fmaf_rn(qc.x, C[4 * i].z, z); z = __fmaf_rn(qc.y, C[4 * i + 1].z, z); z = __fmaf_rn(qc.z, C[4 * i + 2].z, z); z = __fmaf_rn(qc.w, C[4 * i + 3].z, z);
-            z = __fmaf_rn(qd.x, C[4 * i].w, z); z = __fmaf_rn(qd.y, C[4 * i + 1].w, z); z = __fmaf_rn(qd.z, C[4 * i + 2].w, z); z = __fmaf_rn(qd.w, C[4 * i + 3].w, z);
+        for (int j = 0; j < 16; ++j) {
+            const float4 qv = q4[j];
+            z = __fmaf_rn(qv.x, C[j].x, z); z = __fmaf_rn(qv.y, C[j].y, z); z = __fmaf_rn(qv.z, C[j].z, z); z = __fmaf_rn(qv.w, C[j].w, z);
         }
         // (|x_i|^2 + (-2 x_i.x_j)) + |x_j|^2, torch_edge.py:41-43, as in the exact kernel
         const float dd = __fadd_rn(__fmaf_rn(-2.0f, z, sq), sqj);
-        if (f < F) fin[f] = tag | ((unsigned long long)key_of(dd) << 12) | (unsigned long long)idx;
+        if (f < F && p < (unsigned)KB_MAXFIN)
+            sorted[p] = ((unsigned long long)rho << 60) | ((unsigned long long)((ent - base) >> s2) << 50) | ((unsigned long long)key_of(dd) << 12) | (unsigned long long)idx;
         // The bound everything above rests on, L <= D <= L + 2 e_ij, assumes how the bf16 MFMA rounds internally (measured,
         // not documented).  Both sides are in registers here, so it is CHECKED for every finalist: the exact distance in key
         // units must lie in [key - 2, key + margin] (2 = the key's own rounding); a violation (or a NaN) sends the tile to the
@@ -420,23 +505,71 @@ __device__ __noinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFinalA
     wave_lds_fence();
     KB_PH(11);
     int32_t *out = a.out + (size_t)(h * KB_WAVES) * a.k;
+    const unsigned long long m44 = (1ull << 44) - 1ull;
+    // two finalists more than w2 bins apart are ordered by their bins alone (their exact distances were checked against
+    // [key - 2, key + margin + 1] above)
+    const unsigned w2 = (margin + 3u + (1u << sh) - 1u) >> sh;
+    const unsigned *sorted_hi = (const unsigned *)row + 1;          // high dword of composite p at [2 p]
     for (unsigned f0 = 0; f0 < Fmax; f0 += 32) {
-        const unsigned f = f0 + (unsigned)l5;
-        const unsigned long long x = f < F ? fin[f] : ~0ull;
-        const unsigned long long xlo = x & ~m44;              // the smallest value of x's run
-        // rank = first rank of the run + (finalists below x) - (finalists below the run)
-        unsigned below = 0, below_run = 0;
-        for (unsigned g = 0; g < Fmax; g += 2) {
-            const unsigned long long y0 = g < F ? fin[g] : ~0ull, y1 = g + 1 < F ? fin[g + 1] : ~0ull;
-            below += (y0 < x ? 1u : 0u) + (y1 < x ? 1u : 0u);
-            below_run += (y0 < xlo ? 1u : 0u) + (y1 < xlo ? 1u : 0u);
+        const unsigned p = f0 + (unsigned)l5;
+        const bool live = p < F;
+        const unsigned long long x = live ? sorted[p] : 0ull;
+        const unsigned long long xk = x & m44;
+        const uint2 re = rt[(unsigned)(x >> 60)];
+        const unsigned fs = re.y & 0xFFFFu, len = live ? re.y >> 16 : 0u;
+        // exact rank = the run's first rank + the run's composites below x.  Short runs: compare with the whole run.  Long
+        // ones (merged windows, dense ties): the run is sorted by bin, so everything before the first position whose bin is
+        // within w2 of x's is smaller, everything after the last is larger; only the stretch between is compared
+        unsigned lb = fs, ub = fs + len;
+        if (wave_max_u32(len) > 24u) {
+            const unsigned bx = (unsigned)(x >> 50) & 1023u;
+            const unsigned lo_b = bx > w2 ? bx - w2 : 0u, hi_b = bx + w2;
+            unsigned n1 = len, n2 = len;
+            ub = fs;
+#pragma unroll 1
+            for (int it = 0; it < 9; ++it) {
+                const unsigned h1 = n1 >> 1, h2 = n2 >> 1;
+                const unsigned b1 = (sorted_hi[2u * ((lb + h1) & 255u)] >> 18) & 1023u, b2 = (sorted_hi[2u * ((ub + h2) & 255u)] >> 18) & 1023u;
+                const bool r1 = n1 != 0u && b1 < lo_b, r2 = n2 != 0u && b2 <= hi_b;
+                lb = r1 ? lb + h1 + 1u : lb; n1 = r1 ? n1 - h1 - 1u : h1;
+                ub = r2 ? ub + h2 + 1u : ub; n2 = r2 ? n2 - h2 - 1u : h2;
+            }
         }
-        const unsigned rank = (unsigned)(x >> 44) + below - below_run;
+        unsigned below = lb - fs;
+        const unsigned span = wave_max_u32(ub - lb);
+        for (unsigned j = 0; j < span; ++j) {
+            const unsigned pos = lb + j;
+            const bool act = pos < ub;
+            const unsigned long long y = sorted[act ? pos : p & 255u] & m44;
+            below += (act && y < xk) ? 1u : 0u;
+        }
+        const unsigned rank = re.x + below;
         const unsigned t = (rank * a.magic) >> 18;
-        if (f < F && t * a.d == rank && t < a.k) out[t] = (int32_t)(x & 0xFFFull);
+        if (live && t * a.d == rank && t < a.k) out[t] = (int32_t)(x & 0xFFFull);
     }
     KB_PH(12);
     return F + Fo;
+}
+
+// one candidate tile's nine operand fragments (k-steps 0..3 hi, 4..7 lo, 8 augmented), lane-major 16-byte pieces
+__device__ __forceinline__ void kb_load_tile(kb_u32x4 (&fr)[9], const kb_u32x4 *__restrict__ p)
+{
+#pragma unroll
+    for (int s = 0; s < 9; ++s) fr[s] = p[s * 64];
+}
+// acc (see the header) of the tile against the workgroup's 32 queries: 13 chained MFMAs
+__device__ __forceinline__ kb_f32x16 kb_tile_product(const kb_u32x4 (&fr)[9], const kb_u32x4 (&bq)[8], const kb_u32x4 qa)
+{
+    kb_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const kb_bf16x8 ch = __builtin_bit_cast(kb_bf16x8, fr[s]), cl = __builtin_bit_cast(kb_bf16x8, fr[4 + s]);
+        const kb_bf16x8 qh = __builtin_bit_cast(kb_bf16x8, bq[s]), ql = __builtin_bit_cast(kb_bf16x8, bq[4 + s]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch, qh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch, ql, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl, qh, acc, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kb_bf16x8, fr[8]), __builtin_bit_cast(kb_bf16x8, qa), acc, 0, 0, 0);
 }
 
 #ifndef KB_MIN_WAVES_EU
@@ -445,15 +578,15 @@ __device__ __noinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFinalA
 __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(KnnBfArgs a)
 {
     constexpr int CAP = KB_CAP, ROW = KB_ROW;
-    constexpr int PER_STEP = KB_WAVES * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char kb_smem[];
     unsigned *ent = (unsigned *)kb_smem;                      // [KB_Q][ROW]
     float *thr_f = (float *)(ent + KB_Q * ROW);               // [KB_Q] admission threshold on acc
     unsigned *cnt = (unsigned *)(thr_f + KB_Q);               // [KB_Q]
     unsigned *tau = cnt + KB_Q;                               // [KB_Q] key threshold of the row
-    float *rpar = (float *)(tau + KB_Q);                      // [KB_Q][KB_RP] row parameters
-    float *scr = rpar + KB_Q * KB_RP + 192 * (threadIdx.x >> 6);     // [KB_WAVES][2][96] per wave and row: query features + bitmap
-    unsigned *smax = (unsigned *)(rpar + KB_Q * KB_RP + 192 * KB_WAVES);   // [KB_WAVES]
+    unsigned *keyx = tau + KB_Q;                              // [KB_Q] keyX of the cut: KK entries at or below it prove the row complete
+    float *rpar = (float *)(keyx + KB_Q);                     // [KB_Q][KB_RP] row parameters
+    float *scr = rpar + KB_Q * KB_RP + 2 * KB_SCR * (threadIdx.x >> 6);   // [KB_WAVES][2][KB_SCR] per wave and row: query features, bitmap, run table
+    unsigned *smax = (unsigned *)(rpar + KB_Q * KB_RP + 2 * KB_SCR * KB_WAVES);   // [KB_WAVES]
     unsigned *fail = smax + KB_WAVES;                         // [4] (one used)
     unsigned *sink = fail + 4 + threadIdx.x;                  // [KB_WAVES * 64] one word per thread: entries that fail the test
 
@@ -468,6 +601,9 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
     const size_t room_row0 = (size_t)room * a.N;
     const size_t tile0 = (size_t)room * tpr;
     const unsigned KK = (unsigned)a.KK;
+    // wave w streams the tiles w n_steps .. w n_steps + n_steps - 1: step 0 of the workgroup is a strided sample of the room
+    const int n_steps = (tpr + KB_WAVES - 1) / KB_WAVES;
+    const int nv0 = (tpr + n_steps - 1) / n_steps;            // waves that hold a tile at step 0 = sample registers per lane of the cut
 
     {
         unsigned mb = 0u;
@@ -489,7 +625,6 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
     for (int s = 0; s < 8; ++s) bq[s] = a.bp[((size_t)tile * 9 + s) * 64 + lane];
 #ifdef PSG_KF_TL
     unsigned long long tl0 = 0;
-    int n_tl = 0;
     if (tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl0) :: "memory");
 #endif
     __syncthreads();
@@ -508,25 +643,25 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
         float *rp = rpar + tid * KB_RP;
         rp[0] = sqi; rp[1] = sqrtf(sqi); rp[2] = unit; rp[3] = inv_unit;
         rp[4] = __fmaf_rn(sqi * (1.0f - KB_G), inv_unit, KB_OFF);      // key = round(acc * (-2 / u) + this)
-        cnt[tid] = 0u;
-        tau[tid] = KB_KEYMAX;
-        // open row: everything up to the largest key is admitted (acc * m2 + ci < KEYMAX + 1, two units for the evaluation)
+        cnt[tid] = (unsigned)(32 * nv0);
+        tau[tid] = KB_TAUMAX;
+        keyx[tid] = 0u;
+        // step 0 takes everything inside the key range (acc * m2 + ci < KEYMAX - 1, two units for the evaluation)
         thr_f[tid] = (rp[4] - (float)(KB_KEYMAX - 2u)) * (0.5f * unit);
     }
     __syncthreads();
     KB_TL(0);
     const float m2 = -2.0f * rpar[r * KB_RP + 3];
     const float ci23 = rpar[r * KB_RP + 4] + 8388608.0f;      // key = mantissa of acc * m2 + ci23
-    unsigned long long st_fin = 0, st_cut = 0, st_ent = 0;
+    unsigned long long st_fin = 0, st_ent = 0;
     KbRowArgs ra;
     ra.row_dw = (unsigned)(wave * ROW); ra.rp_dw = (unsigned)(rpar - (float *)kb_smem);
     ra.cnt_dw = (unsigned)(cnt - (unsigned *)kb_smem); ra.thr_dw = (unsigned)(thr_f - (float *)kb_smem);
-    ra.tau_dw = (unsigned)(tau - (unsigned *)kb_smem); ra.KK = KK; ra.wave = wave;
+    ra.tau_dw = (unsigned)(tau - (unsigned *)kb_smem); ra.keyx_dw = (unsigned)(keyx - (unsigned *)kb_smem);
+    ra.KK = KK; ra.wave = wave;
+    ra.T[0] = ra.T[1] = 0u;
 
     if (!need_exact) {
-        const int n_steps = (tpr + KB_WAVES - 1) / KB_WAVES;
-        const float grow = a.grow;
-        unsigned next_prune = (unsigned)a.first_cut;
         // the augmented k-step's query side: 1, 1, 1 (x the three pieces of -(1 - B) |x_j|^2 / 2) and |x_i| rounded up to bf16
         // (x (A / 2) |x_j| rounded up) in elements 0..3 of the h = 0 lanes
         kb_u32x4 qa = kb_u32x4{0u, 0u, 0u, 0u};
@@ -534,24 +669,51 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
             const unsigned au = __float_as_uint(rpar[r * KB_RP + 1]);
             qa = kb_u32x4{0x3F803F80u, 0x00003F80u | (((au + 0xFFFFu) >> 16) << 16), 0u, 0u};
         }
-        for (int step = 0; step < n_steps; ++step) {
-            const int t = step * KB_WAVES + wave;
-            if (t < tpr) {
-                kb_u32x4 fr[9];
+        // step 0, the sample: every pair's entry at a fixed slot (wave, half, g); pairs beyond the key range (and NaNs) get the
+        // key KEYMAX, which no threshold keeps
+        if (wave < nv0) {
+            const int t = wave * n_steps;
+            kb_u32x4 fr[9];
+            kb_load_tile(fr, a.bp + (tile0 + t) * 9 * 64 + lane);
+            const kb_f32x16 acc = kb_tile_product(fr, bq, qa);
+            const float th = thr_f[r];
+            const unsigned cb = (unsigned)(32 * t + 4 * h);
+            unsigned *dst = ent + r * ROW + wave * 32 + h * 16;
 #pragma unroll
-                for (int s = 0; s < 9; ++s) fr[s] = a.bp[((tile0 + t) * 9 + s) * 64 + lane];
-                kb_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < 16; g += 2) {
+                unsigned e[2];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const kb_bf16x8 ch = __builtin_bit_cast(kb_bf16x8, fr[s]), cl = __builtin_bit_cast(kb_bf16x8, fr[4 + s]);
-                    const kb_bf16x8 qh = __builtin_bit_cast(kb_bf16x8, bq[s]), ql = __builtin_bit_cast(kb_bf16x8, bq[4 + s]);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch, qh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch, ql, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl, qh, acc, 0, 0, 0);
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned kb = __float_as_uint(__fmaf_rn(acc[g + u], m2, ci23));
+                    const unsigned key = acc[g + u] >= th ? (kb & 0xFFFFFu) : KB_KEYMAX;
+                    e[u] = (key << 12) | cb | (unsigned)(((g + u) & 3) + 8 * ((g + u) >> 2));
                 }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kb_bf16x8, fr[8]), __builtin_bit_cast(kb_bf16x8, qa), acc, 0, 0, 0);
-                // lane (query r, half h) holds the 16 candidates 32 t + (g & 3) + 8 (g >> 2) + 4 h
-                const float th = thr_f[r];
+                *(uint2 *)(dst + g) = make_uint2(e[0], e[1]);
+            }
+        }
+        __syncthreads();
+        KB_TL(1);
+        {
+            const bool bad = kb_cut_sample(ra, lane, nv0, a.rsel);
+            if (__ballot(bad) != 0ull && lane == 0) *fail = 1u;
+        }
+        __syncthreads();
+        KB_TL(2);
+        need_exact = *fail != 0u;
+        if (!need_exact && n_steps > 1) {
+            // the stream: lane (query r, half h) holds the 16 candidates 32 t + (g & 3) + 8 (g >> 2) + 4 h of tile t.  The next
+            // tile's nine operand fragments are requested as soon as the products have consumed this tile's, so that their
+            // latency runs under the append work (requested one by one in front of the MFMAs that use them, each wave waited
+            // nine L2 round trips per tile)
+            const float th = thr_f[r];
+            const int t_first = wave * n_steps + 1;
+            const int t_end = (wave + 1) * n_steps < tpr ? (wave + 1) * n_steps : tpr;
+            kb_u32x4 fr[9];
+            if (t_first < t_end) kb_load_tile(fr, a.bp + (tile0 + t_first) * 9 * 64 + lane);
+            for (int t = t_first; t < t_end; ++t) {
+                const kb_f32x16 acc = kb_tile_product(fr, bq, qa);
+                if (t + 1 < t_end) kb_load_tile(fr, a.bp + (tile0 + t + 1) * 9 * 64 + lane);
+                const unsigned cb = (unsigned)(32 * t + 4 * h);
                 unsigned n = 0;
 #pragma unroll
                 for (int g = 0; g < 16; ++g) n += acc[g] >= th ? 1u : 0u;
@@ -561,7 +723,6 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
                         // branch-free append: every pair builds its entry, the ones that fail the test store it to the
                         // thread's sink word (16 exec-masked blocks with two taken branches each cost more)
                         unsigned *dst = ent + r * ROW + base;
-                        const unsigned cb = (unsigned)(32 * t + 4 * h);
                         unsigned off = 0;
 #pragma unroll
                         for (int g = 0; g < 16; ++g) {
@@ -575,48 +736,28 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
                     }
                 }
             }
-            const unsigned seen = (unsigned)(step + 1) * (unsigned)PER_STEP;
-            if (seen >= next_prune && step + 1 < n_steps) {
-                const unsigned nn = (unsigned)(grow * (float)seen) / (unsigned)PER_STEP * (unsigned)PER_STEP;
-                next_prune = nn > seen ? nn : seen + (unsigned)PER_STEP;
-                __syncthreads();
-#ifdef PSG_KF_TL
-                KB_TL(n_tl < 3 ? 1 + 2 * n_tl : 5);
-#endif
-                // (every wave sees the same counters here: a row is only cut by waves that saw no overflow, and an
-                // overflowing counter stays above CAP)
-                if (__ballot(lane < KB_Q && cnt[lane & (KB_Q - 1)] > (unsigned)CAP) != 0ull) { need_exact = true; break; }
-                {
-                    const unsigned T0 = cnt[wave], T1 = cnt[wave + KB_WAVES];
-                    ra.T[0] = T0 > (unsigned)a.LOW ? T0 : 0u;
-                    ra.T[1] = T1 > (unsigned)a.LOW ? T1 : 0u;
-                    const unsigned Tm = ra.T[0] > ra.T[1] ? ra.T[0] : ra.T[1];
-                    if (Tm) {
-                        if (Tm <= 512u) kb_cut_rows<16>(ra, lane); else kb_cut_rows<32>(ra, lane);
-                        st_cut += (ra.T[0] ? 1u : 0u) + (ra.T[1] ? 1u : 0u);
-                    }
-                }
-                __syncthreads();
-#ifdef PSG_KF_TL
-                KB_TL(n_tl < 3 ? 2 + 2 * n_tl : 6);
-                ++n_tl;
-#endif
-            }
         }
         __syncthreads();
         KB_TL(8);
         // an overflowing row, or one that the key range left with fewer than KK candidates: exact path
-        if (!need_exact) need_exact = __ballot(lane < KB_Q && (cnt[lane & (KB_Q - 1)] > (unsigned)CAP || cnt[lane & (KB_Q - 1)] < KK)) != 0ull;
+        unsigned Twg = 0u;
+        if (!need_exact) {
+            const unsigned cl = cnt[lane & (KB_Q - 1)];
+            need_exact = __ballot(cl > (unsigned)CAP || cl < KK) != 0ull;
+            Twg = wave_max_u32(cl);
+        }
         if (!need_exact) {
             KbFinalArgs fa;
-            fa.xp = a.exact.xp; fa.sq = a.sq; fa.k = (unsigned)a.k; fa.d = (unsigned)a.d; fa.magic = a.magic;
+            fa.x = a.x; fa.ld = (unsigned)a.ld; fa.sq = a.sq; fa.k = (unsigned)a.k; fa.d = (unsigned)a.d; fa.magic = a.magic;
             fa.room_row0 = room_row0; fa.qglob = (size_t)tile * KB_Q + wave;
             fa.out = a.out + fa.qglob * a.k;
             fa.scr_dw = (unsigned)(scr - (float *)kb_smem);
             ra.T[0] = cnt[wave]; ra.T[1] = cnt[wave + KB_WAVES];
             const unsigned Tm = ra.T[0] > ra.T[1] ? ra.T[0] : ra.T[1];
-            const unsigned nf = Tm <= 256u ? kb_final_rows<8>(ra, fa, lane)
-                              : (Tm <= 512u ? kb_final_rows<16>(ra, fa, lane) : kb_final_rows<32>(ra, fa, lane));
+            const int nv = (int)((Tm + 31u) >> 5);
+            // (the bin count follows the workgroup's longest row, so every wave runs the same code at the same time)
+            const unsigned nf = Twg <= 256u ? kb_final_rows<8, 256>(ra, fa, lane, nv)
+                              : (Twg <= 512u ? kb_final_rows<16, 1024>(ra, fa, lane, nv) : kb_final_rows<32, 1024>(ra, fa, lane, nv));
             if (nf == 0xFFFFFFFFu) { if (lane == 0) *fail = 1u; }
             else { st_fin += nf; st_ent += ra.T[0] + ra.T[1]; }
             KB_TL(9);
@@ -634,7 +775,7 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
         unsigned *acc3 = (unsigned *)smax;
         if (tid < 3) acc3[tid] = 0u;
         __syncthreads();
-        if (lane == 0 && !need_exact) { atomicAdd(&acc3[0], (unsigned)st_fin); atomicAdd(&acc3[1], (unsigned)st_cut); atomicAdd(&acc3[2], (unsigned)st_ent); }
+        if (lane == 0 && !need_exact) { atomicAdd(&acc3[0], (unsigned)st_fin); atomicAdd(&acc3[1], 2u); atomicAdd(&acc3[2], (unsigned)st_ent); }
         __syncthreads();
         if (tid == 0) {
             atomicAdd(&a.stats[0], 1ull);
@@ -656,6 +797,6 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
 
 inline size_t knn_bf_lds_bytes()
 {
-    const size_t own = (size_t)KB_Q * KB_ROW * 4 + KB_Q * 12 + KB_Q * KB_RP * 4 + KB_WAVES * 192 * 4 + KB_WAVES * 4 + 16 + KB_WAVES * 64 * 4;
+    const size_t own = (size_t)KB_Q * KB_ROW * 4 + KB_Q * 16 + KB_Q * KB_RP * 4 + KB_WAVES * 2 * KB_SCR * 4 + KB_WAVES * 4 + 16 + KB_WAVES * 64 * 4;
     return own > knn_fused_lds_bytes() ? own : knn_fused_lds_bytes();
 }

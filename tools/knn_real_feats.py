@@ -33,6 +33,19 @@ for e in [int(v) for v in os.environ.get("BLOCKS", "1,2,3,5,9,14,20,27").split("
             w.knn(x, e)
         t1.record(); torch.cuda.synchronize()
         t.append(t0.elapsed_time(t1) * 100)
+    from pointsecguard_amd import _lib
+    lib = _lib.load()
+    if hasattr(lib, "psg_dbg_knn_tl"):
+        import ctypes
+        buf = (ctypes.c_ulonglong * 32)(); lib.psg_dbg_knn_tl(buf)
+        ws.knn(x, e); lib.psg_dbg_knn_tl(buf)
+        names = ("start", "sample", "cut done", "-", "-", "-", "-", "-", "stream end", "wave0 final end", "all final end", "slowest workgroup")
+        print("      timeline: " + "  ".join("%s %.0f" % (names[i], buf[i] / buf[16 + i]) for i in range(12) if buf[16 + i]), flush=True)
+        ph = (ctypes.c_ulonglong * 32)(); lib.psg_dbg_knn_ph(ph)
+        pn = ("cut:load", "cut:minmax", "cut:hist", "cut:find", "cut:compact", "fin:load", "fin:params", "fin:hist", "fin:cum", "fin:search",
+              "fin:collect", "fin:exact", "fin:rank")
+        if any(ph[16 + i] for i in range(13)):
+            print("      phases: " + "  ".join("%s %.0f" % (pn[i], ph[i] / ph[16 + i]) for i in range(13) if ph[16 + i]), flush=True)
     rows = max(st["rows"], 1)
     # spread of the 16 d-th nearest distances relative to the room's largest squared norm
     dist = torch.cdist(x[0, :256], x[0]) ** 2
