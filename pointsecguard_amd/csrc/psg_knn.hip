@@ -115,6 +115,8 @@ hipError_t knn_launch(const KnnBuffers &buf, int B, int N, int k, int d, int32_t
     a.bp = (const kb_u32x4 *)buf.bp; a.sq = buf.sq; a.out = out; a.N = N; a.k = k; a.d = d; a.KK = f.KK; a.magic = f.magic;
     a.rsel = knn_sample_rank(N, a.KK);
     a.x = buf.x; a.ld = buf.ld;
+    static const int fine_from = psg::env_int("PSG_KNN_FINE_CUT_KK", 100);
+    a.fine_cut = a.KK >= fine_from;
     a.exact = f;
     a.stats = buf.stats;
     hipLaunchKernelGGL(knn_bf_kernel, dim3((unsigned)((size_t)B * N / KB_Q)), dim3(KB_WAVES * 64), knn_bf_lds_bytes(), st, a);

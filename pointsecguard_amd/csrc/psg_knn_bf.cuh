@@ -103,6 +103,7 @@ struct KnnBfArgs {
     int k, d, KK;
     unsigned magic;       // ceil(2^18 / d)
     unsigned rsel;        // the cut after step 0 keeps the sample keys up to the rsel-th smallest (+ the row margin)
+    int fine_cut;         // second histogram level inside the threshold's bin (long rows: 20 % fewer entries, no overflows up to d = 20)
     KnnFusedArgs exact;            // the exact path's arguments (xp, sq, out, ...)
     unsigned long long *stats;     // optional [8]: tiles, fallback tiles, rows, finalists, rows cut, entries at the end
 };
@@ -173,7 +174,7 @@ struct KbRowArgs {
 // keyX = that bin's upper edge (exact integers); tau = keyX + E_i(keyX) / u_i; every entry with key <= tau is kept,
 // compacted in place.  Lane 0 of each half stores the row's count and thresholds; returns true (in every lane of the
 // half) when the row cannot go on (fewer than rsel sample keys in range, or a threshold beyond the key range).
-__device__ __forceinline__ bool kb_cut_sample(const KbRowArgs c, int lane, int nv0, unsigned rsel)
+__device__ __forceinline__ bool kb_cut_sample(const KbRowArgs c, int lane, int nv0, unsigned rsel, bool fine)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char kb_smem[];
     const int h = lane >> 5, l5 = lane & 31;
@@ -236,7 +237,7 @@ __device__ __forceinline__ bool kb_cut_sample(const KbRowArgs c, int lane, int n
     // second level inside bin binB (bins wider than one key): 2^(sh - sh2) sub-bins of width 2^sh2 (one key when sh <= 8), so
     // that keyX is the rsel-th smallest sample key itself, not the edge of a bin that may hold a dozen of them
     unsigned keyX = kmn + ((binB + 1u) << sh) - 1u;
-    if (__ballot(sh != 0u) != 0ull) {
+    if (fine && __ballot(sh != 0u) != 0ull) {
         const unsigned sh2 = sh > 8u ? sh - 8u : 0u, smask = (1u << (sh - sh2)) - 1u;
         wave_lds_fence();
 #pragma unroll
@@ -470,9 +471,6 @@ __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFin
         const unsigned idx = ent & 0xFFFu;
         const size_t vc = a.room_row0 + idx;
         const float4 *pc = (const float4 *)(a.x + vc * a.ld);
-        float4 C[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) C[j] = pc[j];
         const float sqj = a.sq[vc];
         // the finalist's run: the last one whose first rank is at most q (runs beyond the row's last read as 0xFFFFFFFF)
         unsigned rho = 0u;
@@ -483,7 +481,12 @@ __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFin
         }
         const uint2 re = rt[rho];
         const unsigned p = (re.y & 0xFFFFu) + q - re.x;
-        // ascending-k fmaf chain from 0, the exact kernel's arithmetic (and a CPU sgemm's)
+        // ascending-k fmaf chain from 0, the exact kernel's arithmetic (and a CPU sgemm's).  (Every lane reads another vertex:
+        // 64 lanes x 16 loads of 16 bytes per round; fetching the 256 bytes in two or four consumed-at-once pieces changed
+        // nothing - the phase is bound by the 64 B / clk of the CU's address path, 4 cycles per finalist.)
+        float4 C[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) C[j] = pc[j];
         float z = 0.0f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
         __syncthreads();
         KB_TL(1);
         {
-            const bool bad = kb_cut_sample(ra, lane, nv0, a.rsel);
+            const bool bad = kb_cut_sample(ra, lane, nv0, a.rsel, a.fine_cut != 0);
             if (__ballot(bad) != 0ull && lane == 0) *fail = 1u;
         }
         __syncthreads();
