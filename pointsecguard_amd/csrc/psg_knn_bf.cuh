@@ -22,9 +22,9 @@
 // hence |x_j| <= 1.0148 |x_i| + 1.015 sqrt(T) and 2 e_ij <= E_i(T) = 2 (A |x_i| t + B t^2 + G |x_i|^2) at that t: one
 // number per row and threshold bounds the gap between L and D for everything the row can hold.
 //
-// Keys.  key = round((L + 16 u_i) / u_i) with the row's own unit u_i = E_i(|x_i|^2) / 8 ~ 2^-13.9 |x_i|^2 (one FMA whose
+// Keys.  key = round((L + 32 u_i) / u_i) with the row's own unit u_i = E_i(|x_i|^2) / 16 ~ 2^-14.9 |x_i|^2 (one FMA whose
 // constant carries 2^23: the key is the result's mantissa); a row entry is key << 12 | index (32 bits: twice the rows of
-// the exact kernel in the same LDS).  Candidates farther than 2^20 units (71 |x_i|^2) are never kept; a row that
+// the exact kernel in the same LDS).  Candidates farther than 2^20 units (35 |x_i|^2) are never kept; a row that
 // needs them takes the exact path.
 //
 // Threshold from a SAMPLE (round 4; rounds 2-3 cut the rows on a growth schedule, 1-3 histogram cuts of 512-1024
@@ -61,7 +61,10 @@ constexpr int KB_Q = 32;                      // query rows per workgroup (one 3
 constexpr int KB_CAP = 1024;                  // entries per row buffer
 constexpr int KB_ROW = KB_CAP + 2;            // dwords between rows: 8-byte aligned, skewed over the LDS banks
 constexpr float KB_A = KNN_BF_A, KB_B = KNN_BF_B, KB_G = KNN_BF_G;   // 2^-13.5, 2^-15.5, 2^-20 (psg_knn_ops.cuh)
-constexpr float KB_OFF = 16.0f;               // key offset in units: L of the query itself (>= -2 e_ii ~ -3.2 u) stays positive
+// (round 4: units of E / 16 instead of E / 8 - the +- 3 units of key quantisation in every margin were a third of it: 20 %
+// fewer finalists at d >= 9; E / 32 gave the same counts, the windows are then limited by the bin width)
+constexpr int KB_UNIT_DIV = 16;               // the key unit is E_i(|x_i|^2) / KB_UNIT_DIV
+constexpr float KB_OFF = 32.0f;               // key offset in units: L of the query itself (>= -2 e_ii ~ -6.4 u) stays positive
 constexpr unsigned KB_KEYMAX = 0xFFFFEu;      // key of a candidate beyond the key range (never kept)
 constexpr unsigned KB_TAUMAX = 0xFFFF0u;      // largest row threshold (admission lets keys up to tau + 3 through: they must fit 20 bits)
 constexpr int KB_MAXFIN = 256;
@@ -626,6 +629,9 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
     kb_u32x4 bq[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) bq[s] = a.bp[((size_t)tile * 9 + s) * 64 + lane];
+    // the wave's sample tile is requested here, so that its latency runs under the prologue
+    kb_u32x4 fr0[9];
+    if (wave < nv0) kb_load_tile(fr0, a.bp + (tile0 + (size_t)(wave * n_steps)) * 9 * 64 + lane);
 #ifdef PSG_KF_TL
     unsigned long long tl0 = 0;
     if (tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl0) :: "memory");
@@ -636,12 +642,12 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
     bool need_exact = !(mbits >= 0x20000000u && mbits <= 0x7C000000u);
     const float sqmaxf = __uint_as_float(mbits);
     if (tid < KB_Q) {
-        // row parameters: the key unit is E_i(|x_i|^2) / 8 (a query far below the room's norms gets a floor, so that the
+        // row parameters: the key unit is E_i(|x_i|^2) / KB_UNIT_DIV (a query far below the room's norms gets a floor, so that the
         // unit stays a normal number)
         const float sqi = a.sq[(size_t)tile * KB_Q + tid];
         const float sqe = fmaxf(sqi, sqmaxf * (1.0f / 4096.0f));
         const float ae = sqrtf(sqe), t0 = 2.0298f * ae;
-        const float unit = 0.25f * (KB_A * ae * t0 + KB_B * t0 * t0 + KB_G * sqe);
+        const float unit = (2.0f / (float)KB_UNIT_DIV) * (KB_A * ae * t0 + KB_B * t0 * t0 + KB_G * sqe);
         const float inv_unit = 1.0f / unit;
         float *rp = rpar + tid * KB_RP;
         rp[0] = sqi; rp[1] = sqrtf(sqi); rp[2] = unit; rp[3] = inv_unit;
@@ -676,9 +682,7 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
         // key KEYMAX, which no threshold keeps
         if (wave < nv0) {
             const int t = wave * n_steps;
-            kb_u32x4 fr[9];
-            kb_load_tile(fr, a.bp + (tile0 + t) * 9 * 64 + lane);
-            const kb_f32x16 acc = kb_tile_product(fr, bq, qa);
+            const kb_f32x16 acc = kb_tile_product(fr0, bq, qa);
             const float th = thr_f[r];
             const unsigned cb = (unsigned)(32 * t + 4 * h);
             unsigned *dst = ent + r * ROW + wave * 32 + h * 16;
