@@ -39,16 +39,16 @@ __global__ void knn_prep_kernel(const float *__restrict__ x, int ld, size_t rows
 // the row's threshold is the r-th smallest sample key (+ margin).  The row ends short of KK keys below it iff the sample
 // holds at least r of the row's KK - 1 nearest candidates: X ~ Hypergeometric(N, KK - 1, S) for candidates in random
 // order.  r = the smallest value with P(X >= r) <= 1e-7 (S = N: r = KK, the plain exact cut).
-unsigned knn_sample_rank(int N, int KK)
+unsigned knn_sample_rank(int N, int KK, int nsamp)
 {
     static std::mutex mu;
     static std::unordered_map<unsigned long long, unsigned> cache;
-    const unsigned long long key = ((unsigned long long)(unsigned)N << 32) | (unsigned)KK;
+    const unsigned long long key = ((unsigned long long)(unsigned)N << 32) | ((unsigned)KK << 2) | (unsigned)nsamp;
     std::lock_guard<std::mutex> lock(mu);
     const auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     const int tpr = N >> 5, n_steps = (tpr + KB_WAVES - 1) / KB_WAVES, nv0 = (tpr + n_steps - 1) / n_steps;
-    const int S = 32 * nv0, K1 = KK - 1;
+    const int S = 32 * nv0 * nsamp, K1 = KK - 1;
     auto lchoose = [](int n, int m) { return std::lgamma((double)n + 1.0) - std::lgamma((double)m + 1.0) - std::lgamma((double)(n - m) + 1.0); };
     const double denom = lchoose(N, S);
     const int hi = K1 < S ? K1 : S;
@@ -113,7 +113,11 @@ hipError_t knn_launch(const KnnBuffers &buf, int B, int N, int k, int d, int32_t
     }
     KnnBfArgs a;
     a.bp = (const kb_u32x4 *)buf.bp; a.sq = buf.sq; a.out = out; a.N = N; a.k = k; a.d = d; a.KK = f.KK; a.magic = f.magic;
-    a.rsel = knn_sample_rank(N, a.KK);
+    // two sample tiles per wave for the longest rows (psg_knn_bf.cuh)
+    static const int two_from = psg::env_int("PSG_KNN_SAMPLE2_KK", 311);
+    const int n_steps = ((N >> 5) + KB_WAVES - 1) / KB_WAVES;
+    a.nsamp = (a.KK >= two_from && (N & 511) == 0 && n_steps >= 4) ? 2 : 1;
+    a.rsel = knn_sample_rank(N, a.KK, a.nsamp);
     a.x = buf.x; a.ld = buf.ld;
     static const int fine_from = psg::env_int("PSG_KNN_FINE_CUT_KK", 100);
     a.fine_cut = a.KK >= fine_from;

@@ -106,6 +106,7 @@ struct KnnBfArgs {
     int k, d, KK;
     unsigned magic;       // ceil(2^18 / d)
     unsigned rsel;        // the cut after step 0 keeps the sample keys up to the rsel-th smallest (+ the row margin)
+    int nsamp;            // sample tiles per wave: 1, or 2 for long rows (N a multiple of 512, at least 4 steps)
     int fine_cut;         // second histogram level inside the threshold's bin (long rows: 20 % fewer entries, no overflows up to d = 20)
     KnnFusedArgs exact;            // the exact path's arguments (xp, sq, out, ...)
     unsigned long long *stats;     // optional [8]: tiles, fallback tiles, rows, finalists, rows cut, entries at the end
@@ -177,6 +178,7 @@ struct KbRowArgs {
 // keyX = that bin's upper edge (exact integers); tau = keyX + E_i(keyX) / u_i; every entry with key <= tau is kept,
 // compacted in place.  Lane 0 of each half stores the row's count and thresholds; returns true (in every lane of the
 // half) when the row cannot go on (fewer than rsel sample keys in range, or a threshold beyond the key range).
+template <int NVC>
 __device__ __forceinline__ bool kb_cut_sample(const KbRowArgs c, int lane, int nv0, unsigned rsel, bool fine)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char kb_smem[];
@@ -184,11 +186,11 @@ __device__ __forceinline__ bool kb_cut_sample(const KbRowArgs c, int lane, int n
     const int ridx = c.wave + KB_WAVES * h;
     unsigned *row = (unsigned *)kb_smem + c.row_dw + h * KB_WAVES * KB_ROW;
     const float *rp = (const float *)kb_smem + c.rp_dw + ridx * KB_RP;
-    unsigned v[16];
+    unsigned v[NVC];
     unsigned mx = 0u, mnn = 0u;                             // mnn = max of ~v = ~min v
     KB_PH_BEGIN;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NVC; ++i) {
         v[i] = 0xFFFFFFFFu;
         if (i < nv0) {
             v[i] = row[i * 32 + l5];
@@ -210,7 +212,7 @@ __device__ __forceinline__ bool kb_cut_sample(const KbRowArgs c, int lane, int n
     wave_lds_fence();
     KB_PH(1);
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < NVC; ++i)
         if (i < nv0) atomicAdd(&row[(v[i] - base) >> s2], 1u);
     wave_lds_fence();
     KB_PH(2);
@@ -247,7 +249,7 @@ __device__ __forceinline__ bool kb_cut_sample(const KbRowArgs c, int lane, int n
         for (int j = 0; j < 4; ++j) ((uint2 *)row)[4 * l5 + j] = make_uint2(0u, 0u);
         wave_lds_fence();
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
+        for (int i = 0; i < NVC; ++i)
             if (i < nv0) {
                 if (((v[i] - base) >> s2) == binB) atomicAdd(&row[((v[i] - base) >> (12u + sh2)) & smask], 1u);
             }
@@ -263,7 +265,7 @@ __device__ __forceinline__ bool kb_cut_sample(const KbRowArgs c, int lane, int n
     KB_PH(3);
     unsigned cb = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NVC; ++i) {
         if (i < nv0) {
             const bool keep = v[i] <= keepmax;
             const unsigned long long bl = __ballot(keep);
@@ -355,7 +357,7 @@ __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFin
     const unsigned kmx = kb_half_max_u32(mx) >> 12, kmn = (~kb_half_max_u32(mnn)) >> 12;
     // the exactness test (see the header): at least KK entries at or below the cut's keyX
     const bool short_row = kb_half_sum_u32(nle) < c.KK;
-    if (__ballot(short_row) != 0ull) return 0xFFFFFFFFu;
+    if (__ballot(short_row) != 0ull) return 0xFFFFFFFFu;           // (codes: FFFFFFFF short row, ..FE finalists, ..FD bound)
     // the gap between L and D for everything the row holds: from its threshold, or from its largest key
     const unsigned ktop = tau_row < kmx ? tau_row : kmx;
     const unsigned margin = kb_margin_keys(aa, sq, inv_unit, ((float)ktop - KB_OFF) * unit);
@@ -464,7 +466,7 @@ __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFin
     KB_PH(10);
     const unsigned Fo = (unsigned)__shfl_xor((int)F, 32);
     const unsigned Fmax = F > Fo ? F : Fo;
-    if (Fmax > (unsigned)KB_MAXFIN) return 0xFFFFFFFFu;
+    if (Fmax > (unsigned)KB_MAXFIN) return 0xFFFFFFFEu;
     const float4 *q4 = (const float4 *)qbuf;
     bool bound_broken = false;
     for (unsigned f0 = 0; f0 < Fmax; f0 += 32) {
@@ -507,7 +509,7 @@ __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFin
         const float dk = __fmaf_rn(dd, inv_unit, KB_OFF), kf = (float)(ent >> 12);
         bound_broken |= f < F && !(dk >= kf - 2.0f && dk <= kf + (float)margin + 1.0f);
     }
-    if (__ballot(bound_broken) != 0ull) return 0xFFFFFFFFu;
+    if (__ballot(bound_broken) != 0ull) return 0xFFFFFFFDu;
     wave_lds_fence();
     KB_PH(11);
     int32_t *out = a.out + (size_t)(h * KB_WAVES) * a.k;
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
         float *rp = rpar + tid * KB_RP;
         rp[0] = sqi; rp[1] = sqrtf(sqi); rp[2] = unit; rp[3] = inv_unit;
         rp[4] = __fmaf_rn(sqi * (1.0f - KB_G), inv_unit, KB_OFF);      // key = round(acc * (-2 / u) + this)
-        cnt[tid] = (unsigned)(32 * nv0);
+        cnt[tid] = (unsigned)(32 * nv0 * a.nsamp);
         tau[tid] = KB_TAUMAX;
         keyx[tid] = 0u;
         // step 0 takes everything inside the key range (acc * m2 + ci < KEYMAX - 1, two units for the evaluation)
@@ -678,14 +680,15 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
             const unsigned au = __float_as_uint(rpar[r * KB_RP + 1]);
             qa = kb_u32x4{0x3F803F80u, 0x00003F80u | (((au + 0xFFFFu) >> 16) << 16), 0u, 0u};
         }
-        // step 0, the sample: every pair's entry at a fixed slot (wave, half, g); pairs beyond the key range (and NaNs) get the
-        // key KEYMAX, which no threshold keeps
-        if (wave < nv0) {
-            const int t = wave * n_steps;
-            const kb_f32x16 acc = kb_tile_product(fr0, bq, qa);
+        // the sample: every pair's entry at a fixed slot (sample step, wave, half, g); pairs beyond the key range (and NaNs) get
+        // the key KEYMAX, which no threshold keeps.  Long rows (nsamp = 2: KK > 310, d >= 21) sample two tiles per wave, the
+        // wave's first and the one half way through its range: the threshold's rank is then known twice as well relative
+        // to its size, rows end with ~1.45 KK entries instead of 1.7 KK and stay inside their 1024-entry buffers
+        const int nsamp = a.nsamp, t_half = n_steps >> 1;
+        auto store_sample = [&](const kb_f32x16 acc, int t, int ss) {
             const float th = thr_f[r];
             const unsigned cb = (unsigned)(32 * t + 4 * h);
-            unsigned *dst = ent + r * ROW + wave * 32 + h * 16;
+            unsigned *dst = ent + r * ROW + (ss * KB_WAVES + wave) * 32 + h * 16;
 #pragma unroll
             for (int g = 0; g < 16; g += 2) {
                 unsigned e[2];
@@ -697,12 +700,20 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
                 }
                 *(uint2 *)(dst + g) = make_uint2(e[0], e[1]);
             }
+        };
+        if (wave < nv0) {
+            const int t = wave * n_steps;
+            const kb_f32x16 acc = kb_tile_product(fr0, bq, qa);
+            if (nsamp == 2) kb_load_tile(fr0, a.bp + (tile0 + t + t_half) * 9 * 64 + lane);
+            store_sample(acc, t, 0);
+            if (nsamp == 2) store_sample(kb_tile_product(fr0, bq, qa), t + t_half, 1);
         }
         __syncthreads();
         KB_TL(1);
         {
-            const bool bad = kb_cut_sample(ra, lane, nv0, a.rsel, a.fine_cut != 0);
-            if (__ballot(bad) != 0ull && lane == 0) *fail = 1u;
+            const bool bad = nsamp == 2 ? kb_cut_sample<32>(ra, lane, 2 * nv0, a.rsel, a.fine_cut != 0)
+                                        : kb_cut_sample<16>(ra, lane, nv0, a.rsel, a.fine_cut != 0);
+            if (__ballot(bad) != 0ull && lane == 0) atomicOr(fail, 1u);
         }
         __syncthreads();
         KB_TL(2);
@@ -713,13 +724,17 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
             // latency runs under the append work (requested one by one in front of the MFMAs that use them, each wave waited
             // nine L2 round trips per tile)
             const float th = thr_f[r];
-            const int t_first = wave * n_steps + 1;
-            const int t_end = (wave + 1) * n_steps < tpr ? (wave + 1) * n_steps : tpr;
+            const int t0w = wave * n_steps;
+            const int n_w = t0w + n_steps <= tpr ? n_steps : (tpr > t0w ? tpr - t0w : 0);       // tiles of this wave
+            const int skip = nsamp == 2 ? t_half : -1;                                          // (its second sample tile)
+            int j = 1 == skip ? 2 : 1;
             kb_u32x4 fr[9];
-            if (t_first < t_end) kb_load_tile(fr, a.bp + (tile0 + t_first) * 9 * 64 + lane);
-            for (int t = t_first; t < t_end; ++t) {
+            if (j < n_w) kb_load_tile(fr, a.bp + (tile0 + t0w + j) * 9 * 64 + lane);
+            while (j < n_w) {
+                const int t = t0w + j;
                 const kb_f32x16 acc = kb_tile_product(fr, bq, qa);
-                if (t + 1 < t_end) kb_load_tile(fr, a.bp + (tile0 + t + 1) * 9 * 64 + lane);
+                j = j + 1 == skip ? j + 2 : j + 1;
+                if (j < n_w) kb_load_tile(fr, a.bp + (tile0 + t0w + j) * 9 * 64 + lane);
                 const unsigned cb = (unsigned)(32 * t + 4 * h);
                 unsigned n = 0;
 #pragma unroll
@@ -750,7 +765,9 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
         unsigned Twg = 0u;
         if (!need_exact) {
             const unsigned cl = cnt[lane & (KB_Q - 1)];
-            need_exact = __ballot(cl > (unsigned)CAP || cl < KK) != 0ull;
+            const bool over = __ballot(cl > (unsigned)CAP) != 0ull, under = __ballot(cl < KK) != 0ull;
+            need_exact = over || under;
+            if (need_exact && tid == 0) atomicOr(fail, (over ? 2u : 0u) | (under ? 4u : 0u));
             Twg = wave_max_u32(cl);
         }
         if (!need_exact) {
@@ -765,7 +782,7 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
             // (the bin count follows the workgroup's longest row, so every wave runs the same code at the same time)
             const unsigned nf = Twg <= 256u ? kb_final_rows<8, 256>(ra, fa, lane, nv)
                               : (Twg <= 512u ? kb_final_rows<16, 1024>(ra, fa, lane, nv) : kb_final_rows<32, 1024>(ra, fa, lane, nv));
-            if (nf == 0xFFFFFFFFu) { if (lane == 0) *fail = 1u; }
+            if (nf >= 0xFFFFFFFDu) { if (lane == 0) atomicOr(fail, 8u << (0xFFFFFFFFu - nf)); }
             else { st_fin += nf; st_ent += ra.T[0] + ra.T[1]; }
             KB_TL(9);
             __syncthreads();
@@ -786,7 +803,14 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
         __syncthreads();
         if (tid == 0) {
             atomicAdd(&a.stats[0], 1ull);
-            if (need_exact) atomicAdd(&a.stats[1], 1ull);
+            if (need_exact) {
+                atomicAdd(&a.stats[1], 1ull);
+                // why (16-bit fields): [6] cut without a threshold | a row above CAP | a row short of KK entries; [7] final: a row short of
+                // KK keys below keyX | more than 256 finalists | a finalist outside the proven bound
+                const unsigned fb = *fail;
+                atomicAdd(&a.stats[6], (unsigned long long)(fb & 1u) | ((unsigned long long)((fb >> 1) & 1u) << 16) | ((unsigned long long)((fb >> 2) & 1u) << 32));
+                atomicAdd(&a.stats[7], (unsigned long long)((fb >> 3) & 1u) | ((unsigned long long)((fb >> 4) & 1u) << 16) | ((unsigned long long)((fb >> 5) & 1u) << 32));
+            }
             else {
                 atomicAdd(&a.stats[2], (unsigned long long)KB_Q); atomicAdd(&a.stats[3], (unsigned long long)acc3[0]);
                 atomicAdd(&a.stats[4], (unsigned long long)acc3[1]); atomicAdd(&a.stats[5], (unsigned long long)acc3[2]);

@@ -365,10 +365,16 @@ class GCNWorkspace:
 
     def knn_stats(self, reset=True):
         """Counters of the bf16-prefilter kNN kernel (workspaces created under PSG_GCN_KNN_STATS=1): dict of tiles,
-        exact_tiles, rows, finalists, cuts, entries."""
+        exact_tiles, rows, finalists, cuts, entries, why (reasons of the exact-path tiles)."""
         buf = (ctypes.c_ulonglong * 8)()
         _lib.call("psg_gcn_knn_stats", self.handle, buf, 1 if reset else 0)
-        return dict(zip(("tiles", "exact_tiles", "rows", "finalists", "cuts", "entries"), [int(v) for v in buf[:6]]))
+        out = dict(zip(("tiles", "exact_tiles", "rows", "finalists", "cuts", "entries"), [int(v) for v in buf[:6]]))
+        # why tiles went to the exact path (a tile can count under several): no threshold from the sample, a row above its
+        # buffer, a row short of KK entries, a row short of KK keys below the cut's key, more than 256 finalists, bound broken
+        a, b = int(buf[6]), int(buf[7])
+        out["why"] = {"cut": a & 0xFFFF, "overflow": (a >> 16) & 0xFFFF, "underflow": (a >> 32) & 0xFFFF,
+                      "short": b & 0xFFFF, "finalists": (b >> 16) & 0xFFFF, "bound": (b >> 32) & 0xFFFF}
+        return out
 
     PROF_TAGS = ("knn_fused", "knn_other", "vertex_gemm", "edge_max", "fusion_prediction", "backward")
 

@@ -51,6 +51,6 @@ for e in [int(v) for v in os.environ.get("BLOCKS", "1,2,3,5,9,14,20,27").split("
     dist = torch.cdist(x[0, :256], x[0]) ** 2
     kth = dist.kthvalue(min(15 * e + 1, N), dim=1).values
     print("block %2d d=%2d |x|^2 max %.3g mean %.3g, KK-th distance / sqmax median %.4f | differing rows %d | bf16 %.0f us f32 %.0f us | "
-          "tiles %d exact %d finalists/row %.1f cuts/row %.2f entries/row %.0f"
+          "tiles %d exact %d finalists/row %.1f cuts/row %.2f entries/row %.0f why %s"
           % (e, e, float(sq.max()), float(sq.mean()), float((kth / sq[0].max()).median()), bad, t[0], t[1], st["tiles"], st["exact_tiles"],
-             st["finalists"] / rows, st["cuts"] / rows, st["entries"] / rows), flush=True)
+             st["finalists"] / rows, st["cuts"] / rows, st["entries"] / rows, {k: v for k, v in st.get("why", {}).items() if v}), flush=True)
