@@ -15,7 +15,7 @@ namespace psg {
 // present in -DPSG_DIAG_BUILD libraries only, so the default library lists none).
 struct EnvSwitch { const char *name; char kind; };
 static const EnvSwitch kEnvSwitches[] = {
-    {"PSG_TRACE_SYNC", 'd'},       {"PSG_GCN_KNN_STATS", 'd'},   {"PSG_KNN_XCD_ORDER", 'p'},  {"PSG_KNN_FINE_CUT_KK", 'p'},  {"PSG_KNN_SAMPLE2_KK", 'p'},
+    {"PSG_TRACE_SYNC", 'd'},       {"PSG_GCN_KNN_STATS", 'd'},   {"PSG_KNN_XCD_ORDER", 'p'},  {"PSG_KNN_FINE_CUT_KK", 'p'},  {"PSG_KNN_SAMPLE2_KK", 'p'},  {"PSG_KNN_F32_SAMPLED_KK", 'p'},
     {"PSG_FP1_WAVE", 'p'},         {"PSG_RLA_NO_FUSE16", 'p'},   {"PSG_RLA_ATOMICS", 'p'},    {"PSG_RLA_NO_SPLIT", 'p'},
     {"PSG_RLA_NO_GRAPH", 'p'},     {"PSG_GEMM_SMALL_BELOW", 'p'}, {"PSG_GCN_KNN", 'p'},        {"PSG_GCN_KNN_BF_MAXD", 'p'},
     {"PSG_GCN_PQ_FUSION", 'p'},    {"PSG_GCN_NO_GRAPH", 'p'},    {"PSG_GCN_EDGE_BWD", 'p'},   {"PSG_BALL_QUERY", 'p'},

@@ -39,16 +39,22 @@ __global__ void knn_prep_kernel(const float *__restrict__ x, int ld, size_t rows
 // the row's threshold is the r-th smallest sample key (+ margin).  The row ends short of KK keys below it iff the sample
 // holds at least r of the row's KK - 1 nearest candidates: X ~ Hypergeometric(N, KK - 1, S) for candidates in random
 // order.  r = the smallest value with P(X >= r) <= 1e-7 (S = N: r = KK, the plain exact cut).
+unsigned knn_sample_rank_S(int N, int KK, int S);
 unsigned knn_sample_rank(int N, int KK, int nsamp)
+{
+    const int tpr = N >> 5, n_steps = (tpr + KB_WAVES - 1) / KB_WAVES, nv0 = (tpr + n_steps - 1) / n_steps;
+    return knn_sample_rank_S(N, KK, 32 * nv0 * nsamp);
+}
+unsigned knn_sample_rank_S(int N, int KK, int S)
 {
     static std::mutex mu;
     static std::unordered_map<unsigned long long, unsigned> cache;
-    const unsigned long long key = ((unsigned long long)(unsigned)N << 32) | ((unsigned)KK << 2) | (unsigned)nsamp;
+    const unsigned long long key = ((unsigned long long)(unsigned)N << 32) | ((unsigned long long)(unsigned)KK << 16) | (unsigned)S;
     std::lock_guard<std::mutex> lock(mu);
     const auto it = cache.find(key);
     if (it != cache.end()) return it->second;
-    const int tpr = N >> 5, n_steps = (tpr + KB_WAVES - 1) / KB_WAVES, nv0 = (tpr + n_steps - 1) / n_steps;
-    const int S = 32 * nv0 * nsamp, K1 = KK - 1;
+    const int K1 = KK - 1;
+    S = S < N ? S : N;
     auto lchoose = [](int n, int m) { return std::lgamma((double)n + 1.0) - std::lgamma((double)m + 1.0) - std::lgamma((double)(n - m) + 1.0); };
     const double denom = lchoose(N, S);
     const int hi = K1 < S ? K1 : S;
@@ -107,7 +113,12 @@ hipError_t knn_launch(const KnnBuffers &buf, int B, int N, int k, int d, int32_t
     f.LOW = f.KK + slack / 4;
     static const int xcd_order = psg::env_int("PSG_KNN_XCD_ORDER", 1);
     f.xcd_order = xcd_order;
+    f.rsel = 0u;
     if (path == KNN_PATH_F32) {
+        // one sampled cut instead of the growth schedule where that saves cuts (KK >= PSG_KNN_F32_SAMPLED_KK): the first CAP
+        // candidates of a row, spread over the room, give the threshold (psg_knn_fused.cuh: KnnFusedArgs::rsel)
+        static const int sampled_from = psg::env_int("PSG_KNN_F32_SAMPLED_KK", 150);
+        if (f.KK >= sampled_from && N > KF_CAP) f.rsel = knn_sample_rank_S(N, f.KK, KF_CAP);
         hipLaunchKernelGGL(knn_fused_kernel, dim3((unsigned)((size_t)B * N / KF_Q)), dim3(KF_WAVES * 64), knn_fused_lds_bytes(), st, f);
         return hipGetLastError();
     }

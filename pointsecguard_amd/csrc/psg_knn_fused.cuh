@@ -95,6 +95,9 @@ struct KnnFusedArgs {
     unsigned magic;    // ceil(2^18 / d): x / d = (x * magic) >> 18 for x < 2^18 / d
     int LOW, TOL;      // a prune event cuts the rows above LOW to [KK, KK + TOL]
     int xcd_order;     // 1: XCD-aware block order (default); 0: identity (PSG_KNN_XCD_ORDER=0, A/B and diagnosis)
+    unsigned rsel;     // 0: rows are cut to KK on the growth schedule.  > 0 (round 4): ONE cut, after the first CAP candidates, to the
+                       // rsel smallest keys - a sampled threshold as in psg_knn_bf.cuh: wave w streams the pairs w S .. w S + S - 1, so
+                       // those CAP candidates are spread over the room; a row that ends with fewer than KK keys takes the per-step path
 };
 
 // inclusive prefix sum over the 64 lanes (row scans by DPP row_shr, then the row totals by row_bcast)
@@ -340,6 +343,9 @@ __device__ __forceinline__ void knn_exact_block(const KnnFusedArgs &a, const int
     const int n_pairs = (a.N + KF_STEP - 1) / KF_STEP;                       // candidate pairs-of-tiles in the room
     const int n_steps = (n_pairs + KF_WAVES - 1) / KF_WAVES;
     const int last_tile = tiles_per_room - 1;
+    // candidate pair-of-tiles of this wave at a step: round robin, or (sampled threshold) a contiguous range per wave
+    const bool sampled = a.rsel != 0u;
+    auto pair_of = [&](int step) { return sampled ? wave * n_steps + step : step * KF_WAVES + wave; };
 #ifdef PSG_KF_TL
     unsigned long long tl0 = 0;
     if (tid == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl0) :: "memory");
@@ -355,7 +361,7 @@ __device__ __forceinline__ void knn_exact_block(const KnnFusedArgs &a, const int
     // tried twice and lost 6 %: the step is bound by the sum of matrix, vector and operand-path time, not by latency.)
     auto step_compute = [&](int step, float (&dd)[8], int &c0) {
         KF_T(t_a);
-        const int pair = step * KF_WAVES + wave;
+        const int pair = pair_of(step);
         const int t0 = min(2 * pair, last_tile), t1 = min(2 * pair + 1, last_tile);   // clamped: masked out below
         float4 a0[4], a1[4];
 #pragma unroll
@@ -413,7 +419,7 @@ __device__ __forceinline__ void knn_exact_block(const KnnFusedArgs &a, const int
             const unsigned c = (unsigned)(c0 + (r < 4 ? r : 12 + r));
             mask |= ((key[r] < tk || (key[r] == tk && c <= ti)) ? 1u : 0u) << r;
         }
-        if ((step * KF_WAVES + wave) * KF_STEP + KF_STEP > a.N) {   // ragged tail (wave-uniform): candidates beyond N never pass
+        if (pair_of(step) * KF_STEP + KF_STEP > a.N) {   // ragged tail (wave-uniform): candidates beyond N never pass
 #pragma unroll
             for (int r = 0; r < 8; ++r)
                 if (c0 + (r < 4 ? r : 12 + r) >= a.N) mask &= ~(1u << r);
@@ -446,7 +452,7 @@ __device__ __forceinline__ void knn_exact_block(const KnnFusedArgs &a, const int
             // ranking; rows they would overflow go through the exact per-step path like any other overflow.  The key and
             // the composite are only built for the few pairs that pass.
             const float tf = dist_of(tau_k[q]);
-            if ((step * KF_WAVES + wave) * KF_STEP + KF_STEP <= a.N) {
+            if (pair_of(step) * KF_STEP + KF_STEP <= a.N) {
                 unsigned n = 0;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) n += !(dd[r] > tf) ? 1u : 0u;
@@ -482,7 +488,7 @@ __device__ __forceinline__ void knn_exact_block(const KnnFusedArgs &a, const int
             const bool sync_now = seen >= next_prune && step + 1 < n_steps;
             if (sync_now) {
                 const unsigned nn = (unsigned)(grow * (float)seen) / (unsigned)PER_STEP * (unsigned)PER_STEP;
-                next_prune = nn > seen ? nn : seen + (unsigned)PER_STEP;
+                next_prune = sampled ? 0xFFFFFFFFu : (nn > seen ? nn : seen + (unsigned)PER_STEP);
                 __syncthreads();
                 KF_TL(n_tl < 3 ? 1 + 2 * n_tl : 5);
                 // (every wave reads the same counters, and no wave rewrites one before all have passed this test: a row is
@@ -492,7 +498,7 @@ __device__ __forceinline__ void knn_exact_block(const KnnFusedArgs &a, const int
                     const unsigned T = cnt[qq];
                     if (T > (unsigned)a.LOW) {
                         unsigned long long thr;
-                        const unsigned c = prune_row<KF_NPL>(ent + qq * ROW, T, KK, (unsigned)a.TOL, lane, thr);
+                        const unsigned c = prune_row<KF_NPL>(ent + qq * ROW, T, sampled ? a.rsel : KK, (unsigned)a.TOL, lane, thr);
                         if (lane == 0) { cnt[qq] = c; tau_k[qq] = (unsigned)(thr >> 12); tau_i[qq] = (unsigned)thr & 0xFFFu; }
                     }
                 }
@@ -510,7 +516,9 @@ __device__ __forceinline__ void knn_exact_block(const KnnFusedArgs &a, const int
         }
         __syncthreads();
         KF_TL(8);
-        if (!need_safe) need_safe = __ballot(lane < KF_Q && cnt[lane & (KF_Q - 1)] > (unsigned)CAP) != 0ull;
+        // (sampled threshold: the row holds every candidate at or below its threshold, so KK of them prove it complete; a row
+        // the sample left short - candidates sorted by distance, one row in 10^7 otherwise - starts over on the per-step path)
+        if (!need_safe) need_safe = __ballot(lane < KF_Q && (cnt[lane & (KF_Q - 1)] > (unsigned)CAP || (sampled && cnt[lane & (KF_Q - 1)] < KK))) != 0ull;
     }
     if (need_safe) {
         // ---- EXACT PER-STEP PATH (rare): start over with a barrier per step, roll-back on overflow
@@ -527,8 +535,6 @@ __device__ __forceinline__ void knn_exact_block(const KnnFusedArgs &a, const int
         int c0;
         step_compute(step, dd, c0);
         exact_filter(step, dd, c0, key, mask);
-        const int pair = step * KF_WAVES + wave;
-        (void)pair;
         const unsigned n = (unsigned)__popc(mask);
         unsigned base = 0;
         if (n) base = atomicAdd(&cnt[q], n);
