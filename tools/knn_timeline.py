@@ -1,4 +1,4 @@
-"""Diagnostic (GPU box, make -C pointsecguard_amd/csrc EXTRA=-DPSG_KF_TL): real lengths of the fused kNN kernel's
+"""Diagnostic (GPU box, tools/build_variant.sh tl psg_knn "-DPSG_KF_TL" + PSG_LIBRARY_OVERRIDE=build/libpsg_tl.so): real lengths of the fused kNN kernel's
 workgroup-wide phases (mean cycles since kernel start at every workgroup barrier exit)."""
 import ctypes, os, sys
 import numpy as np, torch
@@ -13,7 +13,8 @@ if os.environ.get("KNN_KIND", "plain") == "scaled":
 f = torch.from_numpy(f.astype(np.float32)).cuda()
 ws = runtime.GCNWorkspace(B, 4096, 28)
 buf = (ctypes.c_ulonglong * 32)()
-names = ("start", "prune1", "prune1 done", "prune2", "prune2 done", "prune3+", "prune3+ done", "-", "stream end", "wave0 final end", "all final end", "slowest workgroup")
+# exact kernel: prune1 .. prune3+ are its cuts; prefilter kernel (round 4): slot 1 = sample stored, slot 2 = cut done
+names = ("start", "prune1 / sample", "prune1 / cut done", "prune2", "prune2 done", "prune3+", "prune3+ done", "-", "stream end", "wave0 final end", "all final end", "slowest workgroup")
 for d in [int(x) for x in os.environ.get("KNN_D", "1,4,9,17,27").split(",")]:
     ws.knn(f, d); lib.psg_dbg_knn_tl(buf)
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
@@ -25,7 +26,8 @@ for d in [int(x) for x in os.environ.get("KNN_D", "1,4,9,17,27").split(",")]:
     if hasattr(lib, "psg_dbg_knn_ph"):
         ph = (ctypes.c_ulonglong * 32)()
         lib.psg_dbg_knn_ph(ph)
-        pn = ("cut:load", "cut:k2", "cut:hist", "cut:scan", "cut:compact", "fin:load", "fin:k2", "fin:hist", "fin:cum", "fin:search",
+        pn = ("cut:load", "cut:minmax", "cut:hist", "cut:find", "cut:compact", "fin:load", "fin:params", "fin:hist", "fin:cum", "fin:search",
               "fin:collect", "fin:exact", "fin:rank")
-        print("      phases (cycles per call of wave 0): " + "  ".join("%s %.0f" % (pn[i], ph[i] / ph[16 + i]) for i in range(13) if ph[16 + i]), flush=True)
+        if any(ph[16 + i] for i in range(13)):      # (build with -DPSG_KF_TL -DPSG_KF_PH; the stamps inflate every phase by ~2k cycles)
+            print("      phases (cycles per call of wave 0): " + "  ".join("%s %.0f" % (pn[i], ph[i] / ph[16 + i]) for i in range(13) if ph[16 + i]), flush=True)
     print("d=%2d  %.0f us per call  " % (d, t0.elapsed_time(t1) * 100) + "  ".join("%s %.0f" % (names[i], buf[i] / buf[16 + i]) for i in range(12) if buf[16 + i]), flush=True)
