@@ -71,7 +71,20 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
     // plain (non-ASC) path: the global loads of step k0 + 32 are issued right after the barrier that publishes step k0 in
     // LDS, so they are in flight under that step's MFMAs (register double buffering; one LDS buffer)
     float4 vi[NI], vw[NWL];
+    // (workgroup-uniform) the whole tile lies inside both matrices and every row is 16-byte aligned: no per-piece bounds
+    // tests in the k-loop - on this chip every vector instruction of the loop is paid in matrix time (fp32 MFMAs and
+    // vector work of the same SIMD do not overlap), and the tests were a tenth of the loop's issue slots
+    const bool interior = row0 + BR <= a.rows && col0 + BN <= a.M && (a.K & 31) == 0 && (a.ld_in & 3) == 0 && (a.ld_w & 3) == 0;
+    const float *in_t = a.in + (size_t)(row0 + (tid >> 3)) * a.ld_in + 4 * (tid & 7);
+    const float *w_t = a.w + (size_t)(col0 + (tid >> 3)) * a.ld_w + 4 * (tid & 7);
     auto load_plain = [&](int k0) {
+        if (interior) {
+#pragma unroll
+            for (int u = 0; u < NI; ++u) vi[u] = *(const float4 *)(in_t + (size_t)(32 * u) * a.ld_in + k0);
+#pragma unroll
+            for (int u = 0; u < NWL; ++u) vw[u] = *(const float4 *)(w_t + (size_t)(32 * u) * a.ld_w + k0);
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
             const int t = tid + u * 256, r = t >> 3, q = t & 7, k = k0 + 4 * q;
@@ -214,6 +227,88 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
     }
 
     // ---- epilogue: lane (j,h) of tile (i,q) holds channels cbase + 8g + 4h + (0..3) of row rbase + j
+    if (EPI != EPI_KNN_DIST && interior && (a.ld_out & 3) == 0 && (!a.addend || (a.ld_add & 3) == 0)) {
+        // interior tiles: the per-channel terms are read once per 32-channel tile as float4 (they were 3 scalar loads per
+        // value: the epilogue of the 16 384 x 1792 x 1024 fusion layer cost a tenth of its launch), same operations in
+        // the same order as the general path below
+        const int nw = (a.M + 31) >> 5;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int cbase = col0 + wc * 32 * TI + i * 32;
+            float4 b4[4], s4[4], t4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cbase + 8 * g + 4 * h;
+                b4[g] = a.bias ? *(const float4 *)(a.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                s4[g] = a.scale ? *(const float4 *)(a.scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+                t4[g] = a.scale ? *(const float4 *)(a.shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < TQ; ++q) {
+                const int row = row0 + wr * 32 * TQ + q * 32 + j;
+                const unsigned min_bits = a.mask_in ? a.mask_in[(size_t)row * nw + (cbase >> 5)] : 0xFFFFFFFFu;
+                const unsigned post_bits = a.post_mask ? a.post_mask[(size_t)row * nw + (cbase >> 5)] : 0xFFFFFFFFu;
+                const float *gb = a.gbias ? a.gbias + (size_t)(row / a.group_rows) * a.M + cbase + 4 * h : nullptr;
+                float *o = a.out + (size_t)row * a.ld_out + cbase + 4 * h;
+                unsigned mbits = 0;
+                float4 vv[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 g4 = gb ? *(const float4 *)(gb + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float bb[4] = {b4[g].x, b4[g].y, b4[g].z, b4[g].w}, ss[4] = {s4[g].x, s4[g].y, s4[g].z, s4[g].w};
+                    const float tt[4] = {t4[g].x, t4[g].y, t4[g].z, t4[g].w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+                    float e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int cl = 8 * g + 4 * h + u;
+                        float z = acc[i][q][4 * g + u];
+                        if (a.bias) z += bb[u];
+                        if (gb) z += gg[u];
+                        if (EPI == EPI_RELU_AFFINE) {
+                            const bool pos = z > 0.0f;
+                            mbits |= (unsigned)pos << cl;
+                            z = pos ? z : 0.0f;
+                            if (a.scale) z = z * ss[u] + tt[u];
+                        }
+                        if (EPI == EPI_LRELU) {
+                            const bool pos = z > 0.0f;
+                            mbits |= (unsigned)pos << cl;
+                            z = pos ? z : 0.2f * z;
+                        }
+                        if (!((min_bits >> cl) & 1u)) z = 0.0f;
+                        e[u] = z;
+                    }
+                    vv[g] = make_float4(e[0], e[1], e[2], e[3]);
+                }
+                if ((EPI == EPI_RELU_AFFINE || EPI == EPI_LRELU) && a.mask_out) {
+                    const unsigned other = __shfl_xor(mbits, 32);
+                    if (h == 0) a.mask_out[(size_t)row * nw + (cbase >> 5)] = mbits | other;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 v = vv[g];
+                    float4 *dst = (float4 *)(o + 8 * g);
+                    if (a.accumulate) {
+                        float4 old = a.accumulate == 1 ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (a.addend) {
+                            const float4 ad = *(const float4 *)(a.addend + (size_t)row * a.ld_add + cbase + 8 * g + 4 * h);
+                            old.x += ad.x; old.y += ad.y; old.z += ad.z; old.w += ad.w;
+                        }
+                        v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                    }
+                    if (a.post_mask) {
+                        const unsigned pb = post_bits >> (8 * g + 4 * h);
+                        if (!(pb & 1u)) v.x *= a.post_slope;
+                        if (!(pb & 2u)) v.y *= a.post_slope;
+                        if (!(pb & 4u)) v.z *= a.post_slope;
+                        if (!(pb & 8u)) v.w *= a.post_slope;
+                    }
+                    *dst = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < TQ; ++q) {
         const int row = row0 + wr * 32 * TQ + q * 32 + j;
