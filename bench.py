@@ -612,7 +612,10 @@ PMC_SYMBOL = {"fp1_head_fwd": "void psg::fp_fwd_kernel<32, 4, false>(psg::FpFwdA
               "sa1_bwd": "void psg::sa_bwd_kernel<128, 4, 1, 32>(psg::SaBwdArgs)",
               "sa2_fwd": "void psg::sa_fwd_kernel<64, 4, 32, 1>(psg::SaFwdArgs)",
               "sa2_bwd": "void psg::sa_bwd_kernel<64, 4, 2, 32>(psg::SaBwdArgs)",
-              "knn_fused": "(anonymous namespace)::knn_fused_kernel((anonymous namespace)::KnnFusedArgs)"}
+              # the fused kNN launches of the ResGCN path are two kernels since round 3 (the bf16-prefilter kernel for dilations
+              # 1..20, the exact kernel above): the tag's figure is the launch-weighted mean of both
+              "knn_fused": ("(anonymous namespace)::knn_bf_kernel((anonymous namespace)::KnnBfArgs)",
+                            "(anonymous namespace)::knn_fused_kernel((anonymous namespace)::KnnFusedArgs)")}
 
 
 def pmc_traffic(tag, device_batch, pattern="*_pmc_traffic.json"):
@@ -626,7 +629,13 @@ def pmc_traffic(tag, device_batch, pattern="*_pmc_traffic.json"):
         return None, None
     with open(files[-1]) as fh:
         table = json.load(fh)
-    row = table.get(PMC_SYMBOL[tag])
+    sym = PMC_SYMBOL[tag]
+    if isinstance(sym, tuple):
+        rows = [table[x] for x in sym if x in table]
+        n = sum(r["launches_fetch_pass"] for r in rows)
+        row = {"hbm_bytes_per_launch": sum(r["hbm_bytes_per_launch"] * r["launches_fetch_pass"] for r in rows) / n} if n else None
+    else:
+        row = table.get(sym)
     if not row:
         return None, None
     counted = table.get("_meta", {}).get("device_batch_rooms", 32)
