@@ -154,3 +154,48 @@ def test_pairwise_distance_bits(golden_gcn_room):
     f = torch.from_numpy(golden_gcn_room["feat0"][:64][None]).cuda()
     d = pairwise_distance(f)[0].cpu().numpy()
     assert np.array_equal(d.view(np.uint32), golden_gcn_room["pd_bits"])       # the reference's own bits (torch_edge.py:41-43)
+
+
+def test_gemm_interior_tiles_equal_the_general_path():
+    """psg_gemm.cuh stages the operands of INTERIOR tiles (whole tile inside both matrices, 16-byte aligned rows, K a multiple
+    of 32) without bounds tests and reads their epilogue terms as float4 (round 4).  The same product through the general
+    path - forced by a row stride that is not a multiple of 4, by a ragged K, by M / rows that leave edge tiles - must be
+    bit-identical on the common outputs, ReLU bits included; values are checked against float64."""
+    from pointsecguard_amd import _lib, runtime
+    rng = np.random.default_rng(42)
+    rows, K, M = 512, 96, 256
+    x = rng.standard_normal((rows, K)).astype(np.float32)
+    w = (rng.standard_normal((M, K)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, M).astype(np.float32)
+    sh = rng.standard_normal(M).astype(np.float32)
+    dw, db, dsc, dsh = (torch.from_numpy(a).cuda() for a in (w, b, sc, sh))
+
+    def run(x_np, ld, n_rows, k, m, w_t):
+        buf = torch.zeros(n_rows, ld, device="cuda")
+        buf[:, :x_np.shape[1]] = torch.from_numpy(x_np).cuda()
+        out = torch.empty(n_rows, m, device="cuda")
+        mk = torch.zeros(n_rows, (m + 31) // 32, dtype=torch.int32, device="cuda")
+        _lib.call("psg_pw_mlp_fwd", runtime.ptr(buf), ld, n_rows, k, runtime.ptr(w_t), runtime.ptr(db[:m].contiguous()), 1, m,
+                  runtime.ptr(out), m, runtime.ptr(mk), runtime.ptr(dsc[:m].contiguous()), runtime.ptr(dsh[:m].contiguous()), runtime.stream())
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), mk.cpu().numpy()
+
+    ref, ref_bits = run(x, K, rows, K, M, dw)                                   # every tile interior
+    z = np.maximum(x.astype(np.float64) @ w.astype(np.float64).T + b, 0) * sc + sh
+    assert np.abs(ref - z).max() < 2e-4
+    got, bits = run(x, K + 1, rows, K, M, dw)                                   # odd row stride: general path everywhere
+    assert np.array_equal(got, ref) and np.array_equal(bits, ref_bits)
+    got, bits = run(x[:rows - 3], K, rows - 3, K, M, dw)                        # ragged rows: the last row tile is an edge tile
+    assert np.array_equal(got, ref[:rows - 3]) and np.array_equal(bits, ref_bits[:rows - 3])
+    m2 = M - 40                                                                 # ragged M: the last column tile is an edge tile
+    got, bits = run(x, K, rows, K, m2, dw[:m2].contiguous())
+    assert np.array_equal(got, ref[:, :m2])
+    # ragged K (general path) against the interior path on the zero-padded operands
+    k2 = K - 5
+    w2 = dw[:, :k2].contiguous()
+    got, _ = run(x[:, :k2], K, rows, k2, M, w2)
+    xp = x.copy(); xp[:, k2:] = 0
+    wp = w.copy(); wp[:, k2:] = 0
+    pad, _ = run(xp, K, rows, K, M, torch.from_numpy(wp).cuda())
+    assert np.array_equal(got, pad)
