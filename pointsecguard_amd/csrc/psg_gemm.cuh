@@ -46,6 +46,8 @@ struct GemmArgs {
 
 // TQ x TI = 32-row x 32-channel MFMA tiles per wave (2 x 2 by default; 1 x 1 gives 64 x 64 workgroup tiles, i.e. four
 // times as many workgroups, for the per-vertex GEMMs of a single 4096-point room that would otherwise occupy 16-32 CUs)
+// (240 registers with the 64 accumulators: two waves per SIMD.  Asking the compiler for three - 168 registers, 20 bytes spilled
+// outside the loop - left the fusion layer at 555 us, four spilled into the loop: 819 us; tools/gemm_probe.hip)
 template <int WM, int WN, int EPI, bool ASC_K, int TQ = 2, int TI = 2>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
 {

@@ -122,6 +122,7 @@ hipError_t knn_launch(const KnnBuffers &buf, int B, int N, int k, int d, int32_t
         hipLaunchKernelGGL(knn_fused_kernel, dim3((unsigned)((size_t)B * N / KF_Q)), dim3(KF_WAVES * 64), knn_fused_lds_bytes(), st, f);
         return hipGetLastError();
     }
+    if (!buf.x || buf.ld < 64 || (buf.ld & 3)) return hipErrorInvalidValue;      // the prefilter path reads its finalists from the row-major features
     KnnBfArgs a;
     a.bp = (const kb_u32x4 *)buf.bp; a.sq = buf.sq; a.out = out; a.N = N; a.k = k; a.d = d; a.KK = f.KK; a.magic = f.magic;
     // two sample tiles per wave for the longest rows (psg_knn_bf.cuh)
