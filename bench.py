@@ -1044,6 +1044,10 @@ def tarnu_measure(args, R, mode, with_roofline=True):
         net = get_model(13)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         nets.append(net.cuda().eval())
+    for net in nets:
+        # the device copy of every model instance is built HERE, before any thread starts: built lazily by its first attack
+        # it meant allocations and uploads beside another thread's hipGraph capture (one run in three lost a capture to it)
+        net._packed()
     d_images = [torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 1))).cuda() for r in rooms]
     opt_steps, exits, lock = [0], [0], threading.Lock()
 

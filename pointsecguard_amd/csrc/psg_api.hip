@@ -1,3 +1,4 @@
+#include <mutex>
 // Context, error reporting and version of libpsg.so.
 #include <stdarg.h>
 #include <stdlib.h>
@@ -23,6 +24,21 @@ static const EnvSwitch kEnvSwitches[] = {
     {"PSG_DIAG", 'r'},
 #endif
 };
+
+hipError_t copy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    static std::mutex mu;
+    static hipStream_t st = nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!st) {
+        const hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e != hipSuccess) { st = nullptr; return e; }
+    }
+    if (bytes == 0) return hipSuccess;
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    return e;
+}
 
 const char *env_str(const char *name)
 {

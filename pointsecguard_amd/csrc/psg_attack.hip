@@ -1069,7 +1069,10 @@ extern "C" int psg_pn2_nu_window(const psg_nu_window_args *a, psg_nu_graph *grap
             if (crc == PSG_OK && e == hipSuccess && gr && hipGraphInstantiate(&graph->exec, gr, nullptr, nullptr, 0) != hipSuccess)
                 graph->exec = nullptr;
             if (gr) (void)hipGraphDestroy(gr);
-            if (crc != PSG_OK) return crc;
+            // (a capture that failed - another host thread's work can invalidate it: "operation failed due to a previous error
+            // during capture", seen once in three runs of the twelve-thread one-call-per-room leg - has executed nothing:
+            // the window runs eagerly below, and a genuine launch error shows again there)
+            (void)crc;
         }
         (void)hipGetLastError();        // a refused capture (legacy default stream) is not an error of this call
         if (graph->exec) {

@@ -941,16 +941,16 @@ extern "C" int psg_pn2_model_create_arch(psg_ctx *ctx, int arch, const float *co
         L.wf = bp.take<float4>(wf[i].size() / 4);
         L.wb = bp.take<float4>(wb[i].size() / 4);
         L.bias = bp.take<float>(bs[i].size());
-        PSG_CHECK_HIP(hipMemcpy(L.wf, wf[i].data(), wf[i].size() * 4, hipMemcpyHostToDevice));
-        PSG_CHECK_HIP(hipMemcpy(L.wb, wb[i].data(), wb[i].size() * 4, hipMemcpyHostToDevice));
-        PSG_CHECK_HIP(hipMemcpy(L.bias, bs[i].data(), bs[i].size() * 4, hipMemcpyHostToDevice));
+        PSG_CHECK_HIP(psg::copy_sync(L.wf, wf[i].data(), wf[i].size() * 4, hipMemcpyHostToDevice));
+        PSG_CHECK_HIP(psg::copy_sync(L.wb, wb[i].data(), wb[i].size() * 4, hipMemcpyHostToDevice));
+        PSG_CHECK_HIP(psg::copy_sync(L.bias, bs[i].data(), bs[i].size() * 4, hipMemcpyHostToDevice));
         if (!wf4[i].empty()) {
             L.wf4 = bp.take<float4>(wf4[i].size() / 4);
-            PSG_CHECK_HIP(hipMemcpy(L.wf4, wf4[i].data(), wf4[i].size() * 4, hipMemcpyHostToDevice));
+            PSG_CHECK_HIP(psg::copy_sync(L.wf4, wf4[i].data(), wf4[i].size() * 4, hipMemcpyHostToDevice));
         }
         if (!wb4[i].empty()) {
             L.wb4 = bp.take<float4>(wb4[i].size() / 4);
-            PSG_CHECK_HIP(hipMemcpy(L.wb4, wb4[i].data(), wb4[i].size() * 4, hipMemcpyHostToDevice));
+            PSG_CHECK_HIP(psg::copy_sync(L.wb4, wb4[i].data(), wb4[i].size() * 4, hipMemcpyHostToDevice));
         }
     }
     *out = m;
@@ -1015,7 +1015,8 @@ extern "C" size_t psg_pn2_ws_bytes(const psg_pn2_ws *ws) { return ws ? ws->bytes
 extern "C" int psg_pn2_debug_read(psg_pn2_ws *ws, unsigned long long *host_out, int n_words)
 {
     PSG_REQUIRE(ws && host_out && n_words > 0 && n_words <= 16 * 8 * 1024, "psg_pn2_debug_read: bad argument");
-    PSG_CHECK_HIP(hipMemcpy(host_out, ws->dbg, (size_t)n_words * 8, hipMemcpyDeviceToHost));
+    PSG_CHECK_HIP(hipDeviceSynchronize());
+    PSG_CHECK_HIP(psg::copy_sync(host_out, ws->dbg, (size_t)n_words * 8, hipMemcpyDeviceToHost));
     return PSG_OK;
 }
 

@@ -128,8 +128,8 @@ extern "C" int psg_rla_sampler_create(psg_ctx *ctx, const float *points_host, co
         }
     }
     // (from here on a failure releases the sampler and its buffers)
-    hipError_t e = hipMemcpy(s->pts, points_host, M * 12, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(s->poss, possibility_host, M * 8, hipMemcpyHostToDevice);
+    hipError_t e = psg::copy_sync(s->pts, points_host, M * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = psg::copy_sync(s->poss, possibility_host, M * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(iota_kernel, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)0, s->iota, n_points);
         e = hipGetLastError();
@@ -211,6 +211,6 @@ extern "C" int psg_rla_sampler_possibility(psg_rla_sampler *s, double *host_out)
 {
     PSG_REQUIRE(s && host_out, "psg_rla_sampler_possibility: null argument");
     PSG_CHECK_HIP(hipDeviceSynchronize());
-    PSG_CHECK_HIP(hipMemcpy(host_out, s->poss, (size_t)s->M * 8, hipMemcpyDeviceToHost));
+    PSG_CHECK_HIP(psg::copy_sync(host_out, s->poss, (size_t)s->M * 8, hipMemcpyDeviceToHost));
     return PSG_OK;
 }
