@@ -27,16 +27,15 @@ static const EnvSwitch kEnvSwitches[] = {
 
 hipError_t copy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
 {
-    static std::mutex mu;
-    static hipStream_t st = nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!st) {
-        const hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-        if (e != hipSuccess) { st = nullptr; return e; }
-    }
     if (bytes == 0) return hipSuccess;
-    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+    // (a stream of its own per call, not one kept for the process: these are creation-time copies, and a stream that stays
+    // alive takes part in the runtime's stream -> hardware-queue assignment of everything created after it)
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(dst, src, bytes, kind, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
     return e;
 }
 

@@ -15,7 +15,7 @@ void set_error(const char *fmt, ...);
 // Blocking host <-> device copy that does NOT go through the legacy default stream: hipMemcpy synchronises with every
 // blocking stream of the process, which is an error - for the copying thread AND for the capture - while another host
 // thread captures a hipGraph on one ("operation would make the legacy stream depend on a capturing blocking stream":
-// the one-call-per-room NU harness builds its model copies from twelve threads).  One non-blocking stream per process, serialised.
+// the one-call-per-room NU harness builds its model copies from twelve threads).  A non-blocking stream of its own per call.
 hipError_t copy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
 
 #define PSG_CHECK_HIP(expr)                                                                      \
