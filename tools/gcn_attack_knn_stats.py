@@ -1,0 +1,25 @@
+"""GPU box: the prefilter kernel's counters over a whole ResGCN-28 NB attack (4 rooms, N iterations, default kernel split):
+how many tiles took the exact path inside the attack, and why."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["PSG_GCN_KNN_STATS"] = "1"
+os.environ["PSG_GCN_NO_GRAPH"] = "1"
+from pointsecguard_amd import runtime
+from pointsecguard_amd.synthetic import gcn28_state_dict, make_rooms, rule_labels
+
+B, N = 4, 4096
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+model = runtime.GCNModel(gcn28_state_dict(), 28)
+rooms = make_rooms(B, 5000)
+x = torch.from_numpy(np.ascontiguousarray(rooms.transpose(0, 2, 1))).cuda()
+y = torch.from_numpy(rule_labels(rooms).astype(np.int32)).cuda()
+ws = runtime.GCNWorkspace(B, N, 28)
+ws.knn_stats()
+out = torch.empty_like(x)
+ws.nb_attack(model, x, y, 0.3, 2 / 255, iters, out=out)
+torch.cuda.synchronize()
+st = ws.knn_stats()
+print("iterations %d: tiles %d, exact-path tiles %d (%.3f %%), finalists/row %.1f, entries/row %.0f, why %s"
+      % (iters, st["tiles"], st["exact_tiles"], 100.0 * st["exact_tiles"] / max(st["tiles"], 1), st["finalists"] / max(st["rows"], 1),
+         st["entries"] / max(st["rows"], 1), {k: v for k, v in st["why"].items() if v}))
