@@ -133,3 +133,28 @@ def test_default_split_and_both_kernels_agree_on_network_like_features():
         st = ws.knn_stats()
         assert st["tiles"] == 256
         assert torch.equal(a, ex.knn(dev(f), d)), d
+
+
+def test_spatially_sorted_candidates_and_cluster_structure():
+    """The round-4 threshold comes from a strided SAMPLE of the candidates (step 0 of the 16 waves) and is only a guess until
+    the final phase has counted KK keys below it: candidate orders that defeat the sample - points sorted along a coordinate
+    of a low-dimensional manifold, rooms made of a few tight clusters stored cluster by cluster - must still give the
+    oracle's tables (the rows the sample misleads take the exact path), with both kernels (the exact kernel's single sampled
+    cut has the same dependency)."""
+    rng = np.random.default_rng(77)
+    n = 4096
+    t = np.sort(rng.uniform(0, 1, n)).astype(np.float32)                      # a curve, stored in curve order
+    basis = rng.standard_normal((3, 64)).astype(np.float32)
+    curve = (np.stack([np.sin(6 * t), np.cos(4 * t), t], 1) @ basis + rng.standard_normal((n, 64)).astype(np.float32) * 0.01).astype(np.float32)
+    centres = rng.standard_normal((8, 64)).astype(np.float32) * 3
+    clusters = (np.repeat(centres, n // 8, 0) + rng.standard_normal((n, 64)).astype(np.float32) * 0.05).astype(np.float32)
+    ws = bf16_workspace(1, n)
+    ex = bf16_workspace(1, n, "f32")
+    for name, f in (("curve", curve), ("clusters", clusters)):
+        for d in (1, 9, 20, 27):
+            want = oracle_rooms(f[None], d)
+            ws.knn_stats()
+            got = ws.knn(dev(f[None]), d).cpu().numpy()
+            st = ws.knn_stats()
+            assert np.array_equal(got, want), (name, d, "prefilter", st["why"])
+            assert np.array_equal(ex.knn(dev(f[None]), d).cpu().numpy(), want), (name, d, "exact")
