@@ -13,7 +13,7 @@ struct KnnBuffers {
     float *sq = nullptr;              // [rows] squared norms in torch.sum's order
     const float *x = nullptr;         // the features themselves, row-major [rows][ld] (16-byte aligned rows): the prefilter path reads
     int ld = 0;                       // its few finalists' 64 floats from here (256 contiguous bytes instead of 16 pieces of xp)
-    unsigned long long *stats = nullptr;   // optional device counters of the prefilter kernel ([8], see psg_knn_bf.cuh)
+    unsigned long long *stats = nullptr;   // optional device counters of the prefilter kernel ([8], see psg_knn_bf.cuh: KnnBfArgs::stats)
 };
 
 enum KnnPath { KNN_PATH_BF16 = 0, KNN_PATH_F32 = 1 };

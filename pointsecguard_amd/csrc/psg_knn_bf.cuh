@@ -109,7 +109,9 @@ struct KnnBfArgs {
     int nsamp;            // sample tiles per wave: 1, or 2 for long rows (N a multiple of 512, at least 4 steps)
     int fine_cut;         // second histogram level inside the threshold's bin (long rows: 20 % fewer entries, no overflows up to d = 20)
     KnnFusedArgs exact;            // the exact path's arguments (xp, sq, out, ...)
-    unsigned long long *stats;     // optional [8]: tiles, fallback tiles, rows, finalists, rows cut, entries at the end
+    unsigned long long *stats;     // optional [8]: tiles, fallback tiles, rows, finalists, rows cut, entries at the end, and the reasons
+                                   // of the fallback tiles in 16-bit fields: [6] no threshold | row above CAP | row short of KK
+                                   // entries, [7] row short of KK keys below keyX | more than 256 finalists | bound broken
 };
 
 // ---- helpers on the two 32-lane halves of a wave (a row per half)
