@@ -29,6 +29,9 @@ sys.path.insert(0, ROOT)
 # one-call-per-room NU protocol (--nu-mode per-room-calls: 12 host threads, one small attack each) has more than 4 streams
 # with work; its throughput goes from 84 to ~120 rooms/s, the headline (3 streams) is unchanged (576.8 vs 576.9 rooms/s).
 # Reported in the line as config.hip_runtime.
+# (ROCm's default is 4; a library user who wants the one-call-per-room figure must export it too: INTEGRATION.md)
+HIP_RUNTIME = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "16"), "rocm_default": "4",
+               "set_by": "caller" if "GPU_MAX_HW_QUEUES" in os.environ else "bench.py"}
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 EPS, ALPHA, ITERS = 0.05, 2 / 255, 40
@@ -114,14 +117,24 @@ class Ranks:
             self.dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
             torch.cuda.set_device(self.dev_index)
         self.dist = None
-        if self.world > 1:
+        self.pg_info = {"backend": None, "world": self.world, "collective": "none (--no-process-group)"}
+        # A process group at EVERY N, N = 1 included (round 5): the barrier, the max-over-ranks time and n_ranks_seen of the
+        # one-GPU line are then real RCCL collectives, the same code path the 2/4/8-GPU runs take.
+        if self.world > 1 or (cuda and not getattr(args, "no_process_group", False)):
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:          # plain `python bench.py` at N = 1: no launcher set a rendezvous
+                import socket
+                s = socket.socket()
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+                s.close()
             if backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", self.dev_index))
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.dev_index))
             else:
-                dist.init_process_group(backend)
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
             self.dist = dist
+            self.pg_info = {"backend": backend, "world": dist.get_world_size(), "collective": "rccl" if backend == "nccl" else backend}
 
     def fence(self):
         import torch
@@ -226,13 +239,31 @@ def check_env_switches(allow_paths, diag_ok=False):
 
 def base_line(metric, unit, value, R, args, elapsed, workload, extra_config=None):
     cfg = {"workload": workload, "sharding": "independent rooms / clouds sharded by rank, no data-path collective",
-           "env_switches": list(ENV_SWITCHES), "hip_runtime": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}}
+           "env_switches": list(ENV_SWITCHES), "hip_runtime": dict(HIP_RUNTIME), "process_group": dict(R.pg_info),
+           # hipGraph bookkeeping of the replayed loops since the previous line of this process (psg_capture_stats): a failed
+           # capture costs speed, not correctness, so it is counted here instead of raised
+           "hipgraph": capture_delta()}
     if extra_config:
         cfg.update(extra_config)
     # n_ranks_seen: a sum of ones over the process group (RCCL on GPUs): evidence in the line itself that N ranks took part
     return {"metric": metric, "value": value, "unit": unit, "n_gpus": R.world, "n_ranks_seen": int(R.sum(1)), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg}
+
+
+_CAPTURE_MARK = {}
+
+
+def capture_delta():
+    """{captures_tried, captures_failed, replays, eager} of the library's replayed loops since the last call."""
+    try:
+        from pointsecguard_amd import _lib
+        now = _lib.capture_stats()
+    except Exception as exc:            # (the launch rehearsal has no library)
+        return {"error": str(exc)}
+    d = {k: v - _CAPTURE_MARK.get(k, 0) for k, v in now.items()}
+    _CAPTURE_MARK.update(now)
+    return d
 
 
 def cpu_threads():
@@ -299,6 +330,9 @@ def main():
                          "independent (every index stays inside its cloud), one launch of each kernel serves all of them")
     ap.add_argument("--concurrency", type=int, default=3,
                     help="device batches in flight per GPU (one HIP stream + workspace each)")
+    ap.add_argument("--no-process-group", action="store_true",
+                    help="N = 1 only, profiler passes: do not create the one-rank RCCL process group (its kernels and threads stay "
+                         "out of counter collection); the line then says config.process_group.collective = none")
     ap.add_argument("--allow-env-switches", action="store_true",
                     help="accept PSG_* switches that select another TESTED code path (A/B runs); they are listed in "
                          "config.env_switches either way, result-changing ones are always refused")

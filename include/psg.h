@@ -365,6 +365,13 @@ typedef struct psg_nu_graph psg_nu_graph;
 int psg_nu_graph_create(psg_nu_graph **out);
 int psg_nu_graph_destroy(psg_nu_graph *graph);
 int psg_pn2_nu_window(const psg_nu_window_args *args, psg_nu_graph *graph, psg_stream stream);
+/* Bookkeeping of a handle: out4 = {captures tried, captures failed, windows replayed as a graph, windows run eagerly}.  A
+ * failed capture (the legacy default stream refuses capture; another API call can invalidate one) costs speed, not
+ * correctness - the window runs eagerly - so it is counted instead of raised, and not retried for the same shape. */
+int psg_nu_graph_stats(const psg_nu_graph *graph, long long *out4);
+/* The same four counters summed over every replayed loop of the process (psg_pn2_nu_window, psg_gcn_nb_attack,
+ * psg_rla_bim_attack; for the last two the unit is an attack iteration). */
+int psg_capture_stats(long long *out4);
 
 /* Segmentation statistics of NB_nontarget_test_semseg.py:199-205: for every class l accumulates
  * seen[l] += #(gt==l), inter[l] += #(pred==l & gt==l), uni[l] += #(pred==l | gt==l) where

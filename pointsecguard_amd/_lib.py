@@ -78,6 +78,8 @@ SIGNATURES = {
     "psg_pn2_nu_window": (ci, [vp, vp, vp]),
     "psg_nu_graph_create": (ci, [ctypes.POINTER(vp)]),
     "psg_nu_graph_destroy": (ci, [vp]),
+    "psg_nu_graph_stats": (ci, [vp, c_ll]),
+    "psg_capture_stats": (ci, [c_ll]),
     "psg_nu_step_latch": (ci, [vp, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]),
     "psg_nu_tanh_color_rooms": (ci, [vp, vp, ci, ci, vp, vp]),
     "psg_nu_f_loss_grad_rooms": (ci, [vp, vp, ci, ci, ci, ci, cf, cf, vp, vp, vp, vp]),
@@ -185,6 +187,20 @@ def env_switches():
             name, value = nv.split("=", 1)
             out.append((name, value, kind))
     return out
+
+
+CAPTURE_KEYS = ("captures_tried", "captures_failed", "replays", "eager")
+
+
+def capture_stats(graph=None):
+    """hipGraph bookkeeping {captures_tried, captures_failed, replays, eager} of one psg_nu_graph handle, or (graph=None) of
+    every replayed loop of the process (include/psg.h: psg_nu_graph_stats / psg_capture_stats)."""
+    out = (ctypes.c_longlong * 4)()
+    if graph is None:
+        call("psg_capture_stats", out)
+    else:
+        call("psg_nu_graph_stats", graph, out)
+    return dict(zip(CAPTURE_KEYS, (int(v) for v in out)))
 
 
 def check(rc, what=""):

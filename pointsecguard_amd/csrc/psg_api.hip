@@ -1,5 +1,6 @@
 #include <mutex>
 // Context, error reporting and version of libpsg.so.
+#include <atomic>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -37,6 +38,16 @@ hipError_t copy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kin
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipStreamDestroy(st);
     return e;
+}
+
+static std::atomic<uint64_t> g_generation{0};
+uint64_t next_generation() { return ++g_generation; }
+
+static std::atomic<long long> g_capture[4];
+void capture_note(CaptureCounters *own, int tried, int failed, int replays, int eager)
+{
+    if (own) { own->tried += tried; own->failed += failed; own->replays += replays; own->eager += eager; }
+    g_capture[0] += tried; g_capture[1] += failed; g_capture[2] += replays; g_capture[3] += eager;
 }
 
 const char *env_str(const char *name)
@@ -106,6 +117,15 @@ extern "C" int psg_diag_build(void)
 #else
     return 0;
 #endif
+}
+
+// Process-wide hipGraph bookkeeping: out[4] = {captures tried, captures failed, graph replays, windows / iterations that ran
+// eagerly although a graph was wanted}.
+extern "C" int psg_capture_stats(long long *out4)
+{
+    PSG_REQUIRE(out4, "psg_capture_stats: null out pointer");
+    for (int i = 0; i < 4; ++i) out4[i] = psg::g_capture[i].load();
+    return PSG_OK;
 }
 
 extern "C" const char *psg_version(void) { return "libpsg 0.1 (gfx950, fp32 MFMA)"; }

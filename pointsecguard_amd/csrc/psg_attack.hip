@@ -1009,7 +1009,10 @@ static int nu_window_steps(const psg_nu_window_args *a, const float *dconsts_row
 struct psg_nu_graph {
     hipGraphExec_t exec = nullptr;
     psg_nu_window_args key;
+    uint64_t key_model_gen = 0, key_ws_gen = 0;   // generation numbers of key.model / key.ws: addresses can be re-used (psg_common.h)
     bool have_key = false;
+    bool capture_failed = false;    // the capture of this key failed once: its windows stay eager, no retry at every window
+    psg::CaptureCounters cap;
     float *dconsts = nullptr;       // device [PSG_NU_GRAPH_MAX_STEPS][4]
     float host[PSG_NU_GRAPH_MAX_STEPS * 4];
 };
@@ -1032,10 +1035,21 @@ extern "C" int psg_nu_graph_destroy(psg_nu_graph *g)
     return PSG_OK;
 }
 
-static bool nu_same_shape(psg_nu_window_args x, psg_nu_window_args y)
+static bool nu_same_shape(const psg_nu_graph *g, psg_nu_window_args y)
 {
+    psg_nu_window_args x = g->key;
     x.step0 = y.step0 = 0; x.adam_t0 = y.adam_t0 = 0; x.lr = y.lr = 0.0f;      // what the device row carries
-    return memcmp(&x, &y, sizeof(x)) == 0;
+    return memcmp(&x, &y, sizeof(x)) == 0 && g->key_model_gen == psg::pn2_model_generation(y.model) &&
+           g->key_ws_gen == psg::pn2_ws_generation(y.ws);
+}
+
+// out4 = {captures tried, captures failed, windows replayed as a graph, windows that ran eagerly} of this handle (the two
+// eager windows every shape starts with included)
+extern "C" int psg_nu_graph_stats(const psg_nu_graph *g, long long *out4)
+{
+    PSG_REQUIRE(g && out4, "psg_nu_graph_stats: null argument");
+    out4[0] = g->cap.tried; out4[1] = g->cap.failed; out4[2] = g->cap.replays; out4[3] = g->cap.eager;
+    return PSG_OK;
 }
 
 extern "C" int psg_pn2_nu_window(const psg_nu_window_args *a, psg_nu_graph *graph, psg_stream stream)
@@ -1056,37 +1070,47 @@ extern "C" int psg_pn2_nu_window(const psg_nu_window_args *a, psg_nu_graph *grap
         graph->host[4 * i + 3] = 0.0f;
     }
     PSG_CHECK_HIP(hipMemcpyAsync(graph->dconsts, graph->host, (size_t)a->n_steps * 16, hipMemcpyHostToDevice, st));
-    if (graph->exec && nu_same_shape(graph->key, *a)) {
+    const bool same = graph->have_key && nu_same_shape(graph, *a);
+    if (same && graph->exec) {
         PSG_CHECK_HIP(hipGraphLaunch(graph->exec, st));
+        psg::capture_note(&graph->cap, 0, 0, 1, 0);
         return PSG_OK;
     }
-    if (graph->have_key && nu_same_shape(graph->key, *a) && !graph->exec) {
-        // second window of this shape: capture it, then replay
+    if (same && !graph->capture_failed) {
+        // second window of this shape: capture it, then replay.  A capture that fails (refused on the legacy default stream,
+        // or invalidated - DESIGN 5i names what can do that) has executed nothing: the window runs eagerly below and a genuine
+        // launch error shows again there; the failure is COUNTED (psg_nu_graph_stats, psg_capture_stats) and this shape is
+        // not tried again.
+        bool ok = false;
         if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             const int crc = nu_window_steps(a, graph->dconsts, stream);
             hipGraph_t gr = nullptr;
             const hipError_t e = hipStreamEndCapture(st, &gr);
-            if (crc == PSG_OK && e == hipSuccess && gr && hipGraphInstantiate(&graph->exec, gr, nullptr, nullptr, 0) != hipSuccess)
-                graph->exec = nullptr;
+            ok = crc == PSG_OK && e == hipSuccess && gr && hipGraphInstantiate(&graph->exec, gr, nullptr, nullptr, 0) == hipSuccess;
+            if (!ok) graph->exec = nullptr;
             if (gr) (void)hipGraphDestroy(gr);
-            // (a capture that failed - another host thread's work can invalidate it: "operation failed due to a previous error
-            // during capture", seen once in three runs of the twelve-thread one-call-per-room leg - has executed nothing:
-            // the window runs eagerly below, and a genuine launch error shows again there)
-            (void)crc;
         }
-        (void)hipGetLastError();        // a refused capture (legacy default stream) is not an error of this call
-        if (graph->exec) {
+        (void)hipGetLastError();
+        graph->capture_failed = !ok;
+        psg::capture_note(&graph->cap, 1, ok ? 0 : 1, 0, 0);
+        if (ok) {
             PSG_CHECK_HIP(hipGraphLaunch(graph->exec, st));
+            psg::capture_note(&graph->cap, 0, 0, 1, 0);
             return PSG_OK;
         }
-        return nu_window_steps(a, graph->dconsts, stream);
     }
-    if (graph->exec) {                  // another shape: forget the old one
-        PSG_CHECK_HIP(hipStreamSynchronize(st));
-        (void)hipGraphExecDestroy(graph->exec);
-        graph->exec = nullptr;
+    if (!same) {
+        if (graph->exec) {              // another shape: forget the old one
+            PSG_CHECK_HIP(hipStreamSynchronize(st));
+            (void)hipGraphExecDestroy(graph->exec);
+            graph->exec = nullptr;
+        }
+        graph->key = *a;
+        graph->key_model_gen = psg::pn2_model_generation(a->model);
+        graph->key_ws_gen = psg::pn2_ws_generation(a->ws);
+        graph->have_key = true;
+        graph->capture_failed = false;
     }
-    graph->key = *a;
-    graph->have_key = true;
+    psg::capture_note(&graph->cap, 0, 0, 0, 1);
     return nu_window_steps(a, graph->dconsts, stream);
 }

@@ -54,6 +54,19 @@ void trace_sync_point(const char *file, int line);
         if (psg::trace_sync_enabled()) psg::trace_sync_point(__FILE__, __LINE__);                 \
     } while (0)
 
+// Every model / workspace handle gets a process-unique, never re-used generation number at creation.  The hipGraph keys of the
+// replayed loops compare THESE, not handle addresses: the allocator may hand a new handle the address of a freed one, and a
+// graph keyed on the address would then replay kernels whose arguments point into the freed arena (advisor, round 4).
+uint64_t next_generation();
+uint64_t pn2_model_generation(const psg_pn2_model *m);
+uint64_t pn2_ws_generation(const psg_pn2_ws *ws);
+
+// hipGraph bookkeeping of the three replayed loops (psg_pn2_nu_window, psg_gcn_nb_attack, psg_rla_bim_attack): a capture that
+// fails falls back to the eager launches - correct, but slower - so it is COUNTED, per handle and for the process
+// (psg_capture_stats), and a handle whose capture failed does not try again for the same key.
+struct CaptureCounters { long long tried = 0, failed = 0, replays = 0, eager = 0; };
+void capture_note(CaptureCounters *own, int tried, int failed, int replays, int eager);
+
 // Optional per-launch HIP-event timing of a workspace (psg_*_prof_enable / psg_*_prof_read): pairs of events recorded on
 // the LAUNCH stream around a launch (or a group of launches) with a tag and the algorithmic FLOPs of that launch; off in
 // normal operation (one branch per launch).  bench.py's `roofline` objects are computed from these.

@@ -227,7 +227,11 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(const float *__r
 // that passes the test has a true squared distance below r^2 + 1e-5 max|coordinate|^2 - and the cell edge is 1.05 x the
 // root of exactly that, i.e. the point is less than one cell edge away per axis - and both cell indices come from the same
 // monotone formula (a centroid outside the cloud's box is clamped to the border cell: what it can reach lies in the border
-// cells).  A cloud with non-finite coordinates is one cell, i.e. the full scan.  Same indices, bit for bit
+// cells).  A cloud with non-finite coordinates is one cell, i.e. the full scan.  The argument above is about centroids that
+// can REACH the cloud: psg_ball_query is a public entry that takes arbitrary new_xyz, so a centroid that is non-finite
+// (every `dd > r2` is false for a NaN: the scan returns 0 .. K-1) or lies more than one cell edge outside the cloud's box
+// (far enough away, cancellation in the expansion passes points no cell walk would visit) takes ALL N points as its
+// candidates - the scan, inside this kernel (advisor, round 4; tests/test_gpu_ball_grid.py).  Same indices, bit for bit
 // (tests/test_gpu_parity.py: reference fixtures; test_unit_geometry_vs_oracle; tests/test_gpu_edge.py).
 // ---------------------------------------------------------------------------------------------
 constexpr int BQG_CELLS = 4096;     // cells per cloud at most (the edge grows by 1.25x until the box fits)
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_grid_kernel(const float
     int *s_cur = s_start + BQG_CELLS + 1;
     unsigned short *s_sorted = (unsigned short *)(s_cur + BQG_CELLS);
     __shared__ float s_red[BQ_THREADS / 64][6];
-    __shared__ float s_box[4];          // min x, y, z, 1 / cell edge
+    __shared__ float s_box[8];          // min x, y, z, 1 / cell edge; max x, y, z, cell edge
     __shared__ int s_dim[4];            // nx, ny, nz, cells
     __shared__ int s_wsum[BQ_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -302,10 +306,12 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_grid_kernel(const float
             edge *= 1.25f;
         }
         s_box[0] = lo[0]; s_box[1] = lo[1]; s_box[2] = lo[2]; s_box[3] = 1.0f / edge;
+        s_box[4] = hi[0]; s_box[5] = hi[1]; s_box[6] = hi[2]; s_box[7] = edge;
         s_dim[0] = nx; s_dim[1] = ny; s_dim[2] = nz; s_dim[3] = nx * ny * nz;
     }
     __syncthreads();
     const float bx = s_box[0], by = s_box[1], bz = s_box[2], inv = s_box[3];
+    const float hx = s_box[4], hy = s_box[5], hz = s_box[6], edge1 = s_box[7];
     const int nx = s_dim[0], ny = s_dim[1], nz = s_dim[2], ncell = s_dim[3];
     auto cell1 = [&](float v, float b, int n) {
         if (n == 1) return 0;
@@ -351,7 +357,12 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_grid_kernel(const float
         const int ix = cell1(cx, bx, nx), iy = cell1(cy, by, ny), iz = cell1(cz, bz, nz);
         // the 9 runs of the sorted list: rows (iz + dz, iy + dy), cells ix - 1 .. ix + 1 (contiguous: x runs fastest)
         int start = 0, len = 0;
-        if (lane < 9) {
+        // (written so that a NaN coordinate makes it true)
+        const bool off_cloud = !(cx >= bx - edge1 && cx <= hx + edge1 && cy >= by - edge1 && cy <= hy + edge1 && cz >= bz - edge1 &&
+                                 cz <= hz + edge1);
+        if (off_cloud) {
+            len = lane == 0 ? N : 0;      // one run: the whole sorted list = every point of the cloud
+        } else if (lane < 9) {
             const int z = iz + lane / 3 - 1, y = iy + lane % 3 - 1;
             if (z >= 0 && z < nz && y >= 0 && y < ny) {
                 const int x0 = ix > 0 ? ix - 1 : 0, x1 = ix + 1 < nx ? ix + 1 : nx - 1;

@@ -152,6 +152,7 @@ struct PackedLayer {
 }  // namespace
 
 struct psg_pn2_model {
+    uint64_t gen = psg::next_generation();   // never re-used (psg_common.h): what replayed graphs are keyed on
     psg_ctx *ctx;
     const ArchDesc *arch;
     PackedLayer L[MAXL];
@@ -159,6 +160,7 @@ struct psg_pn2_model {
 };
 
 struct psg_pn2_ws {
+    uint64_t gen = psg::next_generation();
     psg_ctx *ctx;
     const ArchDesc *arch;
     int B, N, F;          // batch, points per room, max forwards in the plan
@@ -198,6 +200,11 @@ struct psg_pn2_ws {
     std::vector<int> prof_tag;
     size_t prof_used = 0;
 };
+
+namespace psg {
+uint64_t pn2_model_generation(const psg_pn2_model *m) { return m ? m->gen : 0; }
+uint64_t pn2_ws_generation(const psg_pn2_ws *ws) { return ws ? ws->gen : 0; }
+}  // namespace psg
 
 namespace {
 

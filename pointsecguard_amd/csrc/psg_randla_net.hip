@@ -869,6 +869,7 @@ struct EncLayers { RLayer mlp1, lfa_mlp1, att1_fc, att1_mlp, lfa_mlp2, att2_fc, 
 }  // namespace
 
 struct psg_rla_model {
+    uint64_t gen = psg::next_generation();   // never re-used (psg_common.h): what the replayed BIM iteration is keyed on
     psg_ctx *ctx;
     RLayer fc0, decoder0, dec[RL], fc1, fc2, fc;
     EncLayers enc[RL];
@@ -920,13 +921,15 @@ struct psg_rla_ws {
     bool use_inv = true;          // PSG_RLA_ATOMICS=1: the scatter kernels with float atomics instead of the inverse-list gathers
     size_t scratch_bytes = 0;     // of scratch_a and of scratch_b
     EvLog prof;                   // psg_rla_prof_enable
-    const void *xyz_branch_model = nullptr;   // the model whose xyz-branch features (fxyz1 / fxyz2) are resident
+    uint64_t xyz_branch_model = 0;   // generation number (not the address: a freed model's address can come back) of the model whose xyz-branch features (fxyz1 / fxyz2) are resident
     // hipGraph of one BIM iteration (forward, loss gradient, backward, update: ~150 short launches), valid for the
     // (model, eps, alpha, metric) below; every captured kernel works on workspace buffers, so it is cloud-independent
     hipGraphExec_t bim_exec = nullptr;
-    const void *bim_model = nullptr;
+    uint64_t bim_model_gen = 0;      // the model's generation number, not its address (psg_common.h)
     float bim_eps = 0.f, bim_alpha = 0.f;
     int bim_metric = -1;
+    bool bim_capture_failed = false; // the capture for this key failed once: stay eager instead of trying in every call
+    psg::CaptureCounters cap;
 };
 
 namespace {
@@ -1227,7 +1230,7 @@ static int build_pyramid(psg_rla_ws *ws, psg_stream stream)
     }
     ws->cloud_set = true;
     ws->have_fwd = false;
-    ws->xyz_branch_model = nullptr;
+    ws->xyz_branch_model = 0;
     return PSG_OK;
 }
 
@@ -1254,7 +1257,7 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
     int rc;
     if ((rc = conv_fwd(m->fc0, features, 6, ws->f0, 8, N, true, ws->m_f0, st))) return rc;
     const float *fin = ws->f0;
-    const bool xyz_ready = ws->xyz_branch_model == (const void *)m;
+    const bool xyz_ready = ws->xyz_branch_model == m->gen;
     for (int i = 0; i < RL; ++i) {
         LevelBuf &L = ws->lv[i];
         const EncLayers &E = m->enc[i];
@@ -1356,7 +1359,7 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
     if (logits_out != ws->logits)
         PSG_CHECK_HIP(hipMemcpyAsync(logits_out, ws->logits, (size_t)N * RNCLS * 4, hipMemcpyDeviceToDevice, st));
     ws->have_fwd = true;
-    ws->xyz_branch_model = m;
+    ws->xyz_branch_model = m->gen;
     return PSG_OK;
 }
 
@@ -1684,27 +1687,39 @@ extern "C" int psg_rla_bim_attack(psg_rla_model *m, psg_rla_ws *ws, const float 
     int it = 1;
     static const bool use_graph = !((psg::env_int("PSG_RLA_NO_GRAPH", 0) != 0)) && !trace_sync_enabled();   // (the tracer synchronises after every launch)
     if (use_graph && !ws->prof.on && iters - it >= 2) {
-        if (ws->bim_exec && (ws->bim_model != (const void *)m || ws->bim_eps != eps || ws->bim_alpha != alpha || ws->bim_metric != l2_metric)) {
-            PSG_CHECK_HIP(hipStreamSynchronize(st));
-            (void)hipGraphExecDestroy(ws->bim_exec);
-            ws->bim_exec = nullptr;
+        const bool same_key = ws->bim_model_gen == m->gen && ws->bim_eps == eps && ws->bim_alpha == alpha && ws->bim_metric == l2_metric;
+        if (!same_key) {
+            if (ws->bim_exec) {
+                PSG_CHECK_HIP(hipStreamSynchronize(st));
+                (void)hipGraphExecDestroy(ws->bim_exec);
+                ws->bim_exec = nullptr;
+            }
+            ws->bim_capture_failed = false;
         }
-        if (!ws->bim_exec) {
+        if (!ws->bim_exec && !ws->bim_capture_failed) {
+            // a capture that fails (refused on the legacy stream, or invalidated) has executed nothing: the iterations run
+            // eagerly below - and show a genuine launch error there -, the failure is counted (psg_capture_stats) and this
+            // key is not tried again
+            bool ok = false;
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 const int crc = iteration();
                 hipGraph_t graph = nullptr;
                 const hipError_t e = hipStreamEndCapture(st, &graph);
-                if (crc == PSG_OK && e == hipSuccess && graph) {
-                    if (hipGraphInstantiate(&ws->bim_exec, graph, nullptr, nullptr, 0) != hipSuccess) ws->bim_exec = nullptr;
-                }
+                ok = crc == PSG_OK && e == hipSuccess && graph && hipGraphInstantiate(&ws->bim_exec, graph, nullptr, nullptr, 0) == hipSuccess;
+                if (!ok) ws->bim_exec = nullptr;
                 if (graph) (void)hipGraphDestroy(graph);
-                (void)crc;      // (a failed capture has executed nothing: the iterations run eagerly below and report a genuine error there)
-                ws->bim_model = m; ws->bim_eps = eps; ws->bim_alpha = alpha; ws->bim_metric = l2_metric;
             }
-            (void)hipGetLastError();   // a refused capture (legacy stream) is not an error of this call
+            (void)hipGetLastError();
+            ws->bim_model_gen = m->gen; ws->bim_eps = eps; ws->bim_alpha = alpha; ws->bim_metric = l2_metric;
+            ws->bim_capture_failed = !ok;
+            psg::capture_note(&ws->cap, 1, ok ? 0 : 1, 0, 0);
         }
-        if (ws->bim_exec)
+        if (ws->bim_exec) {
+            psg::capture_note(&ws->cap, 0, 0, iters - it, 0);
             for (; it < iters; ++it) PSG_CHECK_HIP(hipGraphLaunch(ws->bim_exec, st));
+        } else {
+            psg::capture_note(&ws->cap, 0, 0, 0, iters - it);
+        }
     }
     for (; it < iters; ++it)
         if ((rc = iteration())) return rc;

@@ -842,6 +842,7 @@ struct EdgeLayer {
 }  // namespace
 
 struct psg_gcn_model {
+    uint64_t gen = psg::next_generation();   // never re-used (psg_common.h): what the replayed NB iteration is keyed on
     psg_ctx *ctx;
     int n_blocks;
     int block = PSG_GCN_BLOCK_RES, conv = PSG_GCN_CONV_EDGE;   // architecture.py:26-39, torch_vertex.py:44-49
@@ -900,9 +901,11 @@ struct psg_gcn_ws {
     // graph launch; valid for (model, eps, alpha) below, rebuilt when they change
     int32_t *nb_labels;        // [B*N] the attack's labels, copied so that the captured kernels' arguments never change
     hipGraphExec_t nb_exec = nullptr;
-    const void *nb_model = nullptr;
+    uint64_t nb_model_gen = 0;       // the model's generation number, not its address (psg_common.h)
     float nb_eps = 0.f, nb_alpha = 0.f;
     bool nb_fixed = false;
+    bool nb_capture_failed = false;  // the capture for this key failed once: stay eager instead of trying in every call
+    psg::CaptureCounters cap;
     EvLog prof;              // psg_gcn_prof_enable
 };
 
@@ -1668,28 +1671,38 @@ extern "C" int psg_gcn_nb_attack(psg_gcn_model *m, psg_gcn_ws *ws, const float *
     ws->head_graph_frozen = true;
     static const bool use_graph = !((psg::env_int("PSG_GCN_NO_GRAPH", 0) != 0)) && !trace_sync_enabled();   // (the tracer synchronises after every launch)
     if (use_graph && !ws->prof.on && iters - 1 - it >= 2) {
-        if (ws->nb_exec && (ws->nb_model != (const void *)m || ws->nb_eps != eps || ws->nb_alpha != alpha ||
-                            ws->nb_fixed != ws->fixed_graphs)) {
-            PSG_CHECK_HIP(hipStreamSynchronize(st));
-            (void)hipGraphExecDestroy(ws->nb_exec);
-            ws->nb_exec = nullptr;
+        const bool same_key = ws->nb_model_gen == m->gen && ws->nb_eps == eps && ws->nb_alpha == alpha && ws->nb_fixed == ws->fixed_graphs;
+        if (!same_key) {
+            if (ws->nb_exec) {
+                PSG_CHECK_HIP(hipStreamSynchronize(st));
+                (void)hipGraphExecDestroy(ws->nb_exec);
+                ws->nb_exec = nullptr;
+            }
+            ws->nb_capture_failed = false;
         }
-        if (!ws->nb_exec) {
+        if (!ws->nb_exec && !ws->nb_capture_failed) {
+            // a capture that fails (refused on the legacy stream, or invalidated) has executed nothing: the iterations run
+            // eagerly below - and show a genuine launch error there -, the failure is counted (psg_capture_stats) and this
+            // key is not tried again
+            bool ok = false;
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 const int crc = iteration(false);
                 hipGraph_t graph = nullptr;
                 const hipError_t e = hipStreamEndCapture(st, &graph);
-                if (crc == PSG_OK && e == hipSuccess && graph) {
-                    if (hipGraphInstantiate(&ws->nb_exec, graph, nullptr, nullptr, 0) != hipSuccess) ws->nb_exec = nullptr;
-                }
+                ok = crc == PSG_OK && e == hipSuccess && graph && hipGraphInstantiate(&ws->nb_exec, graph, nullptr, nullptr, 0) == hipSuccess;
+                if (!ok) ws->nb_exec = nullptr;
                 if (graph) (void)hipGraphDestroy(graph);
-                (void)crc;      // (a failed capture has executed nothing: the iterations run eagerly below and report a genuine error there)
-                ws->nb_model = m; ws->nb_eps = eps; ws->nb_alpha = alpha; ws->nb_fixed = ws->fixed_graphs;
             }
-            (void)hipGetLastError();   // a refused capture (legacy stream) is not an error of this call
+            (void)hipGetLastError();
+            ws->nb_model_gen = m->gen; ws->nb_eps = eps; ws->nb_alpha = alpha; ws->nb_fixed = ws->fixed_graphs;
+            ws->nb_capture_failed = !ok;
+            psg::capture_note(&ws->cap, 1, ok ? 0 : 1, 0, 0);
         }
         if (ws->nb_exec) {
+            psg::capture_note(&ws->cap, 0, 0, iters - 1 - it, 0);
             for (; it < iters - 1; ++it) PSG_CHECK_HIP(hipGraphLaunch(ws->nb_exec, st));
+        } else {
+            psg::capture_note(&ws->cap, 0, 0, 0, iters - 1 - it);
         }
     }
     for (; it < iters; ++it)

@@ -78,6 +78,36 @@ def test_grid_ball_query_non_finite_cloud_is_the_scan():
     assert np.array_equal(got[0], pn2.ball_query(0.15, 32, xyz[0], new[0]))
 
 
+def test_grid_ball_query_arbitrary_centroids_equal_the_scan():
+    """psg_ball_query takes ARBITRARY new_xyz (advisor, round 4): a NaN / infinite centroid passes `!(d > r^2)` for every point
+    in the reference's test (indices 0 .. K-1), and so does a finite centroid so far away that the expansion -2ab + |a|^2 +
+    |b|^2 overflows to inf - inf (3e38: the dot product and |c|^2 are both infinite) - neither is something a 27-cell walk
+    would find.  (Merely distant centroids pass nothing: the expansion's error is relative to |c|^2, and so is the distance.)
+    Centroids that are non-finite or more than a cell edge outside the box take the whole cloud as candidates inside the
+    grid kernel: same rows as the oracle's scan."""
+    from oracle import pn2
+    from pointsecguard_amd import runtime
+    rng = np.random.default_rng(11)
+    n, radius, k = 4096, 0.1, 32
+    xyz = clouds("uniform", n, rng)[None].copy()
+    new = xyz[:, rng.choice(n, 96, replace=False)].copy()
+    new[0, 0] = np.nan
+    new[0, 1] = (np.inf, 0.0, 1.0)
+    new[0, 2] = (0.1, -np.inf, 1.0)
+    new[0, 3] = (0.2, 0.1, np.nan)
+    for i, far in enumerate((1e3, 1e5, 3e6, 1e20, 3e38)):                 # far away, up to overflow of the expansion
+        new[0, 4 + 2 * i] = xyz[0, 50 + i] + np.float32(far)
+        new[0, 5 + 2 * i] = xyz[0, 80 + i] * np.array([1, 1, -1], np.float32) - np.array([0, far, 0], np.float32)
+    new[0, 14] = xyz[0].min(axis=0) - np.float32(1.5 * radius)           # just beyond one cell edge outside the box
+    new[0, 15] = xyz[0].max(axis=0) + np.float32(0.9 * radius)           # inside one cell edge: the border-cell walk
+    got = runtime.ball_query(radius, k, dev(xyz), dev(new)).cpu().numpy()
+    with np.errstate(all="ignore"):
+        want = pn2.ball_query(radius, k, xyz[0], new[0])
+    assert np.array_equal(got[0], want), np.nonzero((got[0] != want).any(1))[0]
+    assert np.array_equal(got[0, 0], np.arange(k))                       # the NaN centroid: the first K points
+    assert np.array_equal(want[12], np.arange(k)) and (want[4] == n).all()   # overflow: everything passes; merely far: nothing
+
+
 def test_grid_equals_scan_kernel_on_the_network_plan():
     """The whole geometry plan of an attack (4 levels x the reference's FPS starts) under PSG_BALL_QUERY=scan in a child
     process against the default (grid for levels 0 and 1): identical group tables."""

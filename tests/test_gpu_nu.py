@@ -471,8 +471,39 @@ def test_tar_nu_rooms_lockstep_equals_one_call_per_room(weights_sd):
     adv2, steps2 = torchattacks.tar_NU_attack(net, c=1, kappa=0, steps=3, lr=0.01, target=target).forward_rooms(
         images, labels.astype(np.float64), masks)
     assert adv2.shape == images.shape and list(steps2) == [3] * R
-    with pytest.raises(ValueError):
-        nu_mod.nu_attack_rooms(torchattacks.tar_NU_attack(net, steps=51, target=target), images, labels, masks, target, 5, True)
+
+
+def test_tar_nu_rooms_past_the_lr_halving_equals_fresh_objects_per_room(weights_sd):
+    """The reference's harness builds a NEW tar_NU_attack per batch (NU_target_test_semseg.py:181, steps=1000), so every
+    attack starts from the constructor's lr and halves it after step 50 (target.py:123-125, with a new optimiser).  Rooms
+    in lockstep do exactly that - R fresh objects -: 54 steps (windows .. [41..50], [51..53]; halving + moment reset after
+    step 50) give, per room, the image of a fresh one-room attack object bit for bit; the object's lr is back at its value at
+    the call afterwards (a single call leaves it halved, like the reference)."""
+    from pointsecguard_amd.attacks import torchattacks
+    from pointsecguard_amd.attacks.torchattacks.attacks import nu as nu_mod
+    R, steps, target = 2, 54, 6
+    net, rooms, labels, images = _rooms_case(weights_sd, R, 9500)
+    masks = labels == 2
+    rng = np.random.default_rng(29)
+    table = torch.from_numpy(np.stack([rng.integers(0, n, (steps, R)) for n in (4096, 1024, 256, 64)], axis=1).astype(np.int32))
+    single = []
+    for r in range(R):
+        atk = torchattacks.tar_NU_attack(net, c=1, kappa=0, steps=steps, lr=0.01, target=target, mask=masks[r])
+        torch.manual_seed(100 + r)
+        adv, n = nu_mod.nu_attack(atk, images[r:r + 1], labels[r:r + 1].astype(np.float64), masks[r], target, 5, targeted_variant=True,
+                                  starts_fn=lambda step, n_plan, r=r: table[step:step + n_plan, :, r:r + 1].contiguous(), return_steps=True)
+        single.append((adv.cpu().numpy()[0], n))
+        assert atk.lr == (0.005 if n > 51 else 0.01)            # the reference's left-over state of ONE object
+    atk = torchattacks.tar_NU_attack(net, c=1, kappa=0, steps=steps, lr=0.01, target=target, mask=None)
+    torch.manual_seed(5)
+    adv, steps_run = nu_mod.nu_attack_rooms(atk, images, labels.astype(np.float64), masks, target, 5, targeted_variant=True,
+                                            starts_fn=lambda step, n_plan: table[step:step + n_plan].contiguous())
+    out = adv.cpu().numpy()
+    assert atk.lr == 0.01
+    assert max(s[1] for s in single) > 51, "the case must cross the halving at step 50"
+    for r in range(R):
+        assert steps_run[r] == single[r][1], (r, steps_run, single[r][1])
+        assert np.array_equal(out[r].view(np.uint32), single[r][0].view(np.uint32)), r
 
 
 def test_nu_rooms_a_room_that_exits_early_is_frozen(weights_sd):
@@ -618,11 +649,41 @@ def test_nu_windows_without_host_sync_equal_the_per_step_loop(weights_sd):
         torch.cuda.synchronize()
         return adv.cpu().numpy(), n
 
+    from pointsecguard_amd import _lib
+    graph = lambda: next(s.graph for k, s in net._psg_nu_states.items() if k[1] == R and k[2] == 1)
     ref, n_ref = rooms_run(lambda **kw: None)
-    for _ in range(2):                                   # second pass: the graph captured by the first is replayed
-        got, n_got = rooms_run(None)
+    base = _lib.capture_stats(graph())
+    assert base == dict(captures_tried=0, captures_failed=0, replays=0, eager=0), base     # (one-step windows carry no graph handle)
+    # (a) on torch's DEFAULT stream - the legacy stream, which refuses capture: every window runs eagerly, the refused
+    # capture is COUNTED once and not tried again at the next window of the shape
+    got, n_got = rooms_run(None)
+    assert np.array_equal(n_ref, n_got) and np.array_equal(ref.view(np.uint32), got.view(np.uint32))
+    a = _lib.capture_stats(graph())
+    assert a == dict(captures_tried=1, captures_failed=1, replays=0, eager=3), a           # [1..10], [11..20] (refused), [21..30]
+    # (b) on a side stream (what bench.py and a multi-stream caller use): [1..10] is a new key for the handle only if the
+    # buffers changed - they did not, and the failed key is not retried: still eager.  A NEW model instance = new handle:
+    side = torch.cuda.Stream()
+    net2, _, _, _ = _rooms_case(weights_sd, R, 9300)
+
+    def rooms_run2():
+        atk = torchattacks.tar_NU_attack(net2, c=1, kappa=0, steps=steps, lr=0.01, target=target, mask=None)
+        torch.manual_seed(5)
+        with torch.cuda.stream(side):
+            adv, n = nu_mod.nu_attack_rooms(atk, images, labels.astype(np.float64), masks, target, 5, targeted_variant=True,
+                                            starts_fn=starts_for(0, R))
+        side.synchronize()
+        return adv.cpu().numpy(), n
+
+    images.record_stream(side)
+    for k in range(2):                                   # second pass: the graph captured by the first is replayed
+        got, n_got = rooms_run2()
         assert np.array_equal(n_ref, n_got), (n_ref, n_got)
         assert np.array_equal(ref.view(np.uint32), got.view(np.uint32))
+        b = _lib.capture_stats(next(s.graph for s in net2._psg_nu_states.values()))
+        # pass 0: [1..10] eager, [11..20] captured + replayed, [21..30] replayed; pass 1: three replays
+        assert b == dict(captures_tried=1, captures_failed=0, replays=2 + 3 * k, eager=1), (k, b)
+    tot = _lib.capture_stats()
+    assert tot["captures_failed"] >= 1 and tot["replays"] >= 5
 
     def single_run(r, trace):
         atk = torchattacks.tar_NU_attack(net, c=1, kappa=0, steps=steps, lr=0.01, target=target, mask=masks[r])

@@ -150,3 +150,50 @@ def test_fused_attack_invariants_28_blocks(gcn28, g28):
     # every d-th neighbour of a sorted list changes wholesale when one near-tie moves, the edge overlap with the
     # reference's tables falls from 1.0 to 0.62 at block 5 and 0.08 at block 27 from rounding differences alone
     # (tools/gcn28_diag.py) - so parity is pinned with the reference's graphs teacher-forced, above)
+
+
+def test_nb_attack_outcome_parity_with_the_reference_run(gcn28):
+    """Free-running outcome parity at configs[3]'s own size (round 5): tests/golden/gcn28_nb_outcome.npz holds what the
+    reference's experiment loop (sem_seg_dense/attacks.py:125-160) measured when ITS `NB_attack(eps=0.3, alpha=2/255,
+    iters=50)` ran on four single-room batches with the fitted 28-block weights: clean / adversarial accuracy, per-room
+    micro-IoU (sum I / sum U) and the L2 distance of the returned room.  The dynamic graphs make the attack chaotic entry by
+    entry (see above), so the bar is the one the PointNet++ path has (test_gpu_parity.py: 32-room statistics): the
+    attack's OUTCOME, per room and over the rooms together.  Clean predictions are compared directly."""
+    from pointsecguard_amd import _lib, runtime
+    from pointsecguard_amd.synthetic import make_rooms, rule_labels
+    g = dict(np.load(os.path.join(GOLDEN, "gcn28_nb_outcome.npz")))
+    model, ws = gcn28
+    ws.set_graphs(None)
+    eps, alpha, iters = float(g["eps"]), float(g["alpha"]), int(g["iters"])
+    side = torch.cuda.Stream()
+    acc, adv_acc, adv_miou, dis = [], [], [], []
+    for si, seed in enumerate(g["seeds"]):
+        r = make_rooms(1, int(seed))
+        y = rule_labels(r)
+        images_np = np.ascontiguousarray(r.transpose(0, 2, 1))
+        x_pm = dev(r)
+        labels = dev(y.astype(np.int32))
+        pred = ws.forward(model, x_pm).argmax(2)[0].cpu().numpy()
+        clean_ref = g["r%d_clean_pred" % si]
+        # clean predictions: equal up to arg-max near-ties (a chaotic 28-block network: a handful of points may flip)
+        assert (pred == clean_ref).mean() >= 0.98, (si, (pred == clean_ref).mean())
+        with torch.cuda.stream(side):
+            adv = ws.nb_attack(model, dev(images_np), labels, eps, alpha, iters)
+        side.synchronize()
+        adv_pm = adv.permute(0, 2, 1).contiguous()
+        apred = ws.forward(model, adv_pm).argmax(2)[0].cpu().numpy()
+        inter = sum(int(((apred == c) & (y[0] == c)).sum()) for c in range(13))
+        union = sum(int(((apred == c) | (y[0] == c)).sum()) for c in range(13))
+        acc.append(float((pred == y[0]).mean()))
+        adv_acc.append(float((apred == y[0]).mean()))
+        adv_miou.append(inter / union)
+        dis.append(float(torch.dist(adv, dev(images_np)).item()))
+        out = adv.cpu().numpy()
+        assert np.array_equal(out[:, :3], images_np[:, :3]) and np.array_equal(out[:, 6:], images_np[:, 6:])
+    acc, adv_acc, adv_miou, dis = (np.array(v) for v in (acc, adv_acc, adv_miou, dis))
+    print("ResGCN-28 NB outcome: acc", acc, "ref", g["acc"], "| adv_acc", adv_acc, "ref", g["adv_acc"], "| adv micro-IoU", adv_miou, "ref",
+          g["adv_miou"], "| L2", dis, "ref", g["dis"])
+    assert np.abs(acc - g["acc"]).max() <= 0.01
+    assert np.abs(adv_acc - g["adv_acc"]).max() <= 0.03 and abs(adv_acc.mean() - g["adv_acc"].mean()) <= 0.01
+    assert np.abs(adv_miou - g["adv_miou"]).max() <= 0.03 and abs(adv_miou.mean() - g["adv_miou"].mean()) <= 0.01
+    assert np.abs(dis / g["dis"] - 1).max() <= 0.02
