@@ -50,6 +50,18 @@ void capture_note(CaptureCounters *own, int tried, int failed, int replays, int 
     g_capture[0] += tried; g_capture[1] += failed; g_capture[2] += replays; g_capture[3] += eager;
 }
 
+hipError_t memset_sync(void *dst, int value, size_t bytes)
+{
+    if (bytes == 0) return hipSuccess;
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(dst, value, bytes, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+    return e;
+}
+
 const char *env_str(const char *name)
 {
     bool known = false;

@@ -17,6 +17,14 @@ void set_error(const char *fmt, ...);
 // thread captures a hipGraph on one ("operation would make the legacy stream depend on a capturing blocking stream":
 // the one-call-per-room NU harness builds its model copies from twelve threads).  A non-blocking stream of its own per call.
 hipError_t copy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
+// The same for hipMemset.  Measured (tools/capture_probe.hip, round 5): ANOTHER host thread's hipMemcpy / hipMemset on the
+// legacy stream - and its hipDeviceSynchronize - INVALIDATE a hipStreamCaptureModeThreadLocal capture in progress on any
+// stream of the process, blocking or not (the caller gets hipErrorStreamCaptureImplicit / ...Unsupported, the capturing
+// thread's next launch hipErrorStreamCaptureInvalidated); hipMalloc / hipFree, stream and event creation,
+// hipFuncSetAttribute, async work on stream 0 and hipStreamSynchronize do not.  So no entry point that can run beside a
+// capture (creation, upload, forward / backward / attack) uses the legacy-stream forms; only the test read-backs
+// (psg_*_debug_read, psg_gcn_knn_stats, psg_rla_sampler_possibility) synchronise the device.
+hipError_t memset_sync(void *dst, int value, size_t bytes);
 
 #define PSG_CHECK_HIP(expr)                                                                      \
     do {                                                                                         \

@@ -131,10 +131,17 @@ extern "C" int psg_rla_sampler_create(psg_ctx *ctx, const float *points_host, co
     hipError_t e = psg::copy_sync(s->pts, points_host, M * 12, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = psg::copy_sync(s->poss, possibility_host, M * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(iota_kernel, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)0, s->iota, n_points);
-        e = hipGetLastError();
+        // (a stream of its own, not stream 0 + hipDeviceSynchronize: a device synchronise invalidates any hipGraph capture
+        // another host thread has in progress - psg_common.h)
+        hipStream_t cst = nullptr;
+        e = hipStreamCreateWithFlags(&cst, hipStreamNonBlocking);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(iota_kernel, dim3((n_points + 255) / 256), dim3(256), 0, cst, s->iota, n_points);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(cst);
+            (void)hipStreamDestroy(cst);
+        }
     }
-    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         set_error("psg_rla_sampler_create: %s", hipGetErrorString(e));
         (void)psg_rla_sampler_destroy(s);

@@ -1226,7 +1226,7 @@ extern "C" int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n
             }
         }
     }
-    if (ws->knn_stats) (void)hipMemset(ws->knn_stats, 0, 8 * sizeof(unsigned long long));
+    if (ws->knn_stats) (void)psg::memset_sync(ws->knn_stats, 0, 8 * sizeof(unsigned long long));
     *out = ws;
     return PSG_OK;
 }
@@ -1256,7 +1256,7 @@ extern "C" int psg_gcn_knn_stats(psg_gcn_ws *ws, unsigned long long *host_out8, 
     if (!ws->knn_stats) return PSG_OK;
     PSG_CHECK_HIP(hipDeviceSynchronize());
     PSG_CHECK_HIP(psg::copy_sync(host_out8, ws->knn_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (reset) PSG_CHECK_HIP(hipMemset(ws->knn_stats, 0, 8 * sizeof(unsigned long long)));
+    if (reset) PSG_CHECK_HIP(psg::memset_sync(ws->knn_stats, 0, 8 * sizeof(unsigned long long)));
     return PSG_OK;
 }
 

@@ -105,7 +105,7 @@ def test_grid_ball_query_arbitrary_centroids_equal_the_scan():
         want = pn2.ball_query(radius, k, xyz[0], new[0])
     assert np.array_equal(got[0], want), np.nonzero((got[0] != want).any(1))[0]
     assert np.array_equal(got[0, 0], np.arange(k))                       # the NaN centroid: the first K points
-    assert np.array_equal(want[12], np.arange(k)) and (want[4] == n).all()   # overflow: everything passes; merely far: nothing
+    assert (want[12] != n).all() and want[12, 0] == 0 and (want[4] == n).all()   # overflow: a full row of far points; merely far: nothing
 
 
 def test_grid_equals_scan_kernel_on_the_network_plan():
