@@ -129,6 +129,17 @@ ArchDesc make_msg()
     return a;
 }
 
+// The first layer of SA level `lvl` split into a per-point feature product and a per-row xyz chunk (psg_pn2_kernels.cuh,
+// sa_fwd_kernel SPLIT).  SSG levels 1 - 3: 8 x fewer points than grouped rows and 64 / 128 / 256 feature channels.  Level 0 stays
+// whole: its 9 feature channels are 2 of the module's 14 k8-chunk passes, the rows of T (32 floats) would be a larger gather
+// than the 12 floats it replaces, and its backward writes compact 16-byte colour rows (DESIGN.md section 6 has the numbers).
+// PSG_PN2_SPLIT=0 keeps the whole first layers everywhere (A/B runs, tests/test_gpu_alt_paths.py).
+bool arch_split(const ArchDesc &A, int lvl)
+{
+    static const bool on = psg::env_int("PSG_PN2_SPLIT", 1) != 0;
+    return on && A.id == PSG_PN2_ARCH_SSG && lvl >= 1;
+}
+
 const ArchDesc &arch_of(int id)
 {
     static const ArchDesc ssg = make_ssg(), msg = make_msg();
@@ -156,6 +167,10 @@ struct psg_pn2_model {
     psg_ctx *ctx;
     const ArchDesc *arch;
     PackedLayer L[MAXL];
+    // split first layers (arch_split): sx = the xyz columns [C1 x 3] (forward packing only), sf = the feature columns
+    // [C1 x D] with the layer's bias (forward packing for the per-point product, transposed packing for its gradient)
+    PackedLayer sx[4], sf[4];
+    bool split[4] = {false, false, false, false};
     void *arena = nullptr;
 };
 
@@ -179,7 +194,9 @@ struct psg_pn2_ws {
     float *dint[4];       // [B][N_l][C2_l] interpolated-part gradient rows of fp_bwd level l
     int32_t *ginv_off[4][2]; // inverse group lists (CSR by source point, lists sorted by grouped row): [F*B][N_l + 1]
     int32_t *ginv_pos[4][2]; // [F*B][S_l*K] inverse permutation: slot of a grouped row in the concatenated lists
-    float *gsa[4][2];     // [B][S_l*K][CG_l] grouped-input gradient rows of sa_bwd level l (CG = 12, then C[l])
+    float *gsa[4][2];     // [B][S_l*K][CG_l] grouped-input gradient rows of sa_bwd level l (CG = 12, then C[l]; split levels: dZ1 rows, C1)
+    float *tfeat[4];      // split levels: [B][N_l][C1] per-point first-layer products of the resident forward
+    float *dsum[4];       // dsum[l], l = 0..2, when level l + 1 is split: [B][S_l][C_{l+1}] complete gradient of level l's pooled output
     int planned = 0;
     // activations of one forward
     float *act[7];        // l1..l4, fp4 out (64 pts), fp3 out (256), fp2 out (1024)
@@ -297,7 +314,7 @@ BwdLayer bwd_layer(const PackedLayer &p, const uint16_t *mask)
 
 // kernel tags of the per-launch profile (psg_pn2_prof_read)
 enum { TAG_SA_FWD = 0, TAG_FP_FWD = 4, TAG_FP_BWD = 8, TAG_SA_BWD = 12, TAG_FPS = 16, TAG_BALL = 17, TAG_NN = 18,
-       TAG_GATHER = 19, TAG_CE = 20, TAG_PGD = 21, TAG_ZERO = 22, TAG_COUNT = 23 };
+       TAG_GATHER = 19, TAG_CE = 20, TAG_PGD = 21, TAG_ZERO = 22, TAG_PW_FWD = 23, TAG_PW_BWD = 24, TAG_COUNT = 25 };
 
 struct ProfScope {
     psg_pn2_ws *ws;
@@ -351,7 +368,11 @@ int launch_lds(psg_pn2_ws *ws, int tag, KernelT kern, dim3 grid, int threads, in
 }
 
 inline int layer_blocks(int k8, int mb) { return std::max(k8, mb * 4); }
-inline int gsa_stride(const ArchDesc &A, int lvl) { return lvl == 0 ? 12 : A.C[lvl]; }
+inline int gsa_stride(const ArchDesc &A, int lvl)
+{
+    if (arch_split(A, lvl)) return A.cout[A.sc[lvl][0].l0];     // dZ1 rows: the first layer's width
+    return lvl == 0 ? 12 : A.C[lvl];
+}
 
 #define PSG_CFG_KEY(P, NW, KS, MT) ((P) * 10000 + (NW) * 1000 + (KS) * 10 + (MT))
 
@@ -373,10 +394,13 @@ int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, const
     a.ld_out = A.C[lvl + 1];
     a.c_out = d.c_off;
     a.arg = ws->arg[lvl][sc];
-    a.l1 = fwd_layer(L[0], true, ws->mask[d.l0]);
+    const bool split = m->split[lvl];
+    a.l1 = fwd_layer(split ? m->sx[lvl] : L[0], true, ws->mask[d.l0]);
     a.l2 = fwd_layer(L[1], true, ws->mask[d.l0 + 1]);
     a.w3 = L[2].wf; a.b3 = L[2].bias; a.k8_3 = L[2].k8f(); a.nb3 = L[2].mbf();
     a.D = D; a.Np = Np; a.S = S; a.C3 = L[2].cout;
+    a.tfeat = split ? ws->tfeat[lvl] : nullptr;
+    a.ldt = split ? L[0].cout : 0;
     // one in-place activation buffer: the widest of the layers' K / M extents (psg_mlp.cuh)
     const int blocks = std::max(std::max(layer_blocks(a.l1.k8, a.l1.mb), layer_blocks(a.l2.k8, a.l2.mb)), a.k8_3) + PSG_LDS_SPARE;
     if (a.l1.mb * (P / 32) > d.maxt_f * NW || a.l2.mb * (P / 32) > d.maxt_f * NW || a.nb3 * (P / 32) > 2 * NW) {
@@ -388,6 +412,15 @@ int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, const
 #define PSG_SA_FWD_CASE(P_, NW_, KS_, MT_) \
     case PSG_CFG_KEY(P_, NW_, KS_, MT_): \
         return launch_lds(ws, tag, sa_fwd_kernel<P_, NW_, KS_, MT_>, grid, NW_ * 64, blocks, Lds<P_>::BLK, a, st)
+    if (split) {
+        switch (PSG_CFG_KEY(P, NW, KS, d.maxt_f)) {
+        case PSG_CFG_KEY(64, 4, 32, 1): return launch_lds(ws, tag, (sa_fwd_kernel<64, 4, 32, 1, true>), grid, 4 * 64, blocks, Lds<64>::BLK, a, st);
+        case PSG_CFG_KEY(32, 4, 32, 1): return launch_lds(ws, tag, (sa_fwd_kernel<32, 4, 32, 1, true>), grid, 4 * 64, blocks, Lds<32>::BLK, a, st);
+        case PSG_CFG_KEY(32, 8, 32, 1): return launch_lds(ws, tag, (sa_fwd_kernel<32, 8, 32, 1, true>), grid, 8 * 64, blocks, Lds<32>::BLK, a, st);
+        }
+        set_error("run_sa_fwd: no split kernel for P=%d NW=%d K=%d MAXT=%d", P, NW, KS, d.maxt_f);
+        return PSG_ERR_STATE;
+    }
     switch (PSG_CFG_KEY(P, NW, KS, d.maxt_f)) {
         PSG_SA_FWD_CASE(128, 4, 32, 1);   // SSG sa1, MSG sa1 scale 1
         PSG_SA_FWD_CASE(64, 4, 32, 1);    // SSG sa2
@@ -419,7 +452,9 @@ int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, int c
     a.nninv_off = nullptr; a.nninv_ent = nullptr; a.dint = nullptr; a.n_fine = 0;
     a.ginv_off = nullptr; a.gsa = nullptr; a.g_rows = 0;
     a.ginv_off2 = nullptr; a.gsa2 = nullptr; a.g_rows2 = 0;
-    if (lvl < 3) {   // plus the transposed grouping of SA level lvl + 1, gathered through its inverse lists
+    if (lvl < 3 && m->split[lvl + 1]) {
+        a.dout = ws->dsum[lvl];   // skip-link rows + the transposed grouping of level lvl + 1, summed per point by pw_bwd_kernel
+    } else if (lvl < 3) {   // plus the transposed grouping of SA level lvl + 1, gathered through its inverse lists
         a.g_rows = kS[lvl + 1] * A.sc[lvl + 1][0].K;
         a.ginv_off = ws->ginv_off[lvl + 1][0] + prob * (S + 1);
         a.gsa = ws->gsa[lvl + 1][0];
@@ -437,6 +472,8 @@ int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, int c
     a.gsa_out = ws->gsa[lvl][sc];
     a.gpos_out = ws->ginv_pos[lvl][sc] + prob * S * KS;
     a.cg_out = (lvl == 0 && c_hi - c_lo == 3) ? 4 : gsa_stride(A, lvl);   // colour-only: compact float4 rows
+    a.split = m->split[lvl] ? 1 : 0;
+    if (a.split) { c_lo = 0; c_hi = L[0].cout; }   // the rows stored are dZ1 [C1]
     if (lvl == 3) {   // l4_points feed only fp4: its gradient is gathered from fp4's interpolated-part rows
         a.dout = nullptr;
         a.nninv_off = ws->inv_off[3] + prob * (kS[3] + 1);
@@ -452,11 +489,11 @@ int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, int c
     a.D = D; a.Np = Np; a.S = S; a.C3 = C3;
     a.c_lo = c_lo; a.c_hi = c_hi;
     const int main_blocks = std::max(std::max(layer_blocks(a.l3t.k8, a.l3t.mb), layer_blocks(a.l2t.k8, a.l2t.mb)),
-                                     layer_blocks(a.l1t.k8, a.l1t.mb)) + PSG_LDS_SPARE;
+                                     a.split ? 0 : layer_blocks(a.l1t.k8, a.l1t.mb)) + PSG_LDS_SPARE;
     a.dsrc_blk = main_blocks;   // the gathered pooled-output gradient is staged behind the activation buffer
     const int blk_floats = P * 8 + PSG_LDS_PAD;
     const int blocks = main_blocks + ceil_div((P / KS) * C3, blk_floats);
-    if (std::max(std::max(a.l3t.mb, a.l2t.mb), a.l1t.mb) * (P / 32) > d.maxt_b * NW) {
+    if (std::max(std::max(a.l3t.mb, a.l2t.mb), a.split ? 0 : a.l1t.mb) * (P / 32) > d.maxt_b * NW) {
         set_error("run_sa_bwd level %d scale %d: more than %d tiles per wave in a layer", lvl, sc, d.maxt_b);
         return PSG_ERR_STATE;
     }
@@ -497,6 +534,53 @@ inline bool fp1_wave()
 {
     static const bool v = psg::env_int("PSG_FP1_WAVE", 0) != 0;
     return v;
+}
+
+// Per-point side of a split SA level (arch_split): T = act[lvl - 1] . W1f^T + b1 for the Nl[lvl] points of every room, one
+// launch of the cooperative row-MLP kernel (fp_fwd_kernel with a skip part only: C2 = 0, one layer, no ReLU).
+int run_pw_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int fwd, hipStream_t st)
+{
+    constexpr int P = 32, NW = 8;
+    const PackedLayer &F = m->sf[lvl];
+    const int B = ws->B, N = ws->Nl[lvl];
+    FpFwdArgs a;
+    a.feat1 = ws->act[lvl - 1]; a.C1 = F.cin;
+    a.feat2 = ws->act[lvl - 1]; a.C2 = 0;
+    // (the kernel reads a point's three neighbour entries before it looks at C2: any valid table of N rows per room will do)
+    a.nn_idx = ws->nn_idx[lvl] + (size_t)fwd * B * N * 3;
+    a.nn_w = ws->nn_w[lvl] + (size_t)fwd * B * N * 3;
+    a.N = N; a.S = N;
+    a.layer[0] = fwd_layer(F, false, nullptr);
+    a.n_layers = 1;
+    a.out = ws->tfeat[lvl]; a.Cout = F.cout; a.logp = nullptr; a.n_cls = 0;
+    a.diag = 0; a.dbg = ws->dbg;
+    if (a.layer[0].mb > NW || N % P) { set_error("run_pw_fwd level %d: unsupported shape", lvl); return PSG_ERR_STATE; }
+    const int blocks = layer_blocks(a.layer[0].k8, a.layer[0].mb) + PSG_LDS_SPARE;
+    return launch_lds(ws, TAG_PW_FWD, (fp_fwd_kernel<P, NW, false>), dim3(N / P, B), NW * 64, blocks, Lds<P>::BLK, a, st);
+}
+
+// dsum[lvl - 1] = dact[lvl - 1] (skip-link rows of the coarser FP module; level 3 feeds fp4 only: its skip part is that gather,
+// done in sa_bwd) + (sum of the dZ1 rows of level lvl per source point) . W1f
+int run_pw_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int fwd, hipStream_t st)
+{
+    constexpr int P = 32, NW = 8;
+    const ArchDesc &A = *m->arch;
+    const PackedLayer &F = m->sf[lvl];
+    const int B = ws->B, N = ws->Nl[lvl];
+    PwBwdArgs a;
+    a.ginv_off = ws->ginv_off[lvl][0] + (size_t)fwd * B * (N + 1);
+    a.gsa = ws->gsa[lvl][0];
+    a.g_rows = kS[lvl] * A.sc[lvl][0].K;
+    a.skip = ws->dact[lvl - 1];
+    a.out = ws->dsum[lvl - 1];
+    a.wt = bwd_layer(F, nullptr);
+    a.N = N; a.C1 = F.cout; a.D = F.cin;
+    if ((a.C1 != 64 && a.C1 != 128 && a.C1 != 256) || a.wt.mb > NW || N % P || a.D % 32) {
+        set_error("run_pw_bwd level %d: unsupported shape", lvl);
+        return PSG_ERR_STATE;
+    }
+    const int blocks = layer_blocks(a.wt.k8, a.wt.mb) + PSG_LDS_SPARE;
+    return launch_lds(ws, TAG_PW_BWD, (pw_bwd_kernel<P, NW>), dim3(N / P, B), NW * 64, blocks, Lds<P>::BLK, a, st);
 }
 
 template <int LVL>
@@ -867,6 +951,13 @@ size_t ws_layout(psg_pn2_ws *ws, char *base)
     }
     for (int l = 0; l < 4; ++l)
         for (int s = 0; s < A.ns; ++s) ws->gsa[l][s] = bp.take<float>((size_t)B * kS[l] * A.sc[l][s].K * gsa_stride(A, l));
+    for (int l = 0; l < 4; ++l) {
+        ws->tfeat[l] = nullptr; ws->dsum[l] = nullptr;
+        if (arch_split(A, l)) {
+            ws->tfeat[l] = bp.take<float>((size_t)B * ws->Nl[l] * A.cout[A.sc[l][0].l0]);
+            ws->dsum[l - 1] = bp.take<float>((size_t)B * ws->Nl[l] * A.C[l]);
+        }
+    }
     for (int l = 0; l < 4; ++l) {   // interpolated-part gradient rows of FP module l: C2 = its input minus the skip part
         const int c2 = A.cin[A.fp_first[l]] - (l == 0 ? 0 : A.C[l]);
         ws->dint[l] = bp.take<float>((size_t)B * ws->Nl[l] * c2);
@@ -939,9 +1030,43 @@ extern "C" int psg_pn2_model_create_arch(psg_ctx *ctx, int arch, const float *co
         }
         total += ((wf[i].size() + wb[i].size() + bs[i].size() + wf4[i].size() + wb4[i].size()) * 4 + 5 * 256);
     }
+    // split first layers (arch_split): reference column order of the layer is [rel_xyz(3), feats(D)] (SSG: sa_perm)
+    std::vector<float> sxf[4], sff[4], sfb[4], sfbias[4];
+    for (int l = 0; l < 4; ++l) {
+        m->split[l] = arch_split(A, l);
+        if (!m->split[l]) continue;
+        const int li = A.sc[l][0].l0, cin = A.cin[li], cout = A.cout[li], D = cin - 3;
+        const int xo = A.sa_perm ? 0 : D, fo = A.sa_perm ? 3 : 0;
+        std::vector<float> wx((size_t)cout * 3), wfe((size_t)cout * D);
+        for (int o = 0; o < cout; ++o) {
+            for (int c = 0; c < 3; ++c) wx[(size_t)o * 3 + c] = weights[li][(size_t)o * cin + xo + c];
+            for (int c = 0; c < D; ++c) wfe[(size_t)o * D + c] = weights[li][(size_t)o * cin + fo + c];
+        }
+        sxf[l] = pack_fwd(wx.data(), 3, cout, nullptr);
+        sff[l] = pack_fwd(wfe.data(), D, cout, nullptr);
+        sfb[l] = pack_bwd(wfe.data(), D, cout, nullptr);
+        sfbias[l] = bs[li];
+        total += (sxf[l].size() + sff[l].size() + sfb[l].size() + sfbias[l].size()) * 4 + 4 * 256;
+    }
     PSG_CHECK_HIP(hipMalloc(&m->arena, total));
     Bump bp;
     bp.base = (char *)m->arena;
+    for (int l = 0; l < 4; ++l) {
+        if (!m->split[l]) continue;
+        const int li = A.sc[l][0].l0;
+        PackedLayer &X = m->sx[l], &F = m->sf[l];
+        X.cin = 3; X.cout = A.cout[li];
+        F.cin = A.cin[li] - 3; F.cout = A.cout[li];
+        X.wf = bp.take<float4>(sxf[l].size() / 4);
+        F.wf = bp.take<float4>(sff[l].size() / 4);
+        F.wb = bp.take<float4>(sfb[l].size() / 4);
+        F.bias = bp.take<float>(sfbias[l].size());
+        X.bias = F.bias;     // (unused: the bias arrives through T)
+        PSG_CHECK_HIP(psg::copy_sync(X.wf, sxf[l].data(), sxf[l].size() * 4, hipMemcpyHostToDevice));
+        PSG_CHECK_HIP(psg::copy_sync(F.wf, sff[l].data(), sff[l].size() * 4, hipMemcpyHostToDevice));
+        PSG_CHECK_HIP(psg::copy_sync(F.wb, sfb[l].data(), sfb[l].size() * 4, hipMemcpyHostToDevice));
+        PSG_CHECK_HIP(psg::copy_sync(F.bias, sfbias[l].data(), sfbias[l].size() * 4, hipMemcpyHostToDevice));
+    }
     for (int i = 0; i < NLr; ++i) {
         PackedLayer &L = m->L[i];
         L.cin = A.cin[i]; L.cout = A.cout[i];
@@ -1143,9 +1268,11 @@ extern "C" int psg_pn2_forward(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const 
     PSG_REQUIRE(fwd >= 0 && fwd < ws->planned, "psg_pn2_forward: plan slot %d not built (planned %d)", fwd, ws->planned);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    for (int l = 0; l < 4; ++l)
+    for (int l = 0; l < 4; ++l) {
+        if (m->split[l] && (rc = run_pw_fwd(m, ws, l, fwd, st))) return rc;
         for (int sc = 0; sc < m->arch->ns; ++sc)
             if ((rc = run_sa_fwd(m, ws, l, sc, fwd, x0, st))) return rc;
+    }
     if ((rc = run_fp_fwd<3>(m, ws, fwd, nullptr, st))) return rc;
     if ((rc = run_fp_fwd<2>(m, ws, fwd, nullptr, st))) return rc;
     if ((rc = run_fp_fwd<1>(m, ws, fwd, nullptr, st))) return rc;
@@ -1168,9 +1295,11 @@ static int backward_impl(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float 
     if ((rc = run_fp_bwd<1>(m, ws, fwd, nullptr, nullptr, st))) return rc;
     if ((rc = run_fp_bwd<2>(m, ws, fwd, nullptr, nullptr, st))) return rc;
     if ((rc = run_fp_bwd<3>(m, ws, fwd, nullptr, nullptr, st))) return rc;
-    for (int l = 3; l >= 0; --l)
+    for (int l = 3; l >= 0; --l) {
         for (int sc = 0; sc < A.ns; ++sc)
             if ((rc = run_sa_bwd(m, ws, l, sc, fwd, l ? 0 : c_lo, l ? A.C[l] : c_hi, st))) return rc;
+        if (m->split[l] && (rc = run_pw_bwd(m, ws, l, fwd, st))) return rc;
+    }
     {
         ProfScope prof(ws, TAG_ZERO, st);   // (tag kept: the slot that used to be the gradient memset)
         const bool compact = c_hi - c_lo == 3;

@@ -36,6 +36,10 @@ struct SaFwdArgs {
     int k8_3, nb3;
     int xyz_stride, D, Np, S, C3;
     int ld_out, c_out;
+    // SPLIT kernels (see sa_fwd_kernel): per-point first-layer products T = feats . W1f^T + b1, rows [B][Np][ldt]; l1 then
+    // holds the xyz columns of the first layer only (k8 = 1)
+    const float *tfeat;
+    int ldt;
     int diag;              // timing diagnostics only (-DPSG_DIAG_BUILD libraries only): skip sections, results are then wrong
 };
 
@@ -64,6 +68,8 @@ struct SaBwdArgs {
     BwdLayer l3t, l2t, l1t;
     int D, Np, S, C3;
     int c_lo, c_hi;       // feature channels [c_lo, c_hi) of the grouped-input gradient are scattered
+    int split;            // 1: the rows stored are dZ1 (the first layer's pre-activation gradient, channels [c_lo, c_hi) =
+                          // [0, C1)), the first layer's transpose is NOT applied here (pw_bwd_kernel applies it per POINT)
     int dsrc_blk;         // LDS block where the gathered pooled-output gradient is staged
     int diag;             // timing diagnostics only (-DPSG_DIAG_BUILD libraries only)
 };
@@ -107,7 +113,62 @@ struct FpBwdArgs {
 // [rel_xyz, feats], pointnet_util.py:137).
 // KS = samples per group (32, or 16 for the small-radius scale of an MSG level: two groups per 32-point tile);
 // MAXT = tiles a wave may hold in the first two layers.
-template <int P, int NW, int KS = 32, int MAXT = 1>
+//
+// SPLIT (round 5): the first layer is linear in the concatenation, W1 . [x_j - c_i ; f_j] = W1f . f_j + W1x . (x_j - c_i),
+// and its feature part depends on the SOURCE POINT j only - a level has 8 x fewer points than grouped rows (1024 / 256 / 64
+// points against 8192 / 2048 / 512 rows per room at levels 1 - 3).  T[j] = W1f . f_j + b1 is computed once per point by a
+// separate per-point launch; here the rows of T are gathered through the group table straight into the MFMA ACCUMULATORS
+// of the first layer's tiles (lane (j, h) of a tile reads the 4 x 16 bytes of row gidx[j] that its accumulator registers
+// hold: the same bytes per grouped row as the feature gather it replaces, and no LDS staging), and the layer itself is
+// ONE k8-chunk (the three relative coordinates) instead of (D + 3) / 8 chunks: 9 -> 1, 17 -> 1, 33 -> 1 at levels 1 - 3,
+// i.e. 24 % of the module's matrix instructions.  The coordinates are NOT split (W1x x_j - W1x c_i would cancel: |x| ~ 3
+// against |x_j - c_i| < r): the difference is formed first, as the reference does.
+template <int P, int NW, int MAXT, int KS>
+__device__ __forceinline__ void sa_layer1_split(const SaFwdArgs &a, int b, int s0, float *__restrict__ buf, size_t wg_linear)
+{
+    constexpr int PB = P / 32, BLK = Lds<P>::BLK;
+    const FwdLayer &L = a.l1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int ntask = L.mb * PB;
+    const int first = (wave + (int)(wg_linear & (NW - 1))) & (NW - 1);
+    const int32_t *gi = a.gidx + ((size_t)b * a.S + s0) * KS;          // the workgroup's P grouped rows are contiguous
+    const float *trows = a.tfeat + (size_t)b * a.Np * a.ldt;
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int task = first + i * NW;
+        if (task < ntask) {
+            const int mb = task / PB, pb = task - mb * PB;
+            const int src = gi[pb * 32 + j];
+            // accumulator registers 4g .. 4g+3 of lane (j, h) are channels mb*32 + 8g + 4h + (0..3) of point j
+            const float4 *tp = (const float4 *)(trows + __umul24((unsigned)src, (unsigned)a.ldt) + mb * 32 + 4 * h);
+            const float4 t0 = tp[0], t1 = tp[2], t2 = tp[4], t3 = tp[6];
+            f32x16 c;
+            c[0] = t0.x; c[1] = t0.y; c[2] = t0.z; c[3] = t0.w;
+            c[4] = t1.x; c[5] = t1.y; c[6] = t1.z; c[7] = t1.w;
+            c[8] = t2.x; c[9] = t2.y; c[10] = t2.z; c[11] = t2.w;
+            c[12] = t3.x; c[13] = t3.y; c[14] = t3.z; c[15] = t3.w;
+            const float4 wx = L.w[(size_t)mb * 64 + lane];               // k8 = 1: one chunk per 32-channel block
+            const float4 rx = *(const float4 *)(buf + (pb * 32 + j) * 8 + 4 * h);
+            c = mfma4<false>(wx, rx, c);
+            const unsigned m = relu_bits(c);
+            if (L.mask) L.mask[(wg_linear * ntask + task) * 64 + lane] = (uint16_t)m;
+            acc[i] = c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int task = first + i * NW;
+        if (task < ntask) {
+            const int mb = task / PB, pb = task - mb * PB;
+            store_tile<P>(buf, mb, pb * 32 + j, h, acc[i]);
+        }
+    }
+}
+
+template <int P, int NW, int KS = 32, int MAXT = 1, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
 {
     using L = Lds<P>;
@@ -121,7 +182,17 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
     const int s0 = bx * G;
     const size_t wg = (size_t)b * gridDim.x + bx;
 
-    if (!PSG_DIAGBIT(a, 1)) {   // gather the P grouped points
+    if (SPLIT) {
+        // block 0 of the buffer = [x_j - c_i, 0 x 5] of the P grouped rows; the feature part arrives through T (below)
+        if (tid < P) {
+            const int j = tid, s = s0 + j / KS;
+            const int src = a.gidx[((size_t)b * a.S + s) * KS + (j & (KS - 1))];
+            const float *xr = a.xyz + ((size_t)b * a.Np + src) * a.xyz_stride;
+            const float *cr = a.new_xyz + ((size_t)b * a.S + s) * 3;
+            *(float4 *)(buf0 + j * 8) = make_float4(xr[0] - cr[0], xr[1] - cr[1], xr[2] - cr[2], 0.0f);
+            *(float4 *)(buf0 + j * 8 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else if (!PSG_DIAGBIT(a, 1)) {   // gather the P grouped points
         const int j = tid % P, part = tid / P;
         const int s = s0 + j / KS;
         const int src = a.gidx[((size_t)b * a.S + s) * KS + (j & (KS - 1))];
@@ -163,7 +234,8 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
         const int task = wave + i * NW;
         bias3[i] = task < a.nb3 * PB ? a.b3[(task / PB) * 32 + jj] : 0.0f;
     }
-    if (!PSG_DIAGBIT(a, 8)) layer_fwd<P, NW, MAXT>(a.l1, buf0, wg);
+    if (SPLIT) sa_layer1_split<P, NW, MAXT, KS>(a, b, s0, buf0, wg);
+    else if (!PSG_DIAGBIT(a, 8)) layer_fwd<P, NW, MAXT>(a.l1, buf0, wg);
     if (!PSG_DIAGBIT(a, 16)) __syncthreads();
     if (!PSG_DIAGBIT(a, 8)) layer_fwd<P, NW, MAXT>(a.l2, buf0, wg);
     if (!PSG_DIAGBIT(a, 16)) __syncthreads();
@@ -334,8 +406,10 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     if (!PSG_DIAGBIT(a, 16)) __syncthreads();
     if (!PSG_DIAGBIT(a, 8)) layer_bwd<P, NW, MAXT>(a.l2t, buf0, wg);
     if (!PSG_DIAGBIT(a, 16)) __syncthreads();
-    if (!PSG_DIAGBIT(a, 8)) layer_bwd<P, NW, MAXT>(a.l1t, buf0, wg);
-    __syncthreads();
+    if (!a.split) {   // (split: the rows stored below are dZ1 itself; W1f^T is applied per point by pw_bwd_kernel)
+        if (!PSG_DIAGBIT(a, 8)) layer_bwd<P, NW, MAXT>(a.l1t, buf0, wg);
+        __syncthreads();
+    }
     if (PSG_DIAGBIT(a, 32)) return;
     // index_points backward (pointnet_util.py:119,131): the feature rows [c_lo, c_hi) of the grouped-input gradient
     // are stored as plain rows; the consumer (previous level's sa_bwd, or dx0_gather_kernel) sums them through the
@@ -763,6 +837,104 @@ __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
             }
             const unsigned o = __umul24((unsigned)j, (unsigned)a.C2);
             for (int q = ql; q < (a.C2 >> 2); q += 32) *(float4 *)(d2 + (o + 4u * q)) = *(const float4 *)(in + L::off(a.C1 + 4 * q, j));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ per-point side of the SA split
+// Backward of the split first layer (see sa_fwd_kernel): for the 32 points n of a workgroup
+//     dT[n]   = sum of the dZ1 rows of the grouped rows that gathered point n  (the transpose of index_points, as a gather:
+//               sa_bwd stored its rows in list order, so they are the CONTIGUOUS slots [off[n], off[n+1]), ascending row)
+//     out[n]  = skip[n] + dT[n] . W1f                                            (C1 -> D channels, one MFMA layer)
+// `out` is the complete gradient of the level's pooled features: the coarser FP module's skip-link rows plus the transposed
+// grouping of the next SA level - what sa_bwd's prologue used to sum per (group, channel) thread by walking the list of its
+// point (a wave waited for its longest list).  Here the workgroup's entry range is dealt to the WAVES by entry count, a wave
+// walks its rows with all 64 lanes on one row (coalesced C1-float reads, eight in flight), exactly like fp_bwd_gather_rows.
+struct PwBwdArgs {
+    const int32_t *ginv_off;   // [B][N + 1]
+    const float *gsa;          // [B][g_rows][C1] dZ1 rows in list order
+    int g_rows;
+    const float *skip;         // [B][N][D] or null
+    float *out;                // [B][N][D]
+    BwdLayer wt;               // W1f transposed: k8 = C1 / 8, mb = D / 32, no mask
+    int N, C1, D;
+};
+
+template <int P, int NW, int VW>
+__device__ __forceinline__ void pw_bwd_gather_rows(const PwBwdArgs &a, int b, int n0, float *__restrict__ buf, int lane, int wave)
+{
+    static_assert(P == 32, "one 32-point tile per workgroup");
+    typedef float vwf __attribute__((ext_vector_type(VW)));
+    const int32_t *offp = a.ginv_off + (size_t)b * (a.N + 1) + n0;
+    const int offl = offp[lane < 32 ? lane : 32];                       // lanes 32.. hold the end of the range
+    const int e0 = __builtin_amdgcn_readfirstlane(offl), e_end = __builtin_amdgcn_readlane(offl, 32);
+    const int ltot = e_end - e0;
+    const int t_lo = (int)(((long long)ltot * wave) / NW), t_hi = (int)(((long long)ltot * (wave + 1)) / NW);
+    const int r_lo = __popcll(__ballot(lane < 32 && offl - e0 < t_lo));
+    const int r_hi = wave == NW - 1 ? 32 : __popcll(__ballot(lane < 32 && offl - e0 < t_hi));
+    if (r_lo >= r_hi) return;
+    const int lo = __builtin_amdgcn_readlane(offl, r_lo), hi = __builtin_amdgcn_readlane(offl, r_hi);
+    const float *rows = a.gsa + (size_t)b * a.g_rows * a.C1 + lane * VW;
+    float *dst = buf + ((lane * VW) >> 3) * Lds<P>::BLK + ((lane * VW) & 7);    // + 8 * point
+    int cur = r_lo, next = __builtin_amdgcn_readlane(offl, r_lo + 1);
+    vwf acc = 0.0f;
+    for (int base = lo; base < hi; base += 8) {
+        vwf v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = base + k < hi ? *(const vwf *)(rows + (size_t)(base + k) * a.C1) : (vwf)0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = base + k;
+            if (e < hi) {
+                while (e >= next) {                                     // the point's list is complete (or empty): write, take the next
+                    *(vwf *)(dst + 8 * cur) = acc;
+                    acc = 0.0f;
+                    ++cur;
+                    next = __builtin_amdgcn_readlane(offl, cur + 1);
+                }
+                acc += v[k];
+            }
+        }
+    }
+    for (; cur < r_hi; ++cur) {
+        *(vwf *)(dst + 8 * cur) = acc;
+        acc = 0.0f;
+    }
+}
+
+template <int P, int NW>
+__global__ __launch_bounds__(NW * 64) void pw_bwd_kernel(PwBwdArgs a)
+{
+    using L = Lds<P>;
+    constexpr int NT = NW * 64;
+    extern __shared__ float lds[];
+    float *buf0 = lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx, b;
+    xcd_tile(bx, b);
+    const int n0 = bx * P;
+    const size_t wg = (size_t)b * gridDim.x + bx;
+    if (a.C1 == 64) pw_bwd_gather_rows<P, NW, 1>(a, b, n0, buf0, lane, wave);
+    else if (a.C1 == 128) pw_bwd_gather_rows<P, NW, 2>(a, b, n0, buf0, lane, wave);
+    else pw_bwd_gather_rows<P, NW, 4>(a, b, n0, buf0, lane, wave);
+    __syncthreads();
+    layer_bwd<P, NW, 1>(a.wt, buf0, wg);
+    __syncthreads();
+    {
+        constexpr int RG = NT / 32;
+        const int ql = tid & 31, rg = tid >> 5;
+        float *ob = a.out + ((size_t)b * a.N + n0) * a.D;
+        const float *sb = a.skip ? a.skip + ((size_t)b * a.N + n0) * a.D : nullptr;
+        for (int j = rg; j < P; j += RG) {
+            const unsigned o = __umul24((unsigned)j, (unsigned)a.D);
+            for (int q = ql; q < (a.D >> 2); q += 32) {
+                float4 v = *(const float4 *)(buf0 + L::off(4 * q, j));
+                if (sb) {
+                    const float4 s = *(const float4 *)(sb + (o + 4u * q));
+                    v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+                }
+                *(float4 *)(ob + (o + 4u * q)) = v;
+            }
         }
     }
 }

@@ -192,7 +192,7 @@ class PN2Workspace:
 
     PROF_TAGS = ("sa1_fwd", "sa2_fwd", "sa3_fwd", "sa4_fwd", "fp1_head_fwd", "fp2_fwd", "fp3_fwd", "fp4_fwd",
                  "fp1_head_bwd", "fp2_bwd", "fp3_bwd", "fp4_bwd", "sa1_bwd", "sa2_bwd", "sa3_bwd", "sa4_bwd",
-                 "fps", "ball_query", "three_nn", "gather", "ce_grad", "pgd_step", "dx0_gather")
+                 "fps", "ball_query", "three_nn", "gather", "ce_grad", "pgd_step", "dx0_gather", "pw_fwd", "pw_bwd")
 
     def prof_enable(self, on=True):
         _lib.call("psg_pn2_prof_enable", self.handle, 1 if on else 0)
