@@ -65,6 +65,24 @@ def kernel_flops(batch):
     return out
 
 
+def kernel_flops_executed(batch):
+    """FLOPs the SSG launches EXECUTE since round 5: the first layer of SA levels 2-4 is split (psg_pn2_kernels.cuh, sa_fwd_kernel
+    SPLIT) into a per-POINT feature product (pw_fwd / pw_bwd: N_l points, D -> C1) and a per-ROW xyz chunk (3 -> C1); the
+    backward applies the first layer's transpose per point as well.  Levels: rows S_l x 32, points N_l = S_{l-1}.
+    kernel_flops() stays the ALGORITHMIC count of the reference's layers (what `roofline` and the end-to-end figures use)."""
+    out = kernel_flops(batch)
+    pw = 0.0
+    for l in (1, 2, 3):
+        d_in, c1, c2, c3 = SA_DIMS[l]
+        n_pts = SA_ROWS[l - 1] // 32
+        out["sa%d_fwd" % (l + 1)] = 2.0 * batch * SA_ROWS[l] * (3 * c1 + c1 * c2 + c2 * c3)
+        out["sa%d_bwd" % (l + 1)] = 2.0 * batch * SA_ROWS[l] * (c1 * c2 + c2 * c3)
+        pw += 2.0 * batch * n_pts * (d_in - 3) * c1
+    out["pw_fwd"] = pw       # (three launches per forward, one per split level)
+    out["pw_bwd"] = pw
+    return out
+
+
 def kernel_flops_msg(batch):
     """The same for pointnet2_sem_seg_msg (the two scales of an SA level share one tag)."""
     from pointsecguard_amd.synthetic import MSG_FP, MSG_SA
@@ -514,6 +532,7 @@ def run_pointnet2(args, R):
         prof = wsr.prof_read()
         wsr.prof_enable(False)
         flops = kernel_flops(rooms_r)
+        fx = kernel_flops_executed(rooms_r)
         roof = pn2_roofline(prof, flops)
         roof["rooms_per_launch"] = rooms_r
         roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"], rooms_r)
@@ -523,8 +542,11 @@ def run_pointnet2(args, R):
             "roofline": roof,
             "kernel_ms_per_attack": {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
             "kernel_ms_total_per_attack": round(total_ms, 3),
-            "mfma_frac_by_kernel": {k: round(flops[k] / (v[0] / v[1] * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 3)
-                                    for k, v in prof.items() if k in flops},
+            # per kernel: EXECUTED FLOPs / time / peak (since round 5 the SA levels 2-4 execute fewer MACs than the reference's
+            # layers count: kernel_flops_executed); pw_* are three launches per pass under one tag
+            "mfma_frac_by_kernel": {k: round(fx[k] / (v[0] / (v[1] / (3 if k.startswith("pw_") else 1)) * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS, 3)
+                                    for k, v in prof.items() if k in fx},
+            "executed_flop_share": round(sum(fx.values()) / sum(flops.values()), 4),
             "uncoalesced_reference": ref8,
             "parity": {"clean_acc": acc, "adv_acc": adv_acc, "asr": 1.0 - adv_acc, "clean_miou": miou,
                        "adv_miou": adv_miou, "rooms_evaluated": int(clean[0].sum() // NPOINT)},

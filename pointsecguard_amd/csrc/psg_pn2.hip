@@ -139,6 +139,13 @@ bool arch_split(const ArchDesc &A, int lvl)
     static const bool on = psg::env_int("PSG_PN2_SPLIT", 1) != 0;
     return on && A.id == PSG_PN2_ARCH_SSG && lvl >= 1;
 }
+// PSG_PN2_SPLIT=2 (measurement): the FORWARD of level 0 split as well - T0 = W1f . x0 + b1 per point of the
+// room (9 -> 32 on the vector pipe), gathered into the accumulators like the other levels; its backward stays whole.
+bool arch_split_fwd(const ArchDesc &A, int lvl)
+{
+    static const bool l0 = psg::env_int("PSG_PN2_SPLIT", 1) == 2;
+    return arch_split(A, lvl) || (l0 && A.id == PSG_PN2_ARCH_SSG && lvl == 0);
+}
 
 const ArchDesc &arch_of(int id)
 {
@@ -170,7 +177,9 @@ struct psg_pn2_model {
     // split first layers (arch_split): sx = the xyz columns [C1 x 3] (forward packing only), sf = the feature columns
     // [C1 x D] with the layer's bias (forward packing for the per-point product, transposed packing for its gradient)
     PackedLayer sx[4], sf[4];
-    bool split[4] = {false, false, false, false};
+    bool split[4] = {false, false, false, false};        // forward and backward split (levels 1-3)
+    bool split_fwd[4] = {false, false, false, false};    // forward split (the above, + level 0 under PSG_PN2_SPLIT=2)
+    float *w0f = nullptr, *b0f = nullptr;                 // level 0 forward split: W1f [32][9] row-major, b1 [32]
     void *arena = nullptr;
 };
 
@@ -195,6 +204,7 @@ struct psg_pn2_ws {
     int32_t *ginv_off[4][2]; // inverse group lists (CSR by source point, lists sorted by grouped row): [F*B][N_l + 1]
     int32_t *ginv_pos[4][2]; // [F*B][S_l*K] inverse permutation: slot of a grouped row in the concatenated lists
     float *gsa[4][2];     // [B][S_l*K][CG_l] grouped-input gradient rows of sa_bwd level l (CG = 12, then C[l]; split levels: dZ1 rows, C1)
+    const float *x0_fwd = nullptr;   // the input rows of the forward in progress (level 0 forward split)
     float *tfeat[4];      // split levels: [B][N_l][C1] per-point first-layer products of the resident forward
     float *dsum[4];       // dsum[l], l = 0..2, when level l + 1 is split: [B][S_l][C_{l+1}] complete gradient of level l's pooled output
     int planned = 0;
@@ -394,7 +404,7 @@ int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, const
     a.ld_out = A.C[lvl + 1];
     a.c_out = d.c_off;
     a.arg = ws->arg[lvl][sc];
-    const bool split = m->split[lvl];
+    const bool split = m->split_fwd[lvl];
     a.l1 = fwd_layer(split ? m->sx[lvl] : L[0], true, ws->mask[d.l0]);
     a.l2 = fwd_layer(L[1], true, ws->mask[d.l0 + 1]);
     a.w3 = L[2].wf; a.b3 = L[2].bias; a.k8_3 = L[2].k8f(); a.nb3 = L[2].mbf();
@@ -414,6 +424,7 @@ int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, const
         return launch_lds(ws, tag, sa_fwd_kernel<P_, NW_, KS_, MT_>, grid, NW_ * 64, blocks, Lds<P_>::BLK, a, st)
     if (split) {
         switch (PSG_CFG_KEY(P, NW, KS, d.maxt_f)) {
+        case PSG_CFG_KEY(128, 4, 32, 1): return launch_lds(ws, tag, (sa_fwd_kernel<128, 4, 32, 1, true>), grid, 4 * 64, blocks, Lds<128>::BLK, a, st);
         case PSG_CFG_KEY(64, 4, 32, 1): return launch_lds(ws, tag, (sa_fwd_kernel<64, 4, 32, 1, true>), grid, 4 * 64, blocks, Lds<64>::BLK, a, st);
         case PSG_CFG_KEY(32, 4, 32, 1): return launch_lds(ws, tag, (sa_fwd_kernel<32, 4, 32, 1, true>), grid, 4 * 64, blocks, Lds<32>::BLK, a, st);
         case PSG_CFG_KEY(32, 8, 32, 1): return launch_lds(ws, tag, (sa_fwd_kernel<32, 8, 32, 1, true>), grid, 8 * 64, blocks, Lds<32>::BLK, a, st);
@@ -536,6 +547,28 @@ inline bool fp1_wave()
     return v;
 }
 
+// level 0 forward split (PSG_PN2_SPLIT=2): T0[n][c] = b1[c] + sum_k W1f[c][k] x0[n][k], one thread per (point, 4 channels)
+__global__ void pw9_fwd_kernel(const float *__restrict__ x0, const float *__restrict__ w, const float *__restrict__ bias, size_t rows,
+                               float *__restrict__ out)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * 8) return;
+    const size_t n = t >> 3;
+    const int c0 = (int)(t & 7) * 4;
+    float x[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) x[k] = x0[n * 9 + k];
+    float r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float acc = bias[c0 + u];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc = fmaf(w[(c0 + u) * 9 + k], x[k], acc);
+        r[u] = acc;
+    }
+    *(float4 *)(out + n * 32 + c0) = make_float4(r[0], r[1], r[2], r[3]);
+}
+
 // Per-point side of a split SA level (arch_split): T = act[lvl - 1] . W1f^T + b1 for the Nl[lvl] points of every room, one
 // launch of the cooperative row-MLP kernel (fp_fwd_kernel with a skip part only: C2 = 0, one layer, no ReLU).
 int run_pw_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int fwd, hipStream_t st)
@@ -543,6 +576,13 @@ int run_pw_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int fwd, hipStream_t s
     constexpr int P = 32, NW = 8;
     const PackedLayer &F = m->sf[lvl];
     const int B = ws->B, N = ws->Nl[lvl];
+    if (lvl == 0) {
+        ProfScope prof(ws, TAG_PW_FWD, st);
+        const size_t rows = (size_t)B * N;
+        hipLaunchKernelGGL(pw9_fwd_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, st, ws->x0_fwd, m->w0f, m->b0f, rows, ws->tfeat[0]);
+        PSG_LAUNCH_CHECK();
+        return PSG_OK;
+    }
     FpFwdArgs a;
     a.feat1 = ws->act[lvl - 1]; a.C1 = F.cin;
     a.feat2 = ws->act[lvl - 1]; a.C2 = 0;
@@ -953,10 +993,8 @@ size_t ws_layout(psg_pn2_ws *ws, char *base)
         for (int s = 0; s < A.ns; ++s) ws->gsa[l][s] = bp.take<float>((size_t)B * kS[l] * A.sc[l][s].K * gsa_stride(A, l));
     for (int l = 0; l < 4; ++l) {
         ws->tfeat[l] = nullptr; ws->dsum[l] = nullptr;
-        if (arch_split(A, l)) {
-            ws->tfeat[l] = bp.take<float>((size_t)B * ws->Nl[l] * A.cout[A.sc[l][0].l0]);
-            ws->dsum[l - 1] = bp.take<float>((size_t)B * ws->Nl[l] * A.C[l]);
-        }
+        if (arch_split_fwd(A, l)) ws->tfeat[l] = bp.take<float>((size_t)B * ws->Nl[l] * A.cout[A.sc[l][0].l0]);
+        if (arch_split(A, l)) ws->dsum[l - 1] = bp.take<float>((size_t)B * ws->Nl[l] * A.C[l]);
     }
     for (int l = 0; l < 4; ++l) {   // interpolated-part gradient rows of FP module l: C2 = its input minus the skip part
         const int c2 = A.cin[A.fp_first[l]] - (l == 0 ? 0 : A.C[l]);
@@ -1031,10 +1069,11 @@ extern "C" int psg_pn2_model_create_arch(psg_ctx *ctx, int arch, const float *co
         total += ((wf[i].size() + wb[i].size() + bs[i].size() + wf4[i].size() + wb4[i].size()) * 4 + 5 * 256);
     }
     // split first layers (arch_split): reference column order of the layer is [rel_xyz(3), feats(D)] (SSG: sa_perm)
-    std::vector<float> sxf[4], sff[4], sfb[4], sfbias[4];
+    std::vector<float> sxf[4], sff[4], sfb[4], sfbias[4], w0raw;
     for (int l = 0; l < 4; ++l) {
         m->split[l] = arch_split(A, l);
-        if (!m->split[l]) continue;
+        m->split_fwd[l] = arch_split_fwd(A, l);
+        if (!m->split_fwd[l]) continue;
         const int li = A.sc[l][0].l0, cin = A.cin[li], cout = A.cout[li], D = cin - 3;
         const int xo = A.sa_perm ? 0 : D, fo = A.sa_perm ? 3 : 0;
         std::vector<float> wx((size_t)cout * 3), wfe((size_t)cout * D);
@@ -1046,13 +1085,14 @@ extern "C" int psg_pn2_model_create_arch(psg_ctx *ctx, int arch, const float *co
         sff[l] = pack_fwd(wfe.data(), D, cout, nullptr);
         sfb[l] = pack_bwd(wfe.data(), D, cout, nullptr);
         sfbias[l] = bs[li];
-        total += (sxf[l].size() + sff[l].size() + sfb[l].size() + sfbias[l].size()) * 4 + 4 * 256;
+        if (l == 0) w0raw = wfe;
+        total += (sxf[l].size() + sff[l].size() + sfb[l].size() + sfbias[l].size() + (l == 0 ? wfe.size() : 0)) * 4 + 5 * 256;
     }
     PSG_CHECK_HIP(hipMalloc(&m->arena, total));
     Bump bp;
     bp.base = (char *)m->arena;
     for (int l = 0; l < 4; ++l) {
-        if (!m->split[l]) continue;
+        if (!m->split_fwd[l]) continue;
         const int li = A.sc[l][0].l0;
         PackedLayer &X = m->sx[l], &F = m->sf[l];
         X.cin = 3; X.cout = A.cout[li];
@@ -1066,6 +1106,11 @@ extern "C" int psg_pn2_model_create_arch(psg_ctx *ctx, int arch, const float *co
         PSG_CHECK_HIP(psg::copy_sync(F.wf, sff[l].data(), sff[l].size() * 4, hipMemcpyHostToDevice));
         PSG_CHECK_HIP(psg::copy_sync(F.wb, sfb[l].data(), sfb[l].size() * 4, hipMemcpyHostToDevice));
         PSG_CHECK_HIP(psg::copy_sync(F.bias, sfbias[l].data(), sfbias[l].size() * 4, hipMemcpyHostToDevice));
+        if (l == 0) {
+            m->w0f = bp.take<float>(w0raw.size());
+            m->b0f = F.bias;
+            PSG_CHECK_HIP(psg::copy_sync(m->w0f, w0raw.data(), w0raw.size() * 4, hipMemcpyHostToDevice));
+        }
     }
     for (int i = 0; i < NLr; ++i) {
         PackedLayer &L = m->L[i];
@@ -1268,8 +1313,9 @@ extern "C" int psg_pn2_forward(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const 
     PSG_REQUIRE(fwd >= 0 && fwd < ws->planned, "psg_pn2_forward: plan slot %d not built (planned %d)", fwd, ws->planned);
     hipStream_t st = (hipStream_t)stream;
     int rc;
+    ws->x0_fwd = x0;
     for (int l = 0; l < 4; ++l) {
-        if (m->split[l] && (rc = run_pw_fwd(m, ws, l, fwd, st))) return rc;
+        if (m->split_fwd[l] && (rc = run_pw_fwd(m, ws, l, fwd, st))) return rc;
         for (int sc = 0; sc < m->arch->ns; ++sc)
             if ((rc = run_sa_fwd(m, ws, l, sc, fwd, x0, st))) return rc;
     }

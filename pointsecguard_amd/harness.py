@@ -173,8 +173,16 @@ def _miou(counters):
     return float(np.mean(iou[present])) if present.any() else 0.0
 
 
+def _replica(classifier):
+    """A second instance of the same network on the same device (own packed weights, workspaces and attack state): what lets
+    batches of a scene run side by side on separate streams - one model instance serves one stream at a time."""
+    rep = type(classifier)(NUM_CLASSES)
+    rep.load_state_dict(classifier.state_dict())
+    return rep.to(next(classifier.parameters()).device).eval()
+
+
 def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_votes=1, log_path=None, rank=0, world=1,
-                         log=print, targeted=None):
+                         log=print, targeted=None, streams=3):
     """The reference's evaluation loop (NB_nontarget_test_semseg.py:126-291) with the per-point work on the GPU.
 
     classifier: an eval-mode `get_model` on the GPU; make_attack(classifier) -> a torchattacks attack object (e.g.
@@ -188,9 +196,17 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
     NU_target_test_semseg.py): per batch mask = (labels == origin), no attack when the batch holds no such point, the
     attack is built per batch as make_attack(classifier, target, mask[0]) (the reference passes the FIRST block's mask,
     :177), and the TSV rows carry origin, count and the target accuracy over the masked points (:226-229); rows are only
-    written for attacked batches."""
+    written for attacked batches.
+
+    streams (round 5): the batches of a scene are independent (the vote pools take commutative integer adds, the rows are
+    written in batch order at the end of the scene), so batch i runs on HIP stream i % streams with its own replica of the
+    network; the host still issues the batches - and draws their FPS starts from the CPU generator - in the reference's
+    order, so the results are those of streams = 1 (tests/test_gpu_harness.py)."""
     dev = next(classifier.parameters()).device
-    attack = make_attack(classifier) if (make_attack is not None and targeted is None) else None
+    n_streams = max(1, int(streams))
+    nets = [classifier] + [_replica(classifier) for _ in range(n_streams - 1)]
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [None]
+    attacks = [make_attack(n) if (make_attack is not None and targeted is None) else None for n in nets]
     n_pt = dataset.block_points
     total = torch.zeros(2, 3, NUM_CLASSES, dtype=torch.int64, device=dev)   # [clean | adversarial][seen, correct, union]
     scene_rows = []
@@ -208,64 +224,24 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
         adv_pool = torch.zeros_like(pool)
         pending = []                                 # rows of this scene's log: device scalars, read back once per scene
         vote_bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        for ln in lanes:                             # the scene's pools were zeroed on the caller's stream
+            if ln is not None:
+                ln.wait_stream(torch.cuda.current_stream(dev))
+        n_issued = 0
         for _ in range(num_votes):
             scene_data, scene_label, scene_smpw, scene_point_index = dataset[si]
             num_blocks = scene_data.shape[0]
             for sbatch in range((num_blocks + batch_size - 1) // batch_size):
                 lo, hi = sbatch * batch_size, min((sbatch + 1) * batch_size, num_blocks)
-                # (numpy does the float64 -> float32 conversion: a torch CPU op of this size wakes the whole OpenMP pool)
-                torch_data = upload(torch.from_numpy(scene_data[lo:hi].astype(np.float32)), dev, pin=True).transpose(2, 1).contiguous()
-                gt_np = scene_label[lo:hi]
-                gt = upload(torch.from_numpy(gt_np.astype(np.int32)), dev, pin=True)
-                idx = upload(torch.from_numpy(scene_point_index[lo:hi].astype(np.int32)), dev, pin=True)
-                smpw = upload(torch.from_numpy(scene_smpw[lo:hi].astype(np.float32)), dev, pin=True)
-                seg_pred, _ = classifier(torch_data)
-                seg_pred = seg_pred.detach().contiguous()
-                count, mask_np = 0, None
-                if targeted is not None:
-                    mask_np = gt_np == targeted["origin"]
-                    count = int(mask_np.sum())
-                    batch_attack = make_attack(classifier, targeted["target"], mask_np[0]) if count else None
-                else:
-                    batch_attack = attack
-                if batch_attack is not None:
-                    adv_images = batch_attack(torch_data, gt_np)
-                    adv_seg_pred, _ = classifier(adv_images)
-                    adv_seg_pred = adv_seg_pred.detach().contiguous()
-                else:
-                    adv_images, adv_seg_pred = torch_data, seg_pred
-                add_vote(pool, idx, seg_pred, smpw, bad=vote_bad)
-                add_vote(adv_pool, idx, adv_seg_pred, smpw, bad=vote_bad)
-                c_clean, _ = runtime.seg_stats(seg_pred, gt)
-                c_adv, _ = runtime.seg_stats(adv_seg_pred, gt)
-                dis = l2_distance(adv_images, torch_data)
-                # The batch's TSV row needs five scalars; they stay on the device until the scene is done (ONE read-back per
-                # scene instead of four or five host synchronisations per batch: the host slices the next blocks while
-                # the GPU attacks these - the rows and their order are what the reference writes, :213-215)
-                hits = None
-                if targeted is not None and count:
-                    m = upload(torch.from_numpy(mask_np), dev, pin=True)
-                    hits = ((adv_seg_pred.argmax(dim=2) == targeted["target"]) & m).sum()
-                if targeted is None or count:
-                    pending.append((sbatch, (hi - lo) * n_pt, count, dis, c_clean, c_adv, hits))
+                slot = n_issued % n_streams
+                n_issued += 1
+                pending.extend(_scene_batch(nets[slot], attacks[slot], make_attack, targeted, lanes[slot], dev, n_pt, sbatch, lo, hi,
+                                            scene_data, scene_label, scene_smpw, scene_point_index, pool, adv_pool, vote_bad))
+        for ln in lanes:
+            if ln is not None:
+                torch.cuda.current_stream(dev).wait_stream(ln)
         check_votes(vote_bad)
-        if pending:
-            scal = torch.stack([torch.cat([p[3].double().reshape(1), (p[6] if p[6] is not None else p[3].new_zeros(())).double().reshape(1)])
-                                for p in pending]).cpu().numpy()
-            ctr = torch.stack([torch.stack([p[4], p[5]]) for p in pending]).cpu()
-            for k, (sbatch, rows, count, _, _, _, hits) in enumerate(pending):
-                c_clean, c_adv = ctr[k, 0], ctr[k, 1]
-                acc = float(c_clean[1].sum().item()) / float(rows)
-                adv_acc = float(c_adv[1].sum().item()) / float(rows)
-                dis_f = float(np.float32(scal[k, 0]))
-                if targeted is None:
-                    line = LOG_ROW % (sbatch, dis_f, adv_acc, acc, _miou(c_adv), _miou(c_clean))
-                else:
-                    line = TARGETED_LOG_ROW % (targeted["origin"], sbatch, dis_f, count, float(scal[k, 1]) / count, adv_acc, acc,
-                                               _miou(c_adv), _miou(c_clean))
-                if fh is not None:
-                    fh.write(line)
-            pending.clear()
+        _write_rows(pending, targeted, fh)
         c_scene = vote_stats(pool, scene_labels)
         c_scene_adv = vote_stats(adv_pool, scene_labels)
         total[0] += c_scene
@@ -276,6 +252,75 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
         log('Mean IoU of %s: %.4f' % (name, scene_rows[-1][2]))
     if fh is not None:
         fh.close()
+    return _finish(total, scene_rows, rank, log)
+
+
+def _scene_batch(classifier, attack, make_attack, targeted, lane, dev, n_pt, sbatch, lo, hi, scene_data, scene_label, scene_smpw,
+                 scene_point_index, pool, adv_pool, vote_bad):
+    """One batch of a scene on `lane` (a HIP stream, or None = the caller's): clean forward, attack, adversarial forward,
+    votes, counters, L2 - everything stays on the device; returns the batch's pending log row (or nothing)."""
+    import contextlib
+    with (torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext()):
+        # (numpy does the float64 -> float32 conversion: a torch CPU op of this size wakes the whole OpenMP pool)
+        torch_data = upload(torch.from_numpy(scene_data[lo:hi].astype(np.float32)), dev, pin=True).transpose(2, 1).contiguous()
+        gt_np = scene_label[lo:hi]
+        gt = upload(torch.from_numpy(gt_np.astype(np.int32)), dev, pin=True)
+        idx = upload(torch.from_numpy(scene_point_index[lo:hi].astype(np.int32)), dev, pin=True)
+        smpw = upload(torch.from_numpy(scene_smpw[lo:hi].astype(np.float32)), dev, pin=True)
+        seg_pred, _ = classifier(torch_data)
+        seg_pred = seg_pred.detach().contiguous()
+        count, mask_np = 0, None
+        if targeted is not None:
+            mask_np = gt_np == targeted["origin"]
+            count = int(mask_np.sum())
+            batch_attack = make_attack(classifier, targeted["target"], mask_np[0]) if count else None
+        else:
+            batch_attack = attack
+        if batch_attack is not None:
+            adv_images = batch_attack(torch_data, gt_np)
+            adv_seg_pred, _ = classifier(adv_images)
+            adv_seg_pred = adv_seg_pred.detach().contiguous()
+        else:
+            adv_images, adv_seg_pred = torch_data, seg_pred
+        add_vote(pool, idx, seg_pred, smpw, bad=vote_bad)
+        add_vote(adv_pool, idx, adv_seg_pred, smpw, bad=vote_bad)
+        c_clean, _ = runtime.seg_stats(seg_pred, gt)
+        c_adv, _ = runtime.seg_stats(adv_seg_pred, gt)
+        dis = l2_distance(adv_images, torch_data)
+        # The batch's TSV row needs five scalars; they stay on the device until the scene is done (ONE read-back per
+        # scene instead of four or five host synchronisations per batch: the host slices the next blocks while
+        # the GPU attacks these - the rows and their order are what the reference writes, :213-215)
+        hits = None
+        if targeted is not None and count:
+            m = upload(torch.from_numpy(mask_np), dev, pin=True)
+            hits = ((adv_seg_pred.argmax(dim=2) == targeted["target"]) & m).sum()
+        if targeted is None or count:
+            return [(sbatch, (hi - lo) * n_pt, count, dis, c_clean, c_adv, hits)]
+    return []
+
+
+def _write_rows(pending, targeted, fh):
+    """The scene's TSV rows in the order the batches were issued (NB_nontarget_test_semseg.py:213-215): ONE read-back for all."""
+    if not pending:
+        return
+    scal = torch.stack([torch.cat([p[3].double().reshape(1), (p[6] if p[6] is not None else p[3].new_zeros(())).double().reshape(1)])
+                        for p in pending]).cpu().numpy()
+    ctr = torch.stack([torch.stack([p[4], p[5]]) for p in pending]).cpu()
+    for k, (sbatch, rows, count, _, _, _, hits) in enumerate(pending):
+        c_clean, c_adv = ctr[k, 0], ctr[k, 1]
+        acc = float(c_clean[1].sum().item()) / float(rows)
+        adv_acc = float(c_adv[1].sum().item()) / float(rows)
+        dis_f = float(np.float32(scal[k, 0]))
+        if targeted is None:
+            line = LOG_ROW % (sbatch, dis_f, adv_acc, acc, _miou(c_adv), _miou(c_clean))
+        else:
+            line = TARGETED_LOG_ROW % (targeted["origin"], sbatch, dis_f, count, float(scal[k, 1]) / count, adv_acc, acc,
+                                       _miou(c_adv), _miou(c_clean))
+        if fh is not None:
+            fh.write(line)
+
+
+def _finish(total, scene_rows, rank, log):
     reduce_counters(total)
     t = total.to(torch.float64).cpu().numpy()
     out = {"scenes": scene_rows, "counters": total.cpu().numpy()}

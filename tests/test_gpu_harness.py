@@ -86,16 +86,19 @@ def test_whole_scene_loop_end_to_end(tmp_path, weights_sd):
     net.load_state_dict({k: torch.from_numpy(v) for k, v in weights_sd.items()})
     net.eval()
     results, logs = [], []
-    for rep in range(2):
+    for rep in range(3):
         np.random.seed(3)
         torch.manual_seed(3)
         path = tmp_path / ("log%d.txt" % rep)
         lines = []
+        # (round 5) reps 0, 1: the default - three batches of a scene in flight on separate streams and network replicas;
+        # rep 2: one batch at a time on the caller's stream, as rounds 1-4 ran it: same rows, same counters
         results.append(harness.evaluate_whole_scene(
             net, ds, lambda m: torchattacks.NB_attack(m, eps=0.1, alpha=0.05, iters=3), batch_size=4, num_votes=1,
-            log_path=str(path), log=lines.append))
+            log_path=str(path), log=lines.append, **({"streams": 1} if rep == 2 else {})))
         logs.append(path.read_text())
     assert logs[0] == logs[1] and np.array_equal(results[0]["counters"], results[1]["counters"])   # reproducible
+    assert logs[0] == logs[2] and np.array_equal(results[0]["counters"], results[2]["counters"])   # streams do not change results
     rows = logs[0].splitlines()
     assert rows[0] == "index\tL2_dis\tadv_acc\tacc\tadv_miou\tmiou"
     n_batches = sum(-(-ds[i][0].shape[0] // 4) for i in range(2))
