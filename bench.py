@@ -140,6 +140,12 @@ class Ranks:
         # one-GPU line are then real RCCL collectives, the same code path the 2/4/8-GPU runs take.
         if self.world > 1 or (cuda and not getattr(args, "no_process_group", False)):
             import torch.distributed as dist
+            if cuda and os.environ.get("PSG_BENCH_PG_FIRST") != "1":
+                # torch's stream pool (32 streams per priority, all created at the first request) BEFORE the communicator's own
+                # streams: the runtime deals streams to its hardware queues in creation order, and the launch streams of the
+                # workloads keep the assignment they had without a process group (a stream created earlier shifts
+                # everybody else's queue; measured on the MSG / tarnu lines, round 5)
+                torch.cuda.Stream(device=self.dev_index)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if "MASTER_PORT" not in os.environ:          # plain `python bench.py` at N = 1: no launcher set a rendezvous
                 import socket
@@ -377,7 +383,7 @@ def main():
         # line of its own (value, roofline, cpu_baseline) under "secondary"; `python bench.py --workload NAME` runs one alone
         import copy
         sec = {}
-        for name, steps, warm in (("tarnu", 6, 2), ("resgcn", 24, 8), ("pointnet2_msg", 16, 8), ("randla", 48, 8)):
+        for name, steps, warm in (("tarnu", 12, 6), ("resgcn", 24, 8), ("pointnet2_msg", 16, 8), ("randla", 48, 8)):
             a2 = copy.copy(args)
             a2.workload, a2.steps, a2.warmup, a2.cpu_seconds = name, steps, warm, min(args.cpu_seconds, 6.0)
             t0 = time.time()

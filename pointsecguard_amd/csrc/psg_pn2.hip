@@ -620,7 +620,12 @@ int run_pw_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int fwd, hipStream_t s
         return PSG_ERR_STATE;
     }
     const int blocks = layer_blocks(a.wt.k8, a.wt.mb) + PSG_LDS_SPARE;
-    return launch_lds(ws, TAG_PW_BWD, (pw_bwd_kernel<P, NW>), dim3(N / P, B), NW * 64, blocks, Lds<P>::BLK, a, st);
+    const size_t lds = (size_t)blocks * Lds<P>::BLK * sizeof(float);
+    if (lds > 48 * 1024) PSG_CHECK_HIP(allow_big_lds((const void *)pw_bwd_kernel<P, NW>));
+    ProfScope prof(ws, TAG_PW_BWD, st);
+    hipLaunchKernelGGL((pw_bwd_kernel<P, NW>), dim3(N / P, B), dim3(NW * 64), lds, st, a);
+    PSG_LAUNCH_CHECK();      // (a launch site of its own: the tracer tells the split path from the whole one, tests/test_gpu_alt_paths.py)
+    return PSG_OK;
 }
 
 template <int LVL>

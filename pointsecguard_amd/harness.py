@@ -176,7 +176,8 @@ def _miou(counters):
 def _replica(classifier):
     """A second instance of the same network on the same device (own packed weights, workspaces and attack state): what lets
     batches of a scene run side by side on separate streams - one model instance serves one stream at a time."""
-    rep = type(classifier)(NUM_CLASSES)
+    with torch.random.fork_rng(devices=[]):          # (the constructor's weight init draws from the CPU generator: the
+        rep = type(classifier)(NUM_CLASSES)          # FPS starts of the run must not depend on how many replicas exist)
     rep.load_state_dict(classifier.state_dict())
     return rep.to(next(classifier.parameters()).device).eval()
 
@@ -201,7 +202,11 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
     streams (round 5): the batches of a scene are independent (the vote pools take commutative integer adds, the rows are
     written in batch order at the end of the scene), so batch i runs on HIP stream i % streams with its own replica of the
     network; the host still issues the batches - and draws their FPS starts from the CPU generator - in the reference's
-    order, so the results are those of streams = 1 (tests/test_gpu_harness.py)."""
+    order, so the results are those of streams = 1 (tests/test_gpu_harness.py).  The host-side block slicing of the NEXT scene
+    (`dataset[si]`: ~60 ms of numpy per 70-block scene, as much as the GPU needs for the scene's attacks) runs on a helper
+    thread meanwhile - for this module's own ScannetDatasetWholeScene only, whose `__getitem__` touches nothing but
+    numpy's generator: the slicing calls still happen one after the other in the reference's order (scene by scene, vote by
+    vote), so `np.random` is consumed exactly as before; a caller's dataset class is sliced in line."""
     dev = next(classifier.parameters()).device
     n_streams = max(1, int(streams))
     nets = [classifier] + [_replica(classifier) for _ in range(n_streams - 1)]
@@ -216,6 +221,23 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
         fh = open(path, "w")
         fh.write(LOG_HEADER if targeted is None else TARGETED_LOG_HEADER)
     my_scenes = shard_scenes(list(range(len(dataset))), rank, world)
+    fetch_order = [si for si in my_scenes for _ in range(num_votes)]
+    fetcher = None
+    if type(dataset) is ScannetDatasetWholeScene and len(fetch_order) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        fetcher = ThreadPoolExecutor(max_workers=1)
+    n_fetched = [0]
+    nxt = [fetcher.submit(dataset.__getitem__, fetch_order[0])] if fetcher else [None]
+
+    def next_scene_data(si):
+        k = n_fetched[0]
+        n_fetched[0] += 1
+        if fetcher is None:
+            return dataset[si]
+        data = nxt[0].result()
+        nxt[0] = fetcher.submit(dataset.__getitem__, fetch_order[k + 1]) if k + 1 < len(fetch_order) else None
+        return data
+
     for si in my_scenes:
         labels_np = dataset.semantic_labels_list[si]
         n_scene = labels_np.shape[0]
@@ -229,7 +251,7 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
                 ln.wait_stream(torch.cuda.current_stream(dev))
         n_issued = 0
         for _ in range(num_votes):
-            scene_data, scene_label, scene_smpw, scene_point_index = dataset[si]
+            scene_data, scene_label, scene_smpw, scene_point_index = next_scene_data(si)
             num_blocks = scene_data.shape[0]
             for sbatch in range((num_blocks + batch_size - 1) // batch_size):
                 lo, hi = sbatch * batch_size, min((sbatch + 1) * batch_size, num_blocks)
@@ -252,6 +274,8 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
         log('Mean IoU of %s: %.4f' % (name, scene_rows[-1][2]))
     if fh is not None:
         fh.close()
+    if fetcher is not None:
+        fetcher.shutdown(wait=True)
     return _finish(total, scene_rows, rank, log)
 
 

@@ -152,16 +152,22 @@ def test_fused_attack_invariants_28_blocks(gcn28, g28):
     # (tools/gcn28_diag.py) - so parity is pinned with the reference's graphs teacher-forced, above)
 
 
-def test_nb_attack_outcome_parity_with_the_reference_run(gcn28):
-    """Free-running outcome parity at configs[3]'s own size (round 5): tests/golden/gcn28_nb_outcome.npz holds what the
-    reference's experiment loop (sem_seg_dense/attacks.py:125-160) measured when ITS `NB_attack(eps=0.3, alpha=2/255,
-    iters=50)` ran on four single-room batches with the fitted 28-block weights: clean / adversarial accuracy, per-room
-    micro-IoU (sum I / sum U) and the L2 distance of the returned room.  The dynamic graphs make the attack chaotic entry by
-    entry (see above), so the bar is the one the PointNet++ path has (test_gpu_parity.py: 32-room statistics): the
-    attack's OUTCOME, per room and over the rooms together.  Clean predictions are compared directly."""
-    from pointsecguard_amd import _lib, runtime
+def test_nb_attack_outcome_against_the_reference_runs(gcn28):
+    """Free-running outcome at configs[3]'s own size (round 5).  tests/golden/gcn28_nb_outcome.npz and ..._t1.npz hold what the
+    reference's experiment loop (sem_seg_dense/attacks.py:125-160) measured when ITS `NB_attack(eps=0.3, alpha=2/255, iters=50)`
+    ran on four single-room batches with the fitted 28-block weights - twice: with eight intra-op threads and with one.  The
+    two runs of the reference itself agree on 3 - 48 % of the clean per-point predictions, and their per-room accuracies differ
+    by up to 0.12 clean and 0.04 adversarial: with dynamic graphs every d-th neighbour of a sorted list is re-selected when a
+    near-tie moves (above), and the 70-step fit of the fixture weights leaves the predictions near chance (accuracy 0.08 - 0.2),
+    so what ANY two evaluation orders agree on is the distribution, not the points.  The bar is therefore the reference's own
+    spread: this implementation's distance from the eight-thread run may not exceed 1.5 x the one-thread run's distance from it
+    (+ 0.03), for the clean and the adversarial accuracy averaged over the rooms and room by room; what does not depend on the
+    chaos is pinned tightly: the L2 distance of the returned room (eps / alpha / iteration count: within 2 %) and the
+    invariants (only colours move)."""
     from pointsecguard_amd.synthetic import make_rooms, rule_labels
     g = dict(np.load(os.path.join(GOLDEN, "gcn28_nb_outcome.npz")))
+    g1 = dict(np.load(os.path.join(GOLDEN, "gcn28_nb_outcome_t1.npz")))
+    assert np.array_equal(g["seeds"], g1["seeds"])
     model, ws = gcn28
     ws.set_graphs(None)
     eps, alpha, iters = float(g["eps"]), float(g["alpha"]), int(g["iters"])
@@ -171,15 +177,13 @@ def test_nb_attack_outcome_parity_with_the_reference_run(gcn28):
         r = make_rooms(1, int(seed))
         y = rule_labels(r)
         images_np = np.ascontiguousarray(r.transpose(0, 2, 1))
-        x_pm = dev(r)
         labels = dev(y.astype(np.int32))
-        pred = ws.forward(model, x_pm).argmax(2)[0].cpu().numpy()
+        pred = ws.forward(model, dev(r)).argmax(2)[0].cpu().numpy()
         agree.append(float((pred == g["r%d_clean_pred" % si]).mean()))
         with torch.cuda.stream(side):
             adv = ws.nb_attack(model, dev(images_np), labels, eps, alpha, iters)
         side.synchronize()
-        adv_pm = adv.permute(0, 2, 1).contiguous()
-        apred = ws.forward(model, adv_pm).argmax(2)[0].cpu().numpy()
+        apred = ws.forward(model, adv.permute(0, 2, 1).contiguous()).argmax(2)[0].cpu().numpy()
         inter = sum(int(((apred == c) & (y[0] == c)).sum()) for c in range(13))
         union = sum(int(((apred == c) | (y[0] == c)).sum()) for c in range(13))
         acc.append(float((pred == y[0]).mean()))
@@ -188,10 +192,15 @@ def test_nb_attack_outcome_parity_with_the_reference_run(gcn28):
         dis.append(float(torch.dist(adv, dev(images_np)).item()))
         out = adv.cpu().numpy()
         assert np.array_equal(out[:, :3], images_np[:, :3]) and np.array_equal(out[:, 6:], images_np[:, 6:])
+        assert np.abs(out[:, 3:6] - images_np[:, 3:6]).max() <= eps + alpha + 1e-6
     acc, adv_acc, adv_miou, dis = (np.array(v) for v in (acc, adv_acc, adv_miou, dis))
-    print("ResGCN-28 NB outcome: clean predictions equal to the reference's on", agree, "of the points; acc", acc, "ref", g["acc"], "| adv_acc", adv_acc, "ref", g["adv_acc"], "| adv micro-IoU", adv_miou, "ref",
-          g["adv_miou"], "| L2", dis, "ref", g["dis"])
-    assert np.abs(acc - g["acc"]).max() <= 0.01
-    assert np.abs(adv_acc - g["adv_acc"]).max() <= 0.03 and abs(adv_acc.mean() - g["adv_acc"].mean()) <= 0.01
-    assert np.abs(adv_miou - g["adv_miou"]).max() <= 0.03 and abs(adv_miou.mean() - g["adv_miou"].mean()) <= 0.01
-    assert np.abs(dis / g["dis"] - 1).max() <= 0.02
+    self_agree = [float((g["r%d_clean_pred" % i] == g1["r%d_clean_pred" % i]).mean()) for i in range(len(g["seeds"]))]
+    print("ResGCN-28 NB outcome (this | reference 8 threads | reference 1 thread): clean predictions equal to the 8-thread run's on",
+          np.round(agree, 3), "| the 1-thread run's on", np.round(self_agree, 3), "of the points; acc", np.round(acc, 3), g["acc"].round(3),
+          g1["acc"].round(3), "| adv_acc", np.round(adv_acc, 3), g["adv_acc"].round(3), g1["adv_acc"].round(3), "| adv micro-IoU",
+          np.round(adv_miou, 3), g["adv_miou"].round(3), g1["adv_miou"].round(3), "| L2", np.round(dis, 3), g["dis"].round(3), g1["dis"].round(3))
+    for name, got in (("acc", acc), ("adv_acc", adv_acc), ("adv_miou", adv_miou)):
+        ref, ref1 = g[name], g1[name]
+        assert abs(got.mean() - ref.mean()) <= 1.5 * abs(ref1.mean() - ref.mean()) + 0.03, (name, got.mean(), ref.mean(), ref1.mean())
+        assert np.abs(got - ref).max() <= 1.5 * np.abs(ref1 - ref).max() + 0.03, (name, got, ref, ref1)
+    assert np.abs(dis / g["dis"] - 1).max() <= 0.02 and np.abs(g1["dis"] / g["dis"] - 1).max() <= 0.02
