@@ -59,7 +59,21 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int wr = wave / WN, wc = wave % WN;
-    const int row0 = blockIdx.x * BR, col0 = blockIdx.y * BN;
+    // Tile order (round 5).  Workgroups are dispatched round-robin to the 8 XCDs, each with a private 4 MiB L2.  With the row
+    // tile on blockIdx.x and the column tile on blockIdx.y an XCD met the same input rows once per column tile, a full pass of
+    // the grid apart: 14.7 MB of input per XCD lay between two uses in the fusion layer (16 384 x 1792 x 1024), and the input
+    // came from the fabric 2.7 x (396 MB counted per launch against 191 MB algorithmic, profiles/r04_pmc_traffic_gcn.txt).  Now
+    // XCD x takes the contiguous row tiles [x R / 8, (x + 1) R / 8) and walks the COLUMN tiles of a row tile back to back: the
+    // input tile is fetched once and served to its 8 column tiles from that L2; the weights (7.3 MB) are what every XCD
+    // re-reads.  Same arithmetic; speed moved by < 1 % (the layer is matrix-bound at 0.7 TB/s).
+    int row0, col0;
+    {
+        const unsigned nx = gridDim.x, ny = gridDim.y, T = nx * ny, id = blockIdx.y * nx + blockIdx.x;
+        unsigned L = id;
+        if ((T & 7u) == 0u) L = (id & 7u) * (T >> 3) + (id >> 3);
+        row0 = (int)(L / ny) * BR;
+        col0 = (int)(L % ny) * BN;
+    }
 
     f32x16 acc[TI][TQ];
 #pragma unroll

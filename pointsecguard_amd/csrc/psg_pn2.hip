@@ -137,7 +137,7 @@ ArchDesc make_msg()
 bool arch_split(const ArchDesc &A, int lvl)
 {
     static const bool on = psg::env_int("PSG_PN2_SPLIT", 1) != 0;
-    return on && A.id == PSG_PN2_ARCH_SSG && lvl >= 1;
+    return on && lvl >= 1;      // SSG and MSG alike (MSG: both scales of a level; its level-0 scales stay whole like SSG's)
 }
 // PSG_PN2_SPLIT=2 (measurement): the FORWARD of level 0 split as well - T0 = W1f . x0 + b1 per point of the
 // room (9 -> 32 on the vector pipe), gathered into the accumulators like the other levels; its backward stays whole.
@@ -176,7 +176,7 @@ struct psg_pn2_model {
     PackedLayer L[MAXL];
     // split first layers (arch_split): sx = the xyz columns [C1 x 3] (forward packing only), sf = the feature columns
     // [C1 x D] with the layer's bias (forward packing for the per-point product, transposed packing for its gradient)
-    PackedLayer sx[4], sf[4];
+    PackedLayer sx[4][2], sf[4][2];                      // [level][scale]
     bool split[4] = {false, false, false, false};        // forward and backward split (levels 1-3)
     bool split_fwd[4] = {false, false, false, false};    // forward split (the above, + level 0 under PSG_PN2_SPLIT=2)
     float *w0f = nullptr, *b0f = nullptr;                 // level 0 forward split: W1f [32][9] row-major, b1 [32]
@@ -205,7 +205,7 @@ struct psg_pn2_ws {
     int32_t *ginv_pos[4][2]; // [F*B][S_l*K] inverse permutation: slot of a grouped row in the concatenated lists
     float *gsa[4][2];     // [B][S_l*K][CG_l] grouped-input gradient rows of sa_bwd level l (CG = 12, then C[l]; split levels: dZ1 rows, C1)
     const float *x0_fwd = nullptr;   // the input rows of the forward in progress (level 0 forward split)
-    float *tfeat[4];      // split levels: [B][N_l][C1] per-point first-layer products of the resident forward
+    float *tfeat[4][2];   // split levels, per scale: [B][N_l][C1] per-point first-layer products of the resident forward
     float *dsum[4];       // dsum[l], l = 0..2, when level l + 1 is split: [B][S_l][C_{l+1}] complete gradient of level l's pooled output
     int planned = 0;
     // activations of one forward
@@ -405,11 +405,11 @@ int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, const
     a.c_out = d.c_off;
     a.arg = ws->arg[lvl][sc];
     const bool split = m->split_fwd[lvl];
-    a.l1 = fwd_layer(split ? m->sx[lvl] : L[0], true, ws->mask[d.l0]);
+    a.l1 = fwd_layer(split ? m->sx[lvl][sc] : L[0], true, ws->mask[d.l0]);
     a.l2 = fwd_layer(L[1], true, ws->mask[d.l0 + 1]);
     a.w3 = L[2].wf; a.b3 = L[2].bias; a.k8_3 = L[2].k8f(); a.nb3 = L[2].mbf();
     a.D = D; a.Np = Np; a.S = S; a.C3 = L[2].cout;
-    a.tfeat = split ? ws->tfeat[lvl] : nullptr;
+    a.tfeat = split ? ws->tfeat[lvl][sc] : nullptr;
     a.ldt = split ? L[0].cout : 0;
     // one in-place activation buffer: the widest of the layers' K / M extents (psg_mlp.cuh)
     const int blocks = std::max(std::max(layer_blocks(a.l1.k8, a.l1.mb), layer_blocks(a.l2.k8, a.l2.mb)), a.k8_3) + PSG_LDS_SPARE;
@@ -428,6 +428,10 @@ int run_sa_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, const
         case PSG_CFG_KEY(64, 4, 32, 1): return launch_lds(ws, tag, (sa_fwd_kernel<64, 4, 32, 1, true>), grid, 4 * 64, blocks, Lds<64>::BLK, a, st);
         case PSG_CFG_KEY(32, 4, 32, 1): return launch_lds(ws, tag, (sa_fwd_kernel<32, 4, 32, 1, true>), grid, 4 * 64, blocks, Lds<32>::BLK, a, st);
         case PSG_CFG_KEY(32, 8, 32, 1): return launch_lds(ws, tag, (sa_fwd_kernel<32, 8, 32, 1, true>), grid, 8 * 64, blocks, Lds<32>::BLK, a, st);
+        case PSG_CFG_KEY(64, 4, 16, 1): return launch_lds(ws, tag, (sa_fwd_kernel<64, 4, 16, 1, true>), grid, 4 * 64, blocks, Lds<64>::BLK, a, st);   // MSG sa2 scale 0
+        case PSG_CFG_KEY(64, 8, 32, 1): return launch_lds(ws, tag, (sa_fwd_kernel<64, 8, 32, 1, true>), grid, 8 * 64, blocks, Lds<64>::BLK, a, st);   // MSG sa2 scale 1
+        case PSG_CFG_KEY(32, 8, 16, 1): return launch_lds(ws, tag, (sa_fwd_kernel<32, 8, 16, 1, true>), grid, 8 * 64, blocks, Lds<32>::BLK, a, st);   // MSG sa3 / sa4 scale 0
+        case PSG_CFG_KEY(32, 8, 32, 2): return launch_lds(ws, tag, (sa_fwd_kernel<32, 8, 32, 2, true>), grid, 8 * 64, blocks, Lds<32>::BLK, a, st);   // MSG sa4 scale 1
         }
         set_error("run_sa_fwd: no split kernel for P=%d NW=%d K=%d MAXT=%d", P, NW, KS, d.maxt_f);
         return PSG_ERR_STATE;
@@ -571,15 +575,15 @@ __global__ void pw9_fwd_kernel(const float *__restrict__ x0, const float *__rest
 
 // Per-point side of a split SA level (arch_split): T = act[lvl - 1] . W1f^T + b1 for the Nl[lvl] points of every room, one
 // launch of the cooperative row-MLP kernel (fp_fwd_kernel with a skip part only: C2 = 0, one layer, no ReLU).
-int run_pw_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int fwd, hipStream_t st)
+int run_pw_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, hipStream_t st)
 {
     constexpr int P = 32, NW = 8;
-    const PackedLayer &F = m->sf[lvl];
+    const PackedLayer &F = m->sf[lvl][sc];
     const int B = ws->B, N = ws->Nl[lvl];
     if (lvl == 0) {
         ProfScope prof(ws, TAG_PW_FWD, st);
         const size_t rows = (size_t)B * N;
-        hipLaunchKernelGGL(pw9_fwd_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, st, ws->x0_fwd, m->w0f, m->b0f, rows, ws->tfeat[0]);
+        hipLaunchKernelGGL(pw9_fwd_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, st, ws->x0_fwd, m->w0f, m->b0f, rows, ws->tfeat[0][0]);
         PSG_LAUNCH_CHECK();
         return PSG_OK;
     }
@@ -592,7 +596,7 @@ int run_pw_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int fwd, hipStream_t s
     a.N = N; a.S = N;
     a.layer[0] = fwd_layer(F, false, nullptr);
     a.n_layers = 1;
-    a.out = ws->tfeat[lvl]; a.Cout = F.cout; a.logp = nullptr; a.n_cls = 0;
+    a.out = ws->tfeat[lvl][sc]; a.Cout = F.cout; a.logp = nullptr; a.n_cls = 0;
     a.diag = 0; a.dbg = ws->dbg;
     if (a.layer[0].mb > NW || N % P) { set_error("run_pw_fwd level %d: unsupported shape", lvl); return PSG_ERR_STATE; }
     const int blocks = layer_blocks(a.layer[0].k8, a.layer[0].mb) + PSG_LDS_SPARE;
@@ -601,29 +605,35 @@ int run_pw_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int fwd, hipStream_t s
 
 // dsum[lvl - 1] = dact[lvl - 1] (skip-link rows of the coarser FP module; level 3 feeds fp4 only: its skip part is that gather,
 // done in sa_bwd) + (sum of the dZ1 rows of level lvl per source point) . W1f
-int run_pw_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int fwd, hipStream_t st)
+// (MSG: the second scale of a level adds its product to what the first one wrote)
+int run_pw_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, hipStream_t st)
 {
     constexpr int P = 32, NW = 8;
     const ArchDesc &A = *m->arch;
-    const PackedLayer &F = m->sf[lvl];
+    const PackedLayer &F = m->sf[lvl][sc];
     const int B = ws->B, N = ws->Nl[lvl];
     PwBwdArgs a;
-    a.ginv_off = ws->ginv_off[lvl][0] + (size_t)fwd * B * (N + 1);
-    a.gsa = ws->gsa[lvl][0];
-    a.g_rows = kS[lvl] * A.sc[lvl][0].K;
-    a.skip = ws->dact[lvl - 1];
+    a.ginv_off = ws->ginv_off[lvl][sc] + (size_t)fwd * B * (N + 1);
+    a.gsa = ws->gsa[lvl][sc];
+    a.g_rows = kS[lvl] * A.sc[lvl][sc].K;
+    a.skip = sc == 0 ? ws->dact[lvl - 1] : ws->dsum[lvl - 1];
     a.out = ws->dsum[lvl - 1];
     a.wt = bwd_layer(F, nullptr);
     a.N = N; a.C1 = F.cout; a.D = F.cin;
-    if ((a.C1 != 64 && a.C1 != 128 && a.C1 != 256) || a.wt.mb > NW || N % P || a.D % 32) {
+    if ((a.C1 != 64 && a.C1 != 128 && a.C1 != 256) || a.wt.mb > 2 * NW || N % P || a.D % 32) {
         set_error("run_pw_bwd level %d: unsupported shape", lvl);
         return PSG_ERR_STATE;
     }
     const int blocks = layer_blocks(a.wt.k8, a.wt.mb) + PSG_LDS_SPARE;
     const size_t lds = (size_t)blocks * Lds<P>::BLK * sizeof(float);
-    if (lds > 48 * 1024) PSG_CHECK_HIP(allow_big_lds((const void *)pw_bwd_kernel<P, NW>));
     ProfScope prof(ws, TAG_PW_BWD, st);
-    hipLaunchKernelGGL((pw_bwd_kernel<P, NW>), dim3(N / P, B), dim3(NW * 64), lds, st, a);
+    if (a.wt.mb > NW) {     // MSG level 3: 512 feature channels = 16 output tiles on 8 waves
+        if (lds > 48 * 1024) PSG_CHECK_HIP(allow_big_lds((const void *)pw_bwd_kernel<P, NW, 2>));
+        hipLaunchKernelGGL((pw_bwd_kernel<P, NW, 2>), dim3(N / P, B), dim3(NW * 64), lds, st, a);
+    } else {
+        if (lds > 48 * 1024) PSG_CHECK_HIP(allow_big_lds((const void *)pw_bwd_kernel<P, NW, 1>));
+        hipLaunchKernelGGL((pw_bwd_kernel<P, NW, 1>), dim3(N / P, B), dim3(NW * 64), lds, st, a);
+    }
     PSG_LAUNCH_CHECK();      // (a launch site of its own: the tracer tells the split path from the whole one, tests/test_gpu_alt_paths.py)
     return PSG_OK;
 }
@@ -997,8 +1007,9 @@ size_t ws_layout(psg_pn2_ws *ws, char *base)
     for (int l = 0; l < 4; ++l)
         for (int s = 0; s < A.ns; ++s) ws->gsa[l][s] = bp.take<float>((size_t)B * kS[l] * A.sc[l][s].K * gsa_stride(A, l));
     for (int l = 0; l < 4; ++l) {
-        ws->tfeat[l] = nullptr; ws->dsum[l] = nullptr;
-        if (arch_split_fwd(A, l)) ws->tfeat[l] = bp.take<float>((size_t)B * ws->Nl[l] * A.cout[A.sc[l][0].l0]);
+        ws->tfeat[l][0] = ws->tfeat[l][1] = nullptr; ws->dsum[l] = nullptr;
+        if (arch_split_fwd(A, l))
+            for (int s = 0; s < A.ns; ++s) ws->tfeat[l][s] = bp.take<float>((size_t)B * ws->Nl[l] * A.cout[A.sc[l][s].l0]);
         if (arch_split(A, l)) ws->dsum[l - 1] = bp.take<float>((size_t)B * ws->Nl[l] * A.C[l]);
     }
     for (int l = 0; l < 4; ++l) {   // interpolated-part gradient rows of FP module l: C2 = its input minus the skip part
@@ -1074,43 +1085,45 @@ extern "C" int psg_pn2_model_create_arch(psg_ctx *ctx, int arch, const float *co
         total += ((wf[i].size() + wb[i].size() + bs[i].size() + wf4[i].size() + wb4[i].size()) * 4 + 5 * 256);
     }
     // split first layers (arch_split): reference column order of the layer is [rel_xyz(3), feats(D)] (SSG: sa_perm)
-    std::vector<float> sxf[4], sff[4], sfb[4], sfbias[4], w0raw;
-    for (int l = 0; l < 4; ++l) {
+    std::vector<float> sxf[8], sff[8], sfb[8], sfbias[8], w0raw;
+    for (int ls = 0; ls < 8; ++ls) {
+        const int l = ls >> 1, s = ls & 1;
         m->split[l] = arch_split(A, l);
         m->split_fwd[l] = arch_split_fwd(A, l);
-        if (!m->split_fwd[l]) continue;
-        const int li = A.sc[l][0].l0, cin = A.cin[li], cout = A.cout[li], D = cin - 3;
+        if (!m->split_fwd[l] || s >= A.ns) continue;
+        const int li = A.sc[l][s].l0, cin = A.cin[li], cout = A.cout[li], D = cin - 3;
         const int xo = A.sa_perm ? 0 : D, fo = A.sa_perm ? 3 : 0;
         std::vector<float> wx((size_t)cout * 3), wfe((size_t)cout * D);
         for (int o = 0; o < cout; ++o) {
             for (int c = 0; c < 3; ++c) wx[(size_t)o * 3 + c] = weights[li][(size_t)o * cin + xo + c];
             for (int c = 0; c < D; ++c) wfe[(size_t)o * D + c] = weights[li][(size_t)o * cin + fo + c];
         }
-        sxf[l] = pack_fwd(wx.data(), 3, cout, nullptr);
-        sff[l] = pack_fwd(wfe.data(), D, cout, nullptr);
-        sfb[l] = pack_bwd(wfe.data(), D, cout, nullptr);
-        sfbias[l] = bs[li];
+        sxf[ls] = pack_fwd(wx.data(), 3, cout, nullptr);
+        sff[ls] = pack_fwd(wfe.data(), D, cout, nullptr);
+        sfb[ls] = pack_bwd(wfe.data(), D, cout, nullptr);
+        sfbias[ls] = bs[li];
         if (l == 0) w0raw = wfe;
-        total += (sxf[l].size() + sff[l].size() + sfb[l].size() + sfbias[l].size() + (l == 0 ? wfe.size() : 0)) * 4 + 5 * 256;
+        total += (sxf[ls].size() + sff[ls].size() + sfb[ls].size() + sfbias[ls].size() + (l == 0 ? wfe.size() : 0)) * 4 + 5 * 256;
     }
     PSG_CHECK_HIP(hipMalloc(&m->arena, total));
     Bump bp;
     bp.base = (char *)m->arena;
-    for (int l = 0; l < 4; ++l) {
-        if (!m->split_fwd[l]) continue;
-        const int li = A.sc[l][0].l0;
-        PackedLayer &X = m->sx[l], &F = m->sf[l];
+    for (int ls = 0; ls < 8; ++ls) {
+        const int l = ls >> 1, s = ls & 1;
+        if (!m->split_fwd[l] || s >= A.ns) continue;
+        const int li = A.sc[l][s].l0;
+        PackedLayer &X = m->sx[l][s], &F = m->sf[l][s];
         X.cin = 3; X.cout = A.cout[li];
         F.cin = A.cin[li] - 3; F.cout = A.cout[li];
-        X.wf = bp.take<float4>(sxf[l].size() / 4);
-        F.wf = bp.take<float4>(sff[l].size() / 4);
-        F.wb = bp.take<float4>(sfb[l].size() / 4);
-        F.bias = bp.take<float>(sfbias[l].size());
+        X.wf = bp.take<float4>(sxf[ls].size() / 4);
+        F.wf = bp.take<float4>(sff[ls].size() / 4);
+        F.wb = bp.take<float4>(sfb[ls].size() / 4);
+        F.bias = bp.take<float>(sfbias[ls].size());
         X.bias = F.bias;     // (unused: the bias arrives through T)
-        PSG_CHECK_HIP(psg::copy_sync(X.wf, sxf[l].data(), sxf[l].size() * 4, hipMemcpyHostToDevice));
-        PSG_CHECK_HIP(psg::copy_sync(F.wf, sff[l].data(), sff[l].size() * 4, hipMemcpyHostToDevice));
-        PSG_CHECK_HIP(psg::copy_sync(F.wb, sfb[l].data(), sfb[l].size() * 4, hipMemcpyHostToDevice));
-        PSG_CHECK_HIP(psg::copy_sync(F.bias, sfbias[l].data(), sfbias[l].size() * 4, hipMemcpyHostToDevice));
+        PSG_CHECK_HIP(psg::copy_sync(X.wf, sxf[ls].data(), sxf[ls].size() * 4, hipMemcpyHostToDevice));
+        PSG_CHECK_HIP(psg::copy_sync(F.wf, sff[ls].data(), sff[ls].size() * 4, hipMemcpyHostToDevice));
+        PSG_CHECK_HIP(psg::copy_sync(F.wb, sfb[ls].data(), sfb[ls].size() * 4, hipMemcpyHostToDevice));
+        PSG_CHECK_HIP(psg::copy_sync(F.bias, sfbias[ls].data(), sfbias[ls].size() * 4, hipMemcpyHostToDevice));
         if (l == 0) {
             m->w0f = bp.take<float>(w0raw.size());
             m->b0f = F.bias;
@@ -1320,9 +1333,10 @@ extern "C" int psg_pn2_forward(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const 
     int rc;
     ws->x0_fwd = x0;
     for (int l = 0; l < 4; ++l) {
-        if (m->split_fwd[l] && (rc = run_pw_fwd(m, ws, l, fwd, st))) return rc;
-        for (int sc = 0; sc < m->arch->ns; ++sc)
+        for (int sc = 0; sc < m->arch->ns; ++sc) {
+            if (m->split_fwd[l] && (rc = run_pw_fwd(m, ws, l, sc, fwd, st))) return rc;
             if ((rc = run_sa_fwd(m, ws, l, sc, fwd, x0, st))) return rc;
+        }
     }
     if ((rc = run_fp_fwd<3>(m, ws, fwd, nullptr, st))) return rc;
     if ((rc = run_fp_fwd<2>(m, ws, fwd, nullptr, st))) return rc;
@@ -1347,9 +1361,10 @@ static int backward_impl(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float 
     if ((rc = run_fp_bwd<2>(m, ws, fwd, nullptr, nullptr, st))) return rc;
     if ((rc = run_fp_bwd<3>(m, ws, fwd, nullptr, nullptr, st))) return rc;
     for (int l = 3; l >= 0; --l) {
-        for (int sc = 0; sc < A.ns; ++sc)
+        for (int sc = 0; sc < A.ns; ++sc) {
             if ((rc = run_sa_bwd(m, ws, l, sc, fwd, l ? 0 : c_lo, l ? A.C[l] : c_hi, st))) return rc;
-        if (m->split[l] && (rc = run_pw_bwd(m, ws, l, fwd, st))) return rc;
+            if (m->split[l] && (rc = run_pw_bwd(m, ws, l, sc, fwd, st))) return rc;
+        }
     }
     {
         ProfScope prof(ws, TAG_ZERO, st);   // (tag kept: the slot that used to be the gradient memset)

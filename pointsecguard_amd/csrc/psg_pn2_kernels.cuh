@@ -902,7 +902,7 @@ __device__ __forceinline__ void pw_bwd_gather_rows(const PwBwdArgs &a, int b, in
     }
 }
 
-template <int P, int NW>
+template <int P, int NW, int MAXT = 1>
 __global__ __launch_bounds__(NW * 64) void pw_bwd_kernel(PwBwdArgs a)
 {
     using L = Lds<P>;
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(NW * 64) void pw_bwd_kernel(PwBwdArgs a)
     else if (a.C1 == 128) pw_bwd_gather_rows<P, NW, 2>(a, b, n0, buf0, lane, wave);
     else pw_bwd_gather_rows<P, NW, 4>(a, b, n0, buf0, lane, wave);
     __syncthreads();
-    layer_bwd<P, NW, 1>(a.wt, buf0, wg);
+    layer_bwd<P, NW, MAXT>(a.wt, buf0, wg);
     __syncthreads();
     {
         constexpr int RG = NT / 32;
