@@ -112,6 +112,97 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(GemmArgs a)
     if (EPI == EPI_LRELU && a.mask_out) a.mask_out[row] = bits;
 }
 
+// Round 5: the narrow layers of levels 0 and 1 (8 .. 64 output channels over 80 000 .. 330 000 rows per 8-cloud launch, K <= 128)
+// on the matrix cores WITHOUT the LDS-staged tile machinery of gemm_rows_kernel: these launches move 100 - 250 MB for a few
+// MFMAs per row, and a 256 x 64 tile whose whole K is one or two 32-wide steps has no loop to pipeline - stage, barrier, 8
+// MFMAs, barrier, epilogue, at two waves per SIMD (240 registers): 2.0 TB/s (profiles/r04_randla_bench.json); the row-per-thread
+// vector kernel of the <= 32-channel layers: 1.45 TB/s.  Here a wave owns 32 rows: lane (row j, half h) reads its row's K
+// floats straight in MFMA operand order (one 16-byte load per 8 channels: k = 8 k8 + 4 h + t), the weights' rows likewise
+// from L1 / L2 (<= 32 KB per layer), MT = 1 or 2 accumulator tiles of 32 channels, no LDS, no barrier, ~60 registers (8
+// waves per SIMD hide the loads).  Epilogue = gemm_rows_kernel's for the options RandLA-Net uses: bias, leaky ReLU + sign
+// bits, accumulate, the stored leaky-ReLU derivative (post_mask).
+template <int EPI, int MT>
+__global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const size_t row = ((size_t)blockIdx.x * 4 + wave) * 32 + j;
+    const bool live = row < (size_t)a.rows;
+    const float *in = a.in + (live ? row : (size_t)a.rows - 1) * a.ld_in + 4 * h;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    const float *wrow[MT];
+    bool wlive[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = t * 32 + j;
+        wlive[t] = m < a.M;
+        wrow[t] = a.w + (size_t)(wlive[t] ? m : 0) * a.ld_w + 4 * h;
+    }
+    const int k8n = (a.K + 7) >> 3;
+    for (int k8 = 0; k8 < k8n; ++k8) {
+        const bool kin = 8 * k8 + 4 * h < a.K;                   // (K is a multiple of 4: the upper half of the last chunk may be absent)
+        const float4 av = kin ? *(const float4 *)(in + 8 * k8) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const float4 wv = (kin && wlive[t]) ? *(const float4 *)(wrow[t] + 8 * k8) : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc[t] = mfma4<false>(wv, av, acc[t]);
+        }
+    }
+    const int nw = (a.M + 31) >> 5;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int cbase = t * 32;
+        if (cbase >= a.M) break;
+        const unsigned post_bits = (a.post_mask && live) ? a.post_mask[row * nw + t] : 0xFFFFFFFFu;
+        unsigned mbits = 0;
+        float4 vv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = cbase + 8 * g + 4 * h;
+            const float4 b4 = (a.bias && c < a.M) ? *(const float4 *)(a.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+            float e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float z = acc[t][4 * g + u];
+                if (a.bias) z += bb[u];
+                if (EPI == EPI_LRELU) {
+                    const bool pos = z > 0.0f;
+                    mbits |= (unsigned)pos << (8 * g + 4 * h + u);
+                    z = pos ? z : 0.2f * z;
+                }
+                e[u] = z;
+            }
+            vv[g] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        if (EPI == EPI_LRELU && a.mask_out) {
+            const unsigned other = __shfl_xor(mbits, 32);
+            if (h == 0 && live) a.mask_out[row * nw + t] = mbits | other;
+        }
+        if (live) {
+            float *o = a.out + row * a.ld_out + cbase + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (cbase + 8 * g + 4 * h >= a.M) continue;          // (M is a multiple of 4)
+                float4 v = vv[g];
+                float4 *dst = (float4 *)(o + 8 * g);
+                if (a.accumulate == 1) { const float4 old = *dst; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+                if (a.post_mask) {
+                    const unsigned pb = post_bits >> (8 * g + 4 * h);
+                    if (!(pb & 1u)) v.x *= a.post_slope;
+                    if (!(pb & 2u)) v.y *= a.post_slope;
+                    if (!(pb & 4u)) v.z *= a.post_slope;
+                    if (!(pb & 8u)) v.w *= a.post_slope;
+                }
+                *dst = v;
+            }
+        }
+    }
+}
+
 // profile of the launches of the call in progress on this thread (psg_rla_prof_enable), by kernel: tag 0 = 64 x 64
 // tiles (gemm_rows_kernel<2,2,.,.,1,1>: the point-sized layers), 1 = 128 x 128 tiles, 2 = 256 x 64 tiles, 3 = the
 // row-per-thread kernel of the 8-32 channel layers; each launch with its algorithmic FLOPs and bytes (input rows, output
@@ -130,6 +221,16 @@ int rl_gemm(const GemmArgs &a, hipStream_t st)
                                 (a.addend ? (double)a.rows * a.M : 0.0) + (double)a.K * a.M +
                                 ((a.mask_out || a.post_mask) ? (double)a.rows * ((a.M + 31) / 32) : 0.0));
     EvScope prof(tl_prof, skinny ? 3 : (wide ? 2 : (small_tile ? 0 : 1)), 2.0 * a.rows * (double)a.K * a.M, st, bytes);
+    // (PSG_RLA_NO_DIRECT=1: the tile / row-per-thread kernels of rounds 1-4, for A/B runs)
+    static const bool use_direct = psg::env_int("PSG_RLA_NO_DIRECT", 0) == 0;
+    if (use_direct && (skinny || wide) && a.K <= 128 && ((a.K | a.M | a.ld_in | a.ld_w | a.ld_out) & 3) == 0 && !a.addend && !a.gbias && !a.mask_in &&
+        !a.scale && a.accumulate <= 1) {
+        const dim3 grid(ceil_div(a.rows, 128));
+        if (a.M <= 32) hipLaunchKernelGGL((direct_gemm_kernel<EPI, 1>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((direct_gemm_kernel<EPI, 2>), grid, dim3(256), 0, st, a);
+        PSG_LAUNCH_CHECK();
+        return PSG_OK;
+    }
     if (a.M <= 32 && a.K <= 32 && a.rows >= 4096 && !a.addend && !a.gbias && !a.mask_in) {
         hipLaunchKernelGGL(skinny_gemm_kernel<EPI>, dim3(ceil_div(a.rows, 256)), dim3(256), 0, st, a);
         PSG_LAUNCH_CHECK();
@@ -326,15 +427,43 @@ __device__ __forceinline__ float2 lfa16_load_own(const float *__restrict__ f, co
 {
     return q < 4 ? *(const float2 *)(f + (size_t)j * 8 + 2 * q) : *(const float2 *)(fxyz + e * 8 + 2 * (q - 4));
 }
-// scores of the 16 neighbours for the thread's 2 channels, and their softmax over the neighbours (in place)
-__device__ __forceinline__ void lfa16_attention(const float *__restrict__ f, const int32_t *__restrict__ nb, const float *__restrict__ fxyz,
-                                                size_t p, const float (&wr)[2][16], const float (&bias)[2], float (&a)[RK][2])
+// Round 5: the 16 x 16 inputs of a point's pooling - cat[e] = [f[neigh[e]] (8) | fxyz[e] (8)] for its 16 edges - are staged in
+// LDS once per workgroup (32 points), each edge row fetched by ONE thread.  Rounds 2-4 let each of the point's 8 threads
+// (a channel pair each) fetch all 16 rows itself: 80 global 16- / 8-byte loads per thread, 3 GB through the CUs' vector
+// memory path per launch of 8 clouds - the kernels ran at 1.2 TB/s of HBM traffic and 10 % of the vector peak, bound by
+// neither but by that path and its latency.  Same FMAs in the same order: bit-identical results.
+constexpr int LFA_PTS = 32;                       // points per 256-thread workgroup
+constexpr int LFA_PSTRIDE = RK * 16 + 4;          // floats per staged point: + 4 de-phases the 8 points a wave reads at once over the banks
+__device__ __forceinline__ void lfa16_stage(const float *__restrict__ f, const int32_t *__restrict__ neigh, const float *__restrict__ fxyz,
+                                            size_t p0, size_t n, float *__restrict__ s_x, int32_t *__restrict__ s_nb)
+{
+    for (int e = threadIdx.x; e < LFA_PTS * RK; e += 256) {
+        const size_t p = p0 + (size_t)(e >> 4);
+        const size_t pe = (p < n ? p : n - 1) * RK + (e & 15);
+        const int j = neigh[pe];
+        const float4 a0 = *(const float4 *)(f + (size_t)j * 8), a1 = *(const float4 *)(f + (size_t)j * 8 + 4);
+        const float4 b0 = *(const float4 *)(fxyz + pe * 8), b1 = *(const float4 *)(fxyz + pe * 8 + 4);
+        float *d = s_x + (e >> 4) * LFA_PSTRIDE + (e & 15) * 16;
+        *(float4 *)d = a0; *(float4 *)(d + 4) = a1; *(float4 *)(d + 8) = b0; *(float4 *)(d + 12) = b1;
+        if (s_nb) s_nb[e] = j;
+    }
+    __syncthreads();
+}
+
+// scores of the 16 neighbours for the thread's 2 channels, and their softmax over the neighbours (in place); xs = the point's
+// staged rows
+__device__ __forceinline__ void lfa16_attention(const float *__restrict__ xs, const float (&wr)[2][16], const float (&bias)[2], float (&a)[RK][2])
 {
     float m[2] = {-INFINITY, -INFINITY};
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
         float x[16];
-        lfa16_load_x(f, fxyz, nb[k], p * RK + k, x);
+        {
+            const float4 *r = (const float4 *)(xs + k * 16);
+            const float4 a0 = r[0], a1 = r[1], b0 = r[2], b1 = r[3];
+            x[0] = a0.x; x[1] = a0.y; x[2] = a0.z; x[3] = a0.w; x[4] = a1.x; x[5] = a1.y; x[6] = a1.z; x[7] = a1.w;
+            x[8] = b0.x; x[9] = b0.y; x[10] = b0.z; x[11] = b0.w; x[12] = b1.x; x[13] = b1.y; x[14] = b1.z; x[15] = b1.w;
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             float acc = 0.0f;
@@ -359,13 +488,15 @@ __device__ __forceinline__ void lfa16_attention(const float *__restrict__ f, con
 }
 
 // thread = (point, channel pair): 8 threads per point (4 channels per thread took 216 - 256 registers: 1 - 2 waves per SIMD)
-__global__ __launch_bounds__(256, 3) void lfa16_fwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh,
+__global__ __launch_bounds__(256, 4) void lfa16_fwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh,
                                                         const float *__restrict__ fxyz, const float *__restrict__ w,
                                                         const float *__restrict__ b, size_t n, float *__restrict__ agg)
 {
+    __shared__ float s_x[LFA_PTS * LFA_PSTRIDE];
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t p = t >> 3;
     const int q = (int)(t & 7);
+    lfa16_stage(f, neigh, fxyz, (size_t)blockIdx.x * LFA_PTS, n, s_x, nullptr);
     if (p >= n) return;
     float wr[2][16], bias[2];
 #pragma unroll
@@ -374,15 +505,13 @@ __global__ __launch_bounds__(256, 3) void lfa16_fwd_kernel(const float *__restri
 #pragma unroll
         for (int i = 0; i < 16; ++i) wr[c][i] = w[(2 * q + c) * 16 + i];
     }
-    int nb[RK];
-#pragma unroll
-    for (int k = 0; k < RK; ++k) nb[k] = neigh[p * RK + k];
+    const float *xs = s_x + (threadIdx.x >> 3) * LFA_PSTRIDE;
     float a[RK][2];
-    lfa16_attention(f, nb, fxyz, p, wr, bias, a);
+    lfa16_attention(xs, wr, bias, a);
     float2 out = make_float2(0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
-        const float2 x = lfa16_load_own(f, fxyz, nb[k], p * RK + k, q);
+        const float2 x = *(const float2 *)(xs + k * 16 + 2 * q);     // the thread's own 2 channels of cat[e]
         out.x += x.x * a[k][0]; out.y += x.y * a[k][1];
     }
     *(float2 *)(agg + p * 16 + 2 * q) = out;
@@ -392,15 +521,18 @@ __global__ __launch_bounds__(256, 3) void lfa16_fwd_kernel(const float *__restri
 // ds = a * (g - sum_k a g), g = cat * dagg (the position-encoding half carries no colour gradient).  The sum over the 16
 // channels c is split over the 8 threads of the point (each owns 2 rows of W) and closed with three shuffles; lane q then
 // adds column q: the 8 lanes of a point hit 32 consecutive bytes of the neighbour's row.
-__global__ __launch_bounds__(256, 2) void lfa16_bwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh,
+__global__ __launch_bounds__(256, 3) void lfa16_bwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh,
                                                         const float *__restrict__ fxyz, const float *__restrict__ w,
                                                         const float *__restrict__ b, const float *__restrict__ dagg, size_t n,
                                                         float *__restrict__ df, float *__restrict__ dcat8)
 {
+    __shared__ float s_x[LFA_PTS * LFA_PSTRIDE];
+    __shared__ int32_t s_nbs[LFA_PTS * RK];
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = (t >> 3) < n;                 // (all lanes stay for the shuffles)
     const size_t p = live ? (t >> 3) : n - 1;
     const int q = (int)(t & 7);
+    lfa16_stage(f, neigh, fxyz, (size_t)blockIdx.x * LFA_PTS, n, s_x, s_nbs);
     float wr[2][16], bias[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -408,22 +540,21 @@ __global__ __launch_bounds__(256, 2) void lfa16_bwd_kernel(const float *__restri
 #pragma unroll
         for (int i = 0; i < 16; ++i) wr[c][i] = w[(2 * q + c) * 16 + i];
     }
-    int nb[RK];
-#pragma unroll
-    for (int k = 0; k < RK; ++k) nb[k] = neigh[p * RK + k];
+    const float *xs = s_x + (threadIdx.x >> 3) * LFA_PSTRIDE;     // (a dead thread's rows are the clamped point n - 1's: staged the same)
+    const int32_t *nb = s_nbs + (threadIdx.x >> 3) * RK;
     float a[RK][2];
-    lfa16_attention(f, nb, fxyz, p, wr, bias, a);
+    lfa16_attention(xs, wr, bias, a);
     const float2 dg2 = *(const float2 *)(dagg + p * 16 + 2 * q);
     const float dg[2] = {dg2.x, dg2.y};
     float dot[2] = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
-        const float2 x = lfa16_load_own(f, fxyz, nb[k], p * RK + k, q);
+        const float2 x = *(const float2 *)(xs + k * 16 + 2 * q);
         dot[0] += a[k][0] * (x.x * dg[0]); dot[1] += a[k][1] * (x.y * dg[1]);
     }
 #pragma unroll 4
     for (int k = 0; k < RK; ++k) {
-        const float2 x = lfa16_load_own(f, fxyz, nb[k], p * RK + k, q);
+        const float2 x = *(const float2 *)(xs + k * 16 + 2 * q);
         const float xs[2] = {x.x, x.y};
         float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -497,7 +628,7 @@ __global__ void att_pool_split_fwd_kernel(const float *__restrict__ f, const int
     for (int k = 0; k < RK; ++k) {
         const size_t e = n * RK + k;
         const float2 a = make_float2(v[k].x * inv.x, v[k].y * inv.y);
-        *(float2 *)(a_out + e * d + c) = a;
+        if (a_out) *(float2 *)(a_out + e * d + c) = a;
         const float2 x = c < h ? *(const float2 *)(f + (size_t)nb[k] * h + c) : *(const float2 *)(fxyz + e * h + (c - h));
         acc.x += x.x * a.x; acc.y += x.y * a.y;
     }
@@ -507,9 +638,11 @@ __global__ void att_pool_split_fwd_kernel(const float *__restrict__ f, const int
 // ds[e] = a * (g - sum_k a g), g = cat * dagg, for all d channels; ddir[e] = a * dagg for the feature half (c < h).
 // One thread per (point, 2 channels): the 16 attention weights and the 16 products stay in registers, every input is read once
 // (4 channels per thread had to read cat twice or drop to one wave per SIMD).
+// Round 5: the attention weights are RECOMPUTED here from T[neigh] + S2 - the forward's operations in the forward's order, so
+// the same bits - instead of being written per edge by the forward ([E][d] floats, 40 % of its HBM traffic) and read back.
 __global__ void att_pool_split_bwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh, const float *__restrict__ fxyz,
-                                          const float *__restrict__ a, const float *__restrict__ dagg, int h, size_t total2,
-                                          float *__restrict__ ds, float *__restrict__ ddir)
+                                          const float *__restrict__ T, const float *__restrict__ S2, const float *__restrict__ dagg, int h,
+                                          size_t total2, float *__restrict__ ds, float *__restrict__ ddir)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total2) return;
@@ -518,12 +651,33 @@ __global__ void att_pool_split_bwd_kernel(const float *__restrict__ f, const int
     const int c = (int)(t - n * d2) * 2;
     const float2 g0 = ((const float2 *)dagg)[t];
     float2 av[RK], gv[RK];
+    int nb[RK];
+#pragma unroll
+    for (int k = 0; k < RK; ++k) nb[k] = neigh[n * RK + k];
+    {
+        float2 m = make_float2(-INFINITY, -INFINITY);
+#pragma unroll
+        for (int k = 0; k < RK; ++k) {
+            const float2 tt = *(const float2 *)(T + (size_t)nb[k] * d + c);
+            const float2 s2 = *(const float2 *)(S2 + (n * RK + k) * d + c);
+            av[k] = make_float2(tt.x + s2.x, tt.y + s2.y);
+            m.x = fmaxf(m.x, av[k].x); m.y = fmaxf(m.y, av[k].y);
+        }
+        float2 sum = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < RK; ++k) {
+            av[k].x = expf(av[k].x - m.x); av[k].y = expf(av[k].y - m.y);
+            sum.x += av[k].x; sum.y += av[k].y;
+        }
+        const float2 inv = make_float2(1.0f / sum.x, 1.0f / sum.y);
+#pragma unroll
+        for (int k = 0; k < RK; ++k) av[k] = make_float2(av[k].x * inv.x, av[k].y * inv.y);
+    }
     float2 dot = make_float2(0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
         const size_t e = n * RK + k;
-        av[k] = *(const float2 *)(a + e * d + c);
-        const float2 x = c < h ? *(const float2 *)(f + (size_t)neigh[e] * h + c) : *(const float2 *)(fxyz + e * h + (c - h));
+        const float2 x = c < h ? *(const float2 *)(f + (size_t)nb[k] * h + c) : *(const float2 *)(fxyz + e * h + (c - h));
         gv[k] = make_float2(x.x * g0.x, x.y * g0.y);
         dot.x += av[k].x * gv[k].x; dot.y += av[k].y * gv[k].y;
     }
@@ -1277,14 +1431,14 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
         const bool fused16 = d == 16 && ws->fuse16;     // level 0: one kernel per attentive pooling (lfa16_*_kernel)
         const bool split = d > 16 && ws->split;         // levels 1-4: scores = T[neigh] + S2 (att_pool_split_*_kernel)
         if (split) {
-            float *T1 = L.agg2;                          // [n][d] scratch: written by the second pooling only later
+            float *T1 = L.a1;                            // [n][d], kept for the backward (the attention weights are recomputed there from T + S2)
             GemmArgs g = rl_args(L.fpc, h, E.att1_fc.w, d, T1, d, n, h, d);
             g.bias = E.att1_fc.b;
             if ((rc = rl_gemm<EPI_LINEAR>(g, st))) return rc;
             {
                 EvScope prof(tl_prof, 4, 0.0, st, 4.0 * (2.0 * n * d + (double)n * h + (double)ne * (1.0 + 2.0 * d + h)));
                 hipLaunchKernelGGL(att_pool_split_fwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, L.fpc, L.neigh, L.fxyz1, T1,
-                                   L.cat1, h, (size_t)n * d / 2, L.a1, L.agg1);
+                                   L.cat1, h, (size_t)n * d / 2, (float *)nullptr, L.agg1);
             }
             PSG_LAUNCH_CHECK();
         } else if (fused16) {
@@ -1303,14 +1457,14 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
         }
         if ((rc = conv_fwd(E.att1_mlp, L.agg1, d, L.fagg1, h, n, true, L.m_fagg1, st))) return rc;
         if (split) {
-            float *T2 = L.m2;                            // [n][d] scratch inside the [n][2d] buffer mlp2 writes afterwards
+            float *T2 = L.a2;                            // [n][d], kept for the backward like T1
             GemmArgs g = rl_args(L.fagg1, h, E.att2_fc.w, d, T2, d, n, h, d);
             g.bias = E.att2_fc.b;
             if ((rc = rl_gemm<EPI_LINEAR>(g, st))) return rc;
             {
                 EvScope prof(tl_prof, 4, 0.0, st, 4.0 * (2.0 * n * d + (double)n * h + (double)ne * (1.0 + 2.0 * d + h)));
                 hipLaunchKernelGGL(att_pool_split_fwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, L.fagg1, L.neigh, L.fxyz2, T2,
-                                   L.cat2, h, (size_t)n * d / 2, L.a2, L.agg2);
+                                   L.cat2, h, (size_t)n * d / 2, (float *)nullptr, L.agg2);
             }
             PSG_LAUNCH_CHECK();
         } else if (fused16) {
@@ -1431,13 +1585,13 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         const bool split = d > 16 && ws->split;
         // split levels: ds [E][d] and the direct term [E][h] per edge, summed over every point's in-edges (dT [n][d], and
         // straight into the feature gradient), then the score layer's feature half transposed on POINTS: df += dT . W1
-        auto split_bwd = [&](const float *fin_, const float *fxyz_, const float *a_, const float *dagg_, const RLayer &fc, float *df_,
-                             const uint32_t *mask_) -> int {
+        auto split_bwd = [&](const float *fin_, const float *fxyz_, const float *T_, const float *S2_, const float *dagg_, const RLayer &fc,
+                             float *df_, const uint32_t *mask_) -> int {
             float *ds = ws->scratch_b, *ddir = ws->scratch_a, *dT = L.m2;
             {
                 const double ne_ = 16.0 * n;
                 EvScope prof(tl_prof, 5, 0.0, st, 4.0 * ((double)n * (h + d) + ne_ * (1.0 + 2.0 * d + 2.0 * h)));
-                hipLaunchKernelGGL(att_pool_split_bwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, fin_, L.neigh, fxyz_, a_, dagg_,
+                hipLaunchKernelGGL(att_pool_split_bwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, fin_, L.neigh, fxyz_, T_, S2_, dagg_,
                                    h, (size_t)n * d / 2, ds, ddir);
             }
             PSG_LAUNCH_CHECK();
@@ -1454,7 +1608,7 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
             return rl_gemm<EPI_LINEAR>(g, st);
         };
         if (split) {
-            if ((rc = split_bwd(L.fagg1, L.fxyz2, L.a2, g_agg2, E.att2_fc, L.d_fagg1, L.m_fagg1))) return rc;
+            if ((rc = split_bwd(L.fagg1, L.fxyz2, L.a2, L.cat2, g_agg2, E.att2_fc, L.d_fagg1, L.m_fagg1))) return rc;
         } else if (fused16) {
             {
                 EvScope prof(tl_prof, 7, 0.0, st, 4.0 * ((double)n * (2.0 * h + d) + 16.0 * n * (1.0 + h + 8.0)));
@@ -1483,7 +1637,7 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
         float *g_agg1 = L.agg1;
         if ((rc = conv_bwd(E.att1_mlp, L.d_fagg1, h, g_agg1, d, n, 0, st))) return rc;
         if (split) {
-            if ((rc = split_bwd(L.fpc, L.fxyz1, L.a1, g_agg1, E.att1_fc, L.d_fpc, L.m_fpc))) return rc;
+            if ((rc = split_bwd(L.fpc, L.fxyz1, L.a1, L.cat1, g_agg1, E.att1_fc, L.d_fpc, L.m_fpc))) return rc;
         } else if (fused16) {
             {
                 EvScope prof(tl_prof, 7, 0.0, st, 4.0 * ((double)n * (2.0 * h + d) + 16.0 * n * (1.0 + h + 8.0)));

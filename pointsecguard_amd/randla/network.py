@@ -78,7 +78,7 @@ class RandLAWorkspace:
         return ms[0], cnt[0], fl[0]
 
     PROF_KERNELS = ("gemm_rows_kernel<2,2,.,.,1,1> (64x64 tiles)", "gemm_rows_kernel<2,2> (128x128 tiles)",
-                    "gemm_rows_kernel<4,1> (256x64 tiles)", "skinny_gemm_kernel", "att_pool_split_fwd_kernel",
+                    "direct_gemm_kernel<.,2> (33-64 channels, levels 0-1)", "direct_gemm_kernel<.,1> / skinny (<= 32 channels)", "att_pool_split_fwd_kernel",
                     "att_pool_split_bwd_kernel", "lfa16_fwd_kernel", "lfa16_bwd_kernel")
 
     def prof_read_kernels(self):

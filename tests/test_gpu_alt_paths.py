@@ -2,6 +2,8 @@
 
   PSG_FP1_WAVE=1     wave-private fp1 + head chain (psg_chain.cuh) instead of the workgroup-cooperative kernels
   PSG_RLA_ATOMICS=1  RandLA-Net backward scatters with float atomics instead of the inverse-list gathers
+  PSG_RLA_NO_DIRECT=1  RandLA-Net: the narrow layers (<= 64 output channels) on the LDS-tiled GEMM / the row-per-thread vector
+                     kernel (rounds 1-4) instead of the barrier-free direct MFMA kernel (round 5)
   PSG_GCN_PQ_FUSION=1  ResGCN: a block's edge pass also computes the next block's per-vertex [P | Q] product
   PSG_PN2_SPLIT=0    PointNet++ SSG: whole first layers at SA levels 1-3 (rounds 1-4) instead of the split per-point product +
                      per-row xyz chunk (round 5)
@@ -30,6 +32,7 @@ def child(test_file, keyword, extra_env):
     env.pop("PSG_GCN_PQ_FUSION", None)
     env.pop("PSG_GCN_EDGE_BWD", None)
     env.pop("PSG_PN2_SPLIT", None)
+    env.pop("PSG_RLA_NO_DIRECT", None)
     env.update(extra_env)
     env["PSG_TRACE_SYNC"] = "1"
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", test_file), "-x", "-q", "-m", "gpu",
@@ -42,6 +45,7 @@ def child(test_file, keyword, extra_env):
 @pytest.mark.parametrize("test_file,keyword,switch", [
     ("test_gpu_parity.py", "forward_vs_reference or backward_vs_reference or forward_backward_vs_oracle_batch", "PSG_FP1_WAVE"),
     ("test_randla_net.py", "forward_backward_vs_oracle or bim_attack_vs_oracle", "PSG_RLA_ATOMICS"),
+    ("test_randla_net.py", "forward_backward_vs_oracle or bim_attack_vs_oracle", "PSG_RLA_NO_DIRECT"),
     ("test_gpu_resgcn28.py", "not knn_on_reference_features", "PSG_GCN_PQ_FUSION"),
     ("test_gpu_resgcn.py", "forward_backward or nb_attack", "PSG_GCN_EDGE_BWD=atomic"),
     ("test_gpu_parity.py", "forward_vs_reference or backward_vs_reference or forward_backward_vs_oracle_batch or nb_attack_steps_vs_reference",
