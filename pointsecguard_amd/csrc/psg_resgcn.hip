@@ -721,21 +721,32 @@ __global__ __launch_bounds__(256) void matvec_kernel(const float *__restrict__ w
     if (lane == 0) out[room * M + m] = acc;
 }
 
-// column sums over the N rows of each room: out[room][c] = sum_i x[room*N+i][c]; row chunks in parallel,
-// one float atomicAdd per (chunk, channel).  `out` must be zeroed.
+// column sums over the N rows of each room: out[room][c] = sum_i x[room*N+i][c]; row chunks in parallel, every chunk's
+// partial sums written to part[room][chunk][c], added up in chunk order by colsum_finish_kernel (round 5: rounds 1-4 added
+// the chunks with float atomics, the last order-dependent sum of the ResGCN input gradient).
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, int N, int C, int rows_per_chunk,
-                                                     float *__restrict__ out)
+                                                     float *__restrict__ part)
 {
     __shared__ float s_v[4][64];
-    const int cc = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int cc = threadIdx.x & 63, prt = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cc;
     const size_t room = blockIdx.z;
     const int r0 = blockIdx.y * rows_per_chunk, r1 = min(N, r0 + rows_per_chunk);
     float acc = 0.0f;
-    for (int i = r0 + part; i < r1; i += 4) acc += x[(room * N + i) * C + c];
-    s_v[part][cc] = acc;
+    for (int i = r0 + prt; i < r1; i += 4) acc += x[(room * N + i) * C + c];
+    s_v[prt][cc] = acc;
     __syncthreads();
-    if (part == 0) atomicAdd(out + room * C + c, ((s_v[0][cc] + s_v[1][cc]) + s_v[2][cc]) + s_v[3][cc]);
+    if (prt == 0) part[(room * gridDim.y + blockIdx.y) * C + c] = ((s_v[0][cc] + s_v[1][cc]) + s_v[2][cc]) + s_v[3][cc];
+}
+__global__ void colsum_finish_kernel(const float *__restrict__ part, int chunks, int C, size_t total, float *__restrict__ out)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // (room, channel)
+    if (t >= total) return;
+    const size_t room = t / C;
+    const int c = (int)(t - room * C);
+    float acc = 0.0f;
+    for (int k = 0; k < chunks; ++k) acc += part[(room * chunks + k) * C + c];
+    out[t] = acc;
 }
 
 // fusion backward: dfeats[argmax point of channel c][:] += gvec[c] * s_c[active] * Wf[c][:]
@@ -743,15 +754,40 @@ __global__ void fusion_bwd_kernel(const float *__restrict__ gvec, const int32_t 
                                   const uint32_t *__restrict__ mask, const float *__restrict__ scale,
                                   const float *__restrict__ wf, int Cin, int Cout, int N, float *__restrict__ dfeats)
 {
-    // grid (Cout, rooms), block 256 threads over the Cin input channels
+    // grid (Cout, rooms), block 256 threads over the Cin input channels.  Several channels can have their maximum at the same
+    // point; rounds 1-4 let every channel's block add its row with float atomics.  Round 5: the block of the LOWEST channel
+    // of a point is the point's only writer - it adds the rows of all the point's channels in ascending channel order and
+    // stores once; the other blocks leave.  Fixed order, no atomics: the ResGCN input gradient is bit-reproducible.
+    __shared__ int s_arg[1024];
     const int c = blockIdx.x;
     const size_t room = blockIdx.y;
-    const int i = arg[room * Cout + c];
+    for (int t = threadIdx.x; t < Cout; t += blockDim.x) s_arg[t] = arg[room * Cout + t];
+    __syncthreads();
+    const int i = s_arg[c];
+    int earlier = 0;
+    for (int t = threadIdx.x; t < c; t += blockDim.x) earlier |= s_arg[t] == i;
+    if (__syncthreads_or(earlier)) return;
     const size_t row = room * N + i;
-    const bool act = (mask[row * (Cout / 32) + (c >> 5)] >> (c & 31)) & 1u;
-    const float g = act ? gvec[room * Cout + c] * scale[c] : 0.0f;
-    if (g == 0.0f) return;
-    for (int k = threadIdx.x; k < Cin; k += blockDim.x) atomicAdd(dfeats + row * Cin + k, g * wf[(size_t)c * Cin + k]);
+    constexpr int KPT = 8;                                  // input channels per thread: Cin <= 8 * 256
+    float acc[KPT];
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) acc[u] = 0.0f;
+    for (int cc = c; cc < Cout; ++cc) {
+        if (s_arg[cc] != i) continue;
+        const bool act = (mask[row * (Cout / 32) + (cc >> 5)] >> (cc & 31)) & 1u;
+        const float g = act ? gvec[room * Cout + cc] * scale[cc] : 0.0f;
+        if (g == 0.0f) continue;
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) {
+            const int k = threadIdx.x + u * 256;
+            if (k < Cin) acc[u] += g * wf[(size_t)cc * Cin + k];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        const int k = threadIdx.x + u * 256;
+        if (k < Cin) dfeats[row * Cin + k] += acc[u];
+    }
 }
 
 __global__ void scale_rows_kernel(const float *__restrict__ w, int M, int K, const float *__restrict__ s_by_k,
@@ -890,6 +926,7 @@ struct psg_gcn_ws {
     float *h1, *h2;            // [B*N][512], [B*N][256]
     float *g2, *g1;            // backward buffers [B*N][256], [B*N][512]
     float *g1sum, *gfvec;      // [B][512], [B][1024]
+    float *g1part;             // [B][ceil(N / 64)][512] per-chunk column sums (added up in chunk order)
     float *gcur;               // [B*N][64]
     float *logits, *dlogits;   // [B*N][13]
     float *x0, *ori, *dx0;     // attack state [B*N][9], [B*N][3], [B*N][9]
@@ -1207,6 +1244,7 @@ extern "C" int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n
         ws->g2 = (float *)take(R * 256 * 4);
         ws->g1 = (float *)take(R * 512 * 4);
         ws->g1sum = (float *)take((size_t)batch * 512 * 4);
+        ws->g1part = (float *)take((size_t)batch * ceil_div(n_point, 64) * 512 * 4);
         ws->gfvec = (float *)take((size_t)batch * 1024 * 4);
         ws->gcur = (float *)take(R * GC * 4);
         ws->logits = (float *)take(R * NCLS * 4);
@@ -1595,12 +1633,17 @@ extern "C" int psg_gcn_backward(psg_gcn_model *m, psg_gcn_ws *ws, const float *d
     }
     // fusion half: gradient of the broadcast vector = (s1 * W1a)^T . (column sum of g1), then back through the
     // global max (one point per channel), ReLU/BN of the fusion block and its 1x1 conv: 1024 scaled row adds
-    PSG_CHECK_HIP(hipMemsetAsync(ws->g1sum, 0, (size_t)B * 512 * 4, st));
-    hipLaunchKernelGGL(colsum_kernel, dim3(512 / 64, ceil_div(N, 64), B), dim3(256), 0, st, ws->g1, N, 512, 64, ws->g1sum);
-    PSG_LAUNCH_CHECK();
+    {
+        const int chunks = ceil_div(N, 64);
+        hipLaunchKernelGGL(colsum_kernel, dim3(512 / 64, chunks, B), dim3(256), 0, st, ws->g1, N, 512, 64, ws->g1part);
+        PSG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(B * 512, 256)), dim3(256), 0, st, ws->g1part, chunks, 512, (size_t)B * 512, ws->g1sum);
+        PSG_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(matvec_kernel, dim3(ceil_div(1024, 4), B), dim3(256), 0, st, m->wp1a_st, 512, ws->g1sum, 512, 1024,
                        ws->gfvec);
     PSG_LAUNCH_CHECK();
+    PSG_REQUIRE(F <= 8 * 256, "psg_gcn_backward: fusion_bwd_kernel holds at most 2048 input channels per point (F = %d)", F);
     hipLaunchKernelGGL(fusion_bwd_kernel, dim3(1024, B), dim3(256), 0, st, ws->gfvec, ws->farg, ws->mask_f, m->sf, m->wf, F,
                        1024, N, ws->dfeats);
     PSG_LAUNCH_CHECK();
