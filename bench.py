@@ -869,6 +869,8 @@ def run_msg(args, R):
         prof = wss[0].prof_read()
         wss[0].prof_enable(False)
         result["roofline"] = pn2_roofline(prof, kernel_flops_msg(DB), sa_launches_per_call=2)
+        result["roofline"]["rooms_per_launch"] = DB
+        result["roofline"]["traffic"], result["roofline"]["traffic_source"] = pmc_traffic(result["roofline"]["kernel"], DB, "*_pmc_traffic_msg.json")
         result["kernel_ms_per_attack"] = {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         if want_cpu(args, R):
             rooms, labels_h, starts_h = host[0]
@@ -1185,6 +1187,9 @@ def tarnu_measure(args, R, mode, with_roofline=True):
         prof = ws.prof_read()
         ws.prof_enable(False)
         result["roofline"] = pn2_roofline(prof, kernel_flops(rooms_per_call))
+        result["roofline"]["rooms_per_launch"] = rooms_per_call
+        result["roofline"]["traffic"], result["roofline"]["traffic_source"] = pmc_traffic(result["roofline"]["kernel"], rooms_per_call,
+                                                                                          "*_pmc_traffic_tarnu.json")
         result["kernel_ms_per_attack"] = {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         if want_cpu(args, R):
             from oracle import attacks as oatk

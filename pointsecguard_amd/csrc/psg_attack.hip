@@ -1059,7 +1059,9 @@ extern "C" int psg_pn2_nu_window(const psg_nu_window_args *a, psg_nu_graph *grap
                 "psg_pn2_nu_window: null argument");
     PSG_REQUIRE(a->n_steps > 0 && a->G > 0 && a->rows > 0 && (a->G == 1 || a->rows == 1), "psg_pn2_nu_window: (G, rows) must be (1, B) or (R, 1)");
     hipStream_t st = (hipStream_t)stream;
-    if (!graph || a->n_steps > PSG_NU_GRAPH_MAX_STEPS || psg::trace_sync_enabled()) return nu_window_steps(a, nullptr, stream);
+    // (PSG_NU_NO_GRAPH=1: eager windows, for counter passes - per-dispatch counter rows need per-dispatch launches)
+    static const bool no_graph = psg::env_int("PSG_NU_NO_GRAPH", 0) != 0;
+    if (!graph || no_graph || a->n_steps > PSG_NU_GRAPH_MAX_STEPS || psg::trace_sync_enabled()) return nu_window_steps(a, nullptr, stream);
     // the step-dependent constants of this window (torch.optim.Adam: step_size = lr / (1 - beta1^t), sqrt(1 - beta2^t))
     for (int i = 0; i < a->n_steps; ++i) {
         const int t = a->adam_t0 + i + 1;

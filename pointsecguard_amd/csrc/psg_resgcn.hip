@@ -768,12 +768,28 @@ __global__ void fusion_bwd_kernel(const float *__restrict__ gvec, const int32_t 
     for (int t = threadIdx.x; t < c; t += blockDim.x) earlier |= s_arg[t] == i;
     if (__syncthreads_or(earlier)) return;
     const size_t row = room * N + i;
+    // the point's channels, ascending: wave 0 scans the table 64 channels at a time (ballot order = channel order)
+    __shared__ int s_list[1024];
+    __shared__ int s_n;
+    if (threadIdx.x < 64) {
+        int n = 0;
+        for (int c0 = c & ~63; c0 < Cout; c0 += 64) {
+            const int cc = c0 + (int)threadIdx.x;
+            const bool hit = cc >= c && s_arg[cc] == i;
+            const unsigned long long bl = __ballot(hit);
+            if (hit) s_list[n + __popcll(bl & ((1ull << threadIdx.x) - 1ull))] = cc;
+            n += __popcll(bl);
+        }
+        if (threadIdx.x == 0) s_n = n;
+    }
+    __syncthreads();
+    const int n_list = s_n;
     constexpr int KPT = 8;                                  // input channels per thread: Cin <= 8 * 256
     float acc[KPT];
 #pragma unroll
     for (int u = 0; u < KPT; ++u) acc[u] = 0.0f;
-    for (int cc = c; cc < Cout; ++cc) {
-        if (s_arg[cc] != i) continue;
+    for (int q = 0; q < n_list; ++q) {
+        const int cc = s_list[q];
         const bool act = (mask[row * (Cout / 32) + (cc >> 5)] >> (cc & 31)) & 1u;
         const float g = act ? gvec[room * Cout + cc] * scale[cc] : 0.0f;
         if (g == 0.0f) continue;
