@@ -14,6 +14,7 @@
 //   fp4 1536->256,256   fp3 512->256,256   fp2 352->256,128    fp1 128->128,128,128, same head
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <unordered_set>
 #include <vector>
@@ -221,6 +222,19 @@ struct psg_pn2_ws {
     float *x0, *ori;      // [B][N][9], [B][N][3]
     unsigned long long *dbg;  // diagnostics scratch (diagnostic builds, bit 256), 4 words per workgroup
     int fwd_slot = -1;
+    // hipGraph of a whole NB attack (geometry plan + every iteration) on the workspace's own buffers: the caller's labels,
+    // FPS starts and mask are copied in first, so that the captured kernels' arguments never change between calls
+    int32_t *nb_labels;       // [B][N]
+    int32_t *nb_starts;       // [F][4][B]
+    uint8_t *nb_mask;         // [N]
+    hipGraphExec_t nb_exec = nullptr;
+    struct NbKey { uint64_t model_gen; float eps, alpha; int iters, targeted, target, has_mask, has_labels, pad; } nb_key{};   // (no padding bytes: compared with memcmp)
+    bool nb_have_key = false, nb_capture_failed = false;
+    // the graph is captured and replayed on a non-blocking stream of the workspace, fenced against the caller's stream with two
+    // events: the reference's harness calls from the legacy default stream, which cannot capture
+    hipStream_t nb_stream = nullptr;
+    hipEvent_t nb_ev[2] = {nullptr, nullptr};
+    psg::CaptureCounters cap;
     // optional per-launch HIP-event timing (psg_pn2_prof_enable); off in normal operation
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;   // pairs
@@ -1046,6 +1060,9 @@ size_t ws_layout(psg_pn2_ws *ws, char *base)
     ws->x0 = bp.take<float>((size_t)B * ws->N * 9);
     ws->ori = bp.take<float>((size_t)B * ws->N * 3);
     ws->dbg = bp.take<unsigned long long>(16 * 8 * 1024);
+    ws->nb_labels = bp.take<int32_t>((size_t)B * ws->N);
+    ws->nb_starts = bp.take<int32_t>((size_t)F * 4 * B);
+    ws->nb_mask = bp.take<uint8_t>((size_t)ws->N);
     return (bp.off + 255) & ~(size_t)255;
 }
 
@@ -1199,6 +1216,9 @@ extern "C" int psg_pn2_ws_create(psg_ctx *ctx, int batch, int n_point, int max_f
 extern "C" int psg_pn2_ws_destroy(psg_pn2_ws *ws)
 {
     if (!ws) return PSG_OK;
+    if (ws->nb_exec) (void)hipGraphExecDestroy(ws->nb_exec);
+    for (hipEvent_t e : ws->nb_ev) if (e) (void)hipEventDestroy(e);
+    if (ws->nb_stream) (void)hipStreamDestroy(ws->nb_stream);
     if (ws->arena) (void)hipFree(ws->arena);
     for (hipEvent_t e : ws->prof_ev) (void)hipEventDestroy(e);
     delete ws;
@@ -1412,28 +1432,95 @@ extern "C" int psg_pn2_nb_attack(psg_pn2_model *m, psg_pn2_ws *ws, const float *
     hipStream_t st = (hipStream_t)stream;
     const int B = ws->B, N = ws->N;
     int rc;
+    // ---- inputs into the workspace's own buffers (what the captured graph below reads)
     if ((rc = psg_to_point_major(images, B, 9, N, ws->x0, st))) return rc;
-    hipLaunchKernelGGL(extract_color_kernel, dim3(std::min(1024, ceil_div(B * N * 3, 256))), dim3(256), 0, st, ws->x0,
-                       ws->ori, (size_t)B * N);
-    PSG_LAUNCH_CHECK();
-    if ((rc = psg_pn2_plan_build(ws, ws->x0, starts, iters, st))) return rc;
-    const int rows = B * N;
-    for (int it = 0; it < iters; ++it) {
-        if ((rc = psg_pn2_forward(m, ws, it, ws->x0, ws->logp, nullptr, st))) return rc;
-        // non-targeted: CE_sum over all rooms / N (nontarget.py:34); targeted: CE_mean of room 0 (target.py:36-39)
-        {
-            ProfScope prof(ws, TAG_CE, st);
-            if ((rc = psg_ce_logp_grad(ws->logp, targeted ? nullptr : labels, target, rows, targeted ? N : rows, NCLS,
-                                       1.0f / (float)N, ws->dlogp, nullptr, st)))
-                return rc;
+    if (!targeted) PSG_CHECK_HIP(hipMemcpyAsync(ws->nb_labels, labels, (size_t)B * N * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    PSG_CHECK_HIP(hipMemcpyAsync(ws->nb_starts, starts, (size_t)iters * 4 * B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (mask) PSG_CHECK_HIP(hipMemcpyAsync(ws->nb_mask, mask, (size_t)N, hipMemcpyDeviceToDevice, st));
+    const int32_t *labels_ws = targeted ? nullptr : ws->nb_labels;
+    const uint8_t *mask_ws = mask ? ws->nb_mask : nullptr;
+    // ---- the attack proper: colours aside, geometry of all iterations, iters x (forward, CE gradient, backward, step)
+    auto body = [&](hipStream_t st) -> int {         // (`st`: the caller's stream, or the workspace's graph stream)
+        int r;
+        hipLaunchKernelGGL(extract_color_kernel, dim3(std::min(1024, ceil_div(B * N * 3, 256))), dim3(256), 0, st, ws->x0,
+                           ws->ori, (size_t)B * N);
+        PSG_LAUNCH_CHECK();
+        if ((r = psg_pn2_plan_build(ws, ws->x0, ws->nb_starts, iters, st))) return r;
+        const int rows = B * N;
+        for (int it = 0; it < iters; ++it) {
+            if ((r = psg_pn2_forward(m, ws, it, ws->x0, ws->logp, nullptr, st))) return r;
+            // non-targeted: CE_sum over all rooms / N (nontarget.py:34); targeted: CE_mean of room 0 (target.py:36-39)
+            {
+                ProfScope prof(ws, TAG_CE, st);
+                if ((r = psg_ce_logp_grad(ws->logp, labels_ws, target, rows, targeted ? N : rows, NCLS, 1.0f / (float)N, ws->dlogp,
+                                          nullptr, st)))
+                    return r;
+            }
+            if ((r = backward_impl(m, ws, it, ws->logp, ws->dlogp, ws->dx0, 3, 6, st))) return r;
+            {
+                ProfScope prof(ws, TAG_PGD, st);
+                if ((r = psg_pgd_step(ws->x0, ws->dx0, ws->ori, mask_ws, B, N, alpha, eps, targeted ? -1.0f : 1.0f, it == iters - 1, st)))
+                    return r;
+            }
         }
-        if ((rc = backward_impl(m, ws, it, ws->logp, ws->dlogp, ws->dx0, 3, 6, st))) return rc;
-        {
-            ProfScope prof(ws, TAG_PGD, st);
-            if ((rc = psg_pgd_step(ws->x0, ws->dx0, ws->ori, mask, B, N, alpha, eps, targeted ? -1.0f : 1.0f,
-                                   it == iters - 1, st)))
-                return rc;
+        return PSG_OK;
+    };
+    // Round 5: the body is ~33 launches per iteration + the plan (1 300 for the 40-iteration attack).  A harness that
+    // calls the attack batch after batch (NB_nontarget_test_semseg.py:169-171) repeats exactly these launches with exactly
+    // these arguments, so the second call with a key captures them into a hipGraph kept in the workspace and later calls
+    // replay it (first call eager: it also sets kernel attributes).  Only for batches of at most 16 rooms: there a launch
+    // is a few tens of microseconds of GPU work and the launch path shows; a 64-room launch of bench.py's coalesced line is
+    // GPU-bound, and instantiating a 1 300-node graph inside its few calls would only cost.  PSG_PN2_NO_GRAPH=1, a profiled
+    // workspace, the launch tracer or the legacy stream keep the eager launches; a failed capture is counted, not retried.
+    static const bool use_graph = psg::env_int("PSG_PN2_NO_GRAPH", 0) == 0 && !psg::trace_sync_enabled();
+    if (use_graph && B <= 16 && !ws->prof_on) {
+        const psg_pn2_ws::NbKey key{m->gen, eps, alpha, iters, targeted ? 1 : 0, targeted ? target : 0, mask ? 1 : 0, targeted ? 0 : 1, 0};
+        const bool same = ws->nb_have_key && memcmp(&key, &ws->nb_key, sizeof(key)) == 0;
+        if (same && !ws->nb_capture_failed) {
+            if (!ws->nb_stream) {
+                PSG_CHECK_HIP(hipStreamCreateWithFlags(&ws->nb_stream, hipStreamNonBlocking));
+                for (hipEvent_t &e : ws->nb_ev) PSG_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+            hipStream_t gs = ws->nb_stream;
+            // the graph stream starts after everything the caller's stream holds so far (the copies above included) ..
+            PSG_CHECK_HIP(hipEventRecord(ws->nb_ev[0], st));
+            PSG_CHECK_HIP(hipStreamWaitEvent(gs, ws->nb_ev[0], 0));
+            if (!ws->nb_exec) {
+                bool ok = false;
+                if (hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    const int crc = body(gs);
+                    hipGraph_t gr = nullptr;
+                    const hipError_t e = hipStreamEndCapture(gs, &gr);
+                    ok = crc == PSG_OK && e == hipSuccess && gr && hipGraphInstantiate(&ws->nb_exec, gr, nullptr, nullptr, 0) == hipSuccess;
+                    if (!ok) ws->nb_exec = nullptr;
+                    if (gr) (void)hipGraphDestroy(gr);
+                }
+                (void)hipGetLastError();
+                ws->nb_capture_failed = !ok;
+                psg::capture_note(&ws->cap, 1, ok ? 0 : 1, 0, 0);
+            }
+            if (ws->nb_exec) {
+                PSG_CHECK_HIP(hipGraphLaunch(ws->nb_exec, gs));
+                psg::capture_note(&ws->cap, 0, 0, 1, 0);
+                ws->planned = iters; ws->fwd_slot = iters - 1; ws->x0_fwd = ws->x0;      // (the host-side state the eager body leaves)
+                // .. and the caller's stream goes on after the attack
+                PSG_CHECK_HIP(hipEventRecord(ws->nb_ev[1], gs));
+                PSG_CHECK_HIP(hipStreamWaitEvent(st, ws->nb_ev[1], 0));
+                return psg_to_channel_major(ws->x0, B, 9, N, adv_out, st);
+            }
         }
+        if (!same) {
+            if (ws->nb_exec) {
+                PSG_CHECK_HIP(hipStreamSynchronize(st));
+                (void)hipGraphExecDestroy(ws->nb_exec);
+                ws->nb_exec = nullptr;
+            }
+            ws->nb_key = key;
+            ws->nb_have_key = true;
+            ws->nb_capture_failed = false;
+        }
+        psg::capture_note(&ws->cap, 0, 0, 0, 1);
     }
+    if ((rc = body(st))) return rc;
     return psg_to_channel_major(ws->x0, B, 9, N, adv_out, st);
 }

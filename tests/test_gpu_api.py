@@ -163,3 +163,35 @@ def test_global_max():
         mx, arg = ops.global_max(torch.from_numpy(x).cuda())
         assert np.array_equal(mx.cpu().numpy(), x.max(axis=1))
         assert np.array_equal(arg.cpu().numpy(), x.argmax(axis=1).astype(np.int32))
+
+
+def test_nb_attack_whole_attack_graph_equals_eager(weights_sd):
+    """Round 5: psg_pn2_nb_attack on a batch of at most 16 rooms replays the whole attack (plan + iterations) as a hipGraph from
+    its third call with the same settings on (first call eager, second captured on the workspace's own stream - the harness
+    calls from the legacy default stream, which cannot capture).  Same bits as the eager launches, on the default stream and
+    on a side stream; the bookkeeping counts one capture, no failure."""
+    import torch
+    from pointsecguard_amd import _lib, runtime
+    from pointsecguard_amd.synthetic import make_rooms, rule_labels
+    model = runtime.PN2Model(runtime.fold_state_dict(weights_sd))
+    B, iters = 2, 3
+    rng = np.random.default_rng(5)
+    starts = torch.from_numpy(np.stack([rng.integers(0, n, (iters, B)) for n in (4096, 1024, 256, 64)], axis=1).astype(np.int32)).cuda()
+    rooms = [make_rooms(B, 300 + i) for i in range(4)]
+    imgs = [torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 1))).cuda() for r in rooms]
+    labs = [torch.from_numpy(rule_labels(r).astype(np.int32)).cuda() for r in rooms]
+    before = _lib.capture_stats()
+    ws = runtime.PN2Workspace(B, 4096, iters)
+    outs = [ws.nb_attack(model, imgs[i], labs[i], starts, 0.05, 2 / 255, iters).cpu().numpy() for i in range(4)]   # eager, capture, replay, replay
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        out_side = ws.nb_attack(model, imgs[3], labs[3], starts, 0.05, 2 / 255, iters)
+    side.synchronize()
+    after = _lib.capture_stats()
+    for i in (0, 3):                                                 # a fresh workspace's first call is eager: the reference bits
+        eager_out = runtime.PN2Workspace(B, 4096, iters).nb_attack(model, imgs[i], labs[i], starts, 0.05, 2 / 255, iters).cpu().numpy()
+        assert np.array_equal(outs[i].view(np.uint32), eager_out.view(np.uint32)), i
+        if i == 3:
+            assert np.array_equal(out_side.cpu().numpy().view(np.uint32), eager_out.view(np.uint32))
+    d = {k: after[k] - before[k] for k in after}
+    assert d["captures_tried"] == 1 and d["captures_failed"] == 0 and d["replays"] == 4 and d["eager"] == 1, d
