@@ -1465,14 +1465,16 @@ extern "C" int psg_pn2_nb_attack(psg_pn2_model *m, psg_pn2_ws *ws, const float *
         }
         return PSG_OK;
     };
-    // Round 5: the body is ~33 launches per iteration + the plan (1 300 for the 40-iteration attack).  A harness that
-    // calls the attack batch after batch (NB_nontarget_test_semseg.py:169-171) repeats exactly these launches with exactly
-    // these arguments, so the second call with a key captures them into a hipGraph kept in the workspace and later calls
-    // replay it (first call eager: it also sets kernel attributes).  Only for batches of at most 16 rooms: there a launch
-    // is a few tens of microseconds of GPU work and the launch path shows; a 64-room launch of bench.py's coalesced line is
-    // GPU-bound, and instantiating a 1 300-node graph inside its few calls would only cost.  PSG_PN2_NO_GRAPH=1, a profiled
-    // workspace, the launch tracer or the legacy stream keep the eager launches; a failed capture is counted, not retried.
-    static const bool use_graph = psg::env_int("PSG_PN2_NO_GRAPH", 0) == 0 && !psg::trace_sync_enabled();
+    // Round 5, measured and left OFF (PSG_PN2_GRAPH=1 turns it on): the body is ~33 launches per iteration + the plan (1 300
+    // for the 40-iteration attack), and a harness that calls the attack batch after batch (NB_nontarget_test_semseg.py:169-171)
+    // repeats exactly these launches with exactly these arguments, so the second call with a key can capture them into a
+    // hipGraph kept in the workspace and later calls replay it (same bits: tests/test_gpu_api.py).  On this runtime the replay is
+    // SLOWER than the eager launches it replaces: one 8-room attack at a time 324 -> 307 rooms/s, four in flight 541 -> 386,
+    // the whole-scene harness with three streams 1 141 -> 660 blocks/s (gpurun_out/r5m_*) - a linear
+    // 1 300-node graph is dispatched with a dependency between every pair of nodes and the three graphs in flight no longer
+    // interleave, while the eager launches were never launch-bound here (a launch is 20 - 50 us of GPU work against ~5 us
+    // of host time; the graphs of the ResGCN / RandLA-Net / NU loops replace one-room launches of 5 - 15 us: +23 .. +60 %).
+    static const bool use_graph = psg::env_int("PSG_PN2_GRAPH", 0) != 0 && !psg::trace_sync_enabled();
     if (use_graph && B <= 16 && !ws->prof_on) {
         const psg_pn2_ws::NbKey key{m->gen, eps, alpha, iters, targeted ? 1 : 0, targeted ? target : 0, mask ? 1 : 0, targeted ? 0 : 1, 0};
         const bool same = ws->nb_have_key && memcmp(&key, &ws->nb_key, sizeof(key)) == 0;

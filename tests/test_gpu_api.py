@@ -165,33 +165,48 @@ def test_global_max():
         assert np.array_equal(arg.cpu().numpy(), x.argmax(axis=1).astype(np.int32))
 
 
-def test_nb_attack_whole_attack_graph_equals_eager(weights_sd):
-    """Round 5: psg_pn2_nb_attack on a batch of at most 16 rooms replays the whole attack (plan + iterations) as a hipGraph from
-    its third call with the same settings on (first call eager, second captured on the workspace's own stream - the harness
-    calls from the legacy default stream, which cannot capture).  Same bits as the eager launches, on the default stream and
-    on a side stream; the bookkeeping counts one capture, no failure."""
-    import torch
-    from pointsecguard_amd import _lib, runtime
-    from pointsecguard_amd.synthetic import make_rooms, rule_labels
-    model = runtime.PN2Model(runtime.fold_state_dict(weights_sd))
-    B, iters = 2, 3
-    rng = np.random.default_rng(5)
-    starts = torch.from_numpy(np.stack([rng.integers(0, n, (iters, B)) for n in (4096, 1024, 256, 64)], axis=1).astype(np.int32)).cuda()
-    rooms = [make_rooms(B, 300 + i) for i in range(4)]
-    imgs = [torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 1))).cuda() for r in rooms]
-    labs = [torch.from_numpy(rule_labels(r).astype(np.int32)).cuda() for r in rooms]
-    before = _lib.capture_stats()
-    ws = runtime.PN2Workspace(B, 4096, iters)
-    outs = [ws.nb_attack(model, imgs[i], labs[i], starts, 0.05, 2 / 255, iters).cpu().numpy() for i in range(4)]   # eager, capture, replay, replay
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        out_side = ws.nb_attack(model, imgs[3], labs[3], starts, 0.05, 2 / 255, iters)
-    side.synchronize()
-    after = _lib.capture_stats()
-    for i in (0, 3):                                                 # a fresh workspace's first call is eager: the reference bits
-        eager_out = runtime.PN2Workspace(B, 4096, iters).nb_attack(model, imgs[i], labs[i], starts, 0.05, 2 / 255, iters).cpu().numpy()
-        assert np.array_equal(outs[i].view(np.uint32), eager_out.view(np.uint32)), i
-        if i == 3:
-            assert np.array_equal(out_side.cpu().numpy().view(np.uint32), eager_out.view(np.uint32))
-    d = {k: after[k] - before[k] for k in after}
-    assert d["captures_tried"] == 1 and d["captures_failed"] == 0 and d["replays"] == 4 and d["eager"] == 1, d
+def test_nb_attack_whole_attack_graph_equals_eager():
+    """Round 5 (opt-in, PSG_PN2_GRAPH=1: measured slower than the eager launches): psg_pn2_nb_attack on a
+    batch of at most 16 rooms replays the whole attack (plan + iterations) as a hipGraph from its third call with the same
+    settings on (first call eager, second captured on the workspace's own stream - the harness calls from the legacy default
+    stream, which cannot capture).  Same bits as the eager launches, on the default stream and on a side stream; the
+    bookkeeping counts one capture, no failure.  (The switch is read once per process: a child interpreter.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from pointsecguard_amd import _lib, runtime
+from pointsecguard_amd.synthetic import make_rooms, rule_labels
+sd = dict(np.load(os.path.join(%r, "tests", "golden", "pn2_weights.npz")))
+model = runtime.PN2Model(runtime.fold_state_dict(sd))
+B, iters = 2, 3
+rng = np.random.default_rng(5)
+starts = torch.from_numpy(np.stack([rng.integers(0, n, (iters, B)) for n in (4096, 1024, 256, 64)], axis=1).astype(np.int32)).cuda()
+rooms = [make_rooms(B, 300 + i) for i in range(4)]
+imgs = [torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 1))).cuda() for r in rooms]
+labs = [torch.from_numpy(rule_labels(r).astype(np.int32)).cuda() for r in rooms]
+before = _lib.capture_stats()
+ws = runtime.PN2Workspace(B, 4096, iters)
+outs = [ws.nb_attack(model, imgs[i], labs[i], starts, 0.05, 2 / 255, iters).cpu().numpy() for i in range(4)]   # eager, capture, replay, replay
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    out_side = ws.nb_attack(model, imgs[3], labs[3], starts, 0.05, 2 / 255, iters)
+side.synchronize()
+after = _lib.capture_stats()
+for i in (0, 3):                                                 # a fresh workspace's first call is eager: the reference bits
+    eager_out = runtime.PN2Workspace(B, 4096, iters).nb_attack(model, imgs[i], labs[i], starts, 0.05, 2 / 255, iters).cpu().numpy()
+    assert np.array_equal(outs[i].view(np.uint32), eager_out.view(np.uint32)), i
+    if i == 3:
+        assert np.array_equal(out_side.cpu().numpy().view(np.uint32), eager_out.view(np.uint32))
+d = {k: after[k] - before[k] for k in after}
+assert d["captures_tried"] == 1 and d["captures_failed"] == 0 and d["replays"] == 4 and d["eager"] == 1, d
+print("graph == eager", d)
+""" % (root, root)
+    env = dict(os.environ)
+    env["PSG_PN2_GRAPH"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "graph == eager" in r.stdout, r.stderr[-3000:]
