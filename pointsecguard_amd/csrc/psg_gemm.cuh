@@ -42,6 +42,10 @@ struct GemmArgs {
     // last contributor of a gradient buffer applies the activation's derivative itself instead of a separate pass.
     const uint32_t *post_mask = nullptr;   // [rows][ceil(M/32)] words, or null
     float post_slope = 0.0f;
+    // a second operand of the pre-activation sum: z = (acc + bias) + pre_add[row][c], THEN the activation (RandLA-Net's
+    // residual block: leaky_relu(mlp2(x) + shortcut(y)) without a separate add pass); rows of ld_pre floats, or null
+    const float *pre_add = nullptr;
+    int ld_pre = 0;
 };
 
 // TQ x TI = 32-row x 32-channel MFMA tiles per wave (2 x 2 by default; 1 x 1 gives 64 x 64 workgroup tiles, i.e. four
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
     }
 
     // ---- epilogue: lane (j,h) of tile (i,q) holds channels cbase + 8g + 4h + (0..3) of row rbase + j
-    if (EPI != EPI_KNN_DIST && interior && (a.ld_out & 3) == 0 && (!a.addend || (a.ld_add & 3) == 0)) {
+    if (EPI != EPI_KNN_DIST && interior && (a.ld_out & 3) == 0 && (!a.addend || (a.ld_add & 3) == 0) && (!a.pre_add || (a.ld_pre & 3) == 0)) {
         // interior tiles: the per-channel terms are read once per 32-channel tile as float4 (they were 3 scalar loads per
         // value: the epilogue of the 16 384 x 1792 x 1024 fusion layer cost a tenth of its launch), same operations in
         // the same order as the general path below
@@ -265,12 +269,14 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
                 const unsigned min_bits = a.mask_in ? a.mask_in[(size_t)row * nw + (cbase >> 5)] : 0xFFFFFFFFu;
                 const unsigned post_bits = a.post_mask ? a.post_mask[(size_t)row * nw + (cbase >> 5)] : 0xFFFFFFFFu;
                 const float *gb = a.gbias ? a.gbias + (size_t)(row / a.group_rows) * a.M + cbase + 4 * h : nullptr;
+                const float *pa = (a.pre_add && (a.ld_pre & 3) == 0) ? a.pre_add + (size_t)row * a.ld_pre + cbase + 4 * h : nullptr;
                 float *o = a.out + (size_t)row * a.ld_out + cbase + 4 * h;
                 unsigned mbits = 0;
                 float4 vv[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 g4 = gb ? *(const float4 *)(gb + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 g4 = gb ? *(const float4 *)(gb + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 p4 = pa ? *(const float4 *)(pa + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
                     const float bb[4] = {b4[g].x, b4[g].y, b4[g].z, b4[g].w}, ss[4] = {s4[g].x, s4[g].y, s4[g].z, s4[g].w};
                     const float tt[4] = {t4[g].x, t4[g].y, t4[g].z, t4[g].w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
                     float e[4];
@@ -280,6 +286,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
                         float z = acc[i][q][4 * g + u];
                         if (a.bias) z += bb[u];
                         if (gb) z += gg[u];
+                        if (pa) z += u == 0 ? p4.x : (u == 1 ? p4.y : (u == 2 ? p4.z : p4.w));
                         if (EPI == EPI_RELU_AFFINE) {
                             const bool pos = z > 0.0f;
                             mbits |= (unsigned)pos << cl;
@@ -349,6 +356,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
                 } else {
                     if (a.bias && c < a.M) z += a.bias[c];
                     if (a.gbias && c < a.M && row < a.rows) z += a.gbias[(size_t)(row / a.group_rows) * a.M + c];
+                    if (a.pre_add && c < a.M && row < a.rows) z += a.pre_add[(size_t)row * a.ld_pre + c];
                     if (EPI == EPI_RELU_AFFINE) {
                         const bool pos = z > 0.0f;
                         mbits |= (unsigned)pos << cl;

@@ -163,12 +163,14 @@ __global__ __launch_bounds__(256) void direct_gemm_kernel(GemmArgs a)
         for (int g = 0; g < 4; ++g) {
             const int c = cbase + 8 * g + 4 * h;
             const float4 b4 = (a.bias && c < a.M) ? *(const float4 *)(a.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+            const float4 p4 = (a.pre_add && live && c < a.M) ? *(const float4 *)(a.pre_add + row * a.ld_pre + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
             float e[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float z = acc[t][4 * g + u];
                 if (a.bias) z += bb[u];
+                if (a.pre_add) z += pp[u];
                 if (EPI == EPI_LRELU) {
                     const bool pos = z > 0.0f;
                     mbits |= (unsigned)pos << (8 * g + 4 * h + u);
@@ -214,7 +216,7 @@ thread_local EvLog *tl_prof = nullptr;
 template <int EPI>
 int rl_gemm(const GemmArgs &a, hipStream_t st)
 {
-    const bool skinny = a.M <= 32 && a.K <= 32 && a.rows >= 4096 && !a.addend && !a.gbias && !a.mask_in;
+    const bool skinny = a.M <= 32 && a.K <= 32 && a.rows >= 4096 && !a.addend && !a.gbias && !a.mask_in && !a.pre_add;
     const bool wide = !skinny && a.M <= 64 && a.rows >= 32768;
     const bool small_tile = !skinny && !wide && (size_t)ceil_div(a.rows, 128) * ceil_div(a.M, 128) < RL_SMALL_TILE_BELOW;
     const double bytes = 4.0 * ((double)a.rows * a.K + (double)a.rows * a.M * (a.accumulate ? 2.0 : 1.0) +
@@ -223,15 +225,15 @@ int rl_gemm(const GemmArgs &a, hipStream_t st)
     EvScope prof(tl_prof, skinny ? 3 : (wide ? 2 : (small_tile ? 0 : 1)), 2.0 * a.rows * (double)a.K * a.M, st, bytes);
     // (PSG_RLA_NO_DIRECT=1: the tile / row-per-thread kernels of rounds 1-4, for A/B runs)
     static const bool use_direct = psg::env_int("PSG_RLA_NO_DIRECT", 0) == 0;
-    if (use_direct && (skinny || wide) && a.K <= 128 && ((a.K | a.M | a.ld_in | a.ld_w | a.ld_out) & 3) == 0 && !a.addend && !a.gbias && !a.mask_in &&
-        !a.scale && a.accumulate <= 1) {
+    if (use_direct && (skinny || wide) && a.K <= 128 && ((a.K | a.M | a.ld_in | a.ld_w | a.ld_out | a.ld_pre) & 3) == 0 && !a.addend && !a.gbias &&
+        !a.mask_in && !a.scale && a.accumulate <= 1) {
         const dim3 grid(ceil_div(a.rows, 128));
         if (a.M <= 32) hipLaunchKernelGGL((direct_gemm_kernel<EPI, 1>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((direct_gemm_kernel<EPI, 2>), grid, dim3(256), 0, st, a);
         PSG_LAUNCH_CHECK();
         return PSG_OK;
     }
-    if (a.M <= 32 && a.K <= 32 && a.rows >= 4096 && !a.addend && !a.gbias && !a.mask_in) {
+    if (skinny) {
         hipLaunchKernelGGL(skinny_gemm_kernel<EPI>, dim3(ceil_div(a.rows, 256)), dim3(256), 0, st, a);
         PSG_LAUNCH_CHECK();
         return PSG_OK;
@@ -1482,11 +1484,14 @@ extern "C" int psg_rla_forward(psg_rla_model *m, psg_rla_ws *ws, const float *fe
             PSG_LAUNCH_CHECK();
         }
         if ((rc = conv_fwd(E.att2_mlp, L.agg2, d, L.fagg2, d, n, true, L.m_fagg2, st))) return rc;
-        if ((rc = conv_fwd(E.mlp2, L.fagg2, d, L.m2, 2 * d, n, false, nullptr, st))) return rc;
+        // enc = leaky_relu(mlp2(fagg2) + shortcut(fin)) (dilated_res_block, RandLANet.py:330): the shortcut's rows are the second
+        // operand of mlp2's pre-activation sum (round 5: (acc + bias) + shortcut, the order of the separate add pass it replaces)
         if ((rc = conv_fwd(E.shortcut, fin, L.d_in, L.sc, 2 * d, n, false, nullptr, st))) return rc;
-        hipLaunchKernelGGL(add_lrelu_kernel, dim3(blocks_for((size_t)n * 2 * d)), dim3(256), 0, st, L.m2, L.sc, 2 * d, (size_t)n * 2 * d,
-                           L.enc, L.m_enc);
-        PSG_LAUNCH_CHECK();
+        {
+            GemmArgs g = rl_args(L.fagg2, d, E.mlp2.w, E.mlp2.cin, L.enc, 2 * d, n, E.mlp2.cin, E.mlp2.cout);
+            g.bias = E.mlp2.b; g.mask_out = L.m_enc; g.pre_add = L.sc; g.ld_pre = 2 * d;
+            if ((rc = rl_gemm<EPI_LRELU>(g, st))) return rc;
+        }
         hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(blocks_for((size_t)L.n_sub * 2 * d / 4)), dim3(256), 0, st, L.enc, L.neigh, 2 * d,
                            (size_t)L.n_sub * 2 * d / 4, L.nc_sub, L.nc, L.samp, L.arg);
         PSG_LAUNCH_CHECK();
