@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
     // came from the fabric 2.7 x (396 MB counted per launch against 191 MB algorithmic, profiles/r04_pmc_traffic_gcn.txt).  Now
     // XCD x takes the contiguous row tiles [x R / 8, (x + 1) R / 8) and walks the COLUMN tiles of a row tile back to back: the
     // input tile is fetched once and served to its 8 column tiles from that L2; the weights (7.3 MB) are what every XCD
-    // re-reads.  Same arithmetic; speed moved by < 1 % (the layer is matrix-bound at 0.7 TB/s).
+    // re-reads: 396 -> 317 MB per launch counted.  Same arithmetic; time within 1 % (397 against 401 us on one box: the layer
+    // is matrix-bound at 0.7 TB/s).
     int row0, col0;
     {
         const unsigned nx = gridDim.x, ny = gridDim.y, T = nx * ny, id = blockIdx.y * nx + blockIdx.x;
@@ -77,6 +78,9 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a)
         if ((T & 7u) == 0u) L = (id & 7u) * (T >> 3) + (id >> 3);
         row0 = (int)(L / ny) * BR;
         col0 = (int)(L % ny) * BN;
+#ifdef PSG_GEMM_LEGACY_ORDER      // (A/B builds: tools/build_variant.sh legacy psg_resgcn "-DPSG_GEMM_LEGACY_ORDER")
+        row0 = blockIdx.x * BR; col0 = blockIdx.y * BN;
+#endif
     }
 
     f32x16 acc[TI][TQ];
