@@ -2,7 +2,8 @@
 `batched_index_select` + `max` (ResGCN/gcn_lib/dense/torch_nn.py:82-98, torch_vertex.py:31-35) as a gather through the
 inverse graph.  Checked through the C ABI (psg_edgeconv_bwd leaves [dP | dQ] in its scratch argument) against a numpy
 restatement that sums every destination's in-edges in the kernel's documented order (equal slices of the workgroup's flat
-edge list, pieces added in order) - so the comparison is BIT-exact, and the launch is bit-reproducible."""
+edge list, pieces added in order) - so the comparison is BIT-exact, and the launch is bit-reproducible.  That restatement
+is written in this file (it states the ORDER of the sum); the VALUES are checked against oracle/resgcn.py at the end."""
 import numpy as np
 import pytest
 
@@ -101,3 +102,33 @@ def test_gather_backward_is_exact_and_reproducible(rooms, N, hub, dup):
     assert np.array_equal(dq.view(np.uint32), dq2.view(np.uint32)) and np.array_equal(dp.view(np.uint32), dp2.view(np.uint32))
     # conservation: every active (v, c) gradient lands on exactly one destination
     assert np.allclose(dq.astype(np.float64).sum(0), g.astype(np.float64).sum(0), rtol=1e-4, atol=1e-3)
+
+
+def test_gather_backward_values_vs_oracle():
+    """The same launch against oracle/resgcn.py (round 5; the bit-level test above checks the ORDER against a restatement of the
+    kernel's own order, this one the VALUES against the checker that is pinned to the reference): GCNOracle._edge_conv_bwd -
+    autograd's scatter through `batched_index_select` + `max` (torch_nn.py:82-98, torch_vertex.py:31-35) in float64 - on one
+    1024-vertex room with real weights: dx = dP . (W1 - W2) + dQ . W2 within 1e-5 of the largest magnitude."""
+    import torch
+    from oracle import resgcn
+    from pointsecguard_amd import _lib, runtime
+    N = 1024
+    rng = np.random.default_rng(77)
+    dy, nbr, arg, scale = make_case(rng, N, N)
+    w = (rng.standard_normal((GC, 2 * GC)) * 0.1).astype(np.float32)          # Conv2d(2C -> 64) weight [64][128] = [W1 | W2]
+    orc = object.__new__(resgcn.GCNOracle)
+    orc.edge = [(w, np.zeros(GC, np.float32), scale, np.zeros(GC, np.float32))]
+    slot = (arg & 0x7F).astype(np.int64)
+    act = np.repeat(((arg & 0x80) != 0)[:, None, :], K, axis=1)                # the winner's ReLU bit, whatever slot wins
+    want = orc._edge_conv_bwd({"n": N, "ec": [(slot, act)], "nbr": [nbr]}, 0, dy)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    w1, w2 = w[:, :GC], w[:, GC:]
+    wcat_t = np.concatenate([(w1 - w2), w2], axis=0)                           # [128][C]: rows = [W1 - W2 ; W2] ...
+    wt = d(np.ascontiguousarray(wcat_t.T))                                     # ... transposed to [C][128] (include/psg.h)
+    dpq = torch.empty(N * 128, device="cuda")
+    dx = torch.empty(N, GC, device="cuda")
+    _lib.call("psg_edgeconv_bwd", runtime.ptr(d(dy)), GC, N, N, GC, runtime.ptr(d(nbr.astype(np.int32))), runtime.ptr(d(arg)),
+              runtime.ptr(d(scale)), runtime.ptr(wt), runtime.ptr(dpq), runtime.ptr(dx), GC, runtime.stream())
+    torch.cuda.synchronize()
+    got = dx.cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), (np.abs(got - want).max(), np.abs(want).max())
