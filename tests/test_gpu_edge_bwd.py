@@ -127,8 +127,9 @@ def test_gather_backward_values_vs_oracle():
     wt = d(np.ascontiguousarray(wcat_t.T))                                     # ... transposed to [C][128] (include/psg.h)
     dpq = torch.empty(N * 128, device="cuda")
     dx = torch.empty(N, GC, device="cuda")
-    _lib.call("psg_edgeconv_bwd", runtime.ptr(d(dy)), GC, N, N, GC, runtime.ptr(d(nbr.astype(np.int32))), runtime.ptr(d(arg)),
-              runtime.ptr(d(scale)), runtime.ptr(wt), runtime.ptr(dpq), runtime.ptr(dx), GC, runtime.stream())
+    t_dy, t_nbr, t_arg, t_sc = d(dy), d(nbr.astype(np.int32)), d(arg), d(scale)      # (named: a temporary would be freed before the launch runs)
+    _lib.call("psg_edgeconv_bwd", runtime.ptr(t_dy), GC, N, N, GC, runtime.ptr(t_nbr), runtime.ptr(t_arg), runtime.ptr(t_sc),
+              runtime.ptr(wt), runtime.ptr(dpq), runtime.ptr(dx), GC, runtime.stream())
     torch.cuda.synchronize()
     got = dx.cpu().numpy()
     assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), (np.abs(got - want).max(), np.abs(want).max())
