@@ -99,7 +99,14 @@ __device__ __forceinline__ f32x16 tile_mac4(const float4 *__restrict__ w, int k8
     // w already offset to [mb][0][lane]; bptr = act + (pb*32 + (lane&31))*8 + 4*(lane>>5)
     unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)bptr;
     const float4 *wp = w;
-    int n = (k8n >> 2) - 1;  // pipelined iterations; the last 4 chunks run without re-loads
+    // pipelined iterations; the last 4 chunks run without re-loads.  A wave-uniform count that the k-loop wants in an SGPR - and
+    // that the compiler does not always keep there: behind layer_bwd's per-wave task selection (fp_bwd_kernel<32, 8, 2> with
+    // the FP-split layers) it lands in a VGPR and the build ends in "illegal VGPR to SGPR copy", while
+    // __builtin_amdgcn_readfirstlane is folded away where the value is provably uniform.  So the move is spelled out; the
+    // s_nop covers gfx940+'s one wait state between a VALU write of a VGPR and a v_readfirstlane of it, which the hazard
+    // recognizer does not insert inside inline assembly (without it the count was read stale: a memory fault).
+    int n;
+    asm volatile("s_nop 1\n\tv_readfirstlane_b32 %0, %1" : "=s"(n) : "v"((k8n >> 2) - 1));
     const unsigned long long step = 4096ull;  // 4 chunks x 64 lanes x 16 B
     constexpr int S1 = BLK * 4, S2 = 2 * BLK * 4, S3 = 3 * BLK * 4, S4 = 4 * BLK * 4;
     if (FLIP) {

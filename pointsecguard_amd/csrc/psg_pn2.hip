@@ -148,6 +148,16 @@ bool arch_split_fwd(const ArchDesc &A, int lvl)
     return arch_split(A, lvl) || (l0 && A.id == PSG_PN2_ARCH_SSG && lvl == 0);
 }
 
+// The first layer of FP module `lvl` (0 = fp1 .. 2 = fp3) split across the 3-NN interpolation (psg_pn2_kernels.cuh,
+// fp_layer1_split): its interpolated-part columns run per COARSE point inside the coarser module's kernels, forward and
+// backward.  fp4 stays whole (its coarse side is the 16 points of level 4: nothing to fuse into).  PSG_PN2_FPSPLIT=0 keeps the
+// whole first layers (A/B runs, tests/test_gpu_alt_paths.py); the wave-private fp1 kernels (PSG_FP1_WAVE=1) know no split.
+bool arch_fp_split(const ArchDesc &A, int lvl)
+{
+    static const bool on = psg::env_int("PSG_PN2_FPSPLIT", 1) != 0, wave1 = psg::env_int("PSG_FP1_WAVE", 0) != 0;
+    return on && lvl <= 2 && !(lvl == 0 && wave1);
+}
+
 const ArchDesc &arch_of(int id)
 {
     static const ArchDesc ssg = make_ssg(), msg = make_msg();
@@ -181,6 +191,11 @@ struct psg_pn2_model {
     bool split[4] = {false, false, false, false};        // forward and backward split (levels 1-3)
     bool split_fwd[4] = {false, false, false, false};    // forward split (the above, + level 0 under PSG_PN2_SPLIT=2)
     float *w0f = nullptr, *b0f = nullptr;                 // level 0 forward split: W1f [32][9] row-major, b1 [32]
+    // split FP first layers (arch_fp_split), by FP level: fa = the skip columns [cout x C1] (forward and transposed packing,
+    // the layer's own bias), fb = the interpolated-part columns [cout x C2] (forward packing = one more layer of the COARSER
+    // module's forward, transposed packing = one more layer at the front of its backward; zero bias)
+    PackedLayer fa[3], fb[3];
+    bool fsplit[3] = {false, false, false};
     void *arena = nullptr;
 };
 
@@ -208,6 +223,7 @@ struct psg_pn2_ws {
     const float *x0_fwd = nullptr;   // the input rows of the forward in progress (level 0 forward split)
     float *tfeat[4][2];   // split levels, per scale: [B][N_l][C1] per-point first-layer products of the resident forward
     float *dsum[4];       // dsum[l], l = 0..2, when level l + 1 is split: [B][S_l][C_{l+1}] complete gradient of level l's pooled output
+    float *tfp[3];        // FP level l split: [B][N_{l+1}][cout1_l] = (coarser module's output) . W1b^T of the resident forward
     int planned = 0;
     // activations of one forward
     float *act[7];        // l1..l4, fp4 out (64 pts), fp3 out (256), fp2 out (1024)
@@ -381,6 +397,20 @@ hipError_t allow_big_lds(const void *kern)
 template <typename KernelT, typename ArgsT>
 int launch_lds(psg_pn2_ws *ws, int tag, KernelT kern, dim3 grid, int threads, int blocks8, int blk, const ArgsT &args,
                hipStream_t st)
+{
+    size_t lds = (size_t)blocks8 * blk * sizeof(float);
+    if (lds > 160 * 1024) { set_error("LDS request %zu exceeds 160 KiB", lds); return PSG_ERR_ARG; }
+    if (lds > 48 * 1024) PSG_CHECK_HIP(allow_big_lds((const void *)kern));
+    ProfScope prof(ws, tag, st);
+    hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, args);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
+// (the same, from a launch site of its own: the tracer tells the FP-split kernels from the whole ones, tests/test_gpu_alt_paths.py)
+template <typename KernelT, typename ArgsT>
+int launch_lds_fp_split(psg_pn2_ws *ws, int tag, KernelT kern, dim3 grid, int threads, int blocks8, int blk, const ArgsT &args,
+                        hipStream_t st)
 {
     size_t lds = (size_t)blocks8 * blk * sizeof(float);
     if (lds > 160 * 1024) { set_error("LDS request %zu exceeds 160 KiB", lds); return PSG_ERR_ARG; }
@@ -611,6 +641,7 @@ int run_pw_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, hipSt
     a.layer[0] = fwd_layer(F, false, nullptr);
     a.n_layers = 1;
     a.out = ws->tfeat[lvl][sc]; a.Cout = F.cout; a.logp = nullptr; a.n_cls = 0;
+    a.tsrc = nullptr; a.ldt = 0; a.out2 = nullptr; a.Cout2 = 0; a.extra = FwdLayer{};
     a.diag = 0; a.dbg = ws->dbg;
     if (a.layer[0].mb > NW || N % P) { set_error("run_pw_fwd level %d: unsupported shape", lvl); return PSG_ERR_STATE; }
     const int blocks = layer_blocks(a.layer[0].k8, a.layer[0].mb) + PSG_LDS_SPARE;
@@ -692,6 +723,18 @@ int run_fp_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *logp, hipStream
     for (int i = 0; i < nl; ++i)
         a.layer[i] = fwd_layer(m->L[first + i], true, ws->mask[first + i]);
     a.out = nullptr; a.logp = nullptr; a.Cout = 0; a.n_cls = 0;
+    a.tsrc = nullptr; a.ldt = 0; a.out2 = nullptr; a.Cout2 = 0; a.extra = FwdLayer{};
+    if constexpr (LVL <= 2) if (m->fsplit[LVL]) {
+        // this module's first layer split: its interpolated part arrives as rows of T from the coarser module
+        a.layer[0] = fwd_layer(m->fa[LVL], true, ws->mask[first]);
+        a.layer[0].bias = m->L[first].bias;
+        a.tsrc = ws->tfp[LVL]; a.ldt = m->fa[LVL].cout;
+    }
+    if constexpr (LVL >= 1) if (m->fsplit[LVL - 1]) {
+        // the finer module's first layer split: its interpolated-part product, per point of THIS module
+        a.extra = fwd_layer(m->fb[LVL - 1], false, nullptr);
+        a.out2 = ws->tfp[LVL - 1]; a.Cout2 = m->fb[LVL - 1].cout;
+    }
     if (LVL == 0) {
         a.layer[nl] = fwd_layer(m->L[head], true, ws->mask[head]);
         a.layer[nl + 1] = fwd_layer(m->L[head + 1], false, nullptr);
@@ -720,11 +763,20 @@ int run_fp_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *logp, hipStream
             return PSG_ERR_STATE;
         }
     }
+    if (a.out2) {
+        if (a.extra.mb * (P / 32) > NW || a.extra.k8 * 8 != a.Cout || a.Cout2 % 4) {
+            set_error("run_fp_fwd<%d>: unsupported shape of the finer module's split layer", LVL);
+            return PSG_ERR_STATE;
+        }
+        blocks = std::max(blocks, layer_blocks(a.extra.k8, a.extra.mb));
+    }
+    if (a.tsrc && (a.ldt % 32 || a.C1 % 8)) { set_error("run_fp_fwd<%d>: unsupported shape of the split first layer", LVL); return PSG_ERR_STATE; }
     blocks += PSG_LDS_SPARE;
     if constexpr (LVL == 3) if (big) {
         if (a.C1 % 4 || a.C2 % 4 || (a.C1 % 512) || !a.feat1) { set_error("run_fp_fwd: streamed fp4 wants C1 a multiple of 512"); return PSG_ERR_STATE; }
         return launch_lds(ws, TAG_FP_FWD + LVL, (fp_fwd_kernel<P, NW, true>), dim3(N / P, B), NW * 64, blocks, Lds<P>::BLK, a, st);
     }
+    if (a.tsrc) return launch_lds_fp_split(ws, TAG_FP_FWD + LVL, (fp_fwd_kernel<P, NW, false>), dim3(N / P, B), NW * 64, blocks, Lds<P>::BLK, a, st);
     return launch_lds(ws, TAG_FP_FWD + LVL, (fp_fwd_kernel<P, NW, false>), dim3(N / P, B), NW * 64, blocks, Lds<P>::BLK, a, st);
 }
 
@@ -763,6 +815,7 @@ int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, con
     int nl = 0;
     a.dout = nullptr; a.mask_last = nullptr; a.logp = nullptr; a.dlogp = nullptr;
     a.Cout = 0; a.n_cls = 0; a.mb_last = 0;
+    a.Cg = 0; a.pre = BwdLayer{}; a.split = 0; a.Cd = 0; a.skipT = BwdLayer{};
     if (LVL == 0) {
         a.logp = logp; a.dlogp = dlogp; a.n_cls = NCLS;
         a.layer[nl++] = bwd_layer(m->L[head + 1], ws->mask[head]);          // conv2^T, then bn1/conv1 ReLU mask
@@ -777,13 +830,33 @@ int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, con
         a.mask_last = ws->mask[first + cnt - 1];
         a.Cout = m->L[first + cnt - 1].cout;
         a.mb_last = m->L[first + cnt - 1].mbf();
+        a.Cg = a.Cout;
+        if (m->fsplit[LF]) {    // the finer module wrote its dZ1 rows: W1b^T (and this module's last ReLU mask) after the gather
+            a.pre = bwd_layer(m->fb[LF], a.mask_last);
+            a.Cg = m->fb[LF].cout;
+            if ((a.Cg != 128 && a.Cg != 256) || a.pre.mb != a.mb_last) {
+                set_error("run_fp_bwd<%d>: unsupported shape of the finer module's split layer", LVL);
+                return PSG_ERR_STATE;
+            }
+        }
     }
-    for (int i = cnt - 1; i >= 0; --i)
+    const bool fs = LVL <= 2 && m->fsplit[LVL < 3 ? LVL : 0];
+    for (int i = cnt - 1; i >= (fs ? 1 : 0); --i)
         a.layer[nl++] = bwd_layer(m->L[first + i], i > 0 ? ws->mask[first + i - 1] : nullptr);
     a.n_layers = nl;
+    if (fs) {   // the layers stop at dZ1 (written as this module's interpolated-part rows); the skip columns' transpose follows
+        a.split = 1; a.Cd = m->fb[LVL < 3 ? LVL : 0].cout;
+        if (a.C1) a.skipT = bwd_layer(m->fa[LVL < 3 ? LVL : 0], nullptr);
+        if (a.Cd % 4 || a.C1 % 4) { set_error("run_fp_bwd<%d>: unsupported shape of the split first layer", LVL); return PSG_ERR_STATE; }
+    }
     const bool big = LVL == 3 && A.fp4_big;
     const int maxt = A.fp_maxt_b[LVL];
-    int blocks = a.mb_last * 4;
+    int blocks = std::max(a.mb_last * 4, a.Cg / 8);
+    for (const BwdLayer *x : {&a.pre, &a.skipT}) {
+        if (!x->w) continue;
+        blocks = std::max(blocks, layer_blocks(x->k8, x->mb));
+        if (x->mb * (P / 32) > maxt * NW) { set_error("run_fp_bwd<%d>: more than %d tiles per wave in a split layer", LVL, maxt); return PSG_ERR_STATE; }
+    }
     for (int i = 0; i < nl; ++i) {
         if (big && i == nl - 1) {   // streamed last layer: its input plus a staging area of NW tiles
             blocks = std::max(blocks, a.layer[i].k8 + NW * 4);
@@ -798,10 +871,11 @@ int run_fp_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, con
     blocks += PSG_LDS_SPARE;
     const dim3 grid(N / P, B);
     if constexpr (LVL == 3) if (big) return launch_lds(ws, TAG_FP_BWD + LVL, (fp_bwd_kernel<P, NW, 1, true>), grid, NW * 64, blocks, Lds<P>::BLK, a, st);
-    switch (maxt) {
-    case 1: return launch_lds(ws, TAG_FP_BWD + LVL, (fp_bwd_kernel<P, NW, 1, false>), grid, NW * 64, blocks, Lds<P>::BLK, a, st);
-    case 2: return launch_lds(ws, TAG_FP_BWD + LVL, (fp_bwd_kernel<P, NW, 2, false>), grid, NW * 64, blocks, Lds<P>::BLK, a, st);
-    case 3: return launch_lds(ws, TAG_FP_BWD + LVL, (fp_bwd_kernel<P, NW, 3, false>), grid, NW * 64, blocks, Lds<P>::BLK, a, st);
+    // (fp1 + head: 128-wide layers on 4 waves, one tile per wave; the 8-wave modules have ragged layers)
+    if (maxt == 1) return launch_lds(ws, TAG_FP_BWD + LVL, (fp_bwd_kernel<P, NW, 1, false>), grid, NW * 64, blocks, Lds<P>::BLK, a, st);
+    if constexpr (LVL > 0) {
+        if (maxt == 2) return launch_lds(ws, TAG_FP_BWD + LVL, (fp_bwd_kernel<P, NW, 2, false>), grid, NW * 64, blocks, Lds<P>::BLK, a, st);
+        if (maxt == 3) return launch_lds(ws, TAG_FP_BWD + LVL, (fp_bwd_kernel<P, NW, 3, false>), grid, NW * 64, blocks, Lds<P>::BLK, a, st);
     }
     set_error("run_fp_bwd<%d>: no kernel for MAXT=%d", LVL, maxt);
     return PSG_ERR_STATE;
@@ -1027,8 +1101,10 @@ size_t ws_layout(psg_pn2_ws *ws, char *base)
         if (arch_split(A, l)) ws->dsum[l - 1] = bp.take<float>((size_t)B * ws->Nl[l] * A.C[l]);
     }
     for (int l = 0; l < 4; ++l) {   // interpolated-part gradient rows of FP module l: C2 = its input minus the skip part
-        const int c2 = A.cin[A.fp_first[l]] - (l == 0 ? 0 : A.C[l]);
-        ws->dint[l] = bp.take<float>((size_t)B * ws->Nl[l] * c2);
+        const int c2 = A.cin[A.fp_first[l]] - (l == 0 ? 0 : A.C[l]);      // (a split module writes its dZ1 rows instead)
+        const bool fs = l < 3 && arch_fp_split(A, l);
+        ws->dint[l] = bp.take<float>((size_t)B * ws->Nl[l] * (fs ? A.cout[A.fp_first[l]] : c2));
+        if (l < 3) ws->tfp[l] = fs ? bp.take<float>((size_t)B * ws->Nl[l + 1] * A.cout[A.fp_first[l]]) : nullptr;
     }
     const int actN[7] = {1024, 256, 64, 16, 64, 256, 1024};
     for (int i = 0; i < 4; ++i) ws->actC[i] = A.C[i + 1];
@@ -1122,9 +1198,45 @@ extern "C" int psg_pn2_model_create_arch(psg_ctx *ctx, int arch, const float *co
         if (l == 0) w0raw = wfe;
         total += (sxf[ls].size() + sff[ls].size() + sfb[ls].size() + sfbias[ls].size() + (l == 0 ? wfe.size() : 0)) * 4 + 5 * 256;
     }
+    // split FP first layers (arch_fp_split): reference column order is [points1 (skip, C1), interpolated (C2)]
+    std::vector<float> faf[3], fab[3], fbf[3], fbb[3], fzero[3];
+    for (int l = 0; l < 3; ++l) {
+        m->fsplit[l] = arch_fp_split(A, l);
+        if (!m->fsplit[l]) continue;
+        const int li = A.fp_first[l], cin = A.cin[li], cout = A.cout[li], C1 = l == 0 ? 0 : A.C[l], C2 = cin - C1;
+        std::vector<float> wa((size_t)cout * std::max(C1, 1)), wbm((size_t)cout * C2);
+        for (int o = 0; o < cout; ++o) {
+            for (int c = 0; c < C1; ++c) wa[(size_t)o * C1 + c] = weights[li][(size_t)o * cin + c];
+            for (int c = 0; c < C2; ++c) wbm[(size_t)o * C2 + c] = weights[li][(size_t)o * cin + C1 + c];
+        }
+        if (C1) { faf[l] = pack_fwd(wa.data(), C1, cout, nullptr); fab[l] = pack_bwd(wa.data(), C1, cout, nullptr); }
+        fbf[l] = pack_fwd(wbm.data(), C2, cout, nullptr);
+        fbb[l] = pack_bwd(wbm.data(), C2, cout, nullptr);
+        fzero[l].assign((size_t)ceil_div(cout, 32) * 32, 0.0f);
+        total += (faf[l].size() + fab[l].size() + fbf[l].size() + fbb[l].size() + fzero[l].size()) * 4 + 6 * 256;
+    }
     PSG_CHECK_HIP(hipMalloc(&m->arena, total));
     Bump bp;
     bp.base = (char *)m->arena;
+    for (int l = 0; l < 3; ++l) {
+        if (!m->fsplit[l]) continue;
+        const int li = A.fp_first[l], C1 = l == 0 ? 0 : A.C[l];
+        PackedLayer &Fa = m->fa[l], &Fb = m->fb[l];
+        Fa.cin = C1; Fa.cout = A.cout[li];
+        Fb.cin = A.cin[li] - C1; Fb.cout = A.cout[li];
+        if (C1) {
+            Fa.wf = bp.take<float4>(faf[l].size() / 4);
+            Fa.wb = bp.take<float4>(fab[l].size() / 4);
+            PSG_CHECK_HIP(psg::copy_sync(Fa.wf, faf[l].data(), faf[l].size() * 4, hipMemcpyHostToDevice));
+            PSG_CHECK_HIP(psg::copy_sync(Fa.wb, fab[l].data(), fab[l].size() * 4, hipMemcpyHostToDevice));
+        }
+        Fb.wf = bp.take<float4>(fbf[l].size() / 4);
+        Fb.wb = bp.take<float4>(fbb[l].size() / 4);
+        Fb.bias = bp.take<float>(fzero[l].size());
+        PSG_CHECK_HIP(psg::copy_sync(Fb.wf, fbf[l].data(), fbf[l].size() * 4, hipMemcpyHostToDevice));
+        PSG_CHECK_HIP(psg::copy_sync(Fb.wb, fbb[l].data(), fbb[l].size() * 4, hipMemcpyHostToDevice));
+        PSG_CHECK_HIP(psg::copy_sync(Fb.bias, fzero[l].data(), fzero[l].size() * 4, hipMemcpyHostToDevice));
+    }
     for (int ls = 0; ls < 8; ++ls) {
         const int l = ls >> 1, s = ls & 1;
         if (!m->split_fwd[l] || s >= A.ns) continue;

@@ -84,6 +84,15 @@ struct FpFwdArgs {
     FwdLayer layer[MAX_LAYERS];
     int n_layers;
     int C1, C2, N, S, Cout, n_cls;
+    // FP split (see fp_layer1_split).  Consumer side: tsrc = rows [B][S][ldt] of the interpolated part's first-layer product,
+    // computed per COARSE point by the coarser module; layer[0] then holds the skip columns only (k8 = C1 / 8, possibly 0).
+    const float *tsrc;
+    int ldt;
+    // Producer side: after its own last layer the module runs `extra` (the finer module's interpolated-part columns, no bias,
+    // no ReLU) over its output and writes those rows to out2 [B][N][Cout2]
+    float *out2;
+    int Cout2;
+    FwdLayer extra;
     int diag;               // timing diagnostics only (-DPSG_DIAG_BUILD libraries only): skip sections, results are then wrong
     unsigned long long *dbg; // diag & 256: per-workgroup {memtime, memrealtime} at entry and exit
 };
@@ -93,9 +102,14 @@ struct FpBwdArgs {
     // gather form of dout (deterministic transpose of the finer module's 3-NN interpolation):
     const int32_t *nninv_off;   // [B][N+1] or null
     const int2 *nninv_ent;      // [B][3*n_fine]
-    const float *dint;          // [B][n_fine][Cout] interpolated-part gradient rows written by the finer module
+    const float *dint;          // [B][n_fine][Cg] interpolated-part gradient rows written by the finer module
     int n_fine;
-    float *dint_out;            // [B][N][C2]: this module's interpolated-part gradient rows (plain stores)
+    int Cg;                     // = Cout, or (finer module split) the width of ITS first layer: the rows are its dZ1
+    BwdLayer pre;               // finer module split (pre.w != null): gathered rows -> . W1b(finer)^T, masked by mask_last
+    float *dint_out;            // [B][N][C2]: this module's interpolated-part gradient rows (plain stores); split: its dZ1
+                                // rows [B][N][Cd], written BEFORE the skip columns' transpose `skipT` (C1 > 0) runs
+    int split, Cd;
+    BwdLayer skipT;
     const uint16_t *mask_last;  // ReLU mask of that layer
     const float *logp;          // head mode: [B][N][n_cls]
     const float *dlogp;         // head mode: [B][N][n_cls]
@@ -126,7 +140,7 @@ struct FpBwdArgs {
 template <int P, int NW, int MAXT, int KS>
 __device__ __forceinline__ void sa_layer1_split(const SaFwdArgs &a, int b, int s0, float *__restrict__ buf, size_t wg_linear)
 {
-    constexpr int PB = P / 32, BLK = Lds<P>::BLK;
+    constexpr int PB = P / 32;
     const FwdLayer &L = a.l1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -444,6 +458,59 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
 }
 
 // ------------------------------------------------------------------------------------------ FP fwd
+// FP split (round 5): the 3-NN interpolation is linear, so the interpolated part of a module's first layer commutes with it,
+//     W1 . [f1 ; interp(f2)] = W1a . f1 + interp(W1b . f2),
+// and W1b . f2 is a property of the COARSE point: 4 x fewer points than the module has (1024 / 256 / 64 against 4096 / 1024 / 256
+// for fp1 / fp2 / fp3).  The coarser module computes T = out . W1b^T as one more layer behind its own last one (FpFwdArgs::extra,
+// rows out2); here a point's three rows of T are gathered, weighted, straight into the MFMA ACCUMULATORS of the first layer's
+// tiles (lane (j, h) reads the 4 x 16 bytes of each row that its registers hold - the bytes the interpolation read before), and
+// the layer's matrix work is the skip columns only: none at all for fp1 (128 of its 128 input channels are interpolated: one
+// of the five layers of fp1 + head gone), 64 of 320 for fp2, 128 of 384 for fp3.
+template <int P, int NW>
+__device__ __forceinline__ void fp_layer1_split(const FpFwdArgs &a, int b, int n0, float *__restrict__ buf, size_t wg_linear)
+{
+    constexpr int PB = P / 32, BLK = Lds<P>::BLK;
+    const FwdLayer &L = a.layer[0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int ntask = L.mb * PB;
+    const int task = (wave + (int)(wg_linear & (NW - 1))) & (NW - 1);
+    f32x16 c;
+    if (task < ntask) {
+        const int mb = task / PB, pb = task - mb * PB;
+        const size_t n3 = ((size_t)b * a.N + n0 + pb * 32 + j) * 3;
+        const int i0 = a.nn_idx[n3], i1 = a.nn_idx[n3 + 1], i2 = a.nn_idx[n3 + 2];
+        const float w0 = a.nn_w[n3], w1 = a.nn_w[n3 + 1], w2 = a.nn_w[n3 + 2];
+        const float *tb = a.tsrc + (size_t)b * a.S * a.ldt + mb * 32 + 4 * h;
+        const float4 *r0 = (const float4 *)(tb + __umul24((unsigned)i0, (unsigned)a.ldt));
+        const float4 *r1 = (const float4 *)(tb + __umul24((unsigned)i1, (unsigned)a.ldt));
+        const float4 *r2 = (const float4 *)(tb + __umul24((unsigned)i2, (unsigned)a.ldt));
+        const float4 *bp = (const float4 *)(L.bias + mb * 32 + 4 * h);
+        // accumulator registers 4g .. 4g+3 of lane (j, h) are channels mb*32 + 8g + 4h + (0..3) of point j
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 u0 = r0[2 * g], u1 = r1[2 * g], u2 = r2[2 * g];
+            c[4 * g] = u0.x * w0 + u1.x * w1 + u2.x * w2;
+            c[4 * g + 1] = u0.y * w0 + u1.y * w1 + u2.y * w2;
+            c[4 * g + 2] = u0.z * w0 + u1.z * w1 + u2.z * w2;
+            c[4 * g + 3] = u0.w * w0 + u1.w * w1 + u2.w * w2;
+        }
+        const float4 bq0 = bp[0], bq1 = bp[2], bq2 = bp[4], bq3 = bp[6];
+        if (L.k8) c = tile_mac<BLK, false>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, buf + (pb * 32 + j) * 8 + 4 * h, c);
+        c[0] += bq0.x; c[1] += bq0.y; c[2] += bq0.z; c[3] += bq0.w;
+        c[4] += bq1.x; c[5] += bq1.y; c[6] += bq1.z; c[7] += bq1.w;
+        c[8] += bq2.x; c[9] += bq2.y; c[10] += bq2.z; c[11] += bq2.w;
+        c[12] += bq3.x; c[13] += bq3.y; c[14] += bq3.z; c[15] += bq3.w;
+        const unsigned m = relu_bits(c);
+        if (L.mask) L.mask[(wg_linear * ntask + task) * 64 + lane] = (uint16_t)m;
+    }
+    __syncthreads();
+    if (task < ntask) {
+        const int mb = task / PB, pb = task - mb * PB;
+        store_tile<P>(buf, mb, pb * 32 + j, h, c);
+    }
+}
+
 // BIG: the concatenated input does not fit LDS (MSG fp4: 512 + 1024 channels): the first layer's K is streamed
 // through the buffer in chunks of KC blocks, its accumulators staying in registers across the chunks.
 template <int P, int NW, bool BIG = false>
@@ -539,11 +606,13 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
         const float *f2b = a.feat2 + (size_t)b * a.S * a.C2;
         int i0[JI], i1[JI], i2[JI];
         float w0[JI], w1[JI], w2[JI];
+        if (!a.tsrc) {
 #pragma unroll
-        for (int u = 0; u < JI; ++u) {
-            const int n3 = (rg + u * RG) * 3;
-            i0[u] = nn_i[n3]; i1[u] = nn_i[n3 + 1]; i2[u] = nn_i[n3 + 2];
-            w0[u] = nn_wp[n3]; w1[u] = nn_wp[n3 + 1]; w2[u] = nn_wp[n3 + 2];
+            for (int u = 0; u < JI; ++u) {
+                const int n3 = (rg + u * RG) * 3;
+                i0[u] = nn_i[n3]; i1[u] = nn_i[n3 + 1]; i2[u] = nn_i[n3 + 2];
+                w0[u] = nn_wp[n3]; w1[u] = nn_wp[n3 + 1]; w2[u] = nn_wp[n3 + 2];
+            }
         }
         if (a.feat1) {
 #pragma unroll
@@ -555,6 +624,7 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
         }
 #pragma unroll
         for (int u = 0; u < JI; ++u) {
+            if (a.tsrc) break;          // split first layer: the interpolated part arrives through fp_layer1_split
             const int j = rg + u * RG;
             // (uniform base + 32-bit offset: the loads take the SGPR-base form, no 64-bit vector adds per address)
             const unsigned o0 = __umul24((unsigned)i0[u], (unsigned)a.C2), oa = __umul24((unsigned)i1[u], (unsigned)a.C2),
@@ -575,7 +645,8 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
     float *in = buf0;
     if (PSG_DIAGBIT(a, 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 0] = __builtin_amdgcn_s_memtime();
     for (int l = BIG ? 1 : 0; l < a.n_layers; ++l) {
-        if (!PSG_DIAGBIT(a, 8)) layer_fwd<P, NW, 1>(a.layer[l], in, wg);
+        if (!BIG && l == 0 && a.tsrc) fp_layer1_split<P, NW>(a, b, n0, in, wg);
+        else if (!PSG_DIAGBIT(a, 8)) layer_fwd<P, NW, 1>(a.layer[l], in, wg);
         if (PSG_DIAGBIT(a, 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 1 + 2 * l] = __builtin_amdgcn_s_memtime();
         if (!PSG_DIAGBIT(a, 16)) __syncthreads();
         if (PSG_DIAGBIT(a, 512) && (tid & 63) == 0) a.dbg[(wg * 8 + (tid >> 6)) * 16 + 2 + 2 * l] = __builtin_amdgcn_s_memtime();
@@ -595,6 +666,19 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
                 const int j = t / a.Cout, c = t - j * a.Cout;
                 a.out[((size_t)b * a.N + n0 + j) * a.Cout + c] = in[L::off(c, j)];
             }
+        }
+    }
+    if (a.out2) {
+        // producer side of the finer module's split first layer (fp_layer1_split): T = out . W1b^T, in place over the output
+        // (layer_fwd's barrier sits between the row reads above and its stores)
+        layer_fwd<P, NW, 1>(a.extra, in, wg);
+        __syncthreads();
+        constexpr int RG = NT / 32;
+        const int ql = tid & 31, rg = tid >> 5;
+        float *ob = a.out2 + ((size_t)b * a.N + n0) * a.Cout2;
+        for (int j = rg; j < P; j += RG) {
+            const unsigned o = __umul24((unsigned)j, (unsigned)a.Cout2);
+            for (int q = ql; q < (a.Cout2 >> 2); q += 32) *(float4 *)(ob + (o + 4u * q)) = *(const float4 *)(in + L::off(4 * q, j));
         }
     }
     if (a.logp && !PSG_DIAGBIT(a, 4)) {
@@ -633,7 +717,7 @@ __global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
 // for the longest) but to WAVES by entry count: wave w takes the consecutive rows whose lists start inside the w-th
 // NW-th of the workgroup's entry range, walks their entries in order with all 64 lanes on one gradient row (a coalesced
 // Cout-float read per entry, eight rows in flight) and writes every row it owns exactly once (zeros for an empty list).
-// A wave's share is at most the even share plus one list.  VW = Cout / 64 channels per lane (2 or 4).
+// A wave's share is at most the even share plus one list.  VW = Cg / 64 channels per lane (2 or 4).
 template <int P, int NW, int VW>
 __device__ __forceinline__ void fp_bwd_gather_rows(const FpBwdArgs &a, int b, int n0, float *__restrict__ buf, int lane, int wave)
 {
@@ -649,7 +733,7 @@ __device__ __forceinline__ void fp_bwd_gather_rows(const FpBwdArgs &a, int b, in
     const int r_hi = wave == NW - 1 ? 32 : __popcll(__ballot(lane < 32 && offl - e0 < t_hi));
     if (r_lo >= r_hi) return;
     const int lo = __builtin_amdgcn_readlane(offl, r_lo), hi = __builtin_amdgcn_readlane(offl, r_hi);
-    const float *rows = a.dint + (size_t)b * a.n_fine * a.Cout + lane * VW;
+    const float *rows = a.dint + (size_t)b * a.n_fine * a.Cg + lane * VW;
     float *dst = buf + ((lane * VW) >> 3) * Lds<P>::BLK + ((lane * VW) & 7);    // + 8 * point
     int cur = r_lo, next = __builtin_amdgcn_readlane(offl, r_lo + 1);
     vwf acc = 0.0f;
@@ -663,7 +747,7 @@ __device__ __forceinline__ void fp_bwd_gather_rows(const FpBwdArgs &a, int b, in
             for (int k = 0; k < 8; ++k) {
                 const int fine = __builtin_amdgcn_readlane(pe.x, i + k);
                 w[k] = __int_as_float(__builtin_amdgcn_readlane(pe.y, i + k));
-                v[k] = *(const vwf *)(rows + (size_t)fine * a.Cout);
+                v[k] = *(const vwf *)(rows + (size_t)fine * a.Cg);
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -707,14 +791,19 @@ __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
         const int ntask = a.mb_last * PB;
         // the gathered gradient goes through the activation buffer itself: waves gather whole rows (balanced by entry
         // count), then every lane masks its own tile elements in place
-        const bool staged = P == 32 && a.nninv_off && (a.Cout == 128 || a.Cout == 256);
+        const bool staged = P == 32 && a.nninv_off && (a.Cg == 128 || a.Cg == 256);
         if constexpr (P == 32) {
             if (staged) {
-                if (a.Cout == 128) fp_bwd_gather_rows<P, NW, 2>(a, b, n0, buf0, lane, wave);
+                if (a.Cg == 128) fp_bwd_gather_rows<P, NW, 2>(a, b, n0, buf0, lane, wave);
                 else fp_bwd_gather_rows<P, NW, 4>(a, b, n0, buf0, lane, wave);
                 __syncthreads();
             }
         }
+        // finer module split: the rows gathered are the gradient of T = out . W1b^T (fp_layer1_split), one transposed layer
+        // away from the gradient of this module's output; mask_last is that layer's mask (the host only sets `pre` with a
+        // staged gather)
+        if (a.pre.w) layer_bwd<P, NW, MAXT>(a.pre, buf0, wg);
+        else
         for (int task = wave; task < ntask; task += NW) {
             const int mb = task / PB, pb = task - mb * PB;
             const unsigned m = a.mask_last[(wg * ntask + task) * 64 + lane];
@@ -825,19 +914,26 @@ __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
     // division and a 4-byte LDS read + store per element: ~600 vector instructions per thread in fp2 backward).
     // The coarser module gathers the interpolated part through the inverse 3-NN lists (pointnet_util.py:308: the transpose
     // of index_points + weighted sum, without atomics).
-    {
-        constexpr int RG = NT / 32;
-        const int ql = tid & 31, rg = tid >> 5;
-        float *d1 = a.dfeat1 ? a.dfeat1 + ((size_t)b * a.N + n0) * a.C1 : nullptr;     // sole writer of the skip-link gradient
-        float *d2 = a.dint_out + ((size_t)b * a.N + n0) * a.C2;
-        for (int j = rg; j < P; j += RG) {
-            if (d1) {
-                const unsigned o = __umul24((unsigned)j, (unsigned)a.C1);
-                for (int q = ql; q < (a.C1 >> 2); q += 32) *(float4 *)(d1 + (o + 4u * q)) = *(const float4 *)(in + L::off(4 * q, j));
-            }
-            const unsigned o = __umul24((unsigned)j, (unsigned)a.C2);
-            for (int q = ql; q < (a.C2 >> 2); q += 32) *(float4 *)(d2 + (o + 4u * q)) = *(const float4 *)(in + L::off(a.C1 + 4 * q, j));
-        }
+    // Split first layer (a.split): the layers above stopped at dZ1.  Its rows ARE the interpolated part's gradient as the
+    // coarser module wants it (it applies W1b^T per coarse point after its gather: FpBwdArgs::pre); the skip part is
+    // W1a^T . dZ1, run after those rows have been read.
+    constexpr int RG = NT / 32;
+    const int ql = tid & 31, rg = tid >> 5;
+    const int w2 = a.split ? a.Cd : a.C2, o2 = a.split ? 0 : a.C1;
+    float *d1 = a.dfeat1 ? a.dfeat1 + ((size_t)b * a.N + n0) * a.C1 : nullptr;     // sole writer of the skip-link gradient
+    float *d2 = a.dint_out + ((size_t)b * a.N + n0) * w2;
+    for (int j = rg; j < P; j += RG) {
+        const unsigned o = __umul24((unsigned)j, (unsigned)w2);
+        for (int q = ql; q < (w2 >> 2); q += 32) *(float4 *)(d2 + (o + 4u * q)) = *(const float4 *)(in + L::off(o2 + 4 * q, j));
+    }
+    if (!d1) return;
+    if (a.split) {
+        layer_bwd<P, NW, MAXT>(a.skipT, in, wg);      // (its barrier separates the row reads above from its stores)
+        __syncthreads();
+    }
+    for (int j = rg; j < P; j += RG) {
+        const unsigned o = __umul24((unsigned)j, (unsigned)a.C1);
+        for (int q = ql; q < (a.C1 >> 2); q += 32) *(float4 *)(d1 + (o + 4u * q)) = *(const float4 *)(in + L::off(4 * q, j));
     }
 }
 

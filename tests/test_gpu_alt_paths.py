@@ -7,6 +7,8 @@
   PSG_GCN_PQ_FUSION=1  ResGCN: a block's edge pass also computes the next block's per-vertex [P | Q] product
   PSG_PN2_SPLIT=0    PointNet++ SSG: whole first layers at SA levels 1-3 (rounds 1-4) instead of the split per-point product +
                      per-row xyz chunk (round 5)
+  PSG_PN2_FPSPLIT=0  PointNet++: whole first layers in fp1 - fp3 instead of the interpolated-part product per coarse point inside
+                     the coarser module's kernels (round 5)
   PSG_GCN_EDGE_BWD=atomic  ResGCN: the EdgeConv max-pass backward scatters with float atomics (rounds 1-3) instead of the
                      inverse-graph gather
 
@@ -33,6 +35,7 @@ def child(test_file, keyword, extra_env):
     env.pop("PSG_GCN_EDGE_BWD", None)
     env.pop("PSG_PN2_SPLIT", None)
     env.pop("PSG_RLA_NO_DIRECT", None)
+    env.pop("PSG_PN2_FPSPLIT", None)
     env.update(extra_env)
     env["PSG_TRACE_SYNC"] = "1"
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", test_file), "-x", "-q", "-m", "gpu",
@@ -50,6 +53,9 @@ def child(test_file, keyword, extra_env):
     ("test_gpu_resgcn.py", "forward_backward or nb_attack", "PSG_GCN_EDGE_BWD=atomic"),
     ("test_gpu_parity.py", "forward_vs_reference or backward_vs_reference or forward_backward_vs_oracle_batch or nb_attack_steps_vs_reference",
      "PSG_PN2_SPLIT=0"),
+    ("test_gpu_parity.py", "forward_vs_reference or backward_vs_reference or forward_backward_vs_oracle_batch or nb_attack_steps_vs_reference",
+     "PSG_PN2_FPSPLIT=0"),
+    ("test_gpu_msg.py", "forward_vs_reference or backward_vs_reference", "PSG_PN2_FPSPLIT=0"),
 ])
 def test_switch_selects_other_kernels_with_the_same_parity(test_file, keyword, switch):
     base, base_sites = child(test_file, keyword, {})

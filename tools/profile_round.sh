@@ -4,7 +4,7 @@
 # usage (on the GPU box, from the repo root): tools/profile_round.sh TAG   ->  gpurun_out/prof_TAG/, copy what is to be kept
 set -o pipefail
 TAG=${1:-r05}
-WHAT=${2:-all}     # all | stats | pmc_pn2 | pmc_gcn | pmc_knn | pmc_rla | pmc_tarnu | pmc_msg
+WHAT=${2:-all}     # all | stats | stats_pn2 | pmc_pn2 | pmc_gcn | pmc_knn | pmc_rla | pmc_tarnu | pmc_msg
 export TMPDIR=/tmp
 O=gpurun_out/prof_$TAG
 mkdir -p $O
@@ -15,8 +15,10 @@ stats() {   # name, bench args...
     cp $(find $O/$name -name '*kernel_stats.csv' | head -1) $O/${name}_kernel_stats.csv
     rm -rf $O/$name
 }
-if [ $WHAT = all ] || [ $WHAT = stats ]; then
+if [ $WHAT = all ] || [ $WHAT = stats ] || [ $WHAT = stats_pn2 ]; then
 stats pn2 --steps 16 --warmup 8 --concurrency 1 --no-cpu-baseline --no-reference --no-secondary || exit 1
+fi
+if [ $WHAT = all ] || [ $WHAT = stats ]; then
 stats gcn --workload resgcn --steps 4 --warmup 4 --gcn-concurrency 1 --no-cpu-baseline --no-reference || exit 1
 stats msg --workload pointnet2_msg --steps 16 --warmup 8 --concurrency 1 --no-cpu-baseline || exit 1
 stats tarnu --workload tarnu --steps 2 --warmup 1 --nu-concurrency 1 --no-cpu-baseline || exit 1
