@@ -66,7 +66,8 @@ def kernel_flops(batch):
 
 
 def kernel_flops_executed(batch):
-    """FLOPs the SSG launches EXECUTE since round 5: the first layer of SA levels 2-4 is split (psg_pn2_kernels.cuh, sa_fwd_kernel
+    """FLOPs the SSG launches EXECUTE since round 5 (the shipped defaults: PSG_PN2_SPLIT / PSG_PN2_FPSPLIT unset): the first layer
+    of fp1-fp3 is split across the 3-NN interpolation (see the end of this function), and the first layer of SA levels 2-4 is split (psg_pn2_kernels.cuh, sa_fwd_kernel
     SPLIT) into a per-POINT feature product (pw_fwd / pw_bwd: N_l points, D -> C1) and a per-ROW xyz chunk (3 -> C1); the
     backward applies the first layer's transpose per point as well.  Levels: rows S_l x 32, points N_l = S_{l-1}.
     kernel_flops() stays the ALGORITHMIC count of the reference's layers (what `roofline` and the end-to-end figures use)."""
@@ -80,6 +81,19 @@ def kernel_flops_executed(batch):
         pw += 2.0 * batch * n_pts * (d_in - 3) * c1
     out["pw_fwd"] = pw       # (three launches per forward, one per split level)
     out["pw_bwd"] = pw
+    # FP split (fp_layer1_split): the interpolated-part columns of fp1-fp3's first layer run per COARSE point, as one more
+    # layer of the coarser module (forward: behind its last layer; backward: in front of its first)
+    names = ("fp1_head", "fp2", "fp3", "fp4")
+    skip = (0, 64, 128, 256)                                  # C1: the skip-link channels of fp1..fp4's concatenated input
+    for l in range(4):
+        dims = FP_DIMS[l]
+        m = macs(dims)
+        if l < 3:
+            m -= (dims[0] - skip[l]) * dims[1]                # this module's interpolated part leaves its kernels
+        if l > 0:
+            fine = FP_DIMS[l - 1]
+            m += (fine[0] - skip[l - 1]) * fine[1]            # ... and is the extra layer of the next coarser module
+        out[names[l] + "_fwd"] = out[names[l] + "_bwd"] = 2.0 * batch * FP_ROWS[l] * m
     return out
 
 

@@ -486,14 +486,20 @@ __device__ __forceinline__ void fp_layer1_split(const FpFwdArgs &a, int b, int n
         const float4 *r1 = (const float4 *)(tb + __umul24((unsigned)i1, (unsigned)a.ldt));
         const float4 *r2 = (const float4 *)(tb + __umul24((unsigned)i2, (unsigned)a.ldt));
         const float4 *bp = (const float4 *)(L.bias + mb * 32 + 4 * h);
-        // accumulator registers 4g .. 4g+3 of lane (j, h) are channels mb*32 + 8g + 4h + (0..3) of point j
+        // accumulator registers 4g .. 4g+3 of lane (j, h) are channels mb*32 + 8g + 4h + (0..3) of point j.
+        // Two halves of six row pieces each, fenced, the bias behind them: with all twelve pieces and the bias in flight the
+        // kernel does not fit the 96 VGPRs of five waves per SIMD (see fp_fwd_kernel).
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 u0 = r0[2 * g], u1 = r1[2 * g], u2 = r2[2 * g];
-            c[4 * g] = u0.x * w0 + u1.x * w1 + u2.x * w2;
-            c[4 * g + 1] = u0.y * w0 + u1.y * w1 + u2.y * w2;
-            c[4 * g + 2] = u0.z * w0 + u1.z * w1 + u2.z * w2;
-            c[4 * g + 3] = u0.w * w0 + u1.w * w1 + u2.w * w2;
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int g = 2 * half; g < 2 * half + 2; ++g) {
+                const float4 u0 = r0[2 * g], u1 = r1[2 * g], u2 = r2[2 * g];
+                c[4 * g] = u0.x * w0 + u1.x * w1 + u2.x * w2;
+                c[4 * g + 1] = u0.y * w0 + u1.y * w1 + u2.y * w2;
+                c[4 * g + 2] = u0.z * w0 + u1.z * w1 + u2.z * w2;
+                c[4 * g + 3] = u0.w * w0 + u1.w * w1 + u2.w * w2;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         const float4 bq0 = bp[0], bq1 = bp[2], bq2 = bp[4], bq3 = bp[6];
         if (L.k8) c = tile_mac<BLK, false>(L.w + (size_t)mb * L.k8 * 64 + lane, L.k8, buf + (pb * 32 + j) * 8 + 4 * h, c);
@@ -514,7 +520,9 @@ __device__ __forceinline__ void fp_layer1_split(const FpFwdArgs &a, int b, int n
 // BIG: the concatenated input does not fit LDS (MSG fp4: 512 + 1024 channels): the first layer's K is streamed
 // through the buffer in chunks of KC blocks, its accumulators staying in registers across the chunks.
 template <int P, int NW, bool BIG = false>
-__global__ __launch_bounds__(NW * 64) void fp_fwd_kernel(FpFwdArgs a)
+// (five waves per SIMD = at most 96 VGPRs: the split first layer and the extra layer took the allocator from 88 to 112 registers,
+// i.e. from five resident workgroups per CU to four; with fp_layer1_split's row pieces fenced into two halves it fits 96 unspilled)
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5))) void fp_fwd_kernel(FpFwdArgs a)
 {
     using L = Lds<P>;
     constexpr int NT = NW * 64;
