@@ -363,9 +363,12 @@ def main():
     ap.add_argument("--gcn-coalesce", type=int, default=4,
                     help="resgcn workload: steps fused into one device batch per launch (rooms are independent; the CE "
                          "mean's scale changes by an exact power of two, which sign() ignores)")
-    ap.add_argument("--rla-coalesce", type=int, default=16,
+    ap.add_argument("--rla-coalesce", type=int, default=12,
                     help="randla workload: steps (clouds) fused into one device batch per launch; the clouds stay "
                          "independent (every index stays inside its cloud), one launch of each kernel serves all of them")
+    ap.add_argument("--rla-concurrency", type=int, default=4,
+                    help="randla workload: launches in flight (12 clouds x 4 and 16 x 4 measured 20.1 clouds/s, 16 x 3 19.85, "
+                         "24 x 3 20.0, 24 x 2 18.8: tools/r05_m.sh)")
     ap.add_argument("--concurrency", type=int, default=3,
                     help="device batches in flight per GPU (one HIP stream + workspace each)")
     ap.add_argument("--no-process-group", action="store_true",
@@ -397,7 +400,7 @@ def main():
         # line of its own (value, roofline, cpu_baseline) under "secondary"; `python bench.py --workload NAME` runs one alone
         import copy
         sec = {}
-        for name, steps, warm in (("tarnu", 16, 8), ("resgcn", 24, 8), ("pointnet2_msg", 24, 8), ("randla", 48, 16)):
+        for name, steps, warm in (("tarnu", 16, 8), ("resgcn", 24, 8), ("pointnet2_msg", 24, 8), ("randla", 48, 12)):
             a2 = copy.copy(args)
             a2.workload, a2.steps, a2.warmup, a2.cpu_seconds = name, steps, warm, min(args.cpu_seconds, 6.0)
             t0 = time.time()
@@ -910,7 +913,7 @@ def run_randla(args, R):
     model = network.RandLAModel(params)
     G = max(1, min(args.rla_coalesce, args.steps))                 # clouds per launch
     n_launch, n_warm = -(-args.steps // G), (-(-args.warmup // G) if args.warmup > 0 else 0)
-    conc = max(1, min(args.concurrency, n_launch))
+    conc = max(1, min(args.rla_concurrency, n_launch))
     wss = [network.RandLAWorkspace(n_pts, batch=G) for _ in range(conc)]
     streams = [torch.cuda.Stream() for _ in range(conc)]
     rng = np.random.default_rng(4 + R.rank)

@@ -22,7 +22,7 @@ if [ $WHAT = all ] || [ $WHAT = stats ]; then
 stats gcn --workload resgcn --steps 4 --warmup 4 --gcn-concurrency 1 --no-cpu-baseline --no-reference || exit 1
 stats msg --workload pointnet2_msg --steps 16 --warmup 8 --concurrency 1 --no-cpu-baseline || exit 1
 stats tarnu --workload tarnu --steps 2 --warmup 1 --nu-concurrency 1 --no-cpu-baseline || exit 1
-stats randla --workload randla --steps 16 --warmup 16 --concurrency 1 --no-cpu-baseline --no-reference || exit 1
+stats randla --workload randla --steps 12 --warmup 12 --rla-coalesce 12 --rla-concurrency 1 --no-cpu-baseline --no-reference || exit 1
 fi
 pmc() {     # name, counters (quoted), bench args...
     local name=$1 ctr=$2; shift 2
@@ -50,10 +50,10 @@ pmc gmfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" $GCN || exit
 python3 tools/pmc_mfma.py $O/gmfma $O/pmc_mfma_gcn.json > $O/pmc_mfma_gcn.txt
 fi
 if [ $WHAT = all ] || [ $WHAT = pmc_rla ]; then
-RLA="--workload randla --steps 16 --warmup 0 --concurrency 1 --randla-iters 6 --no-cpu-baseline --no-reference"
+RLA="--workload randla --steps 12 --warmup 0 --rla-coalesce 12 --rla-concurrency 1 --randla-iters 6 --no-cpu-baseline --no-reference"
 pmc rfetch FETCH_SIZE $RLA || exit 1
 pmc rwrite WRITE_SIZE $RLA || exit 1
-python3 tools/pmc_traffic.py $O/rfetch $O/rwrite $O/pmc_traffic_randla.json 16 > $O/pmc_traffic_randla.txt
+python3 tools/pmc_traffic.py $O/rfetch $O/rwrite $O/pmc_traffic_randla.json 12 > $O/pmc_traffic_randla.txt
 fi
 if [ $WHAT = all ] || [ $WHAT = pmc_tarnu ]; then
 # configs[2] in lockstep: two 32-room steps per call = 64 rooms per launch of the network kernels, one call in flight, eager windows
