@@ -521,11 +521,14 @@ extern "C" int psg_fps(psg_ctx *ctx, const float *xyz, int n_clouds, int P, int 
     if (N <= 64) return launch_fps<64, 1>(xyz, n_clouds, P, N, S, start, out_idx, st);
     if (N <= 256) return launch_fps<64, 4>(xyz, n_clouds, P, N, S, start, out_idx, st);
     if (N <= 1024) return launch_fps<256, 4>(xyz, n_clouds, P, N, S, start, out_idx, st);
-    // many problems (a whole attack plan: iterations x rooms): 256 threads x 16 points keeps three problems per CU
-    // resident and needs a 4-wave instead of a 16-wave reduction per step (3.1 -> 2.4 ms for 1280 problems);
-    // few problems: 1024 threads x 4 points minimises the latency of each step
-    if (N <= 4096 && P > 512) return launch_fps<256, 16>(xyz, n_clouds, P, N, S, start, out_idx, st);
-    if (N <= 4096) return launch_fps<1024, 4>(xyz, n_clouds, P, N, S, start, out_idx, st);
+    // many problems (a whole attack plan: iterations x rooms): 256 threads x 16 points keeps three problems per CU resident and
+    // needs a 4-wave instead of a 16-wave reduction per step; few problems: the latency of a step is what counts, and 512 threads
+    // x 8 points has it (tools/fps_cfg_probe.py on MI355X, microseconds per 4096 -> 1024 call, 1024 x 4 / 512 x 8 / 256 x 16:
+    // 1 - 128 problems 690 / 672 / 735, 320 problems 1167 / 1010 / 978, 640: 1733 / 1420 / 1324, 2560: 5254 / 4071 / 3798)
+    static const int cfg = psg::env_int("PSG_FPS_CFG", 0);   // measurement switch: 1 = 1024 x 4, 2 = 512 x 8, 3 = 256 x 16
+    if (N <= 4096 && cfg == 1) return launch_fps<1024, 4>(xyz, n_clouds, P, N, S, start, out_idx, st);
+    if (N <= 4096 && (cfg == 3 || (cfg == 0 && P >= 256))) return launch_fps<256, 16>(xyz, n_clouds, P, N, S, start, out_idx, st);
+    if (N <= 4096) return launch_fps<512, 8>(xyz, n_clouds, P, N, S, start, out_idx, st);
     return launch_fps<1024, 8>(xyz, n_clouds, P, N, S, start, out_idx, st);
 }
 
