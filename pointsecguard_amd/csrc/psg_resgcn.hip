@@ -273,9 +273,17 @@ __global__ void edge_max_fwd_kernel(const float *__restrict__ pq, const int32_t 
     int bk = 0;
     bool bact = false;
     const int32_t *nb = nbr + v * KNB;
-#pragma unroll 4
+    // all sixteen neighbour rows in flight at once (the indices are wave-uniform: one 64-byte scalar-side read), then the
+    // max pass in edge order: the kernel is a chain of L2 round trips, four rounds of four cost twice the time of one of sixteen
+    int nbk[KNB];
+#pragma unroll
+    for (int k = 0; k < KNB; ++k) nbk[k] = nb[k];
+    float q[KNB];
+#pragma unroll
+    for (int k = 0; k < KNB; ++k) q[k] = pq[(room_base + nbk[k]) * 2 * GC + GC + c];
+#pragma unroll
     for (int k = 0; k < KNB; ++k) {
-        const float z = p + pq[(room_base + nb[k]) * 2 * GC + GC + c];
+        const float z = p + q[k];
         const bool act = z > 0.0f;
         const float y = (act ? z : 0.0f) * s + sh;
         if (y > best) { best = y; bk = k; bact = act; }
