@@ -196,6 +196,7 @@ struct psg_pn2_model {
     // module's forward, transposed packing = one more layer at the front of its backward; zero bias)
     PackedLayer fa[3], fb[3];
     bool fsplit[3] = {false, false, false};
+    float *w1feat[2] = {nullptr, nullptr};               // level 0, per scale: the first layer's feature columns as plain rows [C1][9] (sa_l1t_colour)
     void *arena = nullptr;
 };
 
@@ -407,6 +408,20 @@ int launch_lds(psg_pn2_ws *ws, int tag, KernelT kern, dim3 grid, int threads, in
     return PSG_OK;
 }
 
+// (the same, from a launch site of its own: sa1 backward with the colour columns on the vector pipe)
+template <typename KernelT, typename ArgsT>
+int launch_lds_colour(psg_pn2_ws *ws, int tag, KernelT kern, dim3 grid, int threads, int blocks8, int blk, const ArgsT &args,
+                      hipStream_t st)
+{
+    size_t lds = (size_t)blocks8 * blk * sizeof(float);
+    if (lds > 160 * 1024) { set_error("LDS request %zu exceeds 160 KiB", lds); return PSG_ERR_ARG; }
+    if (lds > 48 * 1024) PSG_CHECK_HIP(allow_big_lds((const void *)kern));
+    ProfScope prof(ws, tag, st);
+    hipLaunchKernelGGL(kern, grid, dim3(threads), lds, st, args);
+    PSG_LAUNCH_CHECK();
+    return PSG_OK;
+}
+
 // (the same, from a launch site of its own: the tracer tells the FP-split kernels from the whole ones, tests/test_gpu_alt_paths.py)
 template <typename KernelT, typename ArgsT>
 int launch_lds_fp_split(psg_pn2_ws *ws, int tag, KernelT kern, dim3 grid, int threads, int blocks8, int blk, const ArgsT &args,
@@ -547,11 +562,17 @@ int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, int c
     a.l1t = bwd_layer(L[0], nullptr);
     a.D = D; a.Np = Np; a.S = S; a.C3 = C3;
     a.c_lo = c_lo; a.c_hi = c_hi;
+    // colour-only request at level 0: three of the first layer's columns on the vector pipe (psg_pn2_kernels.cuh: sa_l1t_colour;
+    // PSG_PN2_L1T_COLOUR=0 keeps the transposed layer on the matrix pipe)
+    static const bool l1t_colour = psg::env_int("PSG_PN2_L1T_COLOUR", 1) != 0;
+    a.w1c = nullptr; a.C1 = L[0].cout; a.w1c_off = 0;
+    if (l1t_colour && a.cg_out == 4 && !a.split && P == 32 * NW && (a.C1 == 16 || a.C1 == 32)) a.w1c = m->w1feat[sc];
     const int main_blocks = std::max(std::max(layer_blocks(a.l3t.k8, a.l3t.mb), layer_blocks(a.l2t.k8, a.l2t.mb)),
                                      a.split ? 0 : layer_blocks(a.l1t.k8, a.l1t.mb)) + PSG_LDS_SPARE;
     a.dsrc_blk = main_blocks;   // the gathered pooled-output gradient is staged behind the activation buffer
     const int blk_floats = P * 8 + PSG_LDS_PAD;
-    const int blocks = main_blocks + ceil_div((P / KS) * C3, blk_floats);
+    a.w1c_off = round_up((P / KS) * C3, 4);
+    const int blocks = main_blocks + ceil_div(a.w1c_off + (a.w1c ? 3 * a.C1 : 0), blk_floats);
     if (std::max(std::max(a.l3t.mb, a.l2t.mb), a.split ? 0 : a.l1t.mb) * (P / 32) > d.maxt_b * NW) {
         set_error("run_sa_bwd level %d scale %d: more than %d tiles per wave in a layer", lvl, sc, d.maxt_b);
         return PSG_ERR_STATE;
@@ -560,6 +581,7 @@ int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, int c
     const int tag = TAG_SA_BWD + lvl;
 #define PSG_SA_BWD_CASE(P_, NW_, KS_, MT_) \
     case PSG_CFG_KEY(P_, NW_, KS_, MT_): \
+        if (a.w1c) return launch_lds_colour(ws, tag, (sa_bwd_kernel<P_, NW_, MT_, KS_>), grid, NW_ * 64, blocks, Lds<P_>::BLK, a, st); \
         return launch_lds(ws, tag, (sa_bwd_kernel<P_, NW_, MT_, KS_>), grid, NW_ * 64, blocks, Lds<P_>::BLK, a, st)
     switch (PSG_CFG_KEY(P, NW, KS, d.maxt_b)) {
         PSG_SA_BWD_CASE(128, 4, 32, 1);   // SSG sa1, MSG sa1 scale 1
@@ -1215,9 +1237,21 @@ extern "C" int psg_pn2_model_create_arch(psg_ctx *ctx, int arch, const float *co
         fzero[l].assign((size_t)ceil_div(cout, 32) * 32, 0.0f);
         total += (faf[l].size() + fab[l].size() + fbf[l].size() + fbb[l].size() + fzero[l].size()) * 4 + 6 * 256;
     }
+    std::vector<float> w1f_host[2];
+    for (int sc = 0; sc < A.ns; ++sc) {
+        const int li = A.sc[0][sc].l0, cin = A.cin[li], cout = A.cout[li], D = cin - 3, fo = A.sa_perm ? 3 : 0;
+        w1f_host[sc].resize((size_t)cout * D);
+        for (int o = 0; o < cout; ++o)
+            for (int f = 0; f < D; ++f) w1f_host[sc][(size_t)o * D + f] = weights[li][(size_t)o * cin + fo + f];
+        total += w1f_host[sc].size() * 4 + 256;
+    }
     PSG_CHECK_HIP(hipMalloc(&m->arena, total));
     Bump bp;
     bp.base = (char *)m->arena;
+    for (int sc = 0; sc < A.ns; ++sc) {
+        m->w1feat[sc] = bp.take<float>(w1f_host[sc].size());
+        PSG_CHECK_HIP(psg::copy_sync(m->w1feat[sc], w1f_host[sc].data(), w1f_host[sc].size() * 4, hipMemcpyHostToDevice));
+    }
     for (int l = 0; l < 3; ++l) {
         if (!m->fsplit[l]) continue;
         const int li = A.fp_first[l], C1 = l == 0 ? 0 : A.C[l];

@@ -71,6 +71,10 @@ struct SaBwdArgs {
     int split;            // 1: the rows stored are dZ1 (the first layer's pre-activation gradient, channels [c_lo, c_hi) =
                           // [0, C1)), the first layer's transpose is NOT applied here (pw_bwd_kernel applies it per POINT)
     int dsrc_blk;         // LDS block where the gathered pooled-output gradient is staged
+    // colour-only request at level 0 (the attack loop): the first layer's feature columns, plain rows [C1][D] (w1c; null: the
+    // transposed layer runs on the matrix pipe as everywhere else); the three wanted columns are staged behind dsrc
+    const float *w1c;
+    int C1, w1c_off;      // first layer's width (16 or 32); float offset of the LDS copy from the start of the staging block
     int diag;             // timing diagnostics only (-DPSG_DIAG_BUILD libraries only)
 };
 
@@ -309,6 +313,38 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
 }
 
 // ------------------------------------------------------------------------------------------ SA bwd
+// Level 0 of the attack loop wants THREE of the first layer's twelve input-gradient channels (the colours).  As a transposed
+// MFMA layer that is a 32-row output tile per 32 points, sixteen matrix instructions and a barrier for 3 useful rows, then a
+// pass that picks them out of LDS again.  Here: the lanes of a wave take its 32 grouped rows twice - lane half h sums the
+// channels [h C1 / 2, (h + 1) C1 / 2) of dZ1 against the three colour columns (a 3 x C1 table in LDS, read as broadcasts), the
+// halves are added across the wave and lane half 0 stores the compact {r, g, b, 0} row straight from registers.
+// 3 x C1 MACs per row on the vector pipe instead of 32 x C1 on the matrix pipe (sa1 backward 7.8 -> 6.9 ms per attack).
+template <int P, int NW, int C1>
+__device__ __forceinline__ void sa_l1t_colour(const SaBwdArgs &a, const float *__restrict__ buf0, const float *__restrict__ tab,
+                                              const int32_t *__restrict__ pos, float *__restrict__ orow)
+{
+    using L = Lds<P>;
+    static_assert(P == 32 * NW, "one 32-row tile per wave");
+    constexpr int KH = C1 / 2;                           // channels per lane half: 8 or 16
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rr = lane & 31, h = lane >> 5, j = 32 * wave + rr;
+    const int pj = pos[j];
+    float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
+    const float *t = tab + h * 3 * KH;
+#pragma unroll
+    for (int q = 0; q < KH / 4; ++q) {
+        const int c = h * KH + 4 * q;
+        const float4 z = *(const float4 *)(buf0 + L::off(c, j));
+        const float4 w0 = *(const float4 *)(t + 4 * q), w1 = *(const float4 *)(t + KH + 4 * q), w2 = *(const float4 *)(t + 2 * KH + 4 * q);
+        g0 = fmaf(z.x, w0.x, g0); g0 = fmaf(z.y, w0.y, g0); g0 = fmaf(z.z, w0.z, g0); g0 = fmaf(z.w, w0.w, g0);
+        g1 = fmaf(z.x, w1.x, g1); g1 = fmaf(z.y, w1.y, g1); g1 = fmaf(z.z, w1.z, g1); g1 = fmaf(z.w, w1.w, g1);
+        g2 = fmaf(z.x, w2.x, g2); g2 = fmaf(z.y, w2.y, g2); g2 = fmaf(z.z, w2.z, g2); g2 = fmaf(z.w, w2.w, g2);
+    }
+    // lower channels first: (sum over half 0) + (sum over half 1), the same order in both lanes of a pair
+    const float o0 = __shfl_xor(g0, 32), o1 = __shfl_xor(g1, 32), o2 = __shfl_xor(g2, 32);
+    if (h == 0 && pj >= 0) *(float4 *)(orow + (size_t)pj * 4) = make_float4(g0 + o0, g1 + o1, g2 + o2, 0.0f);   // padding rows are not listed
+}
+
 template <int P, int NW, int MAXT, int KS = 32>
 __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
 {
@@ -341,6 +377,10 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     // dout[s][c] = skip-link gradient (plain rows) + transposed 3-NN interpolation + transposed grouping of the
     // next level, every sum in a fixed order (ascending fine point / grouped row)
     float *dsrc = lds + (size_t)a.dsrc_blk * L::BLK;   // staging block(s) behind the activation buffer
+    if (a.w1c && tid < 3 * a.C1) {   // table [half][column][C1 / 2] of the wanted columns (read after the barriers of the layers below)
+        const int kh = a.C1 >> 1, hh = tid / (3 * kh), r = (tid / kh) % 3, cc = tid % kh;
+        dsrc[a.w1c_off + tid] = a.w1c[(hh * kh + cc) * a.D + a.c_lo + r];
+    }
     for (int t = tid; t < G * a.C3; t += NT) {
         const int g = t / a.C3, c = t - g * a.C3;
         const int cc = a.c_off + c;
@@ -420,6 +460,15 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     if (!PSG_DIAGBIT(a, 16)) __syncthreads();
     if (!PSG_DIAGBIT(a, 8)) layer_bwd<P, NW, MAXT>(a.l2t, buf0, wg);
     if (!PSG_DIAGBIT(a, 16)) __syncthreads();
+    if constexpr (P == 32 * NW) {
+        if (a.w1c) {   // colour-only request at level 0: three columns of the first layer on the vector pipe (sa_l1t_colour)
+            const int32_t *posc = a.gpos_out + (size_t)b * a.S * KS + (size_t)s0 * KS;
+            float *orowc = a.gsa_out + (size_t)b * a.S * KS * 4;
+            if (a.C1 == 32) sa_l1t_colour<P, NW, 32>(a, buf0, dsrc + a.w1c_off, posc, orowc);
+            else sa_l1t_colour<P, NW, 16>(a, buf0, dsrc + a.w1c_off, posc, orowc);
+            return;
+        }
+    }
     if (!a.split) {   // (split: the rows stored below are dZ1 itself; W1f^T is applied per point by pw_bwd_kernel)
         if (!PSG_DIAGBIT(a, 8)) layer_bwd<P, NW, MAXT>(a.l1t, buf0, wg);
         __syncthreads();

@@ -9,6 +9,8 @@
                      per-row xyz chunk (round 5)
   PSG_PN2_FPSPLIT=0  PointNet++: whole first layers in fp1 - fp3 instead of the interpolated-part product per coarse point inside
                      the coarser module's kernels (round 5)
+  PSG_PN2_L1T_COLOUR=0  PointNet++ attack loop: the first SA layer's transpose on the matrix pipe (rounds 1-4) instead of its three
+                     colour columns on the vector pipe (round 5)
   PSG_GCN_EDGE_BWD=atomic  ResGCN: the EdgeConv max-pass backward scatters with float atomics (rounds 1-3) instead of the
                      inverse-graph gather
 
@@ -36,6 +38,7 @@ def child(test_file, keyword, extra_env):
     env.pop("PSG_PN2_SPLIT", None)
     env.pop("PSG_RLA_NO_DIRECT", None)
     env.pop("PSG_PN2_FPSPLIT", None)
+    env.pop("PSG_PN2_L1T_COLOUR", None)
     env.update(extra_env)
     env["PSG_TRACE_SYNC"] = "1"
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", test_file), "-x", "-q", "-m", "gpu",
@@ -56,6 +59,7 @@ def child(test_file, keyword, extra_env):
     ("test_gpu_parity.py", "forward_vs_reference or backward_vs_reference or forward_backward_vs_oracle_batch or nb_attack_steps_vs_reference",
      "PSG_PN2_FPSPLIT=0"),
     ("test_gpu_msg.py", "forward_vs_reference or backward_vs_reference", "PSG_PN2_FPSPLIT=0"),
+    ("test_gpu_parity.py", "nb_attack_steps_vs_reference or tar_nb_attack_steps or nb_b8_steps", "PSG_PN2_L1T_COLOUR=0"),
 ])
 def test_switch_selects_other_kernels_with_the_same_parity(test_file, keyword, switch):
     base, base_sites = child(test_file, keyword, {})
