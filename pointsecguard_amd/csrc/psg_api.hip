@@ -23,6 +23,7 @@ static const EnvSwitch kEnvSwitches[] = {
     {"PSG_GCN_PQ_FUSION", 'p'},    {"PSG_GCN_NO_GRAPH", 'p'},    {"PSG_GCN_EDGE_BWD", 'p'},   {"PSG_BALL_QUERY", 'p'},
     {"PSG_PN2_SPLIT", 'p'},          {"PSG_RLA_NO_DIRECT", 'p'},   {"PSG_NU_NO_GRAPH", 'p'},      {"PSG_PN2_GRAPH", 'p'},
     {"PSG_PN2_FPSPLIT", 'p'},        {"PSG_FPS_CFG", 'p'},         {"PSG_PN2_L1T_COLOUR", 'p'},
+    {"PSG_PN2_PGD_FUSE", 'p'},
 #ifdef PSG_DIAG_BUILD
     {"PSG_DIAG", 'r'},
 #endif

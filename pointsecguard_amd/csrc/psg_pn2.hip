@@ -1092,6 +1092,55 @@ __global__ void dx0_gather_kernel(const int32_t *__restrict__ inv_off, const flo
     }
 }
 
+// The attack loop's last two launches in one: the compact gather above, then the PGD step of the point's three colours -
+// the arithmetic of pgd_step_kernel (psg_attack.hip: sign, step, projection onto the eps ball and [0, 1], the un-projected
+// last step of nontarget.py:36-41), on the sum still in registers; dx0 is neither written nor read.
+struct PgdFuse {
+    float *x;               // [B][N][9]
+    const float *ori;       // [B][N][3]
+    const uint8_t *mask;    // [N] or null
+    float step, eps;        // step = dir * alpha, rounded to fp32 on the host like psg_pgd_step does
+    int last;
+};
+__global__ void dx0_gather_pgd_kernel(const int32_t *__restrict__ inv_off, const float *__restrict__ gsa, int g_rows,
+                                      const int32_t *__restrict__ inv_off2, const float *__restrict__ gsa2, int g_rows2,
+                                      int B, int N, int c_lo, PgdFuse f)
+{
+    const size_t total = (size_t)B * N;
+    for (size_t pq = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pq < total; pq += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(pq / N), q = (int)(pq - (size_t)b * N);
+        if (f.mask && !f.mask[q]) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int list = 0; list < 2; ++list) {
+            const int32_t *offs = list ? inv_off2 : inv_off;
+            if (!offs) break;
+            const float *rows = list ? gsa2 : gsa;
+            const int gr = list ? g_rows2 : g_rows;
+            const int32_t *off = offs + (size_t)b * (N + 1) + q;
+            const int e1 = off[1];
+            for (int e = off[0]; e < e1; e += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = e + u < e1 ? *(const float4 *)(rows + ((size_t)b * gr + e + u) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; }
+            }
+        }
+        const float g[3] = {acc.x, acc.y, acc.z};
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const size_t xi = pq * 9 + c_lo + ch;
+            const float sg = g[ch] > 0.0f ? 1.0f : (g[ch] < 0.0f ? -1.0f : 0.0f);
+            const float stepped = __fadd_rn(f.x[xi], __fmul_rn(f.step, sg));
+            const float o = f.ori[pq * 3 + ch];
+            const float eta = fminf(fmaxf(__fsub_rn(stepped, o), -f.eps), f.eps);
+            const float proj = fminf(fmaxf(__fadd_rn(o, eta), 0.0f), 1.0f);
+            f.x[xi] = f.last ? stepped : proj;
+        }
+    }
+}
+
 size_t ws_layout(psg_pn2_ws *ws, char *base)
 {
     Bump bp;
@@ -1517,7 +1566,7 @@ extern "C" int psg_pn2_forward(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const 
 }
 
 static int backward_impl(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *logp, const float *dlogp,
-                         float *dx0, int c_lo, int c_hi, hipStream_t st)
+                         float *dx0, int c_lo, int c_hi, hipStream_t st, const PgdFuse *pgd = nullptr)
 {
     const ArchDesc &A = *m->arch;
     int rc;
@@ -1542,7 +1591,9 @@ static int backward_impl(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float 
         const int32_t *off2 = A.ns > 1 ? ws->ginv_off[0][1] + po : nullptr;
         const float *gsa2 = A.ns > 1 ? ws->gsa[0][1] : nullptr;
         const int gr = kS[0] * A.sc[0][0].K, gr2 = A.ns > 1 ? kS[0] * A.sc[0][1].K : 0;
-        if (compact)
+        if (compact && pgd)
+            hipLaunchKernelGGL(dx0_gather_pgd_kernel, grid, dim3(256), 0, st, off, ws->gsa[0][0], gr, off2, gsa2, gr2, ws->B, ws->N, c_lo, *pgd);
+        else if (compact)
             hipLaunchKernelGGL(dx0_gather_kernel<true>, grid, dim3(256), 0, st, off, ws->gsa[0][0], gr, off2, gsa2, gr2, ws->B,
                                ws->N, 4, c_lo, c_hi, dx0);
         else
@@ -1602,8 +1653,13 @@ extern "C" int psg_pn2_nb_attack(psg_pn2_model *m, psg_pn2_ws *ws, const float *
                                           nullptr, st)))
                     return r;
             }
-            if ((r = backward_impl(m, ws, it, ws->logp, ws->dlogp, ws->dx0, 3, 6, st))) return r;
-            {
+            // (the PGD step rides on the gradient's last gather: dx0_gather_pgd_kernel; PSG_PN2_PGD_FUSE=0: two launches)
+            static const bool pgd_fuse = psg::env_int("PSG_PN2_PGD_FUSE", 1) != 0;
+            if (pgd_fuse) {
+                const PgdFuse pf{ws->x0, ws->ori, mask_ws, (targeted ? -1.0f : 1.0f) * alpha, eps, it == iters - 1 ? 1 : 0};
+                if ((r = backward_impl(m, ws, it, ws->logp, ws->dlogp, ws->dx0, 3, 6, st, &pf))) return r;
+            } else {
+                if ((r = backward_impl(m, ws, it, ws->logp, ws->dlogp, ws->dx0, 3, 6, st))) return r;
                 ProfScope prof(ws, TAG_PGD, st);
                 if ((r = psg_pgd_step(ws->x0, ws->dx0, ws->ori, mask_ws, B, N, alpha, eps, targeted ? -1.0f : 1.0f, it == iters - 1, st)))
                     return r;

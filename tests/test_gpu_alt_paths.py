@@ -11,6 +11,7 @@
                      the coarser module's kernels (round 5)
   PSG_PN2_L1T_COLOUR=0  PointNet++ attack loop: the first SA layer's transpose on the matrix pipe (rounds 1-4) instead of its three
                      colour columns on the vector pipe (round 5)
+  PSG_PN2_PGD_FUSE=0  PointNet++ attack loop: the PGD step as a launch of its own behind the gradient's last gather (rounds 1-4)
   PSG_GCN_EDGE_BWD=atomic  ResGCN: the EdgeConv max-pass backward scatters with float atomics (rounds 1-3) instead of the
                      inverse-graph gather
 
@@ -39,6 +40,7 @@ def child(test_file, keyword, extra_env):
     env.pop("PSG_RLA_NO_DIRECT", None)
     env.pop("PSG_PN2_FPSPLIT", None)
     env.pop("PSG_PN2_L1T_COLOUR", None)
+    env.pop("PSG_PN2_PGD_FUSE", None)
     env.update(extra_env)
     env["PSG_TRACE_SYNC"] = "1"
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", test_file), "-x", "-q", "-m", "gpu",
@@ -60,6 +62,7 @@ def child(test_file, keyword, extra_env):
      "PSG_PN2_FPSPLIT=0"),
     ("test_gpu_msg.py", "forward_vs_reference or backward_vs_reference", "PSG_PN2_FPSPLIT=0"),
     ("test_gpu_parity.py", "nb_attack_steps_vs_reference or tar_nb_attack_steps or nb_b8_steps", "PSG_PN2_L1T_COLOUR=0"),
+    ("test_gpu_parity.py", "nb_attack_steps_vs_reference or tar_nb_attack_steps or nb_b8_steps", "PSG_PN2_PGD_FUSE=0"),
 ])
 def test_switch_selects_other_kernels_with_the_same_parity(test_file, keyword, switch):
     base, base_sites = child(test_file, keyword, {})
