@@ -983,7 +983,7 @@ static int nu_window_steps(const psg_nu_window_args *a, const float *dconsts_row
                         : psg_nu_f_loss_grad(a->logp, f_labels, f_target, B * N, PSG_PN2_NUM_CLASSES, a->kappa, a->tsign, a->dlogp, a->scal,
                                              a->pred, stream)))
             break;
-        if ((rc = psg_pn2_backward(a->model, a->ws, slot, a->dlogp, a->dx0, stream))) break;
+        if ((rc = psg::pn2_backward_colour(a->model, a->ws, slot, a->dlogp, a->dx0, stream))) break;   // (the Adam step reads the colours only)
         if ((rc = psg_smooth_knn_rooms(a->x0 + 3, 9, (size_t)N * 9, a->ori, 3, (size_t)N * 3, G, N, a->neighbour, a->scal + G, a->sgrad,
                                        a->nn_state, (i > 0 || a->warm_first) ? 1 : 0, stream)))
             break;

@@ -1617,6 +1617,22 @@ extern "C" int psg_pn2_backward(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const
     return backward_impl(m, ws, fwd, ws->logp, dlogp, dx0_out, 0, 9, (hipStream_t)stream);
 }
 
+// The colour channels (3..5) of the input gradient only: what the NU loop's Adam step reads (psg_attack.hip: nu_window_steps).
+// Same launches as psg_pn2_backward except at level 0: compact 16-byte rows, the first layer's three colour columns on the vector
+// pipe, one gather thread per point; dx0_out[.][3..5] are written, the other six channels of a row are left untouched.
+namespace psg {
+int pn2_backward_colour(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *dlogp, float *dx0_out, psg_stream stream)
+{
+    PSG_REQUIRE(m && ws && dlogp && dx0_out, "pn2_backward_colour: null argument");
+    PSG_REQUIRE(m->arch == ws->arch, "pn2_backward_colour: model and workspace were created for different architectures");
+    if (ws->fwd_slot != fwd) {
+        set_error("pn2_backward_colour: forward %d is not the one resident in the workspace (%d)", fwd, ws->fwd_slot);
+        return PSG_ERR_STATE;
+    }
+    return backward_impl(m, ws, fwd, ws->logp, dlogp, dx0_out, 3, 6, (hipStream_t)stream);
+}
+}  // namespace psg
+
 // ====================================================================================== NB attack
 extern "C" int psg_pn2_nb_attack(psg_pn2_model *m, psg_pn2_ws *ws, const float *images, const int32_t *labels,
                                  const int32_t *starts, const uint8_t *mask, float eps, float alpha, int iters,
