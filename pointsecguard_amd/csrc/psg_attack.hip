@@ -977,7 +977,7 @@ static int nu_window_steps(const psg_nu_window_args *a, const float *dconsts_row
         const int f_target = a->use_target ? a->target : 0;
         if ((rc = rooms ? psg_nu_tanh_color_rooms(a->w, a->mask, B, N, a->x0, stream) : psg_nu_tanh_color(a->w, a->mask, B, N, a->x0, stream)))
             break;
-        if ((rc = psg_pn2_forward(a->model, a->ws, slot, a->x0, a->logp, nullptr, stream))) break;
+        if ((rc = psg::pn2_forward_lean(a->model, a->ws, slot, a->x0, a->logp, stream))) break;
         if ((rc = rooms ? psg_nu_f_loss_grad_rooms(a->logp, f_labels, f_target, B, N, PSG_PN2_NUM_CLASSES, a->kappa, a->tsign, a->dlogp,
                                                    a->scal, a->pred, stream)
                         : psg_nu_f_loss_grad(a->logp, f_labels, f_target, B * N, PSG_PN2_NUM_CLASSES, a->kappa, a->tsign, a->dlogp, a->scal,

@@ -67,6 +67,7 @@ void trace_sync_point(const char *file, int line);
 // graph keyed on the address would then replay kernels whose arguments point into the freed arena (advisor, round 4).
 uint64_t next_generation();
 uint64_t pn2_model_generation(const psg_pn2_model *m);
+int pn2_forward_lean(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *x0, float *logp_out, psg_stream stream);
 // psg_pn2_backward for the colour channels of the input gradient only (the NU loop; psg_pn2.hip)
 int pn2_backward_colour(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *dlogp, float *dx0_out, psg_stream stream);
 uint64_t pn2_ws_generation(const psg_pn2_ws *ws);

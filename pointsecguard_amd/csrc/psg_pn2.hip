@@ -253,6 +253,8 @@ struct psg_pn2_ws {
     hipEvent_t nb_ev[2] = {nullptr, nullptr};
     psg::CaptureCounters cap;
     // optional per-launch HIP-event timing (psg_pn2_prof_enable); off in normal operation
+    // attack loops: module outputs nobody reads are not written (fp2 - fp4 under the FP split: the finer module gathers T rows)
+    bool lean = false;
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;   // pairs
     std::vector<int> prof_tag;
@@ -793,6 +795,7 @@ int run_fp_fwd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, float *logp, hipStream
         blocks = std::max(blocks, layer_blocks(a.extra.k8, a.extra.mb));
     }
     if (a.tsrc && (a.ldt % 32 || a.C1 % 8)) { set_error("run_fp_fwd<%d>: unsupported shape of the split first layer", LVL); return PSG_ERR_STATE; }
+    if (ws->lean && a.out2) a.out = nullptr;      // (the only reader of this module's output rows is ws.activation())
     blocks += PSG_LDS_SPARE;
     if constexpr (LVL == 3) if (big) {
         if (a.C1 % 4 || a.C2 % 4 || (a.C1 % 512) || !a.feat1) { set_error("run_fp_fwd: streamed fp4 wants C1 a multiple of 512"); return PSG_ERR_STATE; }
@@ -1621,6 +1624,15 @@ extern "C" int psg_pn2_backward(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const
 // Same launches as psg_pn2_backward except at level 0: compact 16-byte rows, the first layer's three colour columns on the vector
 // pipe, one gather thread per point; dx0_out[.][3..5] are written, the other six channels of a row are left untouched.
 namespace psg {
+// psg_pn2_forward without the module outputs only ws.activation() reads (the NU loop)
+int pn2_forward_lean(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *x0, float *logp_out, psg_stream stream)
+{
+    if (!ws) return psg_pn2_forward(m, ws, fwd, x0, logp_out, nullptr, stream);
+    ws->lean = true;
+    const int rc = psg_pn2_forward(m, ws, fwd, x0, logp_out, nullptr, stream);
+    ws->lean = false;
+    return rc;
+}
 int pn2_backward_colour(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *dlogp, float *dx0_out, psg_stream stream)
 {
     PSG_REQUIRE(m && ws && dlogp && dx0_out, "pn2_backward_colour: null argument");
@@ -1661,7 +1673,10 @@ extern "C" int psg_pn2_nb_attack(psg_pn2_model *m, psg_pn2_ws *ws, const float *
         if ((r = psg_pn2_plan_build(ws, ws->x0, ws->nb_starts, iters, st))) return r;
         const int rows = B * N;
         for (int it = 0; it < iters; ++it) {
-            if ((r = psg_pn2_forward(m, ws, it, ws->x0, ws->logp, nullptr, st))) return r;
+            ws->lean = true;
+            r = psg_pn2_forward(m, ws, it, ws->x0, ws->logp, nullptr, st);
+            ws->lean = false;
+            if (r) return r;
             // non-targeted: CE_sum over all rooms / N (nontarget.py:34); targeted: CE_mean of room 0 (target.py:36-39)
             {
                 ProfScope prof(ws, TAG_CE, st);
