@@ -914,21 +914,32 @@ __global__ __launch_bounds__(NW * 64) void fp_bwd_kernel(FpBwdArgs a)
             }
             store_tile<P>(buf0, mb, pb * 32 + j, h, v);
         }
-    } else if (tid < P) {
-        // log_softmax backward: dz = dlogp - exp(logp) * sum(dlogp)   (pointnet2_sem_seg.py:38)
-        const int j = tid;
-        const size_t n = (size_t)b * a.N + n0 + j;
-        const float *lp = a.logp + n * a.n_cls, *dl = a.dlogp + n * a.n_cls;
-        float s = 0.0f;
-        for (int c = 0; c < a.n_cls; ++c) s += dl[c];
-        float z[16];
+    } else {
+        // log_softmax backward: dz = dlogp - exp(logp) * sum(dlogp)   (pointnet2_sem_seg.py:38).
+        // The workgroup's 32 rows of logp and dlogp are two contiguous runs of 32 x n_cls floats: all threads copy them into
+        // LDS (coalesced), then four lanes per point share the row - the first sums dlogp in class order (the order the sum
+        // always had), each computes the classes q, q + 4, q + 8, q + 12.  (One thread per point walking its two rows in
+        // global memory was a chain of 2 x 13 scattered loads at the head of every workgroup: fp1 backward 10.45 -> 10.1 ms.)
+        float *s_lp = buf0 + (size_t)4 * L::BLK, *s_dl = buf0 + (size_t)6 * L::BLK;     // blocks 4 .. 7: free until the first layer stores
+        const int nrow = P * a.n_cls;
+        const float *lp_g = a.logp + ((size_t)b * a.N + n0) * a.n_cls, *dl_g = a.dlogp + ((size_t)b * a.N + n0) * a.n_cls;
+        for (int i = tid; i < nrow; i += NT) { s_lp[i] = lp_g[i]; s_dl[i] = dl_g[i]; }
+        __syncthreads();
+        for (int t = tid; t < P * 4; t += NT) {
+            const int j = t >> 2, q = t & 3;
+            const float *lp = s_lp + j * a.n_cls, *dl = s_dl + j * a.n_cls;
+            float s = 0.0f;
+            if (q == 0)
+                for (int c = 0; c < a.n_cls; ++c) s += dl[c];
+            s = __shfl(s, (tid & 63) & ~3);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) z[c] = c < a.n_cls ? dl[c] - expf(lp[c]) * s : 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            *(float4 *)(buf0 + L::off(4 * q, j)) = make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
-        for (int blk = 2; blk < a.layer[0].k8; ++blk) {  // K-padding blocks of conv2^T
-            float *zp = buf0 + (size_t)blk * L::BLK + j * 8;
+            for (int i = 0; i < 4; ++i) {
+                const int c = q + 4 * i;
+                buf0[L::off(c, j)] = c < a.n_cls ? dl[c] - expf(lp[c]) * s : 0.0f;
+            }
+        }
+        for (int t = tid; t < P * (a.layer[0].k8 - 2); t += NT) {   // K-padding blocks of conv2^T (none for 13 classes)
+            float *zp = buf0 + (size_t)(2 + t / P) * L::BLK + (t % P) * 8;
             *(float4 *)zp = make_float4(0.f, 0.f, 0.f, 0.f);
             *(float4 *)(zp + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
