@@ -574,7 +574,8 @@ int run_sa_bwd(psg_pn2_model *m, psg_pn2_ws *ws, int lvl, int sc, int fwd, int c
     a.dsrc_blk = main_blocks;   // the gathered pooled-output gradient is staged behind the activation buffer
     const int blk_floats = P * 8 + PSG_LDS_PAD;
     a.w1c_off = round_up((P / KS) * C3, 4);
-    const int blocks = main_blocks + ceil_div(a.w1c_off + (a.w1c ? 3 * a.C1 : 0), blk_floats);
+    a.pos_off = a.w1c_off + (a.w1c ? round_up(3 * a.C1, 4) : 0);
+    const int blocks = main_blocks + ceil_div(a.pos_off + P, blk_floats);
     if (std::max(std::max(a.l3t.mb, a.l2t.mb), a.split ? 0 : a.l1t.mb) * (P / 32) > d.maxt_b * NW) {
         set_error("run_sa_bwd level %d scale %d: more than %d tiles per wave in a layer", lvl, sc, d.maxt_b);
         return PSG_ERR_STATE;

@@ -75,6 +75,7 @@ struct SaBwdArgs {
     // transposed layer runs on the matrix pipe as everywhere else); the three wanted columns are staged behind dsrc
     const float *w1c;
     int C1, w1c_off;      // first layer's width (16 or 32); float offset of the LDS copy from the start of the staging block
+    int pos_off;          // float offset (staging block) of the LDS copy of the workgroup's P output slots
     int diag;             // timing diagnostics only (-DPSG_DIAG_BUILD libraries only)
 };
 
@@ -377,6 +378,10 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     // dout[s][c] = skip-link gradient (plain rows) + transposed 3-NN interpolation + transposed grouping of the
     // next level, every sum in a fixed order (ascending fine point / grouped row)
     float *dsrc = lds + (size_t)a.dsrc_blk * L::BLK;   // staging block(s) behind the activation buffer
+    // the rows' slots in the consumer's lists: read now (one coalesced load), used after the last layer - fetched there they
+    // were a cache-line miss at the tail of every workgroup
+    int32_t *s_pos = (int32_t *)(dsrc + a.pos_off);
+    if (!a.w1c && tid < P) s_pos[tid] = a.gpos_out[(size_t)b * a.S * KS + (size_t)s0 * KS + tid];   // (the colour path reads its one slot per lane itself)
     if (a.w1c && tid < 3 * a.C1) {   // table [half][column][C1 / 2] of the wanted columns (read after the barriers of the layers below)
         const int kh = a.C1 >> 1, hh = tid / (3 * kh), r = (tid / kh) % 3, cc = tid % kh;
         dsrc[a.w1c_off + tid] = a.w1c[(hh * kh + cc) * a.D + a.c_lo + r];
@@ -462,8 +467,8 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     if (!PSG_DIAGBIT(a, 16)) __syncthreads();
     if constexpr (P == 32 * NW) {
         if (a.w1c) {   // colour-only request at level 0: three columns of the first layer on the vector pipe (sa_l1t_colour)
-            const int32_t *posc = a.gpos_out + (size_t)b * a.S * KS + (size_t)s0 * KS;
             float *orowc = a.gsa_out + (size_t)b * a.S * KS * 4;
+            const int32_t *posc = a.gpos_out + (size_t)b * a.S * KS + (size_t)s0 * KS;
             if (a.C1 == 32) sa_l1t_colour<P, NW, 32>(a, buf0, dsrc + a.w1c_off, posc, orowc);
             else sa_l1t_colour<P, NW, 16>(a, buf0, dsrc + a.w1c_off, posc, orowc);
             return;
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(NW * 64) void sa_bwd_kernel(SaBwdArgs a)
     // are stored as plain rows; the consumer (previous level's sa_bwd, or dx0_gather_kernel) sums them through the
     // inverse group lists.  (LDS channel order is [feats, rel_xyz]: LDS channel c is feature channel c.)
     const int nc = a.c_hi - a.c_lo;
-    const int32_t *pos = a.gpos_out + (size_t)b * a.S * KS + (size_t)s0 * KS;
+    const int32_t *pos = s_pos;
     float *orow = a.gsa_out + (size_t)b * a.S * KS * a.cg_out;
     if (a.cg_out == 4) {   // colour-only request of the attack loop: one 16-byte row {c_lo, c_lo+1, c_lo+2, 0} per lane
         for (int j = tid; j < P; j += NT) {
