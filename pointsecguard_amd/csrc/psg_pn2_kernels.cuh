@@ -1087,22 +1087,37 @@ __global__ __launch_bounds__(NW * 64) void pw_bwd_kernel(PwBwdArgs a)
     else if (a.C1 == 128) pw_bwd_gather_rows<P, NW, 2>(a, b, n0, buf0, lane, wave);
     else pw_bwd_gather_rows<P, NW, 4>(a, b, n0, buf0, lane, wave);
     __syncthreads();
+    // the skip-link rows this thread will add at the end: issued now, so the round trip runs under the layer (fetched inside the
+    // store loop below they were a chain of misses at the tail of the workgroup); up to 8 pieces per thread (D <= 512)
+    constexpr int RG = NT / 32, ROWS = P / RG, MAXQ = 4;
+    const int ql = tid & 31, rg = tid >> 5;
+    const float *sb = a.skip ? a.skip + ((size_t)b * a.N + n0) * a.D : nullptr;
+    float4 sk[ROWS][MAXQ];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i) {
+            const int q = ql + 32 * i;
+            sk[r][i] = (sb && q < (a.D >> 2)) ? *(const float4 *)(sb + (__umul24((unsigned)(rg + r * RG), (unsigned)a.D) + 4u * q))
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     layer_bwd<P, NW, MAXT>(a.wt, buf0, wg);
     __syncthreads();
     {
-        constexpr int RG = NT / 32;
-        const int ql = tid & 31, rg = tid >> 5;
         float *ob = a.out + ((size_t)b * a.N + n0) * a.D;
-        const float *sb = a.skip ? a.skip + ((size_t)b * a.N + n0) * a.D : nullptr;
-        for (int j = rg; j < P; j += RG) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int j = rg + r * RG;
             const unsigned o = __umul24((unsigned)j, (unsigned)a.D);
-            for (int q = ql; q < (a.D >> 2); q += 32) {
-                float4 v = *(const float4 *)(buf0 + L::off(4 * q, j));
-                if (sb) {
-                    const float4 s = *(const float4 *)(sb + (o + 4u * q));
+#pragma unroll
+            for (int i = 0; i < MAXQ; ++i) {
+                const int q = ql + 32 * i;
+                if (q < (a.D >> 2)) {
+                    float4 v = *(const float4 *)(buf0 + L::off(4 * q, j));
+                    const float4 s = sk[r][i];
                     v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+                    *(float4 *)(ob + (o + 4u * q)) = v;
                 }
-                *(float4 *)(ob + (o + 4u * q)) = v;
             }
         }
     }
