@@ -62,7 +62,7 @@ def child(test_file, keyword, extra_env):
      "PSG_PN2_FPSPLIT=0"),
     ("test_gpu_msg.py", "forward_vs_reference or backward_vs_reference", "PSG_PN2_FPSPLIT=0"),
     ("test_gpu_parity.py", "nb_attack_steps_vs_reference or tar_nb_attack_steps or nb_b8_steps", "PSG_PN2_L1T_COLOUR=0"),
-    ("test_gpu_parity.py", "nb_attack_steps_vs_reference or tar_nb_attack_steps or nb_b8_steps", "PSG_PN2_PGD_FUSE=0"),
+    ("test_gpu_parity.py", "nb_attack_free_run_vs_reference or nb_b8_statistical_parity", "PSG_PN2_PGD_FUSE=0"),
 ])
 def test_switch_selects_other_kernels_with_the_same_parity(test_file, keyword, switch):
     base, base_sites = child(test_file, keyword, {})
