@@ -79,6 +79,9 @@ def kernel_flops_executed(batch):
         out["sa%d_fwd" % (l + 1)] = 2.0 * batch * SA_ROWS[l] * (3 * c1 + c1 * c2 + c2 * c3)
         out["sa%d_bwd" % (l + 1)] = 2.0 * batch * SA_ROWS[l] * (c1 * c2 + c2 * c3)
         pw += 2.0 * batch * n_pts * (d_in - 3) * c1
+    # level 0 of the attack loop's backward: three colour columns of the first layer (on the vector pipe) instead of twelve
+    d_in, c1, c2, c3 = SA_DIMS[0]
+    out["sa1_bwd"] = 2.0 * batch * SA_ROWS[0] * (3 * c1 + c1 * c2 + c2 * c3)
     out["pw_fwd"] = pw       # (three launches per forward, one per split level)
     out["pw_bwd"] = pw
     # FP split (fp_layer1_split): the interpolated-part columns of fp1-fp3's first layer run per COARSE point, as one more
