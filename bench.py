@@ -357,7 +357,7 @@ def main():
     ap.add_argument("--nu-concurrency", type=int, default=12,
                     help="tarnu workload: attacks in flight, one host thread + HIP stream + model instance each (a one-room "
                          "attack is ~30 short launches per optimiser step: several of them side by side fill the GPU)")
-    ap.add_argument("--gcn-concurrency", type=int, default=3, help="resgcn workload: attacks in flight (streams)")
+    ap.add_argument("--gcn-concurrency", type=int, default=4, help="resgcn workload: attacks in flight (streams; 3 -> 4: 14.75 -> 14.93, tools/r05_o.sh)")
     ap.add_argument("--gcn-block", default="res", choices=["res", "plain", "dense"],
                     help="resgcn workload: backbone block (architecture.py:26-39 of the reference); default = BASELINE's")
     ap.add_argument("--gcn-conv", default="edge", choices=["edge", "mr"], help="resgcn workload: graph convolution")
@@ -1137,7 +1137,8 @@ def tarnu_measure(args, R, mode, with_roofline=True):
     def jobs_of(g):
         return [(g, b, 1) for b in range(len(rooms[g]))] if per_room and not lockstep else [(g, 0, len(rooms[g]))]
     n_jobs_timed = sum(len(jobs_of(g)) for g in range(n_warm_g, len(g_sizes)))
-    conc = max(1, min(args.nu_concurrency if not lockstep else min(args.nu_concurrency, 3), n_jobs_timed))
+    lock_conc = int(os.environ.get("PSG_BENCH_NU_LOCK_CONC", "4"))          # (3 / 4 / 5 calls in flight: 597 / 607 / 594 rooms/s, tools/r05_o.sh)
+    conc = max(1, min(args.nu_concurrency if not lockstep else min(args.nu_concurrency, lock_conc), n_jobs_timed))
     nets, streams = [], [torch.cuda.Stream() for _ in range(conc)]
     for _ in range(conc):
         net = get_model(13)
