@@ -403,7 +403,7 @@ def main():
         # line of its own (value, roofline, cpu_baseline) under "secondary"; `python bench.py --workload NAME` runs one alone
         import copy
         sec = {}
-        for name, steps, warm in (("tarnu", 16, 8), ("resgcn", 32, 8), ("pointnet2_msg", 24, 8), ("randla", 48, 12)):
+        for name, steps, warm in (("tarnu", 16, 8), ("resgcn", 32, 16), ("pointnet2_msg", 24, 8), ("randla", 48, 12)):
             a2 = copy.copy(args)
             a2.workload, a2.steps, a2.warmup, a2.cpu_seconds = name, steps, warm, min(args.cpu_seconds, 6.0)
             t0 = time.time()
