@@ -273,13 +273,17 @@ __global__ __launch_bounds__(NW * 64) void sa_fwd_kernel(SaFwdArgs a)
         acc = tile_mac<L::BLK, true>(a.w3 + (size_t)nb * a.k8_3 * 64 + lane, a.k8_3, buf0 + (g * 32 + jj) * 8 + 4 * h,
                                      acc);
         if (KS == 32) {
-            float best = -1.0f;
-            int bidx = 0;
+            // max(relu(x)) = relu(max(x)): the raw maximum first (v_max3: 8 instructions for 16 values), then the lowest row
+            // that holds it (descending scan: the last match written is the lowest), the ReLU once at the end - the values and
+            // arg bytes of the per-element compare / select chain (80 instructions), in about half of them
+            float best = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[r] > 0.0f ? acc[r] : 0.0f;
-                if (v > best) { best = v; bidx = acc_row(r, h); }
-            }
+            for (int r = 3; r < 15; r += 2) best = fmaxf(fmaxf(best, acc[r]), acc[r + 1]);
+            best = fmaxf(best, acc[15]);
+            int bidx = acc_row(15, h);
+#pragma unroll
+            for (int r = 14; r >= 0; --r) bidx = acc[r] == best ? acc_row(r, h) : bidx;
+            best = best > 0.0f ? best : 0.0f;                 // (+0 for a non-positive maximum, as the element-wise ReLU gave)
             float ob = __shfl_xor(best, 32);
             int oi = __shfl_xor(bidx, 32);
             if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
