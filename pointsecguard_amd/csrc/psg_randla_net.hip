@@ -642,52 +642,52 @@ __global__ void att_pool_split_fwd_kernel(const float *__restrict__ f, const int
 // (4 channels per thread had to read cat twice or drop to one wave per SIMD).
 // Round 5: the attention weights are RECOMPUTED here from T[neigh] + S2 - the forward's operations in the forward's order, so
 // the same bits - instead of being written per edge by the forward ([E][d] floats, 40 % of its HBM traffic) and read back.
-__global__ void att_pool_split_bwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh, const float *__restrict__ fxyz,
+__global__ __launch_bounds__(256) void att_pool_split_bwd_kernel(const float *__restrict__ f, const int32_t *__restrict__ neigh, const float *__restrict__ fxyz,
                                           const float *__restrict__ T, const float *__restrict__ S2, const float *__restrict__ dagg, int h,
-                                          size_t total2, float *__restrict__ ds, float *__restrict__ ddir)
+                                          size_t total, float *__restrict__ ds, float *__restrict__ ddir)
 {
+    // one thread per (point, channel): half the registers of the channel-pair version (116 -> about 70: seven waves per SIMD
+    // instead of four for a kernel that waits on gathered rows), 256-byte instead of 512-byte wave accesses
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total2) return;
-    const int d = 2 * h, d2 = d >> 1;
-    const size_t n = t / d2;
-    const int c = (int)(t - n * d2) * 2;
-    const float2 g0 = ((const float2 *)dagg)[t];
-    float2 av[RK], gv[RK];
+    if (t >= total) return;
+    const int d = 2 * h;
+    const size_t n = t / d;
+    const int c = (int)(t - n * d);
+    const float g0 = dagg[t];
+    float av[RK], gv[RK];
     int nb[RK];
 #pragma unroll
     for (int k = 0; k < RK; ++k) nb[k] = neigh[n * RK + k];
     {
-        float2 m = make_float2(-INFINITY, -INFINITY);
+        float m = -INFINITY;
 #pragma unroll
         for (int k = 0; k < RK; ++k) {
-            const float2 tt = *(const float2 *)(T + (size_t)nb[k] * d + c);
-            const float2 s2 = *(const float2 *)(S2 + (n * RK + k) * d + c);
-            av[k] = make_float2(tt.x + s2.x, tt.y + s2.y);
-            m.x = fmaxf(m.x, av[k].x); m.y = fmaxf(m.y, av[k].y);
+            av[k] = T[(size_t)nb[k] * d + c] + S2[(n * RK + k) * d + c];
+            m = fmaxf(m, av[k]);
         }
-        float2 sum = make_float2(0.f, 0.f);
+        float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < RK; ++k) {
-            av[k].x = expf(av[k].x - m.x); av[k].y = expf(av[k].y - m.y);
-            sum.x += av[k].x; sum.y += av[k].y;
+            av[k] = expf(av[k] - m);
+            sum += av[k];
         }
-        const float2 inv = make_float2(1.0f / sum.x, 1.0f / sum.y);
+        const float inv = 1.0f / sum;
 #pragma unroll
-        for (int k = 0; k < RK; ++k) av[k] = make_float2(av[k].x * inv.x, av[k].y * inv.y);
+        for (int k = 0; k < RK; ++k) av[k] *= inv;
     }
-    float2 dot = make_float2(0.f, 0.f);
+    float dot = 0.f;
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
         const size_t e = n * RK + k;
-        const float2 x = c < h ? *(const float2 *)(f + (size_t)nb[k] * h + c) : *(const float2 *)(fxyz + e * h + (c - h));
-        gv[k] = make_float2(x.x * g0.x, x.y * g0.y);
-        dot.x += av[k].x * gv[k].x; dot.y += av[k].y * gv[k].y;
+        const float x = c < h ? f[(size_t)nb[k] * h + c] : fxyz[e * h + (c - h)];
+        gv[k] = x * g0;
+        dot += av[k] * gv[k];
     }
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
         const size_t e = n * RK + k;
-        *(float2 *)(ds + e * d + c) = make_float2(av[k].x * (gv[k].x - dot.x), av[k].y * (gv[k].y - dot.y));
-        if (c < h) *(float2 *)(ddir + e * h + c) = make_float2(av[k].x * g0.x, av[k].y * g0.y);
+        ds[e * d + c] = av[k] * (gv[k] - dot);
+        if (c < h) ddir[e * h + c] = av[k] * g0;
     }
 }
 
@@ -1596,8 +1596,8 @@ extern "C" int psg_rla_backward(psg_rla_model *m, psg_rla_ws *ws, const float *d
             {
                 const double ne_ = 16.0 * n;
                 EvScope prof(tl_prof, 5, 0.0, st, 4.0 * ((double)n * (h + d) + ne_ * (1.0 + 2.0 * d + 2.0 * h)));
-                hipLaunchKernelGGL(att_pool_split_bwd_kernel, dim3(blocks_for((size_t)n * d / 2)), dim3(256), 0, st, fin_, L.neigh, fxyz_, T_, S2_, dagg_,
-                                   h, (size_t)n * d / 2, ds, ddir);
+                hipLaunchKernelGGL(att_pool_split_bwd_kernel, dim3(blocks_for((size_t)n * d)), dim3(256), 0, st, fin_, L.neigh, fxyz_, T_, S2_, dagg_,
+                                   h, (size_t)n * d, ds, ddir);
             }
             PSG_LAUNCH_CHECK();
             hipLaunchKernelGGL(gather_inv_kernel<true>, dim3(blocks_for((size_t)n * d)), dim3(256), 0, st, ds, d, d, L.inv_off, L.inv_ent,
