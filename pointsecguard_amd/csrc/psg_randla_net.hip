@@ -607,7 +607,10 @@ __global__ void att_pool_split_fwd_kernel(const float *__restrict__ f, const int
     const int c = (int)(t - n * d2) * 2;
     int nb[RK];
 #pragma unroll
-    for (int k = 0; k < RK; ++k) nb[k] = neigh[n * RK + k];
+    for (int k = 0; k < RK; k += 4) {     // (the row of 16 indices as four 16-byte loads)
+        const int4 q = *(const int4 *)(neigh + n * RK + k);
+        nb[k] = q.x; nb[k + 1] = q.y; nb[k + 2] = q.z; nb[k + 3] = q.w;
+    }
     float2 v[RK];
     float2 m = make_float2(-INFINITY, -INFINITY);
 #pragma unroll
@@ -657,7 +660,10 @@ __global__ __launch_bounds__(256) void att_pool_split_bwd_kernel(const float *__
     float av[RK], gv[RK];
     int nb[RK];
 #pragma unroll
-    for (int k = 0; k < RK; ++k) nb[k] = neigh[n * RK + k];
+    for (int k = 0; k < RK; k += 4) {     // (the row of 16 indices as four 16-byte loads)
+        const int4 q = *(const int4 *)(neigh + n * RK + k);
+        nb[k] = q.x; nb[k + 1] = q.y; nb[k + 2] = q.z; nb[k + 3] = q.w;
+    }
     {
         float m = -INFINITY;
 #pragma unroll
