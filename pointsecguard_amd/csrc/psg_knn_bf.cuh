@@ -5,16 +5,21 @@
 // the same launch as the fallback for every tile whose bound cannot be kept.
 //
 // Approximation.  x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-18 |x|.  One 32 x 32 tile of
-//     acc = (hi_i.hi_j + hi_i.lo_j + lo_i.hi_j) - (1 - B) |x_j|^2 / 2 + (A / 2) |x_i||x_j|
+//     acc = (hi_i.lo_j + lo_i.hi_j) + hi_i.hi_j - (1 - B) |x_j|^2 / 2 + (A / 2) |x_i||x_j|
 // is 13 v_mfma_f32_32x32x16_bf16 (K = 3 x 64 + one augmented step): 3/16 of the fp32 MFMA time of the exact kernel.
 // L = (1 - G) |x_i|^2 - 2 acc = D~ - e_ij with D~ the approximate distance and e_ij = A |x_i||x_j| + B |x_j|^2 + G |x_i|^2.
 // Error of D~ against the reference's fp32 distance D (psg_knn_ops.cuh builds the operands): dropped products (lo.lo and
-// the split residues) <= 3 * 2^-18 |x_i||x_j|; fp32 accumulation of 13 instructions of 16 exact products each, every
-// addition rounded to nearest: <= 13 * 17 * 2^-24 (|x_i||x_j| + |x_j|^2 / 2); the reference's own chain 64 * 2^-24
-// |x_i||x_j| and its two distance roundings <= 2^-23 (|x_i|^2 + |x_j|^2) + 2^-22 |x_i||x_j|: in distance units (dot errors
-// count twice) |D~ - D| <= 2^-14.1 |x_i||x_j| + 2^-16.2 |x_j|^2 + 2^-23 |x_i|^2.  The kernel uses A = 2^-13.5, B = 2^-15.5,
-// G = 2^-20 (1.5 x that bound; tools/bf16_split_probe.hip measured 2^-16 of the largest |x|^2 on hardware over eight data
-// sets: random, offset, 1e6 dynamic range, near-cancelling pairs, 1e-15 and 1e15 magnitudes), so L <= D <= L + 2 e_ij.
+// the split residues) <= 3.02 * 2^-18 |x_i||x_j|; fp32 accumulation, every one of an instruction's 17 additions rounded to
+// nearest against the partial sums it can meet: the chain runs the eight SMALL products first (round 6; partial sums <=
+// 2^-8 |x_i||x_j|: 8 * 17 * 2^-24 * 2^-8), then the four hi.hi steps (4 * 17 * 2^-24 (1 + 2^-8) |x_i||x_j|), the augmented step
+// last (17 * 2^-24 (|x_i||x_j| + |x_j|^2 / 2)): <= 86 * 2^-24 |x_i||x_j| + 8.5 * 2^-24 |x_j|^2 (rounds 3-5 interleaved hi.hi, hi.lo,
+// lo.hi per k-step, so all 13 instructions met full-size partial sums, and the |x_j|^2 term all 13: 221 * 2^-24 of both); the
+// reference's own chain 64 * 2^-24 |x_i||x_j| and its two distance roundings <= 2^-23 (|x_i|^2 + |x_j|^2) + 2^-22 |x_i||x_j|:
+// in distance units (dot errors count twice) |D~ - D| <= 2^-14.57 |x_i||x_j| + 2^-19.75 |x_j|^2 + 2^-23 |x_i|^2.  The kernel
+// uses A = 2^-14, B = 2^-19, G = 2^-20 (1.48 x, 1.7 x, 8 x that bound; tools/bf16_split_probe.hip measured 2^-16 of the
+// largest |x|^2 on hardware over eight data sets: random, offset, 1e6 dynamic range, near-cancelling pairs, 1e-15 and 1e15
+// magnitudes), so L <= D <= L + 2 e_ij - and that is CHECKED for every finalist (kb_final_rows).  Rounds 3-5 ran with
+// A = 2^-13.5, B = 2^-15.5: the row margin E_i, and with it the finalists per wanted rank, is ~40 % smaller now.
 // The error scales with the PAIR's norms, not with the room's largest norm: the network's own features have a few points
 // whose |x|^2 is 40 x the mean, and a bound in units of that maximum was wider than the neighbour distances themselves.
 //
@@ -60,7 +65,7 @@ constexpr int KB_WAVES = 16;
 constexpr int KB_Q = 32;                      // query rows per workgroup (one 32-column MFMA tile)
 constexpr int KB_CAP = 1024;                  // entries per row buffer
 constexpr int KB_ROW = KB_CAP + 2;            // dwords between rows: 8-byte aligned, skewed over the LDS banks
-constexpr float KB_A = KNN_BF_A, KB_B = KNN_BF_B, KB_G = KNN_BF_G;   // 2^-13.5, 2^-15.5, 2^-20 (psg_knn_ops.cuh)
+constexpr float KB_A = KNN_BF_A, KB_B = KNN_BF_B, KB_G = KNN_BF_G;   // 2^-14, 2^-19, 2^-20 (psg_knn_ops.cuh)
 // (round 4: units of E / 16 instead of E / 8 - the +- 3 units of key quantisation in every margin were a third of it: 20 %
 // fewer finalists at d >= 9; E / 32 gave the same counts, the windows are then limited by the bin width)
 constexpr int KB_UNIT_DIV = 16;               // the key unit is E_i(|x_i|^2) / KB_UNIT_DIV
@@ -68,7 +73,11 @@ constexpr float KB_OFF = 32.0f;               // key offset in units: L of the q
 constexpr unsigned KB_KEYMAX = 0xFFFFEu;      // key of a candidate beyond the key range (never kept)
 constexpr unsigned KB_TAUMAX = 0xFFFF0u;      // largest row threshold (admission lets keys up to tau + 3 through: they must fit 20 bits)
 constexpr int KB_MAXFIN = 256;
-constexpr int KB_SCR = 128;                   // dwords of scratch per row in the final ranking: 64 query features, 32 bitmap, 32 run table
+#ifndef KB_LONG_BINS
+#define KB_LONG_BINS 2048                     // bins of the final ranking for rows of more than 256 entries (A/B builds: 1024)
+#endif
+constexpr int KB_SCR_BITMAP = 64;             // dwords of flagged-bin bitmap (2048 bins)
+constexpr int KB_SCR = 64 + KB_SCR_BITMAP + 32;   // dwords of scratch per row in the final ranking: 64 query features, the bitmap, 32 run table
 constexpr int KB_RP = 8;                      // floats of row parameters: |x|^2, |x|, unit, 1 / unit, key constant, spare x3
 
 typedef __bf16 kb_bf16x8 __attribute__((ext_vector_type(8)));
@@ -153,6 +162,10 @@ __device__ __forceinline__ unsigned kb_half_count(unsigned long long ballot, int
 {
     return (unsigned)__popc(h ? (unsigned)(ballot >> 32) : (unsigned)ballot);
 }
+
+// the value of quad lane g ^ 1 / g ^ 2 (quad_perm [1,0,3,2] / [2,3,0,1])
+__device__ __forceinline__ float kb_quad_xor1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float kb_quad_xor2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)); }
 
 // E_i(T) / u_i: the gap between L and D, in key units, for every candidate of the row with L <= T (see the header)
 __device__ __forceinline__ unsigned kb_margin_keys(float a, float sq, float inv_unit, float T)
@@ -286,20 +299,27 @@ __device__ __forceinline__ bool kb_cut_sample(const KbRowArgs c, int lane, int n
     return bad;
 }
 
-// Final ranking (see the header).  Row LDS: NB bins of 16 bits (counts, then first ranks, then - advanced by the collect
-// pass - the position of every finalist in bin order) in dwords [0, 512), 256 finalists (entry, position) from dword
-// 512; after the collect pass dwords [0, 512) hold the finalists' exact composites sorted by run.  scr = KB_SCR words of
-// wave-private LDS per row: the query's 64 features, up to 32 words of flagged-bin bitmap, the run table (first rank,
-// first finalist | finalists << 16 per run).  nv = the registers per lane the longer of the two rows needs (<= NV).
+// Final ranking (see the header).  Row LDS: NB bins of 16 bits (counts, then the entries below each bin) in dwords
+// [0, NB / 2) - the whole row buffer at NB = 2048 -; once the windows are flagged the bins are dead and the same words hold
+// the finalists' exact composites grouped by run (dwords [0, 512)) and the finalist list (entries, dwords [512, 768)).
+// scr = KB_SCR words of wave-private LDS per row: the query's 64 features, up to 64 words of flagged-bin bitmap (whose
+// first 16 words count the finalists placed per run afterwards), the run table {first bin | first rank << 16, first
+// finalist slot | finalists << 16}.  nv = the registers per lane the longer of the two rows needs (<= NV).
 // Returns the number of finalists of the two rows, or 0xFFFFFFFF when a row must take the exact path.
+//
+// Bins.  A window is the bin of the wanted rank and w = ceil(margin / bin width) bins to each side, and with 1024 bins over
+// a long row a bin was 2 - 4 margins wide (w = 1: three bins where +- one margin would do) - the finalists were a matter of
+// bin width, not of the bound (round 6, tests/golden/gcn28_room.npz features: 88 finalists per row at d = 20 with 1024 bins,
+// 55 with 2048, 42 with windows of exactly +- one margin; rounds 4-5 had 1024).  Rows of more than 256 entries now take
+// 2048 bins; the finalist list dropped its per-finalist position in bin order (a returning LDS atomic on the bin) to fit.
 //
 // Runs.  The windows of the wanted ranks are ordered; window j opens a new run when it neither overlaps nor touches window
 // j - 1.  A run is a stretch of bins; EVERY entry of its bins is a finalist, so the finalists of run R are exactly the
-// entries of ranks-by-bin [cs_R, ce_R) (cs = entries below the run's first bin).  The collect pass hands every finalist
-// its position q in bin order (one returning LDS atomic on the bin's first rank), the exact pass stores its composite
-// at fs_R + q - cs_R (fs = finalists of earlier runs): finalists end up grouped by run, and a finalist ranks itself
-// against its own run only: exact rank = cs_R + the number of smaller composites among the run's len_R (rounds 2-3 compared
-// every finalist with every other: 36 instructions per pair of the row, 60 % of the phase at d >= 12).
+// entries of ranks-by-bin [cs_R, ce_R) (cs = entries below the run's first bin).  The exact pass finds a finalist's run
+// from its bin and takes the next free slot of the run's stretch [fs_R, fs_R + len_R) of the composite array (fs =
+// finalists of earlier runs): finalists end up grouped by run, and a finalist ranks itself against its own run only:
+// exact rank = cs_R + the number of smaller composites among the run's len_R (a run is a handful of finalists per wanted
+// rank it covers; rounds 2-3 compared every finalist with every other of the row: 36 instructions per pair).
 struct KbFinalArgs {
     const float *x, *sq;      // row-major features [rows][ld], squared norms
     unsigned ld;
@@ -311,9 +331,9 @@ struct KbFinalArgs {
 template <int NV, int NB>
 __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFinalArgs a, int lane, int nv)
 {
-    constexpr int LOGNB = NB == 1024 ? 10 : 8;
-    constexpr int DW = NB / 64;                             // dwords of packed bins per lane (2 bins each)
-    static_assert(NB == 1024 || NB == 256, "bins");
+    constexpr int LOGNB = NB == 2048 ? 11 : (NB == 1024 ? 10 : 8);
+    static_assert(NB == 2048 || NB == 1024 || NB == 256, "bins");
+    static_assert(NB / 32 <= KB_SCR_BITMAP, "bitmap words");
     extern __shared__ __attribute__((aligned(16))) unsigned char kb_smem[];
     const int h = lane >> 5, l5 = lane & 31;
     const int ridx = c.wave + KB_WAVES * h;
@@ -321,12 +341,13 @@ __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFin
     const float *rp = (const float *)kb_smem + c.rp_dw + ridx * KB_RP;
     float *qbuf = (float *)kb_smem + a.scr_dw + h * KB_SCR;
     unsigned *bitmap = (unsigned *)kb_smem + a.scr_dw + h * KB_SCR + 64;
-    uint2 *rt = (uint2 *)((unsigned *)kb_smem + a.scr_dw + h * KB_SCR + 96);       // [16] {cs, fs | len << 16}
+    unsigned *rcnt = bitmap;                                                       // [16] finalists placed per run (after the collect pass)
+    uint2 *rt = (uint2 *)((unsigned *)kb_smem + a.scr_dw + h * KB_SCR + 64 + KB_SCR_BITMAP);   // [16] {first bin | cs << 16, fs | len << 16}
     const unsigned T = h ? c.T[1] : c.T[0];
     const unsigned tl5 = T > (unsigned)l5 ? T - (unsigned)l5 : 0u;      // entry 32 i + l5 exists iff 32 i < tl5
     const unsigned keyx_ent = (((const unsigned *)kb_smem)[c.keyx_dw + ridx] << 12) | 0xFFFu;
     const unsigned tau_row = ((const unsigned *)kb_smem)[c.tau_dw + ridx];
-    unsigned v[NV], bn[NV];
+    unsigned v[NV];
     unsigned mx = 0u, mnn = 0u, nle = 0u;
     KB_PH_BEGIN;
 #pragma unroll
@@ -349,11 +370,14 @@ __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFin
         qbuf[l5] = xq[l5];
         qbuf[l5 + 32] = xq[l5 + 32];
     }
-    if (l5 < NB / 32) bitmap[l5] = 0u;
-    if (l5 < 16) rt[l5] = make_uint2(0xFFFFFFFFu, 0u);             // (runs the row does not have: never at or below a position)
-    // packed 16-bit counters: the lane owns bins (NB / 32) l .. + NB / 32 - 1
 #pragma unroll
-    for (int j = 0; j < DW / 2; ++j) ((uint2 *)row)[(DW / 2) * l5 + j] = make_uint2(0u, 0u);
+    for (int j = 0; j < NB / 1024; ++j) bitmap[l5 + 32 * j] = 0u;
+    if (NB < 1024 && l5 < NB / 32) bitmap[l5] = 0u;
+    if (l5 < 16) rt[l5] = make_uint2(0xFFFFFFFFu, 0u);             // (runs the row does not have: their first bin is beyond every bin)
+    wave_lds_fence();                                              // (the entries are in registers: their words become the bins)
+    // packed 16-bit counters
+#pragma unroll
+    for (int j = 0; j < NB / 256; ++j) ((uint4 *)row)[32 * j + l5] = make_uint4(0u, 0u, 0u, 0u);
     wave_lds_fence();
     KB_PH(5);
     const unsigned kmx = kb_half_max_u32(mx) >> 12, kmn = (~kb_half_max_u32(mnn)) >> 12;
@@ -370,43 +394,52 @@ __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFin
     const unsigned base = kmn << 12, s2 = 12u + sh;
     unsigned short *cum16 = (unsigned short *)row;
     unsigned long long *sorted = (unsigned long long *)row;         // [256] composites grouped by run (after the collect pass)
-    uint2 *fin = (uint2 *)(row + 512);                              // [256] {entry, position in bin order}
+    unsigned *fin = row + 512;                                      // [256] entries of the finalists
     KB_PH(6);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        bn[i] = 0u;
         if (i < nv) {
             if ((unsigned)(32 * i) < tl5) {
                 const unsigned bb = (v[i] - base) >> s2;
-                bn[i] = bb;
                 atomicAdd(&row[bb >> 1], 1u << ((bb & 1u) << 4));
             }
         }
     }
     wave_lds_fence();
     KB_PH(7);
-    // the lane's own bins -> the number of entries below each bin, written back in place
+    // the number of entries below each bin, written back in place.  Lane l takes the 16-byte groups (8 bins) 32 j + l: the 32
+    // lanes of a row read consecutive addresses (a lane that owned NB / 32 CONSECUTIVE bins, rounds 3-5, made every one of these
+    // accesses a 16-way bank conflict at 2048 bins, and the LDS pipe is shared by the workgroup's 16 waves); the price is one
+    // half-wave scan per j instead of one per row
     {
-        unsigned wd[DW];
+        constexpr int NJ = NB / 256;
+        uint4 *grp = (uint4 *)row;
+        uint4 t[NJ];
+        unsigned carry = 0u;
 #pragma unroll
-        for (int j = 0; j < DW / 2; ++j) { const uint2 t = ((const uint2 *)row)[(DW / 2) * l5 + j]; wd[2 * j] = t.x; wd[2 * j + 1] = t.y; }
-        unsigned tot = 0;
+        for (int j = 0; j < NJ; ++j) t[j] = grp[32 * j + l5];
 #pragma unroll
-        for (int j = 0; j < DW; ++j) tot += (wd[j] & 0xFFFFu) + (wd[j] >> 16);
-        unsigned s = kb_half_incl_scan_u32(tot) - tot;
+        for (int j = 0; j < NJ; ++j) {
+            const unsigned gs = (t[j].x & 0xFFFFu) + (t[j].x >> 16) + (t[j].y & 0xFFFFu) + (t[j].y >> 16) + (t[j].z & 0xFFFFu) + (t[j].z >> 16) + (t[j].w & 0xFFFFu) + (t[j].w >> 16);
+            const unsigned incl = kb_half_incl_scan_u32(gs);
+            unsigned sacc = carry + incl - gs;
+            const unsigned t0 = (unsigned)__builtin_amdgcn_readlane((int)incl, 31), t1 = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+            carry += h ? t1 : t0;
+            unsigned wd[4] = {t[j].x, t[j].y, t[j].z, t[j].w};
 #pragma unroll
-        for (int j = 0; j < DW; ++j) {
-            const unsigned lo = wd[j] & 0xFFFFu, hi = wd[j] >> 16;
-            wd[j] = s | ((s + lo) << 16);
-            s += lo + hi;
+            for (int e = 0; e < 4; ++e) {
+                const unsigned lo = wd[e] & 0xFFFFu, hi = wd[e] >> 16;
+                wd[e] = sacc | ((sacc + lo) << 16);
+                sacc += lo + hi;
+            }
+            grp[32 * j + l5] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
         }
-#pragma unroll
-        for (int j = 0; j < DW / 2; ++j) ((uint2 *)row)[(DW / 2) * l5 + j] = make_uint2(wd[2 * j], wd[2 * j + 1]);
     }
     wave_lds_fence();
     KB_PH(8);
     // lane j < k of each half: the bin that holds approximate rank j d = the last bin with at most j d entries below it; its
     // window is flagged, and the windows that neither overlap nor touch their predecessor open the runs
+    unsigned F;
     {
         const bool win = l5 < (int)a.k;
         const unsigned m = (unsigned)l5 * a.d;
@@ -441,59 +474,94 @@ __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFin
             const unsigned ce = Hend + 1u < (unsigned)NB ? (unsigned)cum16[Hend + 1u] : T;
             len = ce - cs;
         }
-        const unsigned fs = kb_half_incl_scan_u32(len) - len;
-        if (leader) rt[__popc(lmask & ((1u << l5) - 1u))] = make_uint2(cs, fs | (len << 16));
+        const unsigned incl = kb_half_incl_scan_u32(len);
+        const unsigned fs = incl - len;
+        if (leader) rt[__popc(lmask & ((1u << l5) - 1u))] = make_uint2(L | (cs << 16), fs | (len << 16));
+        F = (unsigned)__shfl((int)incl, 31 + 32 * h);                // the row's finalists = the entries of all its runs
     }
-    wave_lds_fence();
+    const unsigned Fo = (unsigned)__shfl_xor((int)F, 32);
+    const unsigned Fmax = F > Fo ? F : Fo;
+    if (Fmax > (unsigned)KB_MAXFIN) return 0xFFFFFFFEu;
+    wave_lds_fence();                                              // (the bins are dead from here: their words take the finalists)
     KB_PH(9);
-    // collect: every entry of a flagged bin takes its position in bin order from the bin's first rank (advanced by one)
-    unsigned F = 0;
+    // collect: every entry of a flagged bin joins the finalist list (register-major order)
+    {
+        unsigned Fc = 0;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        if (i < nv) {
-            const bool take = (unsigned)(32 * i) < tl5 && ((bitmap[bn[i] >> 5] >> (bn[i] & 31u)) & 1u);
-            const unsigned long long bl = __ballot(take);
-            if (bl != 0ull) {
-                const unsigned pos = F + kb_half_prefix(bl, h);
-                if (take) {
-                    const unsigned sft = (bn[i] & 1u) << 4;
-                    const unsigned q = (atomicAdd(&row[bn[i] >> 1], 1u << sft) >> sft) & 0xFFFFu;
-                    if (pos < (unsigned)KB_MAXFIN) fin[pos] = make_uint2(v[i], q);
+        for (int i = 0; i < NV; ++i) {
+            if (i < nv) {
+                const unsigned bb = (v[i] - base) >> s2;
+                const bool take = (unsigned)(32 * i) < tl5 && ((bitmap[(bb >> 5) & (unsigned)(KB_SCR_BITMAP - 1)] >> (bb & 31u)) & 1u);
+                const unsigned long long bl = __ballot(take);
+                if (bl != 0ull) {
+                    if (take) fin[(Fc + kb_half_prefix(bl, h)) & (unsigned)(KB_MAXFIN - 1)] = v[i];
+                    Fc += kb_half_count(bl, h);
                 }
-                F += kb_half_count(bl, h);
             }
         }
     }
     wave_lds_fence();
+    if (l5 < 16) rcnt[l5] = 0u;                                     // (the bitmap is dead: its first words count the slots taken per run)
+    wave_lds_fence();
     KB_PH(10);
-    const unsigned Fo = (unsigned)__shfl_xor((int)F, 32);
-    const unsigned Fmax = F > Fo ? F : Fo;
-    if (Fmax > (unsigned)KB_MAXFIN) return 0xFFFFFFFEu;
     const float4 *q4 = (const float4 *)qbuf;
     bool bound_broken = false;
     for (unsigned f0 = 0; f0 < Fmax; f0 += 32) {
         const unsigned f = f0 + (unsigned)l5;
-        const uint2 fe = f < F ? fin[f] : make_uint2(base, 0u);
-        const unsigned ent = fe.x, q = fe.y;
+        const unsigned ent = f < F ? fin[f] : base;
         const unsigned idx = ent & 0xFFFu;
         const size_t vc = a.room_row0 + idx;
-        const float4 *pc = (const float4 *)(a.x + vc * a.ld);
         const float sqj = a.sq[vc];
-        // the finalist's run: the last one whose first rank is at most q (runs beyond the row's last read as 0xFFFFFFFF)
+        // The finalist's 256-byte feature row, fetched by the QUAD (round 6): lane g of a quad loads bytes [64 s + 16 g, + 16) of
+        // the row of quad member phi, for (phi, s) in 4 x 4 - one 64-byte sector per instruction and finalist - and a 4 x 4
+        // transpose over (lane of the quad, register) then hands every lane its own finalist's row in ascending k.  One lane
+        // per row (rounds 3-5: 64 different rows per wave instruction, sixteen 16-byte requests into each) cost 19 cycles of
+        // the CU's vector-memory path per finalist, the quad form 9.4 with the transpose included, same bits
+        // (tools/finalist_load_probe.hip: the path looks up one 64-byte piece per cycle whatever its lanes use of it; groups of
+        // lanes 16 apart - gfx950's v_permlane swaps would transpose those in half the instructions - gain nothing).
+        float4 C[16];
+        {
+            const int g = lane & 3;
+            unsigned id4[4];
+            id4[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)idx, 0x00, 0xF, 0xF, true);      // quad_perm [0,0,0,0]
+            id4[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)idx, 0x55, 0xF, 0xF, true);
+            id4[2] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)idx, 0xAA, 0xF, 0xF, true);
+            id4[3] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)idx, 0xFF, 0xF, 0xF, true);
+#pragma unroll
+            for (int phi = 0; phi < 4; ++phi) {
+                const float4 *pq = (const float4 *)(a.x + (a.room_row0 + id4[phi]) * a.ld) + g;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) C[4 * s4 + phi] = pq[4 * s4];
+            }
+        }
+        // the finalist's run: the last one whose first bin is at most the finalist's (runs beyond the row's last read as
+        // 0xFFFF), and the next free slot of the run's stretch of the composite array
+        const unsigned bbf = (ent - base) >> s2;
         unsigned rho = 0u;
 #pragma unroll
         for (int st = 8; st >= 1; st >>= 1) {
             const unsigned cand = rho + (unsigned)st;
-            rho = (cand < 16u && rt[cand & 15u].x <= q) ? cand : rho;
+            rho = (cand < 16u && (rt[cand & 15u].x & 0xFFFFu) <= bbf) ? cand : rho;
         }
-        const uint2 re = rt[rho];
-        const unsigned p = (re.y & 0xFFFFu) + q - re.x;
-        // ascending-k fmaf chain from 0, the exact kernel's arithmetic (and a CPU sgemm's).  (Every lane reads another vertex:
-        // 64 lanes x 16 loads of 16 bytes per round; fetching the 256 bytes in two or four consumed-at-once pieces changed
-        // nothing - the phase is bound by the 64 B / clk of the CU's address path, 4 cycles per finalist.)
-        float4 C[16];
+        unsigned p = (unsigned)KB_MAXFIN;
+        if (f < F) p = (rt[rho].y & 0xFFFFu) + atomicAdd(&rcnt[rho], 1u);
+        {
+            // in: lane g holds piece g of quad member phi's sector s4 in C[4 s4 + phi]; out: C[4 s4 + p] = piece p of the lane's own row
+            const bool odd = lane & 1, up = lane & 2;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) C[j] = pc[j];
+            for (int s4 = 0; s4 < 4; ++s4) {
+                float *fc = (float *)&C[4 * s4];
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const float a0 = fc[c4], a1 = fc[4 + c4], a2 = fc[8 + c4], a3 = fc[12 + c4];
+                    const float n0 = kb_quad_xor1(a0), n1 = kb_quad_xor1(a1), n2 = kb_quad_xor1(a2), n3 = kb_quad_xor1(a3);
+                    const float b0 = odd ? n1 : a0, b1 = odd ? a1 : n0, b2 = odd ? n3 : a2, b3 = odd ? a3 : n2;
+                    const float m0 = kb_quad_xor2(b0), m1 = kb_quad_xor2(b1), m2 = kb_quad_xor2(b2), m3 = kb_quad_xor2(b3);
+                    fc[c4] = up ? m2 : b0; fc[4 + c4] = up ? m3 : b1; fc[8 + c4] = up ? b2 : m0; fc[12 + c4] = up ? b3 : m1;
+                }
+            }
+        }
+        // ascending-k fmaf chain from 0, the exact kernel's arithmetic (and a CPU sgemm's)
         float z = 0.0f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -502,8 +570,8 @@ __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFin
         }
         // (|x_i|^2 + (-2 x_i.x_j)) + |x_j|^2, torch_edge.py:41-43, as in the exact kernel
         const float dd = __fadd_rn(__fmaf_rn(-2.0f, z, sq), sqj);
-        if (f < F && p < (unsigned)KB_MAXFIN)
-            sorted[p] = ((unsigned long long)rho << 60) | ((unsigned long long)((ent - base) >> s2) << 50) | ((unsigned long long)key_of(dd) << 12) | (unsigned long long)idx;
+        if (p < (unsigned)KB_MAXFIN)
+            sorted[p] = ((unsigned long long)rho << 60) | ((unsigned long long)key_of(dd) << 12) | (unsigned long long)idx;
         // The bound everything above rests on, L <= D <= L + 2 e_ij, assumes how the bf16 MFMA rounds internally (measured,
         // not documented).  Both sides are in registers here, so it is CHECKED for every finalist: the exact distance in key
         // units must lie in [key - 2, key + margin] (2 = the key's own rounding); a violation (or a NaN) sends the tile to the
@@ -516,10 +584,6 @@ __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFin
     KB_PH(11);
     int32_t *out = a.out + (size_t)(h * KB_WAVES) * a.k;
     const unsigned long long m44 = (1ull << 44) - 1ull;
-    // two finalists more than w2 bins apart are ordered by their bins alone (their exact distances were checked against
-    // [key - 2, key + margin + 1] above)
-    const unsigned w2 = (margin + 3u + (1u << sh) - 1u) >> sh;
-    const unsigned *sorted_hi = (const unsigned *)row + 1;          // high dword of composite p at [2 p]
     for (unsigned f0 = 0; f0 < Fmax; f0 += 32) {
         const unsigned p = f0 + (unsigned)l5;
         const bool live = p < F;
@@ -527,33 +591,15 @@ __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFin
         const unsigned long long xk = x & m44;
         const uint2 re = rt[(unsigned)(x >> 60)];
         const unsigned fs = re.y & 0xFFFFu, len = live ? re.y >> 16 : 0u;
-        // exact rank = the run's first rank + the run's composites below x.  Short runs: compare with the whole run.  Long
-        // ones (merged windows, dense ties): the run is sorted by bin, so everything before the first position whose bin is
-        // within w2 of x's is smaller, everything after the last is larger; only the stretch between is compared
-        unsigned lb = fs, ub = fs + len;
-        if (wave_max_u32(len) > 24u) {
-            const unsigned bx = (unsigned)(x >> 50) & 1023u;
-            const unsigned lo_b = bx > w2 ? bx - w2 : 0u, hi_b = bx + w2;
-            unsigned n1 = len, n2 = len;
-            ub = fs;
-#pragma unroll 1
-            for (int it = 0; it < 9; ++it) {
-                const unsigned h1 = n1 >> 1, h2 = n2 >> 1;
-                const unsigned b1 = (sorted_hi[2u * ((lb + h1) & 255u)] >> 18) & 1023u, b2 = (sorted_hi[2u * ((ub + h2) & 255u)] >> 18) & 1023u;
-                const bool r1 = n1 != 0u && b1 < lo_b, r2 = n2 != 0u && b2 <= hi_b;
-                lb = r1 ? lb + h1 + 1u : lb; n1 = r1 ? n1 - h1 - 1u : h1;
-                ub = r2 ? ub + h2 + 1u : ub; n2 = r2 ? n2 - h2 - 1u : h2;
-            }
-        }
-        unsigned below = lb - fs;
-        const unsigned span = wave_max_u32(ub - lb);
+        // exact rank = the run's first rank + the run's composites below x
+        unsigned below = 0u;
+        const unsigned span = wave_max_u32(len);
         for (unsigned j = 0; j < span; ++j) {
-            const unsigned pos = lb + j;
-            const bool act = pos < ub;
-            const unsigned long long y = sorted[act ? pos : p & 255u] & m44;
+            const bool act = j < len;
+            const unsigned long long y = sorted[act ? fs + j : p & 255u] & m44;
             below += (act && y < xk) ? 1u : 0u;
         }
-        const unsigned rank = re.x + below;
+        const unsigned rank = (re.x >> 16) + below;
         const unsigned t = (rank * a.magic) >> 18;
         if (live && t * a.d == rank && t < a.k) out[t] = (int32_t)(x & 0xFFFull);
     }
@@ -571,14 +617,17 @@ __device__ __forceinline__ void kb_load_tile(kb_u32x4 (&fr)[9], const kb_u32x4 *
 __device__ __forceinline__ kb_f32x16 kb_tile_product(const kb_u32x4 (&fr)[9], const kb_u32x4 (&bq)[8], const kb_u32x4 qa)
 {
     kb_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // the small products first (see the header: the accumulation error of an instruction scales with the partial sums it meets)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const kb_bf16x8 ch = __builtin_bit_cast(kb_bf16x8, fr[s]), cl = __builtin_bit_cast(kb_bf16x8, fr[4 + s]);
         const kb_bf16x8 qh = __builtin_bit_cast(kb_bf16x8, bq[s]), ql = __builtin_bit_cast(kb_bf16x8, bq[4 + s]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch, qh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ch, ql, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cl, qh, acc, 0, 0, 0);
     }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kb_bf16x8, fr[s]), __builtin_bit_cast(kb_bf16x8, bq[s]), acc, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(kb_bf16x8, fr[8]), __builtin_bit_cast(kb_bf16x8, qa), acc, 0, 0, 0);
 }
 
@@ -783,7 +832,7 @@ __global__ __launch_bounds__(KB_WAVES * 64, KB_MIN_WAVES_EU) void knn_bf_kernel(
             const int nv = (int)((Tm + 31u) >> 5);
             // (the bin count follows the workgroup's longest row, so every wave runs the same code at the same time)
             const unsigned nf = Twg <= 256u ? kb_final_rows<8, 256>(ra, fa, lane, nv)
-                              : (Twg <= 512u ? kb_final_rows<16, 1024>(ra, fa, lane, nv) : kb_final_rows<32, 1024>(ra, fa, lane, nv));
+                              : (Twg <= 512u ? kb_final_rows<16, KB_LONG_BINS>(ra, fa, lane, nv) : kb_final_rows<32, KB_LONG_BINS>(ra, fa, lane, nv));
             if (nf >= 0xFFFFFFFDu) { if (lane == 0) atomicOr(fail, 8u << (0xFFFFFFFFu - nf)); }
             else { st_fin += nf; st_ent += ra.T[0] + ra.T[1]; }
             KB_TL(9);

@@ -12,8 +12,13 @@
 namespace {
 
 // the per-pair error term of the bf16 prefilter (psg_knn_bf.cuh): |D~ - D| <= A |x_i||x_j| + B |x_j|^2 + G |x_i|^2
-constexpr float KNN_BF_A = 8.631674575031098e-05f;    // 2^-13.5
-constexpr float KNN_BF_B = 2.1579186437577745e-05f;   // 2^-15.5
+// (round 6: 2^-13.5 / 2^-15.5 -> 2^-14 / 2^-19 with the small products accumulated first, derivation in psg_knn_bf.cuh)
+#ifndef KNN_BF_A_VALUE
+#define KNN_BF_A_VALUE 6.103515625e-05f               // 2^-14
+#define KNN_BF_B_VALUE 1.9073486328125e-06f           // 2^-19
+#endif
+constexpr float KNN_BF_A = KNN_BF_A_VALUE;
+constexpr float KNN_BF_B = KNN_BF_B_VALUE;
 constexpr float KNN_BF_G = 9.5367431640625e-07f;      // 2^-20
 
 // round-to-nearest-even bf16 of a finite float (non-finite inputs never reach the bf16 path: the kernel falls back)
