@@ -935,7 +935,7 @@ struct psg_gcn_ws {
     float *xp;                 // [B*N][64] the current block's features in fp32 MFMA operand order (exact fused kNN)
     void *bp;                  // [B*N/32][9][64] 16-byte bf16 hi / lo / augmented fragments (prefilter kNN, psg_knn_ops.cuh)
     int knn_mode = 2;          // 1 = exact fused kernel only (PSG_GCN_KNN=f32), 2 = bf16 prefilter up to knn_bf_max_d, 0 = round-1 path (=matrix)
-    int knn_bf_max_d = 20;     // the prefilter kernel serves dilations up to this (PSG_GCN_KNN_BF_MAXD), the exact kernel the rest
+    int knn_bf_max_d = 27;     // the prefilter kernel serves dilations up to this (PSG_GCN_KNN_BF_MAXD), the exact kernel the rest
     unsigned long long *knn_stats = nullptr;   // PSG_GCN_KNN_STATS=1: device counters of the prefilter kernel
     float *pq, *dpq;           // [B*N][128]
     float *pq2 = nullptr;      // second [P | Q] buffer: a block's edge pass writes the NEXT block's products while it reads its own
@@ -1212,11 +1212,13 @@ extern "C" int psg_gcn_ws_create_cfg(psg_ctx *ctx, int batch, int n_point, int n
     {
         const char *kv = psg::env_str("PSG_GCN_KNN");
         const std::string mode = kv ? kv : "";
-        // default: the bf16-prefilter kernel for dilations 1..20, where it is the faster one on the network's own features
-        // (round 4, DESIGN.md section 2: 92-156 us against 142-168 us per 4-room call; above d = 20 rows start to overflow
-        // their 1024-entry buffers), the exact fused kernel for the rest; both give the same graph bit for bit.  PSG_GCN_KNN=f32 / =bf16 force one kernel for every dilation, =matrix the round-1 path
+        // default: the bf16-prefilter kernel for every dilation of the network (1..27): since round 6 (2048-bin final ranking,
+        // DESIGN.md section 2) it is the faster one on the network's own features up to d = 27 (148-153 us against 178-184 us
+        // per 4-room call at d = 21..27, no tile on the exact path; rounds 4-5 split at 20, where rows of more than 256
+        // finalists started to fall back); the exact fused kernel stays as the in-launch fallback and for PSG_GCN_KNN=f32; both
+        // give the same graph bit for bit.  PSG_GCN_KNN=f32 / =bf16 force one kernel for every dilation, =matrix the round-1 path
         ws->knn_mode = mode == "matrix" ? 0 : (mode == "f32" ? 1 : 2);
-        ws->knn_bf_max_d = mode == "bf16" ? 1 << 30 : 20;
+        ws->knn_bf_max_d = mode == "bf16" ? 1 << 30 : 27;
         if (const char *md = psg::env_str("PSG_GCN_KNN_BF_MAXD")) ws->knn_bf_max_d = atoi(md);
         // the fused kNN kernels need 129 KB of dynamic LDS (raised once, outside any stream capture); a device that does
         // not grant it keeps the round-1 path (distance matrix in HBM + selection kernel)

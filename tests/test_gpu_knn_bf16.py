@@ -113,15 +113,15 @@ def test_degenerate_rooms_take_the_exact_path():
 def test_default_split_and_both_kernels_agree_on_network_like_features():
     """Features with a few huge-norm points (what the fitted ResGCN-28 produces: largest squared norm 40 x the mean): the
     exact-kernel workspace and the prefilter workspace return identical tables; the latter reports how many tiles it had
-    to hand to the exact path.  The DEFAULT workspace runs the prefilter kernel for dilations 1..20 and the exact kernel
-    above (psg_resgcn.hip: knn_bf_max_d), which its counters show."""
+    to hand to the exact path.  The DEFAULT workspace runs the prefilter kernel for dilations 1..27 (round 6; 1..20 before)
+    and the exact kernel above (psg_resgcn.hip: knn_bf_max_d), which its counters show."""
     rng = np.random.default_rng(5)
     f = np.maximum(rng.standard_normal((2, 4096, 64)) * 2 + 1, 0).astype(np.float32)
     f[:, :40] *= 6.0
     ws = bf16_workspace(2, 4096)
     ex = bf16_workspace(2, 4096, "f32")
     dflt = bf16_workspace(2, 4096, None)
-    for d, tiles in ((1, 256), (3, 256), (20, 256), (21, 0), (27, 0)):
+    for d, tiles in ((1, 256), (3, 256), (20, 256), (21, 256), (27, 256), (28, 0)):
         dflt.knn_stats()
         t = dflt.knn(dev(f), d)
         assert dflt.knn_stats()["tiles"] == tiles, d
