@@ -155,6 +155,24 @@ int psg_pn2_forward(psg_pn2_model *model, psg_pn2_ws *ws, int forward, const flo
 int psg_pn2_backward(psg_pn2_model *model, psg_pn2_ws *ws, int forward, const float *dlogp, float *dx0_out,
                      psg_stream stream);
 
+/* The per-iteration launches of psg_pn2_nb_attack one at a time (round 6), so that a caller - the teacher-forced parity
+ * tests - can drive exactly the kernels the fused attack loop runs between nontarget.py:29 and :39 / target.py:31 and :43:
+ *   psg_pn2_forward_lean         psg_pn2_forward without the module outputs only psg_pn2_activation reads (no l4_out);
+ *   psg_pn2_backward_colour      the input gradient on the colour channels only: dx0_out[.][3..5] are written, the other six
+ *                                channels of a row are left untouched (level 0: compact rows, the first layer's three colour
+ *                                columns on the vector pipe, one gather thread per point);
+ *   psg_pn2_backward_colour_pgd  the same backward with the update of nontarget.py:37-39 / target.py:41-43 applied by the
+ *                                gradient's last gather: x [batch][n_point][9] is updated in place on channels 3..5 exactly as
+ *                                psg_pgd_step would (ori [batch][n_point][3], mask nullable [n_point], dir = +1 ascent / -1
+ *                                descent, last = the reference's un-projected final step); no gradient is written. */
+int psg_pn2_forward_lean(psg_pn2_model *model, psg_pn2_ws *ws, int forward, const float *x0, float *logp_out,
+                         psg_stream stream);
+int psg_pn2_backward_colour(psg_pn2_model *model, psg_pn2_ws *ws, int forward, const float *dlogp, float *dx0_out,
+                            psg_stream stream);
+int psg_pn2_backward_colour_pgd(psg_pn2_model *model, psg_pn2_ws *ws, int forward, const float *dlogp, float *x,
+                                const float *ori, const uint8_t *mask, float alpha, float eps, float dir, int last,
+                                psg_stream stream);
+
 /* Per-layer activations of the last forward, for parity tests: which 0..3 = l1..l4 points (sa1..sa4
  * outputs), 4..6 = fp4, fp3, fp2 outputs.  Returns a device pointer [batch][points][channels]. */
 const float *psg_pn2_activation_ptr(const psg_pn2_ws *ws, int which);

@@ -62,6 +62,9 @@ SIGNATURES = {
     "psg_pn2_plan_ptr": (vp, [vp, ci, ci, ci, ci]),
     "psg_pn2_forward": (ci, [vp, vp, ci, vp, vp, vp, vp]),
     "psg_pn2_backward": (ci, [vp, vp, ci, vp, vp, vp]),
+    "psg_pn2_forward_lean": (ci, [vp, vp, ci, vp, vp, vp]),
+    "psg_pn2_backward_colour": (ci, [vp, vp, ci, vp, vp, vp]),
+    "psg_pn2_backward_colour_pgd": (ci, [vp, vp, ci, vp, vp, vp, vp, cf, cf, cf, ci, vp]),
     "psg_pn2_activation_ptr": (vp, [vp, ci]),
     "psg_pn2_activation_channels": (ci, [vp, ci]),
     "psg_to_point_major": (ci, [vp, ci, ci, ci, vp, vp]),

@@ -1646,6 +1646,31 @@ int pn2_backward_colour(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *
 }
 }  // namespace psg
 
+// The attack loop's own launches one at a time through the C ABI (round 6; include/psg.h): what psg_pn2_nb_attack runs per
+// iteration, so that a teacher-forced test drives exactly the kernels the benchmark times
+extern "C" int psg_pn2_forward_lean(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *x0, float *logp_out, psg_stream stream)
+{
+    PSG_REQUIRE(m && ws && x0, "psg_pn2_forward_lean: null argument");
+    return psg::pn2_forward_lean(m, ws, fwd, x0, logp_out, stream);
+}
+extern "C" int psg_pn2_backward_colour(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *dlogp, float *dx0_out, psg_stream stream)
+{
+    return psg::pn2_backward_colour(m, ws, fwd, dlogp, dx0_out, stream);
+}
+extern "C" int psg_pn2_backward_colour_pgd(psg_pn2_model *m, psg_pn2_ws *ws, int fwd, const float *dlogp, float *x, const float *ori,
+                                           const uint8_t *mask, float alpha, float eps, float dir, int last, psg_stream stream)
+{
+    PSG_REQUIRE(m && ws && dlogp && x && ori, "psg_pn2_backward_colour_pgd: null argument");
+    PSG_REQUIRE(m->arch == ws->arch, "psg_pn2_backward_colour_pgd: model and workspace were created for different architectures");
+    PSG_REQUIRE(dir == 1.0f || dir == -1.0f, "psg_pn2_backward_colour_pgd: dir must be +1 or -1");
+    if (ws->fwd_slot != fwd) {
+        set_error("psg_pn2_backward_colour_pgd: forward %d is not the one resident in the workspace (%d)", fwd, ws->fwd_slot);
+        return PSG_ERR_STATE;
+    }
+    const PgdFuse pf{x, ori, mask, dir * alpha, eps, last ? 1 : 0};
+    return backward_impl(m, ws, fwd, ws->logp, dlogp, ws->dx0, 3, 6, (hipStream_t)stream, &pf);
+}
+
 // ====================================================================================== NB attack
 extern "C" int psg_pn2_nb_attack(psg_pn2_model *m, psg_pn2_ws *ws, const float *images, const int32_t *labels,
                                  const int32_t *starts, const uint8_t *mask, float eps, float alpha, int iters,

@@ -162,19 +162,39 @@ class PN2Workspace:
         assert x0.shape == (self.batch, self.n_point, 9) and starts.numel() == n_forward * 4 * self.batch
         _lib.call("psg_pn2_plan_build", self.handle, ptr(x0), ptr(starts), n_forward, stream())
 
-    def forward(self, model, slot, x0, logp=None, l4=None):
+    def forward(self, model, slot, x0, logp=None, l4=None, lean=False):
+        """lean=True: the forward the fused attack loops run (no module outputs kept for activation(); l4 not available)."""
         require_cuda(x0, "x0", torch.float32)
         if logp is None:
             logp = torch.empty(self.batch, self.n_point, NUM_CLASSES, device=x0.device, dtype=torch.float32)
-        _lib.call("psg_pn2_forward", model.handle, self.handle, slot, ptr(x0), ptr(logp), ptr(l4), stream())
+        if lean:
+            assert l4 is None
+            _lib.call("psg_pn2_forward_lean", model.handle, self.handle, slot, ptr(x0), ptr(logp), stream())
+        else:
+            _lib.call("psg_pn2_forward", model.handle, self.handle, slot, ptr(x0), ptr(logp), ptr(l4), stream())
         return logp
 
-    def backward(self, model, slot, dlogp, dx0=None):
+    def backward(self, model, slot, dlogp, dx0=None, colour_only=False):
+        """colour_only=True: the backward of the fused attack loops - channels 3..5 of dx0 only (the rest is zero here)."""
         require_cuda(dlogp, "dlogp", torch.float32)
         if dx0 is None:
-            dx0 = torch.empty(self.batch, self.n_point, 9, device=dlogp.device, dtype=torch.float32)
-        _lib.call("psg_pn2_backward", model.handle, self.handle, slot, ptr(dlogp), ptr(dx0), stream())
+            dx0 = (torch.zeros if colour_only else torch.empty)(self.batch, self.n_point, 9, device=dlogp.device, dtype=torch.float32)
+        _lib.call("psg_pn2_backward_colour" if colour_only else "psg_pn2_backward", model.handle, self.handle, slot, ptr(dlogp),
+                  ptr(dx0), stream())
         return dx0
+
+    def backward_pgd(self, model, slot, dlogp, x0, ori, alpha, eps, mask=None, descent=False, last=False):
+        """The colour-only backward with the NB / tar_NB update applied to x0 in place by the gradient's last gather (what
+        psg_pn2_nb_attack runs per iteration; nontarget.py:37-39, target.py:41-43)."""
+        require_cuda(dlogp, "dlogp", torch.float32)
+        require_cuda(x0, "x0", torch.float32)
+        require_cuda(ori, "ori", torch.float32)
+        if mask is not None:
+            require_cuda(mask, "mask", torch.uint8)
+        assert x0.shape == (self.batch, self.n_point, 9) and ori.shape == (self.batch, self.n_point, 3) and x0.is_contiguous() and ori.is_contiguous()
+        _lib.call("psg_pn2_backward_colour_pgd", model.handle, self.handle, slot, ptr(dlogp), ptr(x0), ptr(ori), ptr(mask),
+                  float(alpha), float(eps), -1.0 if descent else 1.0, 1 if last else 0, stream())
+        return x0
 
     def nb_attack(self, model, images, labels, starts, eps, alpha, iters, mask=None, target=None, out=None):
         require_cuda(images, "images", torch.float32)

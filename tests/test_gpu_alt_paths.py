@@ -61,8 +61,13 @@ def child(test_file, keyword, extra_env):
     ("test_gpu_parity.py", "forward_vs_reference or backward_vs_reference or forward_backward_vs_oracle_batch or nb_attack_steps_vs_reference",
      "PSG_PN2_FPSPLIT=0"),
     ("test_gpu_msg.py", "forward_vs_reference or backward_vs_reference", "PSG_PN2_FPSPLIT=0"),
-    ("test_gpu_parity.py", "nb_attack_steps_vs_reference or tar_nb_attack_steps or nb_b8_steps", "PSG_PN2_L1T_COLOUR=0"),
-    ("test_gpu_parity.py", "nb_attack_free_run_vs_reference or nb_b8_statistical_parity", "PSG_PN2_PGD_FUSE=0"),
+    # (round 6: the "timed" parametrisations of the step tests and the fused first-iterations test are the ones that run the
+    # colour-only backward / the fused call, i.e. the tests in which these two switches act; round 5 pointed them at the
+    # general entry points, where PSG_PN2_L1T_COLOUR cannot act)
+    ("test_gpu_parity.py", "(nb_attack_steps_vs_reference or tar_nb_attack_steps or nb_b8_steps) and timed or fused_nb_attack_first_iterations",
+     "PSG_PN2_L1T_COLOUR=0"),
+    ("test_gpu_parity.py", "fused_nb_attack_first_iterations or nb_attack_free_run_vs_reference or nb_b8_statistical_parity",
+     "PSG_PN2_PGD_FUSE=0"),
 ])
 def test_switch_selects_other_kernels_with_the_same_parity(test_file, keyword, switch):
     base, base_sites = child(test_file, keyword, {})
