@@ -119,24 +119,70 @@ def test_msg_l4_points(room_run, room, model):
     assert np.abs(l4[0].cpu().numpy().T - room["l4"]).max() <= TOL * max(1.0, np.abs(room["l4"]).max())
 
 
-def near_tie_room(ours, ref):
-    """A room in which ONE max-pool / ReLU near-tie fell the other way than in the oracle (whose sums are rounded differently):
-    the winner of a pooled channel takes that channel's whole gradient, so ~10^3 entries of the room move by 10^-3 .. 10^-1
-    relative while everything structural stays equal.  Both first-layer paths of the library show such rooms, in different
-    seeds (tools/msg_grad_probe.py, round 5: whole layers - room 0 of seed 516: 1915 entries beyond 1e-3, the split layers -
-    room 1 of seed 515: 1207); the bars for such a room: same zero pattern, >= 99.8 % sign agreement, every disagreement below
-    5e-3 max |g|, median relative error still below 1e-4."""
+TIE_TOL = 2e-5      # a max-pool gap below this (relative to max(1, |winner|)) is inside the two implementations' rounding difference
+
+
+def _n_beyond(ours, ref, rel=1e-3):
     nz = ref != 0
-    if not np.array_equal(ours != 0, nz):
-        return False
-    agree = np.sign(ours[nz]) == np.sign(ref[nz])
-    rel = np.abs(ours - ref)[nz] / np.abs(ref[nz])
-    return agree.mean() >= 0.998 and (agree.all() or np.abs(ref[nz][~agree]).max() <= 5e-3 * np.abs(ref).max()) and np.median(rel) < 1e-4
+    return int((np.abs(ours - ref)[nz] > rel * np.abs(ref[nz])).sum()) + int((ours != 0)[~nz].sum())
+
+
+def prove_near_ties(oracle, cache, dl, ours, geom):
+    """A room whose colour gradient misses the strict bars of check_grad is accepted ONLY with a proof that the deviation
+    is a max-pool near-tie that fell the other way than in the oracle (round-5 advisor: the round-5 test accepted any room
+    with the same zero pattern, >= 99.8 % sign agreement and a small median error, which a mis-routed pooled channel of the
+    split first-layer kernels would also have shown).  The proof: (1) list every pooled (level, scale, group, channel) of
+    the ORACLE's forward whose winner leads the best row of ANOTHER source point by less than TIE_TOL (rows of the same
+    source point - ball-query padding - route the gradient to the same place whichever wins) and whose upstream gradient
+    is not zero; (2) hand the oracle's arg-max of such a channel to the runner-up, re-run the oracle's backward, keep the
+    flip iff the number of entries beyond 1e-3 relative falls (a tie moves one channel's whole gradient, so the flips are
+    independent of each other); (3) with the kept flips the STRICT bars of check_grad must hold.  At least one flip must
+    have been kept, every flip is a listed near-tie, and nothing else in the oracle is touched - a routing or mask bug in
+    the library cannot be repaired by re-deciding ties of width 2e-5.  Returns the kept flips."""
+    from oracle import pn2_msg
+    ref = oracle.backward_color(cache, dl)                       # (fills cache["dsa"]: the upstream gradients per level)
+    base = _n_beyond(ours, ref)
+    cands = []
+    for lvl in range(4):
+        npoint, _, nsamples = pn2_msg.SA_CFG[lvl]
+        c_off = 0
+        for i, ns in enumerate(nsamples):
+            acts, arg = cache["sa"][lvl][i]
+            c = acts[-1].shape[1]
+            h = acts[-1].reshape(npoint, ns, c)
+            src = geom["group"][lvl][i].reshape(npoint, ns)
+            win = np.take_along_axis(h, arg[:, None, :], axis=1)[:, 0, :]                      # [npoint, c]
+            win_src = np.take_along_axis(src, arg.reshape(npoint, c), axis=1)                  # [npoint, c] source point of the winner
+            other = np.where(src[:, :, None] == win_src[:, None, :], -np.inf, h)                # rows of other source points
+            second = other.argmax(axis=1)
+            gap = win - other.max(axis=1)
+            up = cache["dsa"][lvl + 1][:, c_off:c_off + c]
+            # (win > 0: the pooled activations are post-ReLU; a channel whose maximum is 0 passes no gradient whoever wins)
+            near = np.isfinite(gap) & (gap <= TIE_TOL * np.maximum(1.0, np.abs(win))) & (up != 0) & (win > 0)
+            for g, ch in zip(*np.nonzero(near)):
+                cands.append((lvl, i, int(g), int(ch), int(second[g, ch]), float(gap[g, ch])))
+            c_off += c
+    assert 0 < len(cands) <= 24, "no max-pool near-tie in the oracle's forward explains the deviation (%d candidates)" % len(cands)
+    kept = []
+    for lvl, i, g, ch, second, gap in cands:
+        arg = cache["sa"][lvl][i][1]
+        old = int(arg[g, ch])
+        arg[g, ch] = second
+        n = _n_beyond(ours, oracle.backward_color(cache, dl))
+        if n < base:
+            base = n
+            kept.append((lvl, i, g, ch, gap))
+        else:
+            arg[g, ch] = old
+    assert kept, "re-deciding the %d near-ties of the oracle's forward does not explain the deviation" % len(cands)
+    check_grad(ours, oracle.backward_color(cache, dl))           # the STRICT bars, with only proven ties re-decided
+    return kept
 
 
 def test_msg_batch_vs_oracle(model, oracle):
     """B = 3 rooms of 2048 points (another N than the fixture), full 9-channel gradient against the oracle: the strict bars
-    of check_grad for every room, except that ONE room of the batch may be a near-tie room (above)."""
+    of check_grad for every room; a room that misses them must be PROVEN a max-pool near-tie room (prove_near_ties: at most
+    one room of the batch, and the strict bars must hold once the oracle's proven ties are decided the library's way)."""
     from oracle import pn2
     from pointsecguard_amd import runtime
     B, N = 3, 2048
@@ -166,7 +212,9 @@ def test_msg_batch_vs_oracle(model, oracle):
             check_grad(ours, ref)
         except AssertionError:
             n_tie_rooms += 1
-            assert n_tie_rooms <= 1 and near_tie_room(ours, ref), b
+            assert n_tie_rooms <= 1, b
+            kept = prove_near_ties(oracle, cache, dl, ours, geom)
+            print("room %d: near-tie room, proven: %s" % (b, kept))
 
 
 def test_msg_nb_attack_steps_vs_reference(model, nb):
