@@ -105,8 +105,12 @@ __device__ __forceinline__ f32x16 tile_mac4(const float4 *__restrict__ w, int k8
     // __builtin_amdgcn_readfirstlane is folded away where the value is provably uniform.  So the move is spelled out; the
     // s_nop covers gfx940+'s one wait state between a VALU write of a VGPR and a v_readfirstlane of it, which the hazard
     // recognizer does not insert inside inline assembly (without it the count was read stale: a memory fault).
-    int n;
-    asm volatile("s_nop 1\n\tv_readfirstlane_b32 %0, %1" : "=s"(n) : "v"((k8n >> 2) - 1));
+    // Round 6 (advisor): the value is laundered through an EMPTY asm (the compiler can no longer prove it uniform and fold the
+    // builtin away) and moved by the compiler's own v_readfirstlane, so that the hazard recognizer sees both sides: the VGPR
+    // write in front of it and whatever reads the SGPR behind it (tools/check_asm_hazards.py lints the boundary cases).
+    int n_v = (k8n >> 2) - 1;
+    asm volatile("" : "+v"(n_v));
+    int n = __builtin_amdgcn_readfirstlane(n_v);
     const unsigned long long step = 4096ull;  // 4 chunks x 64 lanes x 16 B
     constexpr int S1 = BLK * 4, S2 = 2 * BLK * 4, S3 = 3 * BLK * 4, S4 = 4 * BLK * 4;
     if (FLIP) {
@@ -259,6 +263,14 @@ __device__ __forceinline__ f32x16 tile_mac4(const float4 *__restrict__ w, int k8
     return acc;
 }
 
+// The 18 wait states between a 16-pass MFMA and the first vector instruction that touches its result, spelled out for
+// the places where the COMPILER's MFMAs (the K tails below) are followed by a consumer inside inline assembly (relu_bits):
+// the hazard recognizer counts wait states only between instructions it can see, so it emitted v_mfma x 4, v_cmp_lt_f32 on
+// the accumulator back to back (tools/check_asm_hazards.py, round 6: 36 sites in the sa_fwd kernels).  Results were right
+// all the same - every K tail of this network ends in a zero-padded k-step, and a stale read sees the accumulator one
+// dependent MFMA earlier - but that is luck, not design.
+__device__ __forceinline__ void mfma_fence(f32x16 &acc) { asm volatile("s_nop 15\n\ts_nop 1" : "+v"(acc)); }
+
 // ReLU of an accumulator tile in place + its 16 "was positive" bits (bit r = register r).  Three vector instructions
 // per register (compare, select, add-with-carry shifts the bit in: registers 15 .. 0 so bit r lands at position r); the
 // compiler's version of `pos ? c : 0; m |= pos << r` took five to six, and on this chip a vector instruction of an
@@ -301,6 +313,7 @@ __device__ __forceinline__ f32x16 tile_mac(const float4 *__restrict__ w, int k8n
         const float4 b = *(const float4 *)(bptr + (size_t)k8 * BLK);
         acc = mfma4<FLIP>(a, b, acc);
     }
+    if (k8n > k4) mfma_fence(acc);
     return acc;
 }
 

@@ -171,6 +171,7 @@ __device__ __forceinline__ void sa_layer1_split(const SaFwdArgs &a, int b, int s
             const float4 wx = L.w[(size_t)mb * 64 + lane];               // k8 = 1: one chunk per 32-channel block
             const float4 rx = *(const float4 *)(buf + (pb * 32 + j) * 8 + 4 * h);
             c = mfma4<false>(wx, rx, c);
+            mfma_fence(c);                                               // (compiler MFMAs -> inline-asm consumer: psg_mlp.cuh)
             const unsigned m = relu_bits(c);
             if (L.mask) L.mask[(wg_linear * ntask + task) * 64 + lane] = (uint16_t)m;
             acc[i] = c;

@@ -77,3 +77,20 @@ def test_switch_selects_other_kernels_with_the_same_parity(test_file, keyword, s
     assert alt.returncode == 0, alt.stdout[-3000:]
     assert " passed" in alt.stdout and "skipped" not in alt.stdout.splitlines()[-1]
     assert base_sites and alt_sites and alt_sites != base_sites, (switch, sorted(alt_sites ^ base_sites))
+
+
+@pytest.mark.parametrize("arch", ["ssg", "msg"])
+def test_traced_forward_backward_completes(arch):
+    """Round 5's stale wave-uniform trip count (a v_readfirstlane one instruction behind the VALU write of its source, inside
+    inline assembly: the k-loop ran off its weights, a memory fault) was found with the launch tracer: one plan + forward +
+    backward with a synchronisation and an error check after every launch (tools/fp_split_probe.py).  Pinned here so that
+    one run shows a regression of that class launch by launch (round-5 advisor); the static side of the same class is
+    tools/check_asm_hazards.py over the compiler's assembly."""
+    env = dict(os.environ)
+    env["PSG_TRACE_SYNC"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fp_split_probe.py"), arch], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "forward ok" in out.stdout and "backward ok" in out.stdout
+    issued = re.findall(r"\[psg trace\] launch (\d+) at (\S+) issued", out.stderr + out.stdout)
+    assert len(issued) >= 40, len(issued)
