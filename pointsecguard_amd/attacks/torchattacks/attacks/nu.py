@@ -31,7 +31,14 @@ from pointsecguard_amd.models.pointnet2_sem_seg import draw_fps_starts, upload
 from ._common import labels_to_device, mask_to_device, psg_model
 
 BETA1, BETA2, ADAM_EPS = 0.9, 0.999, 1e-8
-CHUNK = 10  # geometry plan horizon: restarts can only happen after steps that are multiples of 10
+CHUNK = 10  # control-flow window: restarts can only happen after steps that are multiples of 10
+# Geometry plan horizon (round 6).  Rounds 3-5 planned one window at a time: 640 problems per plan at 64 rooms, where FPS is
+# bound by the latency of its 1360 dependent steps, not by throughput - 1.71 ms of geometry per forward against 0.24 ms in
+# the 2 560-problem plan of the NB attack (profiles/r05_bench_default.json: 17.1 of a window's 40.9 ms).  The plan now runs
+# up to PLAN_AHEAD forwards ahead (the windows stay what the control flow reads back); what a restart or an early exit
+# leaves unused of it is re-drawn / given back to the generator (the FPS draws come from the CPU generator in forward
+# order, pointnet_util.py:75; the restart noise of target.py:131 from the device's: the two streams do not interleave).
+PLAN_AHEAD = 50
 
 
 class _NuState:
@@ -57,13 +64,17 @@ class _NuState:
         self.exit = torch.empty(G, device=dev, dtype=torch.int32)
         self.n_mask = torch.empty(G, device=dev, dtype=torch.int32)
         self.out = f32(B, 9, N)
-        self.graph = ctypes.c_void_p()
-        _lib.call("psg_nu_graph_create", ctypes.byref(self.graph))
+        # one graph handle per window position inside a geometry plan (a captured window holds its plan slots)
+        self.graphs = [ctypes.c_void_p() for _ in range(PLAN_AHEAD // CHUNK)]
+        for g in self.graphs:
+            _lib.call("psg_nu_graph_create", ctypes.byref(g))
+        self.graph = self.graphs[0]
 
     def __del__(self):
         try:
-            if self.graph:
-                _lib.load().psg_nu_graph_destroy(self.graph)
+            for g in self.graphs:
+                if g:
+                    _lib.load().psg_nu_graph_destroy(g)
         except Exception:
             pass
 
@@ -89,7 +100,7 @@ def _nu_core(atk, images, labels, masks, target, neighbour, targeted_variant, tr
     S = _state(net, dev, G, rows, N, neighbour)
     model = net._packed()
     net._generation += 1
-    ws = net._workspace(B, N, CHUNK + 1)
+    ws = net._workspace(B, N, PLAN_AHEAD)
     use_target = targeted_variant and target is not None
     mode = 0 if not targeted_variant else (2 if use_target else 1)
     S.labels.copy_(labels_to_device(labels, dev))
@@ -117,7 +128,7 @@ def _nu_core(atk, images, labels, masks, target, neighbour, targeted_variant, tr
     prev_cost = np.full((atk.steps, G), 1e10)
     lr, adam_t = float(atk.lr), 0
     tsign = float(atk._targeted)
-    planned_until = 0
+    planned_until, rng_at = 0, None
     exited = np.full(G, -1, np.int64)                                # step at which an attack's exit test fired (-1: running)
     win = _lib.NuWindowArgs(
         model=model.handle.value, ws=ws.handle.value, G=G, rows=rows, N=N, mode=mode, use_target=int(use_target),
@@ -137,18 +148,34 @@ def _nu_core(atk, images, labels, masks, target, neighbour, targeted_variant, tr
             # attack right after it (at batch 32 the targeted one always does, target.py:105-121), and a plan for
             # eleven forwards would then be ten too many; the rest of the first window follows with step 1.
             # (the plan reads the coordinates only; the colours of a step are written inside the window call)
-            window_end = 1 if step == 0 else ((step - 1) // CHUNK + 1) * CHUNK + 1      # [0], [1..10], [11..20], ..
-            n_plan = min(window_end - step, atk.steps - step)
-            starts = upload(draw_fps_starts(B, N, n_plan) if starts_fn is None else starts_fn(step, n_plan), dev)
+            # (round 6) ... and the plan itself runs up to PLAN_AHEAD forwards ahead: [0], [1..50], [51..100], ..; the draws are
+            # made window by window with the generator's state kept at every window end, so that what is not consumed can
+            # be given back (end of the attack) or drawn again (a restart moved the coordinates)
+            n_plan = 1 if step == 0 else min(PLAN_AHEAD, atk.steps - step)
+            if starts_fn is not None:
+                starts = upload(starts_fn(step, n_plan), dev)
+                rng_at = None
+            else:
+                if rng_at is not None and step in rng_at:
+                    torch.set_rng_state(rng_at[step])                # the unused draws of the plan this one replaces
+                parts, rng_at, s_ = [], {}, step
+                while s_ < step + n_plan:
+                    e_ = min(1 if s_ == 0 else ((s_ - 1) // CHUNK + 1) * CHUNK + 1, step + n_plan)
+                    parts.append(draw_fps_starts(B, N, e_ - s_))
+                    rng_at[e_] = torch.get_rng_state()
+                    s_ = e_
+                starts = upload(torch.cat(parts), dev)
             ws.plan_build(x0, starts, n_plan)
             plan_base, planned_until = step, step + n_plan
-        # ---- the steps up to the end of the geometry window (= up to the next point where the reference's host work needs
+        # ---- the steps up to the end of the control-flow window (= up to the next point where the reference's host work needs
         # values) in ONE call: colours, forward, f-loss, backward, Smooth term, Adam step, statistics + exit latch per step;
         # full windows of the same shape are replayed as a hipGraph (psg_pn2_nu_window)
-        n_run = 1 if trace is not None else planned_until - step
+        window_end = 1 if step == 0 else ((step - 1) // CHUNK + 1) * CHUNK + 1          # [0], [1..10], [11..20], ..
+        n_run = 1 if trace is not None else min(planned_until, window_end) - step
         win.slot0, win.step0, win.n_steps = step - plan_base, step, n_run
         win.adam_t0, win.lr, win.warm_first = adam_t, lr, 1 if step > 0 else 0
-        _lib.call("psg_pn2_nu_window", ctypes.byref(win), S.graph if n_run == CHUNK else None, st())
+        graph = S.graphs[((step - plan_base) // CHUNK) % len(S.graphs)] if n_run == CHUNK and (step - plan_base) % CHUNK == 0 else None
+        _lib.call("psg_pn2_nu_window", ctypes.byref(win), graph, st())
         adam_t += n_run
         last = step + n_run - 1
         # ---- the reference's control flow, per attack, where the reference's host work needs the values (ONE read-back)
@@ -188,6 +215,11 @@ def _nu_core(atk, images, labels, masks, target, neighbour, targeted_variant, tr
                 sums = ((d[:, :, 0:3] ** 2).sum(dim=(1, 2)) + (d[:, :, 6:9] ** 2).sum(dim=(1, 2))).reshape(len(again), rows)
                 extra_l2[again] = sums.sum(dim=1).cpu().numpy().astype(np.float64)   # one read-back for all of them
                 planned_until = step                     # xyz may have moved: rebuild the plan before the next forward
+    if rng_at is not None and planned_until > step:
+        # draws of forwards that never ran go back to the generator - all but those of the window the attack stopped in
+        # (rounds 3-5 drew window by window: the generator is left where it was left then)
+        e_ = step if step in rng_at else min(k for k in rng_at if k >= step)
+        torch.set_rng_state(rng_at[e_])
     out = S.out.clone()                                  # (the caller owns what it gets; the state buffer is reused)
     for g in np.nonzero(exited < 0)[0]:                  # attacks that ran to the cap: the current image
         _lib.call("psg_to_channel_major", runtime.ptr(x0[g * rows:(g + 1) * rows]), rows, 9, N, runtime.ptr(out[g * rows:(g + 1) * rows]), st())

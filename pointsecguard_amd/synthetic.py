@@ -169,6 +169,22 @@ def gcn28_state_dict():
     return sd
 
 
+def gcn28_fit_state_dict():
+    """The 28-block ResGCN weights of the free-running outcome fixture (tests/golden/gcn28_nb_outcome_fit*.npz, round 6):
+    gcn_state_dict(7, 28) for the two big matrices and tests/golden/gcn28_weights_fit.npz for everything else - the reference
+    network fitted IN EVAL MODE with small residual branches until it is right on ~0.9 of the rule labels of a 4096-point
+    room (tests/golden/make_golden_big.py: fit_gcn28_frozen).  gcn28_state_dict() above (70 steps, accuracy 0.1 - 0.2, the
+    reference chaotic against itself) stays what the teacher-forced 28-block fixture and bench.py use."""
+    import os
+    sd = gcn_state_dict(7, 28)
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "gcn28_weights_fit.npz")
+    small = np.load(path)
+    for k in small.files:
+        assert k in sd and sd[k].shape == small[k].shape, k
+        sd[k] = small[k]
+    return sd
+
+
 # RandLA-Net for S3DIS (RandLA-Net/helper_tool.py:41-60 ConfigS3DIS, RandLANet.py:150-190 of the reference)
 RANDLA_D_OUT = (16, 64, 128, 256, 512)
 RANDLA_RATIOS = (4, 4, 4, 4, 2)
