@@ -117,6 +117,46 @@ def kernel_flops_msg(batch):
     return out
 
 
+def kernel_flops_msg_executed(batch):
+    """FLOPs the MSG launches EXECUTE with the shipped defaults (round-5 review: the MSG line printed the algorithmic count
+    only, although the same splits are active there): SA levels 2-4 run their first layer as a per-POINT feature product
+    (pw_fwd / pw_bwd) + a per-ROW xyz chunk, per scale; fp1-fp3's interpolated first-layer columns run per COARSE point inside
+    the coarser module; level 0 of the attack loop's backward applies three colour columns of the first layer (vector
+    pipe) instead of all twelve.  Mirrors kernel_flops_executed."""
+    from pointsecguard_amd.synthetic import MSG_FP, MSG_SA
+    out = kernel_flops_msg(batch)
+    S, KS = (1024, 256, 64, 16), (16, 32)
+    pw = 0.0
+    for l in (1, 2, 3):
+        cin, mlps = MSG_SA[l]
+        f = b = 0.0
+        for (c1, c2, c3), k in zip(mlps, KS):
+            f += S[l] * k * (3 * c1 + c1 * c2 + c2 * c3)
+            b += S[l] * k * (c1 * c2 + c2 * c3)
+            pw += S[l - 1] * cin * c1
+        out["sa%d_fwd" % (l + 1)] = 2.0 * batch * f
+        out["sa%d_bwd" % (l + 1)] = 2.0 * batch * b
+    cin, mlps = MSG_SA[0]
+    out["sa1_bwd"] = 2.0 * batch * sum(S[0] * k * (3 * c1 + c1 * c2 + c2 * c3) for (c1, c2, c3), k in zip(mlps, KS))
+    out["pw_fwd"] = out["pw_bwd"] = 2.0 * batch * pw
+    # FP split: modules in MSG_FP order fp4, fp3, fp2, fp1; skip-link channels of their concatenated inputs
+    mods = {name: ((cin,) + tuple(mlp) + ((128, 13) if name == "fp1" else ()), n_l)
+            for (name, cin, mlp), n_l in zip(MSG_FP, (64, 256, 1024, 4096))}
+    skip = {"fp1": 0, "fp2": MSG_SA[1][0], "fp3": MSG_SA[2][0], "fp4": MSG_SA[3][0]}
+    order = ("fp1", "fp2", "fp3", "fp4")
+    for i, name in enumerate(order):
+        dims, n_l = mods[name]
+        m = macs(dims)
+        if name != "fp4":
+            m -= (dims[0] - skip[name]) * dims[1]              # this module's interpolated part leaves its kernels
+        if i > 0:
+            fine, _ = mods[order[i - 1]]
+            m += (fine[0] - skip[order[i - 1]]) * fine[1]      # ... and is the extra layer of the next coarser module
+        tag = "fp1_head" if name == "fp1" else name
+        out[tag + "_fwd"] = out[tag + "_bwd"] = 2.0 * batch * n_l * m
+    return out
+
+
 def pn2_roofline(prof, flops, sa_launches_per_call=1):
     """roofline object of the MLP module with the largest total time in a HIP-event profile {tag: (ms, launches)}.
     (MSG network: an SA level is two launches, one per scale, under one tag; flops[tag] covers both.)"""
@@ -164,18 +204,27 @@ class Ranks:
                 # everybody else's queue; measured on the MSG / tarnu lines, round 5)
                 torch.cuda.Stream(device=self.dev_index)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if "MASTER_PORT" not in os.environ:          # plain `python bench.py` at N = 1: no launcher set a rendezvous
-                import socket
-                s = socket.socket()
-                s.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
-                s.close()
-            if backend == "nccl":
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.dev_index))
-            else:
-                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
-            self.dist = dist
-            self.pg_info = {"backend": backend, "world": dist.get_world_size(), "collective": "rccl" if backend == "nccl" else backend}
+            init_kw = {}
+            if "MASTER_PORT" not in os.environ and self.world == 1:
+                # plain `python bench.py` at N = 1: no launcher set a rendezvous, and none is needed across processes - a
+                # file store in a private directory (round-5 advisor: picking a free TCP port by bind-then-close races when
+                # several benches start together, as the tools/ sweeps do)
+                import tempfile
+                self._pg_dir = tempfile.mkdtemp(prefix="psg_bench_pg_")
+                init_kw["init_method"] = "file://" + os.path.join(self._pg_dir, "store")
+            try:
+                if backend == "nccl":
+                    dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.dev_index), **init_kw)
+                else:
+                    dist.init_process_group(backend, rank=self.rank, world_size=self.world, **init_kw)
+                self.dist = dist
+                self.pg_info = {"backend": backend, "world": dist.get_world_size(), "collective": "rccl" if backend == "nccl" else backend}
+            except Exception as exc:
+                if self.world > 1:
+                    raise
+                # one rank: the group only makes the barrier / max / n_ranks_seen real collectives; a box whose communicator
+                # does not come up still gets its line, which says so
+                self.pg_info = {"backend": backend, "world": 1, "collective": "none (init_process_group failed: %s: %s)" % (type(exc).__name__, str(exc)[:200])}
 
     def fence(self):
         import torch
@@ -704,27 +753,42 @@ PMC_SYMBOL = {"fp1_head_fwd": "void psg::fp_fwd_kernel<32, 4, false>(psg::FpFwdA
               "sa2_fwd": "void psg::sa_fwd_kernel<64, 4, 32, 1>(psg::SaFwdArgs)",
               "sa2_bwd": "void psg::sa_bwd_kernel<64, 4, 2, 32>(psg::SaBwdArgs)",
               # the fused kNN launches of the ResGCN path are two kernels since round 3 (the bf16-prefilter kernel for dilations
-              # 1..20, the exact kernel above): the tag's figure is the launch-weighted mean of both
+              # 1..20 in rounds 4-5 and for all of 1..27 since round 6, the exact kernel above): the tag's figure is the launch-weighted mean of both
               "knn_fused": ("(anonymous namespace)::knn_bf_kernel((anonymous namespace)::KnnBfArgs)",
                             "(anonymous namespace)::knn_fused_kernel((anonymous namespace)::KnnFusedArgs)")}
+# MSG network: an SA level is TWO launches (one per scale) under one tag - the tag's traffic is their SUM per call (psg_pn2.hip:
+# PSG_SA_BWD_CASE / the sa_fwd switch name the instantiations; sa3 / sa4 forward share their scale-0 instantiation, so only
+# the backward tags and the FP modules are listed)
+PMC_SYMBOL_MSG = {"sa1_bwd": ("void psg::sa_bwd_kernel<128, 4, 1, 16>(psg::SaBwdArgs)", "void psg::sa_bwd_kernel<128, 4, 1, 32>(psg::SaBwdArgs)"),
+                  "sa2_bwd": ("void psg::sa_bwd_kernel<64, 4, 2, 16>(psg::SaBwdArgs)", "void psg::sa_bwd_kernel<64, 8, 1, 32>(psg::SaBwdArgs)"),
+                  "sa3_bwd": ("void psg::sa_bwd_kernel<32, 8, 2, 16>(psg::SaBwdArgs)", "void psg::sa_bwd_kernel<32, 8, 2, 32>(psg::SaBwdArgs)"),
+                  "sa4_bwd": ("void psg::sa_bwd_kernel<32, 8, 3, 16>(psg::SaBwdArgs)", "void psg::sa_bwd_kernel<32, 8, 3, 32>(psg::SaBwdArgs)"),
+                  "sa1_fwd": ("void psg::sa_fwd_kernel<128, 4, 16, 1, false>(psg::SaFwdArgs)", "void psg::sa_fwd_kernel<128, 4, 32, 1, false>(psg::SaFwdArgs)"),
+                  "sa2_fwd": ("void psg::sa_fwd_kernel<64, 4, 16, 1, true>(psg::SaFwdArgs)", "void psg::sa_fwd_kernel<64, 8, 32, 1, true>(psg::SaFwdArgs)"),
+                  "fp1_head_fwd": "void psg::fp_fwd_kernel<32, 4, false>(psg::FpFwdArgs)",
+                  "fp1_head_bwd": "void psg::fp_bwd_kernel<32, 4, 1, false>(psg::FpBwdArgs)"}
 
 
-def pmc_traffic(tag, device_batch, pattern="*_pmc_traffic.json"):
+def pmc_traffic(tag, device_batch, pattern="*_pmc_traffic.json", symbols=None, combine="mean"):
     """HBM bytes per launch of kernel `tag` from the newest committed PMC summary (profiles/<round>_pmc_traffic*.json,
     written by tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE passes of this bench at the default device
     batch, gfx950 read-doubling correction applied).  PMC cannot be sampled from inside the process, so the
     figure is the committed one (scaled by the room count when this run's device batch differs from the counted one)."""
     import glob
+    symbols = PMC_SYMBOL if symbols is None else symbols
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
-    if not files or tag not in PMC_SYMBOL:
+    if not files or tag not in symbols:
         return None, None
     with open(files[-1]) as fh:
         table = json.load(fh)
-    sym = PMC_SYMBOL[tag]
+    sym = symbols[tag]
     if isinstance(sym, tuple):
         rows = [table[x] for x in sym if x in table]
         n = sum(r["launches_fetch_pass"] for r in rows)
-        row = {"hbm_bytes_per_launch": sum(r["hbm_bytes_per_launch"] * r["launches_fetch_pass"] for r in rows) / n} if n else None
+        if combine == "sum":        # one call of the tag = one launch of EACH symbol (the two scales of an MSG SA level)
+            row = {"hbm_bytes_per_launch": sum(r["hbm_bytes_per_launch"] for r in rows)} if len(rows) == len(sym) else None
+        else:
+            row = {"hbm_bytes_per_launch": sum(r["hbm_bytes_per_launch"] * r["launches_fetch_pass"] for r in rows) / n} if n else None
     else:
         row = table.get(sym)
     if not row:
@@ -897,9 +961,16 @@ def run_msg(args, R):
         torch.cuda.synchronize()
         prof = wss[0].prof_read()
         wss[0].prof_enable(False)
-        result["roofline"] = pn2_roofline(prof, kernel_flops_msg(DB), sa_launches_per_call=2)
-        result["roofline"]["rooms_per_launch"] = DB
-        result["roofline"]["traffic"], result["roofline"]["traffic_source"] = pmc_traffic(result["roofline"]["kernel"], DB, "*_pmc_traffic_msg.json")
+        roof = pn2_roofline(prof, kernel_flops_msg(DB), sa_launches_per_call=2)
+        fx = kernel_flops_msg_executed(DB)
+        # (as on the SSG line: `frac` counts the reference's layers, `frac_executed` what the launches execute with the split
+        # first layers; an SA tag's launch = its two scales, so its traffic is the two kernels' sum per call)
+        roof["flop_per_launch_executed"] = fx[roof["kernel"]]
+        roof["frac_executed"] = fx[roof["kernel"]] / (roof["avg_launch_us"] * 1e-6) / 1e12 / PEAK_FP32_MATRIX_TFLOPS
+        roof["rooms_per_launch"] = DB
+        roof["traffic"], roof["traffic_source"] = pmc_traffic(roof["kernel"], DB, "*_pmc_traffic_msg.json", PMC_SYMBOL_MSG, "sum")
+        result["roofline"] = roof
+        result["executed_flop_share"] = round(sum(fx[k] for k in fx) / sum(kernel_flops_msg(DB).values()), 4)
         result["kernel_ms_per_attack"] = {k: round(v[0], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         if want_cpu(args, R):
             rooms, labels_h, starts_h = host[0]

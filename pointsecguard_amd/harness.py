@@ -206,10 +206,17 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
     (`dataset[si]`: ~60 ms of numpy per 70-block scene, as much as the GPU needs for the scene's attacks) runs on a helper
     thread meanwhile - for this module's own ScannetDatasetWholeScene only, whose `__getitem__` touches nothing but
     numpy's generator: the slicing calls still happen one after the other in the reference's order (scene by scene, vote by
-    vote), so `np.random` is consumed exactly as before; a caller's dataset class is sliced in line."""
+    vote), so `np.random` is consumed exactly as before; a caller's dataset class is sliced in line.  While the helper
+    thread runs, `make_attack` / the attack must not draw from numpy's GLOBAL generator (the attacks of this package use torch's
+    generators only); replicas that cannot be built (another constructor signature) fall back to one stream with a log line."""
     dev = next(classifier.parameters()).device
     n_streams = max(1, int(streams))
-    nets = [classifier] + [_replica(classifier) for _ in range(n_streams - 1)]
+    nets = [classifier]
+    try:
+        nets += [_replica(classifier) for _ in range(n_streams - 1)]
+    except Exception as exc:          # a caller's model class with another constructor, or state outside state_dict (advisor, round 5)
+        log("evaluate_whole_scene: no replica of %s (%s: %s); running on one stream" % (type(classifier).__name__, type(exc).__name__, exc))
+        nets, n_streams = [classifier], 1
     lanes = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [None]
     attacks = [make_attack(n) if (make_attack is not None and targeted is None) else None for n in nets]
     n_pt = dataset.block_points
@@ -238,44 +245,47 @@ def evaluate_whole_scene(classifier, dataset, make_attack, batch_size=8, num_vot
         nxt[0] = fetcher.submit(dataset.__getitem__, fetch_order[k + 1]) if k + 1 < len(fetch_order) else None
         return data
 
-    for si in my_scenes:
-        labels_np = dataset.semantic_labels_list[si]
-        n_scene = labels_np.shape[0]
-        scene_labels = torch.from_numpy(labels_np.astype(np.int32)).to(dev)
-        pool = torch.zeros(n_scene, NUM_CLASSES, dtype=torch.int32, device=dev)
-        adv_pool = torch.zeros_like(pool)
-        pending = []                                 # rows of this scene's log: device scalars, read back once per scene
-        vote_bad = torch.zeros(1, dtype=torch.int32, device=dev)
-        for ln in lanes:                             # the scene's pools were zeroed on the caller's stream
-            if ln is not None:
-                ln.wait_stream(torch.cuda.current_stream(dev))
-        n_issued = 0
-        for _ in range(num_votes):
-            scene_data, scene_label, scene_smpw, scene_point_index = next_scene_data(si)
-            num_blocks = scene_data.shape[0]
-            for sbatch in range((num_blocks + batch_size - 1) // batch_size):
-                lo, hi = sbatch * batch_size, min((sbatch + 1) * batch_size, num_blocks)
-                slot = n_issued % n_streams
-                n_issued += 1
-                pending.extend(_scene_batch(nets[slot], attacks[slot], make_attack, targeted, lanes[slot], dev, n_pt, sbatch, lo, hi,
-                                            scene_data, scene_label, scene_smpw, scene_point_index, pool, adv_pool, vote_bad))
-        for ln in lanes:
-            if ln is not None:
-                torch.cuda.current_stream(dev).wait_stream(ln)
-        check_votes(vote_bad)
-        _write_rows(pending, targeted, fh)
-        c_scene = vote_stats(pool, scene_labels)
-        c_scene_adv = vote_stats(adv_pool, scene_labels)
-        total[0] += c_scene
-        total[1] += c_scene_adv
-        name = dataset.file_list[si][:-4]
-        scene_rows.append((name, _miou(c_scene), _miou(c_scene_adv)))
-        log('Mean IoU of %s: %.4f' % (name, scene_rows[-1][1]))
-        log('Mean IoU of %s: %.4f' % (name, scene_rows[-1][2]))
-    if fh is not None:
-        fh.close()
-    if fetcher is not None:
-        fetcher.shutdown(wait=True)
+    try:
+      for si in my_scenes:
+          labels_np = dataset.semantic_labels_list[si]
+          n_scene = labels_np.shape[0]
+          scene_labels = torch.from_numpy(labels_np.astype(np.int32)).to(dev)
+          pool = torch.zeros(n_scene, NUM_CLASSES, dtype=torch.int32, device=dev)
+          adv_pool = torch.zeros_like(pool)
+          pending = []                                 # rows of this scene's log: device scalars, read back once per scene
+          vote_bad = torch.zeros(1, dtype=torch.int32, device=dev)
+          for ln in lanes:                             # the scene's pools were zeroed on the caller's stream
+              if ln is not None:
+                  ln.wait_stream(torch.cuda.current_stream(dev))
+          n_issued = 0
+          for _ in range(num_votes):
+              scene_data, scene_label, scene_smpw, scene_point_index = next_scene_data(si)
+              num_blocks = scene_data.shape[0]
+              for sbatch in range((num_blocks + batch_size - 1) // batch_size):
+                  lo, hi = sbatch * batch_size, min((sbatch + 1) * batch_size, num_blocks)
+                  slot = n_issued % n_streams
+                  n_issued += 1
+                  pending.extend(_scene_batch(nets[slot], attacks[slot], make_attack, targeted, lanes[slot], dev, n_pt, sbatch, lo, hi,
+                                              scene_data, scene_label, scene_smpw, scene_point_index, pool, adv_pool, vote_bad))
+          for ln in lanes:
+              if ln is not None:
+                  torch.cuda.current_stream(dev).wait_stream(ln)
+          check_votes(vote_bad)
+          _write_rows(pending, targeted, fh)
+          c_scene = vote_stats(pool, scene_labels)
+          c_scene_adv = vote_stats(adv_pool, scene_labels)
+          total[0] += c_scene
+          total[1] += c_scene_adv
+          name = dataset.file_list[si][:-4]
+          scene_rows.append((name, _miou(c_scene), _miou(c_scene_adv)))
+          log('Mean IoU of %s: %.4f' % (name, scene_rows[-1][1]))
+          log('Mean IoU of %s: %.4f' % (name, scene_rows[-1][2]))
+    finally:
+        # (also when a batch raises: the helper thread and its pending slice must not outlive the call)
+        if fh is not None:
+            fh.close()
+        if fetcher is not None:
+            fetcher.shutdown(wait=True, cancel_futures=True)
     return _finish(total, scene_rows, rank, log)
 
 
