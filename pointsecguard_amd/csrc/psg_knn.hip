@@ -125,8 +125,13 @@ hipError_t knn_launch(const KnnBuffers &buf, int B, int N, int k, int d, int32_t
     if (!buf.x || buf.ld < 64 || (buf.ld & 3)) return hipErrorInvalidValue;      // the prefilter path reads its finalists from the row-major features
     KnnBfArgs a;
     a.bp = (const kb_u32x4 *)buf.bp; a.sq = buf.sq; a.out = out; a.N = N; a.k = k; a.d = d; a.KK = f.KK; a.magic = f.magic;
-    // two sample tiles per wave for the longest rows (psg_knn_bf.cuh)
-    static const int two_from = psg::env_int("PSG_KNN_SAMPLE2_KK", 311);
+    // two sample tiles per wave for the longest rows (psg_knn_bf.cuh).  Round 4 switched them on from KK = 311 (d >= 21): rows then
+    // end with 1.45 KK entries instead of 1.7 KK, which kept them inside their 1024-entry buffers AND under the 256-finalist
+    // limit.  Since round 6 (2048-bin final ranking: 64 finalists per row at d = 27) only the buffers matter, and on the
+    // network's features 1.7 KK = 570 - 690 entries fit: one sample tile is 10 - 12 us faster per call at d = 21..27 (the
+    // second tile's cut costs more than the shorter rows save; tools/r06_f.sh: 158 / 154 / 157 / 154 -> 147 / 142 / 144 / 144 us,
+    // one exact-path tile in 165 888 over a 12-iteration attack either way), so the second tile starts at KK = 430 now
+    static const int two_from = psg::env_int("PSG_KNN_SAMPLE2_KK", 430);
     const int n_steps = ((N >> 5) + KB_WAVES - 1) / KB_WAVES;
     a.nsamp = (a.KK >= two_from && (N & 511) == 0 && n_steps >= 4) ? 2 : 1;
     a.rsel = knn_sample_rank(N, a.KK, a.nsamp);

@@ -94,3 +94,13 @@ def test_traced_forward_backward_completes(arch):
     assert "forward ok" in out.stdout and "backward ok" in out.stdout
     issued = re.findall(r"\[psg trace\] launch (\d+) at (\S+) issued", out.stderr + out.stdout)
     assert len(issued) >= 40, len(issued)
+
+
+def test_knn_prefilter_with_two_sample_tiles_per_wave():
+    """PSG_KNN_SAMPLE2_KK: the prefilter kernel's second sample tile per wave (rows of 1.45 KK instead of 1.7 KK entries) was
+    the default from KK = 311 in rounds 4-5 and starts at KK = 430 since round 6 (psg_knn.hip: one tile is faster once the
+    finalists no longer limit the rows), i.e. no dilation of the 28-block network takes it by default any more.  The path
+    stays a switch and keeps its parity: the kNN tests that reach d >= 21 run in a child with the round-5 setting."""
+    out, _ = child("test_gpu_knn_bf16.py", "default_split or adversarial or spatially_sorted", {"PSG_KNN_SAMPLE2_KK": "311"})
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert " passed" in out.stdout and "skipped" not in out.stdout.splitlines()[-1]
