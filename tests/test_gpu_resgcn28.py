@@ -161,7 +161,7 @@ def test_nb_attack_outcome_against_the_reference_runs(gcn28):
     near-tie moves (above), and the 70-step fit of the fixture weights leaves the predictions near chance (accuracy 0.08 - 0.2),
     so what ANY two evaluation orders agree on is the distribution, not the points.  The bar is therefore the reference's own
     spread: this implementation's distance from the eight-thread run may not exceed 2 x the one-thread run's distance from it
-    (+ 0.06), for the clean and the adversarial accuracy averaged over the rooms and room by room; what does not depend on the
+    (round 5 added 0.06 to that; round 6 does not), for the clean and the adversarial accuracy averaged over the rooms and room by room; what does not depend on the
     chaos is pinned tightly: the L2 distance of the returned room (eps / alpha / iteration count: within 2 %) and the
     invariants (only colours move)."""
     from pointsecguard_amd.synthetic import make_rooms, rule_labels
@@ -201,8 +201,11 @@ def test_nb_attack_outcome_against_the_reference_runs(gcn28):
           np.round(adv_miou, 3), g["adv_miou"].round(3), g1["adv_miou"].round(3), "| L2", np.round(dis, 3), g["dis"].round(3), g1["dis"].round(3))
     for name, got in (("acc", acc), ("adv_acc", adv_acc), ("adv_miou", adv_miou)):
         ref, ref1 = g[name], g1[name]
-        assert abs(got.mean() - ref.mean()) <= 2.0 * abs(ref1.mean() - ref.mean()) + 0.06, (name, got.mean(), ref.mean(), ref1.mean())
-        assert np.abs(got - ref).max() <= 2.0 * np.abs(ref1 - ref).max() + 0.06, (name, got, ref, ref1)
+        # (round 6: the "+ 0.06" of round 5 is gone - the bar is the reference's own spread alone; this implementation's attack is
+        # bit-reproducible, so the margins below are the same on every box: mean 0.066 / 0.008 / 0.005 against bars of 0.110 /
+        # 0.027 / 0.015, per room 0.099 / 0.062 / 0.035 against 0.236 / 0.086 / 0.048.  The test with teeth is the next one.)
+        assert abs(got.mean() - ref.mean()) <= 2.0 * abs(ref1.mean() - ref.mean()), (name, got.mean(), ref.mean(), ref1.mean())
+        assert np.abs(got - ref).max() <= 2.0 * np.abs(ref1 - ref).max(), (name, got, ref, ref1)
     assert np.abs(dis / g["dis"] - 1).max() <= 0.02 and np.abs(g1["dis"] / g["dis"] - 1).max() <= 0.02
 
 
@@ -214,7 +217,8 @@ def test_nb_attack_outcome_on_fitted_weights_against_the_reference_runs():
     and stable: tests/golden/gcn28_nb_outcome_fit.npz / ..._fit_t1.npz hold what the reference's experiment loop
     (sem_seg_dense/attacks.py:125-160) measured when ITS `NB_attack(eps=0.3, alpha=2/255, iters=50)` ran on four single-room
     batches, with six intra-op threads and with one, and the two runs agree with each other on >= 0.95 of the clean
-    per-point predictions, within 0.004 on every room's clean accuracy and 0.01 on its adversarial accuracy (asserted
+    per-point predictions (0.958 - 0.966), within 0.004 on every room's clean accuracy (0.0032) and 0.012 on its adversarial
+    accuracy (0.0103) (asserted
     below, so the premise of the bars is part of the test).  The attack takes the accuracy from 0.91 to 0.47: nothing here
     is degenerate.  Bars, ABSOLUTE and per room (the ones test_nb_b8_statistical_parity_32_rooms uses for PointNet++): clean
     accuracy within 0.01 of the reference's, clean predictions equal on >= 0.95 of the points, adversarial accuracy and
@@ -229,7 +233,7 @@ def test_nb_attack_outcome_on_fitted_weights_against_the_reference_runs():
     # ---- the premise: the reference agrees with itself on these weights
     self_agree = [float((g["r%d_clean_pred" % i] == g1["r%d_clean_pred" % i]).mean()) for i in range(n_rooms)]
     assert min(self_agree) >= 0.95, self_agree
-    assert np.abs(g["acc"] - g1["acc"]).max() <= 0.004 and np.abs(g["adv_acc"] - g1["adv_acc"]).max() <= 0.01
+    assert np.abs(g["acc"] - g1["acc"]).max() <= 0.004 and np.abs(g["adv_acc"] - g1["adv_acc"]).max() <= 0.012
     assert g["acc"].min() >= 0.8 and g["adv_acc"].max() <= 0.6
     model = runtime.GCNModel(gcn28_fit_state_dict(), 28)
     ws = runtime.GCNWorkspace(1, 4096, 28)
