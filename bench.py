@@ -403,6 +403,8 @@ def main():
                     help="randla workload: distance metric of the BIM update.  l_2 (default) is what the reference's tester runs "
                          "(RandLA-Net/tester_S3DIS.py:37,142-145: NBattack(..., distance_metric='l_2'), magnitude 17, alpha 1.7); "
                          "l_inf (eps 0.05, alpha 0.01) is reported beside it as `l_inf`")
+    ap.add_argument("--nu-plan-ahead", type=int, default=0,
+                    help="tarnu workload: forwards per geometry plan (multiple of 10; 0 = the package's default, nu.plan_ahead)")
     ap.add_argument("--nu-concurrency", type=int, default=12,
                     help="tarnu workload: attacks in flight, one host thread + HIP stream + model instance each (a one-room "
                          "attack is ~30 short launches per optimiser step: several of them side by side fill the GPU)")
@@ -1188,6 +1190,8 @@ def tarnu_measure(args, R, mode, with_roofline=True):
     from pointsecguard_amd.models.pointnet2_sem_seg import get_model
     from pointsecguard_amd.synthetic import make_rooms, rule_labels
     target, src_cls = 6, 2
+    if getattr(args, "nu_plan_ahead", 0):
+        nu_mod.plan_ahead = int(args.nu_plan_ahead)
     strong = args.scaling == "strong"
     per_step = max(1, 32 // R.world) if strong else 32          # rooms of one step on this rank
     cap = args.nu_steps if args.nu_steps else (40 if mode in ("per-room", "per-room-calls") else 100)

@@ -32,13 +32,17 @@ from ._common import labels_to_device, mask_to_device, psg_model
 
 BETA1, BETA2, ADAM_EPS = 0.9, 0.999, 1e-8
 CHUNK = 10  # control-flow window: restarts can only happen after steps that are multiples of 10
-# Geometry plan horizon (round 6).  Rounds 3-5 planned one window at a time: 640 problems per plan at 64 rooms, where FPS is
-# bound by the latency of its 1360 dependent steps, not by throughput - 1.71 ms of geometry per forward against 0.24 ms in
-# the 2 560-problem plan of the NB attack (profiles/r05_bench_default.json: 17.1 of a window's 40.9 ms).  The plan now runs
-# up to PLAN_AHEAD forwards ahead (the windows stay what the control flow reads back); what a restart or an early exit
-# leaves unused of it is re-drawn / given back to the generator (the FPS draws come from the CPU generator in forward
-# order, pointnet_util.py:75; the restart noise of target.py:131 from the device's: the two streams do not interleave).
-PLAN_AHEAD = 50
+# Geometry plan horizon (round 6).  A plan may run up to PLAN_AHEAD forwards ahead of the control-flow windows (`plan_ahead`
+# forwards at once; what a restart or an early exit leaves unused of it is re-drawn / given back to the generator: the FPS
+# draws come from the CPU generator in forward order, pointnet_util.py:75, the restart noise of target.py:131 from the
+# device's - the two streams do not interleave).  The round-5 review expected that to pay (a 640-problem plan per window is
+# bound by FPS latency: 17.1 of a window's 40.9 ms in the profiled call) and it does not: rooms/s of the configs[2] bench at
+# plan_ahead = 10 / 20 / 30 / 50: 614 / 591 / 587 / 572 with four calls in flight, 478 / 468 / 461 / 456 with one
+# (tools/r06_g.sh) - the small plans run in the shadow of the network kernels around them, a 2 496-problem plan is a
+# 24-ms block that nothing overlaps.  So the default stays one plan per window (= rounds 3-5); the knob and its bookkeeping
+# stay, tested at 50 (tests/test_gpu_nu.py), for callers whose attacks run one at a time with long step caps.
+PLAN_AHEAD = 50          # capacity: forwards a geometry plan may hold (graph handles, workspace slots)
+plan_ahead = CHUNK       # forwards actually planned at once (a multiple of CHUNK, <= PLAN_AHEAD): module-level knob
 
 
 class _NuState:
@@ -148,10 +152,10 @@ def _nu_core(atk, images, labels, masks, target, neighbour, targeted_variant, tr
             # attack right after it (at batch 32 the targeted one always does, target.py:105-121), and a plan for
             # eleven forwards would then be ten too many; the rest of the first window follows with step 1.
             # (the plan reads the coordinates only; the colours of a step are written inside the window call)
-            # (round 6) ... and the plan itself runs up to PLAN_AHEAD forwards ahead: [0], [1..50], [51..100], ..; the draws are
+            # (round 6) ... the plan may run up to `plan_ahead` forwards ahead ([0], [1..50], [51..100], .. at 50); the draws are
             # made window by window with the generator's state kept at every window end, so that what is not consumed can
             # be given back (end of the attack) or drawn again (a restart moved the coordinates)
-            n_plan = 1 if step == 0 else min(PLAN_AHEAD, atk.steps - step)
+            n_plan = 1 if step == 0 else min(max(CHUNK, min(int(plan_ahead), PLAN_AHEAD)) // CHUNK * CHUNK, atk.steps - step)
             if starts_fn is not None:
                 starts = upload(starts_fn(step, n_plan), dev)
                 rng_at = None

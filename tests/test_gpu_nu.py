@@ -623,7 +623,8 @@ def test_smooth_knn_kernel_vs_oracle_and_across_launch_shapes(n, nb):
         assert torch.equal(warm, cold), label
 
 
-def test_nu_windows_without_host_sync_equal_the_per_step_loop(weights_sd):
+@pytest.mark.parametrize("plan_ahead", [10, 50])
+def test_nu_windows_without_host_sync_equal_the_per_step_loop(weights_sd, plan_ahead, monkeypatch):
     """Round 4: without a trace callback the steps of a geometry window run in ONE call (psg_pn2_nu_window: statistics and
     the exit latch on the device, full windows replayed as a hipGraph) and the host only looks after step 0 and every 10th
     step.  The result must be what the per-step loop (trace given: one read-back per step, no graph) returns: bit-equal
@@ -633,6 +634,9 @@ def test_nu_windows_without_host_sync_equal_the_per_step_loop(weights_sd):
     and again on a second call that replays from its first full window on."""
     from pointsecguard_amd.attacks import torchattacks
     from pointsecguard_amd.attacks.torchattacks.attacks import nu as nu_mod
+    # plan_ahead = 10: one geometry plan per window (the default; rounds 3-5); 50: the plan runs ahead of the windows (round 6
+    # knob, nu.plan_ahead), one graph handle per window position inside a plan
+    monkeypatch.setattr(nu_mod, "plan_ahead", plan_ahead)
     R, steps, target = 3, 34, 6
     net, rooms, labels, images = _rooms_case(weights_sd, R, 9300)
     masks = labels == 2
@@ -668,8 +672,9 @@ def test_nu_windows_without_host_sync_equal_the_per_step_loop(weights_sd):
     got, n_got = rooms_run(None)
     assert np.array_equal(n_ref, n_got) and np.array_equal(ref.view(np.uint32), got.view(np.uint32))
     a = stats_of(net)
-    # [1..10] (position 0: new shape, eager), [11..20] (position 1: new shape, eager), restart -> new plan from 21:
-    # [21..30] (position 0 again: capture tried, refused on this stream, eager)
+    # plan_ahead 10: [1..10] eager (new shape), [11..20] capture tried - refused on this stream - eager, [21..30] eager (not retried);
+    # plan_ahead 50: [1..10] (position 0: new shape, eager), [11..20] (position 1: new shape, eager), restart -> new plan from 21:
+    # [21..30] (position 0 again: capture tried, refused, eager).  The same sums either way.
     assert a == dict(captures_tried=1, captures_failed=1, replays=0, eager=3), a
     # (b) on a side stream (what bench.py and a multi-stream caller use): [1..10] is a new key for the handle only if the
     # buffers changed - they did not, and the failed key is not retried: still eager.  A NEW model instance = new handle:
@@ -691,9 +696,13 @@ def test_nu_windows_without_host_sync_equal_the_per_step_loop(weights_sd):
         assert np.array_equal(n_ref, n_got), (n_ref, n_got)
         assert np.array_equal(ref.view(np.uint32), got.view(np.uint32))
         b = stats_of(net2)
-        # pass 0: [1..10] eager (position 0), [11..20] eager (position 1), [21..30] = position 0 of the plan after the restart:
-        # captured + replayed; pass 1: position 0 replayed, position 1 captured + replayed, position 0 replayed
-        assert b == dict(captures_tried=1 + k, captures_failed=0, replays=1 + 3 * k, eager=2), (k, b)
+        if plan_ahead == 10:
+            # pass 0: [1..10] eager, [11..20] captured + replayed, [21..30] replayed; pass 1: three replays
+            assert b == dict(captures_tried=1, captures_failed=0, replays=2 + 3 * k, eager=1), (k, b)
+        else:
+            # pass 0: [1..10] eager (position 0), [11..20] eager (position 1), [21..30] = position 0 of the plan after the restart:
+            # captured + replayed; pass 1: position 0 replayed, position 1 captured + replayed, position 0 replayed
+            assert b == dict(captures_tried=1 + k, captures_failed=0, replays=1 + 3 * k, eager=2), (k, b)
     tot = _lib.capture_stats()
     assert tot["captures_failed"] >= 1 and tot["replays"] >= 4
 
