@@ -6,11 +6,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PSG_GCN_KNN_STATS"] = "1"
 os.environ["PSG_GCN_NO_GRAPH"] = "1"
 from pointsecguard_amd import runtime
-from pointsecguard_amd.synthetic import gcn28_state_dict, make_rooms, rule_labels
+from pointsecguard_amd.synthetic import gcn28_fit_state_dict, gcn28_state_dict, make_rooms, rule_labels
 
 B, N = 4, 4096
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-model = runtime.GCNModel(gcn28_state_dict(), 28)
+model = runtime.GCNModel(gcn28_fit_state_dict() if os.environ.get("WEIGHTS") == "fit" else gcn28_state_dict(), 28)
 rooms = make_rooms(B, 5000)
 x = torch.from_numpy(np.ascontiguousarray(rooms.transpose(0, 2, 1))).cuda()
 y = torch.from_numpy(rule_labels(rooms).astype(np.int32)).cuda()
