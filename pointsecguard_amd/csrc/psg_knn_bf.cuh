@@ -344,6 +344,9 @@ __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFin
     unsigned *rcnt = bitmap;                                                       // [16] finalists placed per run (after the collect pass)
     uint2 *rt = (uint2 *)((unsigned *)kb_smem + a.scr_dw + h * KB_SCR + 64 + KB_SCR_BITMAP);   // [16] {first bin | cs << 16, fs | len << 16}
     const unsigned T = h ? c.T[1] : c.T[0];
+#if defined(KB_ABLATE) && KB_ABLATE == 3      // (timing experiments only, tools/knn_ablate.py: results are wrong)
+    return T & 1u;
+#endif
     const unsigned tl5 = T > (unsigned)l5 ? T - (unsigned)l5 : 0u;      // entry 32 i + l5 exists iff 32 i < tl5
     const unsigned keyx_ent = (((const unsigned *)kb_smem)[c.keyx_dw + ridx] << 12) | 0xFFFu;
     const unsigned tau_row = ((const unsigned *)kb_smem)[c.tau_dw + ridx];
@@ -482,6 +485,9 @@ __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFin
     const unsigned Fo = (unsigned)__shfl_xor((int)F, 32);
     const unsigned Fmax = F > Fo ? F : Fo;
     if (Fmax > (unsigned)KB_MAXFIN) return 0xFFFFFFFEu;
+#if defined(KB_ABLATE) && KB_ABLATE == 2
+    return F + Fo;
+#endif
     wave_lds_fence();                                              // (the bins are dead from here: their words take the finalists)
     KB_PH(9);
     // collect: every entry of a flagged bin joins the finalist list (register-major order)
@@ -504,6 +510,9 @@ __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFin
     if (l5 < 16) rcnt[l5] = 0u;                                     // (the bitmap is dead: its first words count the slots taken per run)
     wave_lds_fence();
     KB_PH(10);
+#if defined(KB_ABLATE) && KB_ABLATE == 1
+    return F + Fo;
+#endif
     const float4 *q4 = (const float4 *)qbuf;
     bool bound_broken = false;
     for (unsigned f0 = 0; f0 < Fmax; f0 += 32) {
@@ -582,6 +591,9 @@ __device__ __forceinline__ unsigned kb_final_rows(const KbRowArgs c, const KbFin
     if (__ballot(bound_broken) != 0ull) return 0xFFFFFFFDu;
     wave_lds_fence();
     KB_PH(11);
+#if defined(KB_ABLATE) && KB_ABLATE == 4
+    return F + Fo;
+#endif
     int32_t *out = a.out + (size_t)(h * KB_WAVES) * a.k;
     const unsigned long long m44 = (1ull << 44) - 1ull;
     for (unsigned f0 = 0; f0 < Fmax; f0 += 32) {
