@@ -18,7 +18,8 @@
 // in distance units (dot errors count twice) |D~ - D| <= 2^-14.57 |x_i||x_j| + 2^-19.75 |x_j|^2 + 2^-23 |x_i|^2.  The kernel
 // uses A = 2^-14, B = 2^-19, G = 2^-20 (1.48 x, 1.7 x, 8 x that bound; tools/bf16_split_probe.hip measured 2^-16 of the
 // largest |x|^2 on hardware over eight data sets: random, offset, 1e6 dynamic range, near-cancelling pairs, 1e-15 and 1e15
-// magnitudes), so L <= D <= L + 2 e_ij - and that is CHECKED for every finalist (kb_final_rows).  Rounds 3-5 ran with
+// magnitudes; round 6, per PAIR against these constants: |D~ - D| <= 0.19 - 0.56 e_ij over 8 x 1M pairs, the worst set the one
+// with per-channel scales 1e-3..1e3), so L <= D <= L + 2 e_ij - and that is CHECKED for every finalist (kb_final_rows).  Rounds 3-5 ran with
 // A = 2^-13.5, B = 2^-15.5: the row margin E_i, and with it the finalists per wanted rank, is ~40 % smaller now.
 // The error scales with the PAIR's norms, not with the room's largest norm: the network's own features have a few points
 // whose |x|^2 is 40 x the mean, and a bound in units of that maximum was wider than the neighbour distances themselves.

@@ -26,7 +26,7 @@ __device__ __forceinline__ float bf16_f(unsigned short h) { return __uint_as_flo
 union Frag { bf16x8 v; unsigned short s[8]; };
 
 // one wave per (candidate tile, query tile); x row-major [n][64], sq [n]; out[i_query][j_cand] = acc
-__global__ void probe_kernel(const float *x, const float *sq, int n, float *out)
+__global__ void probe_kernel(const float *x, const float *sq, int n, float *out, int small_first)
 {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int ct = blockIdx.x, qt = blockIdx.y;
@@ -48,10 +48,18 @@ __global__ void probe_kernel(const float *x, const float *sq, int n, float *out)
     for (int j = 0; j < 8; ++j) { aa.s[j] = 0; qa.s[j] = 0; }
     if (h == 0) { aa.s[0] = p1; aa.s[1] = p2; aa.s[2] = p3; qa.s[0] = qa.s[1] = qa.s[2] = 0x3F80; }
     f32x16 acc = {0};
-    for (int s = 0; s < 4; ++s) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s].v, qh[s].v, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s].v, ql[s].v, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s].v, qh[s].v, acc, 0, 0, 0);
+    if (small_first) {      // round 6 (psg_knn_bf.cuh: kb_tile_product): the eight small products, then hi.hi, the augmented step last
+        for (int s = 0; s < 4; ++s) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s].v, ql[s].v, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s].v, qh[s].v, acc, 0, 0, 0);
+        }
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s].v, qh[s].v, acc, 0, 0, 0);
+    } else {
+        for (int s = 0; s < 4; ++s) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s].v, qh[s].v, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s].v, ql[s].v, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s].v, qh[s].v, acc, 0, 0, 0);
+        }
     }
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa.v, qa.v, acc, 0, 0, 0);
     // D: col = lane & 31 (B = query), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (A = candidate)
@@ -99,9 +107,10 @@ int main()
         for (int i = 0; i < n; ++i) { sq[i] = sumsq_torch(&s.x[(size_t)i * 64]); sqmax = std::fmax(sqmax, sq[i]); }
         hipMemcpy(dx, s.x.data(), (size_t)n * 64 * 4, hipMemcpyHostToDevice);
         hipMemcpy(dsq, sq.data(), n * 4, hipMemcpyHostToDevice);
-        hipLaunchKernelGGL(probe_kernel, dim3(n / 32, n / 32), dim3(64), 0, 0, dx, dsq, n, dout);
+      for (int order = 0; order < 2; ++order) {
+        hipLaunchKernelGGL(probe_kernel, dim3(n / 32, n / 32), dim3(64), 0, 0, dx, dsq, n, dout, order);
         hipMemcpy(out.data(), dout, (size_t)n * n * 4, hipMemcpyDeviceToHost);
-        double worst_d = 0, worst_acc = 0;
+        double worst_d = 0, worst_acc = 0, worst_pair_old = 0, worst_pair_new = 0;
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j) {
                 const float *a = &s.x[(size_t)i * 64], *b = &s.x[(size_t)j * 64];
@@ -111,10 +120,16 @@ int main()
                 const double acc = out[(size_t)i * n + j];
                 const double Dt = (double)sq[i] - 2.0 * acc;
                 worst_d = std::fmax(worst_d, std::fabs(Dt - (double)D) / sqmax);
+                // against the PER-PAIR bound the kernel uses, e_ij = A |x_i||x_j| + B |x_j|^2 + G |x_i|^2 (must stay below 1):
+                // rounds 3-5: A = 2^-13.5, B = 2^-15.5; round 6 (small products first): A = 2^-14, B = 2^-19; G = 2^-20
+                const double ai = std::sqrt((double)sq[i]), aj = std::sqrt((double)sq[j]), err = std::fabs(Dt - (double)D);
+                worst_pair_old = std::fmax(worst_pair_old, err / (8.631674575031098e-05 * ai * aj + 2.1579186437577745e-05 * sq[j] + 9.5367431640625e-07 * sq[i] + 1e-300));
+                worst_pair_new = std::fmax(worst_pair_new, err / (6.103515625e-05 * ai * aj + 1.9073486328125e-06 * sq[j] + 9.5367431640625e-07 * sq[i] + 1e-300));
                 worst_acc = std::fmax(worst_acc, std::fabs(acc - (ze - 0.5 * sq[j])) / (sabs + 0.5 * sq[j] + 1e-300));
             }
-        printf("%-32s sqmax %.3e   max |D~ - D| / sqmax = 2^%.2f   max |acc - exact| / sum|terms| = 2^%.2f\n", s.name, sqmax,
-               std::log2(worst_d + 1e-300), std::log2(worst_acc + 1e-300));
+        printf("%-30s %-13s sqmax %.3e  max |D~ - D| / sqmax = 2^%.2f  |acc - exact| / sum|terms| = 2^%.2f  error / pair bound: round-5 constants %.3f, round-6 constants %.3f\n",
+               s.name, order ? "small first" : "interleaved", sqmax, std::log2(worst_d + 1e-300), std::log2(worst_acc + 1e-300), worst_pair_old, worst_pair_new);
+      }
     }
     return 0;
 }
