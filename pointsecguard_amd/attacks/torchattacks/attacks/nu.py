@@ -104,7 +104,7 @@ def _nu_core(atk, images, labels, masks, target, neighbour, targeted_variant, tr
     S = _state(net, dev, G, rows, N, neighbour)
     model = net._packed()
     net._generation += 1
-    ws = net._workspace(B, N, PLAN_AHEAD)
+    ws = net._workspace(B, N, max(CHUNK + 1, min(int(plan_ahead), PLAN_AHEAD)))      # plan slots: what a plan can hold, no more
     use_target = targeted_variant and target is not None
     mode = 0 if not targeted_variant else (2 if use_target else 1)
     S.labels.copy_(labels_to_device(labels, dev))
